@@ -1,0 +1,212 @@
+"""ctypes binding of the CPU oracle (oracle/p25fe_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under p25rx_amd/ imports this module.
+PARITY UNPINNED -- see the header of p25fe_oracle.c.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SPEC_JSON = os.path.join(ROOT, "tests", "golden", "spec.json")
+MAX_TAPS = 64
+NCOEF = 8
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("decim", C.c_int32), ("t1", C.c_int32), ("t2", C.c_int32), ("boxcar", C.c_int32),
+        ("sps", C.c_int32), ("peak_w", C.c_int32), ("sync_sign_mask", C.c_uint32),
+        ("decim_taps", C.c_float * MAX_TAPS), ("chan_taps", C.c_float * MAX_TAPS),
+        ("atan_c", C.c_float * NCOEF),
+        ("fm_gain", C.c_float), ("u8_scale", C.c_float), ("boxcar_scale", C.c_float),
+        ("pi", C.c_float), ("half_pi", C.c_float),
+        ("inv_npos", C.c_float), ("inv_nneg", C.c_float), ("rho2_n", C.c_float),
+        ("e_min", C.c_float), ("slice_frac", C.c_float),
+    ]
+
+
+def load_spec(path=SPEC_JSON):
+    with open(path) as f:
+        return json.load(f)
+
+
+def make_config(spec=None, decim_taps=None, chan_taps=None):
+    s = spec or load_spec()
+    c = Config()
+    c.decim, c.sps, c.boxcar, c.peak_w = s["decim"], s["sps"], s["boxcar_len"], s["sync_peak_w"]
+    dt = list(s["decim_taps"] if decim_taps is None else decim_taps)
+    ct = list(s["chan_taps"] if chan_taps is None else chan_taps)
+    c.t1, c.t2 = len(dt), len(ct)
+    for i, v in enumerate(dt):
+        c.decim_taps[i] = v
+    for i, v in enumerate(ct):
+        c.chan_taps[i] = v
+    for i, v in enumerate(s["atan_coeffs"]):
+        c.atan_c[i] = v
+    c.sync_sign_mask = s["sync_sign_mask"]
+    c.fm_gain, c.u8_scale, c.boxcar_scale = s["fm_gain"], s["u8_scale"], s["boxcar_scale"]
+    c.pi, c.half_pi = s["pi"], s["half_pi"]
+    c.inv_npos, c.inv_nneg = s["sync_inv_npos"], s["sync_inv_nneg"]
+    c.rho2_n, c.e_min, c.slice_frac = s["sync_rho2_n"], s["sync_e_min"], s["slice_frac"]
+    return c
+
+
+def build(force=False):
+    so = os.path.join(HERE, "libp25fe_oracle.so")
+    src = os.path.join(HERE, "p25fe_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return so
+
+
+def _bind(lib):
+    vp, sz = C.c_void_p, C.c_size_t
+    fp = C.POINTER(C.c_float)
+    lib.p25o_demod_create.restype = vp
+    lib.p25o_demod_create.argtypes = [C.POINTER(Config)]
+    lib.p25o_demod_destroy.argtypes = [vp]
+    lib.p25o_demod_u8.restype = sz
+    lib.p25o_demod_u8.argtypes = [vp, vp, sz, vp, fp]
+    lib.p25o_demod_cf32.restype = sz
+    lib.p25o_demod_cf32.argtypes = [vp, vp, sz, vp, fp]
+    lib.p25o_demod_cf32_stages.restype = sz
+    lib.p25o_demod_cf32_stages.argtypes = [vp, vp, sz, vp, vp, vp]
+    lib.p25o_power_dbm.restype = C.c_float
+    lib.p25o_power_dbm.argtypes = [vp, sz, C.c_float]
+    lib.p25o_atan2f.restype = C.c_float
+    lib.p25o_atan2f.argtypes = [C.POINTER(Config), C.c_float, C.c_float]
+    lib.p25o_recv_create.restype = vp
+    lib.p25o_recv_create.argtypes = [C.POINTER(Config)]
+    lib.p25o_recv_destroy.argtypes = [vp]
+    lib.p25o_recv_resync.argtypes = [vp]
+    lib.p25o_recv_feed.restype = C.c_int
+    lib.p25o_recv_feed.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp, vp, sz, C.POINTER(sz)]
+    lib.p25o_recv_state.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_float * 3), C.POINTER(C.c_uint64)]
+    lib.p25o_run_cf32.restype = C.c_int64
+    lib.p25o_run_cf32.argtypes = [C.POINTER(Config), vp, sz, vp, sz]
+    lib.p25o_has_fma.restype = C.c_int
+    return lib
+
+
+_LIB = None
+
+
+def lib(path=None):
+    global _LIB
+    if path is not None:
+        return _bind(C.CDLL(path))
+    if _LIB is None:
+        _LIB = _bind(C.CDLL(build()))
+        if not _LIB.p25o_has_fma():
+            raise RuntimeError("oracle was built with -mfma but this CPU has no FMA")
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Demod:
+    """demod::DemodTask state + one run-loop body per call (src/demod.rs:62-119)."""
+
+    def __init__(self, cfg=None, libpath=None):
+        self.L = lib(libpath)
+        self.cfg = cfg or make_config()
+        self.h = self.L.p25o_demod_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("p25o_demod_create failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.p25o_demod_destroy(self.h)
+            self.h = None
+
+    def feed_u8(self, data, want_power=False):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        bb = np.empty(data.size // 2 // self.cfg.decim + 2, dtype=np.float32)
+        p = C.c_float(0)
+        n = self.L.p25o_demod_u8(self.h, _ptr(data), data.size, _ptr(bb), C.byref(p) if want_power else None)
+        return (bb[:n].copy(), p.value) if want_power else bb[:n].copy()
+
+    def feed_cf32(self, iq, want_power=False):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        bb = np.empty(iq.size // self.cfg.decim + 2, dtype=np.float32)
+        p = C.c_float(0)
+        n = self.L.p25o_demod_cf32(self.h, _ptr(iq), iq.size, _ptr(bb), C.byref(p) if want_power else None)
+        return (bb[:n].copy(), p.value) if want_power else bb[:n].copy()
+
+    def feed_cf32_stages(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        cap = iq.size // self.cfg.decim + 2
+        ch = np.empty(cap, dtype=np.complex64)
+        fm = np.empty(cap, dtype=np.float32)
+        bb = np.empty(cap, dtype=np.float32)
+        n = self.L.p25o_demod_cf32_stages(self.h, _ptr(iq), iq.size, _ptr(ch), _ptr(fm), _ptr(bb))
+        return ch[:n].copy(), fm[:n].copy(), bb[:n].copy()
+
+
+class Recv:
+    """Front half of MessageReceiver::feed + resync (src/recv.rs:136, 179, 207)."""
+
+    def __init__(self, cfg=None, libpath=None):
+        self.L = lib(libpath)
+        self.cfg = cfg or make_config()
+        self.h = self.L.p25o_recv_create(C.byref(self.cfg))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.p25o_recv_destroy(self.h)
+            self.h = None
+
+    def resync(self):
+        self.L.p25o_recv_resync(self.h)
+
+    def feed(self, bb):
+        bb = np.ascontiguousarray(bb, dtype=np.float32)
+        cap = bb.size // self.cfg.sps + 2
+        dib = np.empty(cap, dtype=np.uint8)
+        scap = bb.size // (self.cfg.peak_w + 1) + 2
+        spos = np.empty(scap, dtype=np.int64)
+        sdib = np.empty(scap, dtype=np.uint64)
+        nd, ns = C.c_size_t(0), C.c_size_t(0)
+        rc = self.L.p25o_recv_feed(self.h, _ptr(bb), bb.size, _ptr(dib), cap, C.byref(nd),
+                                   _ptr(spos), _ptr(sdib), scap, C.byref(ns))
+        if rc:
+            raise RuntimeError("oracle recv overflow")
+        return dib[:nd.value].copy(), spos[:ns.value].copy(), sdib[:ns.value].copy()
+
+    def state(self):
+        t, v, s, nd = C.c_int64(), C.c_int(), C.c_int64(), C.c_uint64()
+        thr = (C.c_float * 3)()
+        self.L.p25o_recv_state(self.h, C.byref(t), C.byref(v), C.byref(s), C.byref(thr), C.byref(nd))
+        return dict(t=t.value, valid=bool(v.value), s=s.value, hi=thr[0], mid=thr[1], lo=thr[2], n_dibits=nd.value)
+
+
+def power_dbm(samples, resistance=1.0):
+    samples = np.ascontiguousarray(samples, dtype=np.complex64)
+    return lib().p25o_power_dbm(_ptr(samples), samples.size, resistance)
+
+
+def atan2f(y, x, cfg=None):
+    cfg = cfg or make_config()
+    return lib().p25o_atan2f(C.byref(cfg), y, x)
+
+
+def run_cf32(iq, cfg=None, libpath=None):
+    """IQ -> dibits through the whole oracle path in the reference's 16384-sample chunks."""
+    L = lib(libpath)
+    cfg = cfg or make_config()
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    cap = iq.size // (cfg.decim * cfg.sps) + 16
+    dib = np.empty(cap, dtype=np.uint8)
+    n = L.p25o_run_cf32(C.byref(cfg), _ptr(iq), iq.size, _ptr(dib), cap)
+    if n < 0:
+        raise RuntimeError("oracle run overflow")
+    return dib[:n].copy()

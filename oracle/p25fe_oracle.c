@@ -1,0 +1,440 @@
+/*
+ * p25fe_oracle.c -- CPU restatement of the kchmck/p25rx IQ -> symbol hot path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load it.  The product (p25rx_amd/, include/) never
+ * includes, links or calls anything under oracle/.
+ *
+ * PARITY UNPINNED.  The reference keeps every number of this path (FIR taps, LUT values,
+ * discriminator gain, sync/slicer rules) in crates that are not vendored in /root/reference
+ * and cannot be fetched or compiled here (no rustc/cargo, no network):
+ *     rtlsdr_iq 0.1.0, static_fir 0.2.0, demod_fm 1.0.0, moving_avg 0.1.0 (crates.io),
+ *     static_decimate 1.0.0 @e9e00a0e, p25_filts 1.0.0 @0d34fc28, p25 1.0.0 @a96c564b (git)
+ * (Cargo.lock:134-136, 320-322, 442-444, 458-460, 575-577, 655-657, 664-666), and none of
+ * the reference's five #[test]s touches the path.  What this file follows from the reference
+ * is therefore the STRUCTURE it can cite -- stage order, rates, buffer sizes, in-place
+ * semantics, per-sample feed() objects whose state persists across chunks -- with the
+ * build-defined numbers of docs/SPEC.md (frozen in tests/golden/spec.json) plugged in.
+ * It is pinned instead against (i) an independent fp64 numpy/scipy model, (ii) physical
+ * known-answer tests and (iii) the known symbols of a seeded C4FM modulator (tests/).
+ *
+ * Arithmetic contract (docs/SPEC.md section 3): fp32 throughout, every multiply-add that the
+ * spec writes as fma() is one fused operation, nothing else may be contracted or
+ * re-associated: build with -ffp-contract=off, no -ffast-math.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define P25O_MAX_TAPS 64
+#define P25O_ATAN_NCOEF 8
+#define P25O_SYNC_DIBITS 24
+
+typedef struct { float re, im; } cf32;
+
+/* Numbers of docs/SPEC.md; the tests fill this from tests/golden/spec.json. */
+typedef struct {
+    int32_t decim;                       /* src/demod.rs:50            -> 5  */
+    int32_t t1, t2;                      /* tap counts                        */
+    int32_t boxcar;                      /* src/demod.rs:52            -> 10 */
+    int32_t sps;                         /* baseband samples per symbol -> 10 */
+    int32_t peak_w;                      /* sync peak window (+-W)            */
+    uint32_t sync_sign_mask;             /* bit j: sync symbol j (oldest first) is +3 */
+    float decim_taps[P25O_MAX_TAPS];
+    float chan_taps[P25O_MAX_TAPS];
+    float atan_c[P25O_ATAN_NCOEF];
+    float fm_gain, u8_scale, boxcar_scale;
+    float pi, half_pi;
+    float inv_npos, inv_nneg, rho2_n, e_min, slice_frac;
+} p25o_config;
+
+/* ------------------------------------------------------------------------------------------
+ * stage 1: rtlsdr_iq::IQ -- 65536-entry LUT indexed by the native-endian u16 made of two
+ * consecutive bytes (src/demod.rs:74-76, 82-84).  Little endian: low byte = first byte = I.
+ * Value (build-defined): fma((float)b, 2/255, -1).
+ * ---------------------------------------------------------------------------------------- */
+static void build_iq_lut(cf32 *lut, float scale)
+{
+    for (uint32_t s = 0; s < 65536u; s++) {
+        lut[s].re = fmaf((float)(s & 0xffu), scale, -1.0f);
+        lut[s].im = fmaf((float)(s >> 8), scale, -1.0f);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * static_fir::FirFilter<_>::feed(Complex32) -> Complex32 (src/demod.rs:29, 51, 93) and the
+ * FIR inside static_decimate::Decimator (src/demod.rs:27, 50, 87).  History is a doubled
+ * ring so the newest T samples are contiguous.  Accumulation order (SPEC 3.2): single
+ * accumulator from +0, tap 0 (newest sample) to tap T-1 (oldest), one fma per component.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int ntaps, pos;
+    float taps[P25O_MAX_TAPS];
+    cf32 hist[2 * P25O_MAX_TAPS];
+} fir_c;
+
+static void fir_init(fir_c *f, const float *taps, int ntaps)
+{
+    memset(f, 0, sizeof *f);
+    f->ntaps = ntaps;
+    memcpy(f->taps, taps, sizeof(float) * (size_t)ntaps);
+}
+
+static inline void fir_push(fir_c *f, cf32 x)
+{
+    /* newest sample at hist[pos]; older ones at increasing addresses */
+    f->pos = f->pos == 0 ? f->ntaps - 1 : f->pos - 1;
+    f->hist[f->pos] = x;
+    f->hist[f->pos + f->ntaps] = x;
+}
+
+static inline cf32 fir_eval(const fir_c *f)
+{
+    const cf32 *h = f->hist + f->pos;
+    float re = 0.0f, im = 0.0f;
+    for (int k = 0; k < f->ntaps; k++) {
+        re = fmaf(f->taps[k], h[k].re, re);
+        im = fmaf(f->taps[k], h[k].im, im);
+    }
+    return (cf32){re, im};
+}
+
+/* ------------------------------------------------------------------------------------------
+ * demod_fm::FmDemod::feed (src/demod.rs:33, 54, 110): angle of s * conj(prev), times
+ * fs / (2 pi dev).  atan2 is the spec's own polynomial (SPEC 3.4) so that two compilers
+ * agree bit for bit; tests bound its distance to libm atan2f.
+ * ---------------------------------------------------------------------------------------- */
+static inline float spec_atan2f(const p25o_config *c, float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    if (mx == 0.0f)
+        return 0.0f;
+    float t = mn / mx;
+    float s = t * t;
+    float p = c->atan_c[P25O_ATAN_NCOEF - 1];
+    for (int i = P25O_ATAN_NCOEF - 2; i >= 0; i--)
+        p = fmaf(p, s, c->atan_c[i]);
+    float r = p * t;
+    if (ay > ax)
+        r = c->half_pi - r;
+    if (x < 0.0f)
+        r = c->pi - r;
+    if (y < 0.0f)
+        r = -r;
+    return r;
+}
+
+static inline float fm_feed(const p25o_config *c, cf32 *prev, cf32 s)
+{
+    float t = s.im * prev->im;
+    float re = fmaf(s.re, prev->re, t);
+    float u = s.re * prev->im;
+    float im = fmaf(s.im, prev->re, -u);
+    *prev = s;
+    return spec_atan2f(c, im, re) * c->fm_gain;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * moving_avg::MovingAverage<f32>::feed (src/demod.rs:31, 52, 114).  SPEC 3.5: direct sum,
+ * newest first, then one multiply by 1/10 -- no running sum, so it cannot drift and has
+ * finite memory.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int len, pos; float hist[2 * 32]; } boxcar;
+
+static inline float boxcar_feed(boxcar *b, float scale, float x)
+{
+    b->pos = b->pos == 0 ? b->len - 1 : b->pos - 1;
+    b->hist[b->pos] = x;
+    b->hist[b->pos + b->len] = x;
+    const float *h = b->hist + b->pos;
+    float acc = h[0];
+    for (int i = 1; i < b->len; i++)
+        acc = acc + h[i];
+    return acc * scale;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * demod::DemodTask (src/demod.rs:25-40): decimator, channel filter, moving average, FM
+ * demodulator; state lives in the struct and persists across chunks (src/demod.rs:62-119).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    p25o_config cfg;
+    cf32 *lut;
+    fir_c decim;          /* Decimator<DecimFir>     src/demod.rs:27 */
+    int decim_phase;      /* samples since last output; output when it reaches decim */
+    fir_c bandpass;       /* FirFilter<BandpassFir>  src/demod.rs:29 */
+    boxcar avg;           /* MovingAverage<f32>      src/demod.rs:31 */
+    cf32 fm_prev;         /* FmDemod                 src/demod.rs:33 */
+    cf32 *scratch;
+    size_t scratch_cap;
+} p25o_demod;
+
+p25o_demod *p25o_demod_create(const p25o_config *cfg)
+{
+    if (cfg->t1 > P25O_MAX_TAPS || cfg->t2 > P25O_MAX_TAPS || cfg->boxcar > 32)
+        return NULL;
+    p25o_demod *d = calloc(1, sizeof *d);
+    d->cfg = *cfg;
+    d->lut = malloc(sizeof(cf32) * 65536);
+    build_iq_lut(d->lut, cfg->u8_scale);
+    fir_init(&d->decim, cfg->decim_taps, cfg->t1);       /* Decimator::new(5)  :50 */
+    fir_init(&d->bandpass, cfg->chan_taps, cfg->t2);     /* FirFilter::new()   :51 */
+    d->avg.len = cfg->boxcar;                            /* MovingAverage::new(10) :52 */
+    return d;
+}
+
+void p25o_demod_destroy(p25o_demod *d)
+{
+    if (!d) return;
+    free(d->lut);
+    free(d->scratch);
+    free(d);
+}
+
+/* static_decimate::Decimator::decim_in_place (src/demod.rs:87): filter + keep every 5th,
+ * in place, return the new length.  Phase persists, so 16384-sample chunks give 3276 or
+ * 3277 outputs (src/demod.rs:87-90).  SPEC 3.2: output m is produced by input n = 5m + 4. */
+static size_t decim_in_place(p25o_demod *d, cf32 *buf, size_t n)
+{
+    size_t len = 0;
+    for (size_t i = 0; i < n; i++) {
+        fir_push(&d->decim, buf[i]);
+        if (++d->decim_phase == d->cfg.decim) {
+            d->decim_phase = 0;
+            buf[len++] = fir_eval(&d->decim);
+        }
+    }
+    return len;
+}
+
+/* demod::power_dbm (src/demod.rs:123-134), transcribed operation for operation. */
+float p25o_power_dbm(const cf32 *samples, size_t n, float resistance)
+{
+    float s = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        float a = samples[i].re * samples[i].re;
+        float b = samples[i].im * samples[i].im;
+        s = s + (a + b);                 /* s + x.norm_sqr()  :125-127 */
+    }
+    float avg = s / (float)n;
+    float power = avg / resistance;      /* :130 */
+    return 30.0f + 10.0f * log10f(power);/* :133 */
+}
+
+/* Stages after the LUT, on a chunk already in `samples` (src/demod.rs:86-114).
+ * Returns the baseband length; *power (if non-NULL) gets power_dbm of the post-bandpass
+ * chunk (src/demod.rs:97) -- the caller decides the every-4th-chunk throttle (:67, :95). */
+static size_t demod_tail(p25o_demod *d, cf32 *samples, size_t n, float *bb, float *power)
+{
+    size_t len = decim_in_place(d, samples, n);                  /* :87-90  */
+    for (size_t i = 0; i < len; i++) {                           /* :93     */
+        fir_push(&d->bandpass, samples[i]);
+        samples[i] = fir_eval(&d->bandpass);
+    }
+    if (power)
+        *power = len ? p25o_power_dbm(samples, len, 1.0f) : 0.0f;/* :97     */
+    for (size_t i = 0; i < len; i++)                             /* :109-111 */
+        bb[i] = fm_feed(&d->cfg, &d->fm_prev, samples[i]);
+    for (size_t i = 0; i < len; i++)                             /* :114    */
+        bb[i] = boxcar_feed(&d->avg, d->cfg.boxcar_scale, bb[i]);
+    return len;
+}
+
+static cf32 *scratch(p25o_demod *d, size_t n)
+{
+    if (n > d->scratch_cap) {
+        free(d->scratch);
+        d->scratch = malloc(sizeof(cf32) * n);
+        d->scratch_cap = n;
+    }
+    return d->scratch;
+}
+
+/* One pass of the DemodTask::run loop body on one chunk of interleaved u8 I/Q
+ * (src/demod.rs:70-117).  The reference's chunk is 32768 bytes (src/consts.rs:6); any even
+ * size is accepted so tests can prove chunk-size invariance. */
+size_t p25o_demod_u8(p25o_demod *d, const uint8_t *bytes, size_t nbytes, float *bb, float *power)
+{
+    size_t n = nbytes / 2;
+    cf32 *samples = scratch(d, n);
+    for (size_t i = 0; i < n; i++) {                             /* :74-84 */
+        uint16_t s = (uint16_t)(bytes[2 * i] | (bytes[2 * i + 1] << 8));
+        samples[i] = d->lut[s];
+    }
+    return demod_tail(d, samples, n, bb, power);
+}
+
+/* Same, for input that is already Complex32 (BASELINE.json configs 2-5). */
+size_t p25o_demod_cf32(p25o_demod *d, const float *iq, size_t n, float *bb, float *power)
+{
+    cf32 *samples = scratch(d, n);
+    memcpy(samples, iq, sizeof(cf32) * n);
+    return demod_tail(d, samples, n, bb, power);
+}
+
+/* Export the post-bandpass complex samples too (for stage-level cross-checks). */
+size_t p25o_demod_cf32_stages(p25o_demod *d, const float *iq, size_t n, float *chan_out, float *fm_out,
+                              float *bb)
+{
+    cf32 *samples = scratch(d, n);
+    memcpy(samples, iq, sizeof(cf32) * n);
+    size_t len = decim_in_place(d, samples, n);
+    for (size_t i = 0; i < len; i++) {
+        fir_push(&d->bandpass, samples[i]);
+        samples[i] = fir_eval(&d->bandpass);
+    }
+    if (chan_out)
+        memcpy(chan_out, samples, sizeof(cf32) * len);
+    for (size_t i = 0; i < len; i++) {
+        float f = fm_feed(&d->cfg, &d->fm_prev, samples[i]);
+        if (fm_out) fm_out[i] = f;
+        bb[i] = boxcar_feed(&d->avg, d->cfg.boxcar_scale, f);
+    }
+    return len;
+}
+
+float p25o_atan2f(const p25o_config *c, float y, float x) { return spec_atan2f(c, y, x); }
+
+/* ------------------------------------------------------------------------------------------
+ * Symbol receiver: the front half of p25::message::receiver::MessageReceiver::feed(f32)
+ * (src/recv.rs:207, src/replay.rs:44) down to the point where a dibit exists, and
+ * MessageReceiver::resync (src/recv.rs:136, 179).  The p25 crate is not available, so the
+ * rule is build-defined (SPEC 3.6-3.8):
+ *   c[n]   = sum_j sign_j * b[n - 10 (23 - j)]          (frame-sync correlation, 24 taps)
+ *   e[n]   = sum_j b[n - 10 (23 - j)]^2
+ *   cand   = c > 0 && e >= e_min && c*c >= 24*0.85 * e   (normalised correlation >= ~0.92)
+ *   detect = cand[n] && c[n] > c[n-i] && c[n] >= c[n+i], i = 1..W
+ *   a detection at s sets thresholds from the sync word's own levels and anchors symbol
+ *   instants n = s + 10 k (k >= 1); instant n is sliced under the latest detection s with
+ *   s + W < n, so a re-anchor that moves the timing by up to half a symbol neither drops
+ *   nor repeats a symbol.  A detection at s is decided when sample s + W has been fed;
+ *   dibits have no lag.
+ * ---------------------------------------------------------------------------------------- */
+#define RING 512
+typedef struct {
+    p25o_config cfg;
+    int64_t t;                  /* samples fed so far */
+    float b[RING], c[RING];
+    uint8_t cand[RING];
+    int anchor_valid;
+    int64_t anchor_s;
+    float hi, mid, lo;
+    uint64_t n_dibits;
+} p25o_recv;
+
+p25o_recv *p25o_recv_create(const p25o_config *cfg)
+{
+    p25o_recv *r = calloc(1, sizeof *r);
+    r->cfg = *cfg;
+    return r;
+}
+
+void p25o_recv_destroy(p25o_recv *r) { free(r); }
+
+/* MessageReceiver::resync (src/recv.rs:136, 179): drop lock. */
+void p25o_recv_resync(p25o_recv *r) { r->anchor_valid = 0; }
+
+static inline float bget(const p25o_recv *r, int64_t n) { return n < 0 ? 0.0f : r->b[n & (RING - 1)]; }
+static inline float cget(const p25o_recv *r, int64_t n) { return n < 0 ? 0.0f : r->c[n & (RING - 1)]; }
+
+/* Feed n baseband samples (the `for &s in samples.iter()` loop of src/recv.rs:148-150).
+ * Writes dibits (one per byte, values 0..3) and sync events (sample position of the sync
+ * word's last symbol; index of the first dibit after it). Returns 0, or -1 on overflow. */
+int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, size_t cap, size_t *n_dibits,
+                   int64_t *sync_pos, uint64_t *sync_dibit, size_t sync_cap, size_t *n_sync)
+{
+    const p25o_config *g = &r->cfg;
+    const int W = g->peak_w, S = g->sps;
+    size_t nd = 0, ns = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int64_t t = r->t;
+        r->b[t & (RING - 1)] = bb[i];
+        float c = 0.0f, e = 0.0f;
+        for (int j = 0; j < P25O_SYNC_DIBITS; j++) {
+            float v = bget(r, t - (int64_t)S * (P25O_SYNC_DIBITS - 1 - j));
+            c = ((g->sync_sign_mask >> j) & 1u) ? c + v : c - v;
+            e = fmaf(v, v, e);
+        }
+        r->c[t & (RING - 1)] = c;
+        r->cand[t & (RING - 1)] = (c > 0.0f) && (e >= g->e_min) && (c * c >= g->rho2_n * e);
+
+        /* 1. slice instant t under the latest detection s with s + W < t */
+        if (r->anchor_valid && (t - r->anchor_s) % S == 0) {
+            float v = bb[i];
+            uint8_t d = v >= r->hi ? 1 : v >= r->mid ? 0 : v >= r->lo ? 2 : 3;
+            if (nd >= cap) return -1;
+            dibits[nd++] = d;
+            r->n_dibits++;
+        }
+        /* 2. decide detection at m = t - W (needs c[m-W .. m+W] = c[.. t]) */
+        const int64_t m = t - W;
+        if (m >= 0 && r->cand[m & (RING - 1)]) {
+            float cm = cget(r, m);
+            int peak = 1;
+            for (int k = 1; k <= W; k++)
+                peak = peak && (cm > cget(r, m - k)) && (cm >= cget(r, m + k));
+            if (peak) {
+                float P = 0.0f, N = 0.0f;
+                for (int j = 0; j < P25O_SYNC_DIBITS; j++) {
+                    float v = bget(r, m - (int64_t)S * (P25O_SYNC_DIBITS - 1 - j));
+                    if ((g->sync_sign_mask >> j) & 1u) P = P + v; else N = N + v;
+                }
+                P = P * g->inv_npos;
+                N = N * g->inv_nneg;
+                float mid = (P + N) * 0.5f;
+                float span = (P - N) * 0.5f;
+                float dlt = span * g->slice_frac;
+                r->mid = mid; r->hi = mid + dlt; r->lo = mid - dlt;
+                r->anchor_s = m;
+                r->anchor_valid = 1;
+                if (ns < sync_cap) {
+                    if (sync_pos) sync_pos[ns] = m;
+                    if (sync_dibit) sync_dibit[ns] = r->n_dibits;
+                }
+                ns++;
+            }
+        }
+        r->t++;
+    }
+    *n_dibits = nd;
+    if (n_sync) *n_sync = ns;
+    return 0;
+}
+
+/* Introspection for tests (thresholds of the current anchor). */
+void p25o_recv_state(const p25o_recv *r, int64_t *t, int *valid, int64_t *s, float *thr3, uint64_t *nd)
+{
+    *t = r->t; *valid = r->anchor_valid; *s = r->anchor_s;
+    thr3[0] = r->hi; thr3[1] = r->mid; thr3[2] = r->lo; *nd = r->n_dibits;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-path convenience used by the cpu_baseline timing leg of bench.py: cf32 IQ in 16384-
+ * sample chunks (the reference's BUF_SAMPLES, src/consts.rs:8) through DemodTask then the
+ * receiver loop, like the two threads of src/main.rs:270-287 run back to back.
+ * ---------------------------------------------------------------------------------------- */
+int64_t p25o_run_cf32(const p25o_config *cfg, const float *iq, size_t n, uint8_t *dibits, size_t cap)
+{
+    enum { CH = 16384 };
+    p25o_demod *d = p25o_demod_create(cfg);
+    p25o_recv *r = p25o_recv_create(cfg);
+    float *bb = malloc(sizeof(float) * CH);
+    size_t total = 0;
+    int64_t rc = 0;
+    for (size_t off = 0; off < n; off += CH) {
+        size_t m = n - off < CH ? n - off : CH;
+        size_t len = p25o_demod_cf32(d, iq + 2 * off, m, bb, NULL);
+        size_t nd = 0;
+        if (p25o_recv_feed(r, bb, len, dibits + total, cap - total, &nd, NULL, NULL, 0, NULL)) { rc = -1; break; }
+        total += nd;
+    }
+    free(bb);
+    p25o_demod_destroy(d);
+    p25o_recv_destroy(r);
+    return rc ? rc : (int64_t)total;
+}
+
+int p25o_has_fma(void) { return __builtin_cpu_supports("fma"); }

@@ -1,0 +1,187 @@
+"""CPU tests that pin the oracle (oracle/p25fe_oracle.c).
+
+The reference has no golden vectors for this path (parity unpinned), so the
+oracle is pinned against an independent fp64 numpy/scipy model, physical known answers, its
+own streaming invariances and the known symbols of the seeded modulator.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy import signal
+
+from oracle import oracle as O
+from p25rx_amd import c4fm
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def fp64_model(iq, spec):
+    """Independent model: scipy lfilter / np.angle in fp64."""
+    h1 = np.array(spec["decim_taps"], dtype=np.float64)
+    h2 = np.array(spec["chan_taps"], dtype=np.float64)
+    x = iq.astype(np.complex128)
+    d = signal.lfilter(h1, 1.0, x)[spec["decim"] - 1::spec["decim"]]
+    y = signal.lfilter(h2, 1.0, d)
+    prev = np.concatenate([[0.0], y[:-1]])
+    fm = np.angle(y * np.conj(prev)) * (48000.0 / (2 * np.pi * 5000.0))
+    bb = signal.lfilter(np.ones(10) / 10.0, 1.0, fm)
+    return y, fm, bb
+
+
+def test_fp64_cross_check(spec, c4fm_1s):
+    iq, _, _ = c4fm_1s
+    iq = iq[:60000]
+    ch, fm, bb = O.Demod().feed_cf32_stages(iq)
+    y, fm64, bb64 = fp64_model(iq, spec)
+    assert len(bb) == len(bb64) == 12000
+    assert np.abs(ch - y).max() < 2e-6
+    # skip the first samples where |y| ~ 0 makes the angle ill-conditioned
+    assert np.abs(fm[100:] - fm64[100:]).max() < 2e-5
+    assert np.abs(bb[100:] - bb64[100:]).max() < 1e-5
+
+
+def test_chunk_lengths_and_invariance(c4fm_1s):
+    """16384-sample chunks give 3276/3277 outputs (src/demod.rs:87-90) and any chunking is bit-identical."""
+    iq, _, _ = c4fm_1s
+    one = O.Demod().feed_cf32(iq)
+    d = O.Demod()
+    lens, parts = [], []
+    for off in range(0, len(iq), 16384):
+        p = d.feed_cf32(iq[off:off + 16384])
+        lens.append(len(p))
+        parts.append(p)
+    assert lens[:5] == [3276, 3277, 3277, 3277, 3277][:5] or set(lens[:-1]) == {3276, 3277}
+    assert set(lens[:-1]) == {3276, 3277}
+    assert np.array_equal(np.concatenate(parts), one)
+    rng = np.random.default_rng(3)
+    d = O.Demod()
+    parts, off = [], 0
+    while off < len(iq):
+        n = int(rng.integers(1, 5000))
+        parts.append(d.feed_cf32(iq[off:off + n]))
+        off += n
+    assert np.array_equal(np.concatenate(parts), one)
+
+
+def test_u8_lut_path(spec):
+    """u8 pairs -> LUT (src/demod.rs:74-84): byte 2i is I, byte 2i+1 is Q; value fma(b, 2/255, -1)."""
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 256, size=2 * 20000, dtype=np.uint8)
+    lut = (raw.astype(np.float64) * np.float64(np.float32(spec["u8_scale"])) - 1.0).astype(np.float32)
+    iq = (lut[0::2] + 1j * lut[1::2]).astype(np.complex64)
+    a = O.Demod().feed_u8(raw)
+    b = O.Demod().feed_cf32(iq)
+    assert np.array_equal(a, b)
+
+
+def test_kat_dc_and_tone(spec):
+    n = 48000
+    t = np.arange(n) / 240000.0
+    dc = (0.5 * np.ones(n)).astype(np.complex64)
+    bb = O.Demod().feed_cf32(dc)
+    assert np.all(bb[80:] == 0.0)
+    for f in (1800.0, -600.0, 2500.0):
+        tone = (0.5 * np.exp(2j * np.pi * f * t)).astype(np.complex64)
+        bb = O.Demod().feed_cf32(tone)
+        assert np.abs(bb[80:] - f / 5000.0).max() < 5e-6
+
+
+def test_kat_impulse_reads_back_taps(spec):
+    """An impulse at input n0 = 5k+4 puts decim tap 5j into output k+j; channel taps follow."""
+    x = np.zeros(2000, dtype=np.complex64)
+    x[4] = 1.0
+    ch, _, _ = O.Demod().feed_cf32_stages(x)
+    h1 = np.array(spec["decim_taps"], dtype=np.float32)[0::5]
+    h2 = np.array(spec["chan_taps"], dtype=np.float32)
+    ref = np.convolve(h1.astype(np.float64), h2.astype(np.float64))
+    assert np.abs(ch[:len(ref)].real - ref).max() < 1e-7
+    assert np.all(ch.imag == 0)
+
+
+def test_power_dbm_formula():
+    """demod::power_dbm (src/demod.rs:123-134): constant envelope A -> 30 + 10 log10(A^2)."""
+    for a in (1.0, 0.5, 0.01):
+        x = (a * np.exp(1j * np.linspace(0, 50, 3277))).astype(np.complex64)
+        assert abs(O.power_dbm(x) - (30 + 20 * np.log10(a))) < 1e-3
+
+
+def test_atan2_against_libm(spec):
+    rng = np.random.default_rng(11)
+    xs = rng.standard_normal(20000).astype(np.float32)
+    ys = rng.standard_normal(20000).astype(np.float32)
+    cfg = O.make_config()
+    got = np.array([O.atan2f(float(y), float(x), cfg) for x, y in zip(xs[:4000], ys[:4000])])
+    ref = np.arctan2(ys[:4000].astype(np.float64), xs[:4000].astype(np.float64))
+    assert np.abs(got - ref).max() < 4e-7
+    assert O.atan2f(0.0, 0.0, cfg) == 0.0
+    assert abs(O.atan2f(0.0, -1.0, cfg) - np.pi) < 1e-6
+    assert abs(O.atan2f(1.0, 0.0, cfg) - np.pi / 2) < 1e-6
+    assert abs(O.atan2f(-1.0, 0.0, cfg) + np.pi / 2) < 1e-6
+
+
+def test_recv_decodes_ground_truth(c4fm_1s):
+    iq, truth, _ = c4fm_1s
+    bb = O.Demod().feed_cf32(iq)
+    dib, spos, sdib = O.Recv().feed(bb)
+    assert len(spos) == 6 and np.all(np.diff(spos) == 8640)
+    assert list(sdib[:3]) == [0, 864, 1728]
+    n = min(len(dib), len(truth) - 24)
+    assert n > 4700
+    assert np.array_equal(dib[:n], truth[24:24 + n])
+
+
+def test_recv_chunk_invariance_and_resync(c4fm_1s):
+    iq, truth, _ = c4fm_1s
+    bb = O.Demod().feed_cf32(iq)
+    ref = O.Recv().feed(bb)
+    r = O.Recv()
+    rng = np.random.default_rng(9)
+    outs, off = [], 0
+    while off < len(bb):
+        n = int(rng.integers(1, 3000))
+        outs.append(r.feed(bb[off:off + n]))
+        off += n
+    assert np.array_equal(np.concatenate([o[0] for o in outs]), ref[0])
+    assert np.array_equal(np.concatenate([o[1] for o in outs]), ref[1])
+    assert np.array_equal(np.concatenate([o[2] for o in outs]), ref[2])
+    # resync (src/recv.rs:136,179) before sample 20000: no dibits until the next sync word (26222)
+    r = O.Recv()
+    a = r.feed(bb[:20000])
+    r.resync()
+    b = r.feed(bb[20000:])
+    assert b[1][0] == 26222
+    assert len(a[0]) == len(ref[0][ref_instants(ref, 20000)])
+    assert np.array_equal(b[0], ref[0][len(ref[0]) - len(b[0]):])
+    assert len(b[0]) == (len(bb) - 1 - 26222) // 10
+
+
+def ref_instants(ref, upto):
+    """Slice selecting the dibits of `ref` whose instants are < upto (first sync at ref[1][0], stride 10)."""
+    s0 = int(ref[1][0])
+    return slice(0, (upto - 1 - s0) // 10)
+
+
+def test_recv_with_offsets_and_noise():
+    """Frequency offset (DC after FM) and 15 dB SNR still decode: thresholds track the sync levels."""
+    iq, truth, _ = c4fm.synth(0.5, seed=4, snr_db=15.0, freq_offset_hz=300.0, timing_offset=17)
+    bb = O.Demod().feed_cf32(iq)
+    dib, spos, _ = O.Recv().feed(bb)
+    assert len(spos) >= 2
+    n = min(len(dib), len(truth) - 24)
+    err = np.count_nonzero(dib[:n] != truth[24:24 + n])
+    assert err <= n * 0.01
+
+
+def test_golden_fixture_matches():
+    """Self-generated golden (tools/gen_golden.py): pins the oracle across rounds."""
+    g = np.load(os.path.join(GOLDEN, "c4fm_seed7_u8.npz"))
+    d = O.Demod()
+    bb = np.concatenate([d.feed_u8(g["iq_u8"][o:o + 32768]) for o in range(0, len(g["iq_u8"]), 32768)])
+    assert np.array_equal(bb.view(np.uint32), g["bb_bits"])
+    dib, spos, sdib = O.Recv().feed(bb)
+    assert np.array_equal(dib, g["dibits"])
+    assert np.array_equal(spos, g["sync_pos"])
+    with open(os.path.join(GOLDEN, "spec.json")) as f:
+        assert json.load(f)["t1"] == 31
