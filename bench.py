@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s through FM-demod + C4FM slice on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (K1 front end -> K2 sync -> K3 scan -> K4 slice) over one
+resident capture: BASELINE.json configs[1], 1 channel x 600 s of synthetic C4FM IQ at 240 ksps
+(1.44e8 cf32 samples, 1.152 GB) per GPU, generated in HBM before the timed region.
+
+N > 1 (one rank per GPU, RCCL): BASELINE.json configs[4]'s structure -- one long capture cut
+into N contiguous 600 s time shards (weak scaling).  Each step exchanges the filter halo with
+the left neighbour (send/recv), runs pass 1, all-gathers the 56-byte shard summaries, resolves
+the symbol-timing carry, runs pass 2 and gathers the dibit counts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
+dominant kernel (K1) from HIP events recorded inside the library on the launch stream, and
+`cpu_baseline` from the CPU oracle timed on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_SAMPLE_K1 = 8.0 + 0.8  # algorithmic: 8 B cf32 read + 4 B baseband written per 5 samples
+
+
+def cpu_baseline(iq_host, seconds_label):
+    """Time the oracle (scalar C port of the reference structure) on one host core."""
+    from oracle import oracle as O
+    so = "/tmp/p25fe_oracle_timing_%d.so" % os.getpid()
+    kind_flags = "-O3 -march=native"
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "timing", "OUT=" + so])
+    except Exception:
+        so, kind_flags = None, "-O2 -mfma (prebuilt)"
+    O.run_cf32(iq_host[:240000], libpath=so)                      # warm
+    t0 = time.perf_counter()
+    dib = O.run_cf32(iq_host, libpath=so)
+    dt = time.perf_counter() - t0
+    if so and os.path.exists(so):
+        os.unlink(so)
+    return {"value": round(len(iq_host) / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%s of the same capture (%d IQ samples), oracle/p25fe_oracle.c built %s, 1 thread, %.2f s"
+                      % (seconds_label, len(iq_host), kind_flags, dt)}, dib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seconds", type=float, default=600.0, help="capture length per GPU (configs[1]: 600)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=600.0, help="length of the capture prefix timed on the CPU")
+    args = ap.parse_args()
+
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import FrontEnd, parse_results, n_baseband
+    from p25rx_amd._lib import RESULT_DTYPE
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n = int(round(args.seconds * 240000))
+    n -= n % 8                                                     # shard cut points stay 16-B aligned
+    fe = FrontEnd(device=local)
+    halo = fe.shard_halo()
+    # resident capture: [halo | owned shard]; the halo region is filled by the neighbour exchange
+    buf = torch.zeros((halo + n, 2), dtype=torch.float32, device=dev)
+    iq = buf[halo:]
+    _, truth = c4fm.synth_torch(n, seed=1000 + rank, device=dev, snr_db=30.0, out=iq)
+    torch.cuda.synchronize()
+
+    cap = (n // 50 + 64 + 15) // 16 * 16
+    dibits = torch.empty((1, cap), dtype=torch.uint8, device=dev)
+    result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    abs0 = rank * n
+    bb0 = n_baseband(0, abs0)
+    bbn = n_baseband(abs0, n)
+
+    if world == 1:
+        def step():
+            fe.run_dev(iq, dibits=dibits, result=result)
+    else:
+        summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        my_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        bb0s = [n_baseband(0, r * n) for r in range(world)]
+        bbns = [n_baseband(r * n, n) for r in range(world)]
+        halo_src = buf[halo + n - halo:]                           # my last `halo` samples -> right neighbour
+
+        def step():
+            # 1. filter-state overlap: last `halo` IQ samples to rank+1 (xGMI point-to-point)
+            ops = []
+            if rank + 1 < world:
+                ops.append(dist.P2POp(dist.isend, halo_src, rank + 1))
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, buf[:halo], rank - 1))
+            for w in dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+            # 2. pass 1 on the owned range with left context
+            h = halo if rank > 0 else 0
+            fe.shard_pass1(buf[halo - h:], offset=h, n_hist=h, abs0=abs0, result=result)
+            # 3. exchange the shard summaries, resolve the symbol-timing carry
+            dist.all_gather_into_tensor(summ_all.view(-1), result.view(-1))
+            summ = np.frombuffer(summ_all.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+            anc, off = fe.shard_resolve(summ, bb0s, bbns)
+            # 4. pass 2: slice under the resolved carry-in
+            fe.shard_pass2(anc[rank:rank + 1], bbn, dev, result=result, dibits=dibits)
+            # 5. reduced dibit stream: counts to everyone (the dibits stay sharded in HBM; rank 0 can
+            #    fetch them with a gather of sum(counts) bytes -- 2.9 MB per shard)
+            my_count[0] = int(off[rank])
+            dist.all_gather_into_tensor(counts, my_count)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    fe.profile_enable(True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, ncalls = fe.profile_read()
+    fe.profile_enable(False)
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # correctness gate on what the timed steps produced: demod(mod(d)) == d for this rank's shard
+    r = parse_results(result)[0]
+    nd = int(r["n_dibits"])
+    got = dibits[0, :nd].cpu().numpy()
+    ok = True
+    if world == 1:
+        k = min(nd, len(truth) - 24)
+        ok = bool(k > 0 and np.array_equal(got[:k], truth[24:24 + k]))
+    else:
+        # a shard starts mid-stream: align on its first own sync word (dibits after it must equal truth)
+        first = int(r["n_dibits"]) - int(r["n_dibits_after_first"]) if int(r["first_event"]) >= 0 else None
+        if first is not None:
+            k = min(nd - first, len(truth) - 24)
+            ok = bool(k > 0 and np.array_equal(got[first:first + k], truth[24:24 + k]))
+        else:
+            ok = False
+    if dist:
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    if rank == 0:
+        total_samples = float(n) * world * args.steps
+        value = total_samples / dt / 1e6
+        k1_ms = kms[0] / max(ncalls, 1)
+        achieved = BYTES_PER_SAMPLE_K1 * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "IQ Msamples/s through FM-demod+C4FM slice",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1 channel x %.0f s synthetic C4FM cf32 IQ @ 240 ksps per GPU "
+                                   "(%d samples, %.3f GB), decimating FIR + FM + boxcar + sync + 4-level slice"
+                                   % (args.seconds, n, n * 8 / 1e9),
+                       "sharding": "none" if world == 1 else "time shards, halo %d samples, RCCL send/recv + all_gather" % halo,
+                       "parity_gate": "dibits == modulator symbols: %s" % ok},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "k_frontend<cf32>", "kernel_ms": round(k1_ms, 4),
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_K1 * n,
+                         "other_kernels_ms": {"k_sync": round(kms[1] / max(ncalls, 1), 4),
+                                              "k_scan": round(kms[2] / max(ncalls, 1), 4),
+                                              "k_slice": round(kms[3] / max(ncalls, 1), 4)}},
+        }
+        if world == 1 and not args.no_cpu:
+            ncpu = min(n, int(args.cpu_seconds * 240000))
+            host = iq[:ncpu].cpu().numpy().view(np.complex64).reshape(-1)
+            cb, cpu_dib = cpu_baseline(host, "first %.0f s" % (ncpu / 240000))
+            out["cpu_baseline"] = cb
+            kk = min(len(cpu_dib), nd)
+            # the oracle on the same samples must agree with the GPU bit for bit (full prefix)
+            out["config"]["oracle_gate"] = "GPU dibits == oracle dibits on the CPU sample: %s" % bool(
+                np.array_equal(cpu_dib[:kk - 1], got[:kk - 1]))
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

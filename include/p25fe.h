@@ -1,0 +1,190 @@
+/*
+ * p25fe.h -- C ABI of the MI355X-native P25 front end (IQ -> 48 kHz baseband -> C4FM dibits).
+ *
+ * Drop-in boundary for the hot path of kchmck/p25rx.  The reference has no FFI for this path:
+ * it is two Rust task types wired by channels.  Each entry point below names
+ * the reference item whose work it replaces; INTEGRATION.md shows the Rust `extern "C"` block
+ * and the DemodTask / RecvTask edits a maintainer would make.
+ *
+ *   reference item (file:line in /root/reference)                  replaced by
+ *   -------------------------------------------------------------  ---------------------------
+ *   DemodTask::new   src/demod.rs:44-59  (decim 5, avg 10, FM 5k)   p25fe_create
+ *   DemodTask::run   src/demod.rs:70-117 loop body, u8 chunk        p25fe_demod_u8
+ *     IQ[s] LUT                         :74-84
+ *     decim.decim_in_place              :87-90
+ *     bandpass.feed                     :93
+ *     power_dbm                         :95-101, :123-134           (power_dbm out-parameter)
+ *     demod.feed / avg.feed             :109-114
+ *   RecvTask::run sample loop  src/recv.rs:148-150, 204-210         p25fe_slice
+ *     msg.feed(s) down to "a dibit exists" (p25 crate, un-vendored)
+ *   MessageReceiver::resync    src/recv.rs:136, 179                 p25fe_resync
+ *   (state hand-off for time-sharded captures; no reference item)   p25fe_state_export/import,
+ *                                                                   p25fe_shard_*
+ *
+ * Conventions kept from the reference: streaming semantics -- any chunking of the input gives
+ * the same concatenated output, state lives in the handle (src/demod.rs:25-40); the output count
+ * is data dependent (src/demod.rs:87-90).  Convention NOT kept: the reference aborts on every
+ * error (`expect`, panic = "abort", Cargo.toml:50-51); here every call returns 0 or a negative
+ * p25fe_status, because unwinding across extern "C" is undefined.
+ *
+ * Threading: one handle per thread (the reference moves each task into its own thread,
+ * src/main.rs:270-287).  No globals, no callbacks.  Host-pointer calls are synchronous.
+ * *_dev calls take device pointers, enqueue on `stream` (a hipStream_t passed as void*) and do
+ * not synchronise.  There is no CPU fallback: without a HIP device p25fe_create fails.
+ */
+#ifndef P25FE_H
+#define P25FE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P25FE_MAX_TAPS 64
+#define P25FE_ABI_VERSION 1
+
+typedef enum p25fe_status {
+    P25FE_OK = 0,
+    P25FE_ERR_ARG = -1,        /* null pointer, bad size, bad config */
+    P25FE_ERR_NO_DEVICE = -2,  /* no HIP device / wrong architecture */
+    P25FE_ERR_HIP = -3,        /* a HIP runtime call failed (see p25fe_last_hip_error) */
+    P25FE_ERR_CAPACITY = -4,   /* output buffer too small; nothing consumed */
+    P25FE_ERR_FORMAT = -5,     /* u8 / cf32 mixed within one stream */
+    P25FE_ERR_NOMEM = -6
+} p25fe_status;
+
+typedef enum p25fe_format {
+    P25FE_FMT_CF32 = 0,        /* interleaved float32 I,Q (num::Complex32 layout) */
+    P25FE_FMT_U8 = 1           /* interleaved uint8 I,Q (RTL-SDR; src/demod.rs:74-76) */
+} p25fe_format;
+
+/* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54) and the
+ * type-level tap tables of p25_filts.  Tap COUNTS are limited to P25FE_T1 / P25FE_T2 of
+ * p25fe_spec.h (shorter filters are zero-padded at the old end, which is bit-neutral). */
+typedef struct p25fe_config {
+    int32_t abi_version;                 /* P25FE_ABI_VERSION */
+    int32_t device;                      /* HIP device ordinal */
+    int32_t n_channels;                  /* independent channels per call, channel-major */
+    int32_t n_decim_taps;
+    int32_t n_chan_taps;
+    float decim_taps[P25FE_MAX_TAPS];    /* 240k -> 48k anti-alias, tap 0 multiplies the newest sample */
+    float chan_taps[P25FE_MAX_TAPS];     /* 48 kHz channel-select low-pass */
+} p25fe_config_t;
+
+typedef struct p25fe p25fe_t;
+
+/* Symbol-timing anchor carried between calls / shards: the last frame-sync detection. */
+typedef struct p25fe_anchor {
+    int64_t s;                           /* absolute baseband index of the sync word's last symbol */
+    float hi, mid, lo;                   /* slicer thresholds derived from that sync word */
+    int32_t valid;
+} p25fe_anchor_t;
+
+/* Per-channel summary of one processed range (device or host memory, see each call). */
+typedef struct p25fe_result {
+    uint64_t n_baseband;                 /* baseband samples produced */
+    uint64_t n_dibits;                   /* dibits produced */
+    uint64_t n_sync;                     /* frame-sync detections */
+    p25fe_anchor_t anchor_out;           /* anchor after the range */
+    int64_t first_event;                 /* baseband index where the range's first own detection takes effect, -1 if none */
+    uint64_t n_dibits_after_first;       /* dibits governed by the range's own detections */
+} p25fe_result_t;
+
+void p25fe_default_config(p25fe_config_t *cfg);
+int p25fe_create(const p25fe_config_t *cfg, p25fe_t **out);
+void p25fe_destroy(p25fe_t *h);
+const char *p25fe_strerror(int status);
+int p25fe_last_hip_error(const p25fe_t *h);      /* raw hipError_t of the last P25FE_ERR_HIP */
+
+/* ---- streaming, host buffers: the bodies of DemodTask::run and RecvTask::run ----------------
+ * Multi-channel handles take channel-major buffers: channel c starts at c * (elements per
+ * channel) of the call; every channel gets the same number of input samples. */
+
+/* src/demod.rs:70-117 for one chunk of interleaved u8 I/Q.  n_bytes even.  Writes *n_out
+ * baseband samples per channel to bb (channel c at bb + c * bb_cap).  power_dbm (nullable)
+ * receives power_dbm() of the post-channel-filter chunk per channel (src/demod.rs:97); the
+ * every-4th-chunk throttle (src/demod.rs:67, 95) is the caller's. */
+int p25fe_demod_u8(p25fe_t *h, const uint8_t *iq, size_t n_bytes, float *bb, size_t bb_cap, size_t *n_out,
+                   float *power_dbm);
+/* Same for Complex32 input (BASELINE.json configs 2-5). */
+int p25fe_demod_cf32(p25fe_t *h, const float *iq, size_t n_samples, float *bb, size_t bb_cap, size_t *n_out,
+                     float *power_dbm);
+
+/* src/recv.rs:148-150: feed n baseband samples per channel; one dibit per byte (0..3) to
+ * dibits (channel c at dibits + c * cap), counts to n_dibits[c].  sync_pos / sync_dibit
+ * (nullable) receive, per detection, the absolute baseband index of the sync word's last
+ * symbol and the index (in the channel's dibit stream) of the first dibit it governs;
+ * n_sync[c] gets the number of detections (may exceed sync_cap; extra ones are not stored). */
+int p25fe_slice(p25fe_t *h, const float *bb, size_t n, uint8_t *dibits, size_t cap, size_t *n_dibits,
+                int64_t *sync_pos, uint64_t *sync_dibit, size_t sync_cap, size_t *n_sync);
+
+/* Both halves with the baseband kept in HBM (DemodTask -> RecvTask without the channel hop). */
+int p25fe_run_u8(p25fe_t *h, const uint8_t *iq, size_t n_bytes, uint8_t *dibits, size_t cap, size_t *n_dibits);
+int p25fe_run_cf32(p25fe_t *h, const float *iq, size_t n_samples, uint8_t *dibits, size_t cap, size_t *n_dibits);
+
+/* MessageReceiver::resync (src/recv.rs:136, 179): drop symbol lock at the current position. */
+int p25fe_resync(p25fe_t *h);
+/* Forget all stream state (a new DemodTask + MessageReceiver). */
+int p25fe_reset(p25fe_t *h);
+
+/* Filter histories, decimator phase, FM/boxcar context and symbol lock as an opaque blob. */
+int p25fe_state_size(const p25fe_t *h, size_t *n);
+int p25fe_state_export(const p25fe_t *h, void *buf, size_t cap, size_t *n);
+int p25fe_state_import(p25fe_t *h, const void *buf, size_t n);
+
+/* ---- device-resident ranges: the measured path -------------------------------------------------
+ * d_iq points at the first OWNED sample of channel 0; channel c starts ch_stride elements
+ * (complex samples for CF32, byte pairs for U8) later.  n_hist valid samples precede each
+ * channel's first owned sample in memory (0 at the start of a stream: history reads as zero,
+ * exactly like the zero-initialised filters of DemodTask::new); abs0 is the absolute index of
+ * the first owned sample in its stream (fixes the 5:1 grid, src/demod.rs:87-90).
+ * All outputs are device pointers; nothing is synchronised. */
+
+/* stages 1-5: writes n_baseband(n, abs0) samples per channel to d_bb (+ c * bb_stride). */
+int p25fe_demod_dev(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
+                    uint64_t abs0, float *d_bb, size_t bb_stride, float *d_power_dbm, void *stream);
+
+/* stages 6-7 on device baseband.  d_bb points at the first owned sample; n_hist_bb valid
+ * samples precede it; abs_bb0 is its absolute index; d_anchor_in (nullable = no lock) is the
+ * carry-in per channel.  d_result[c] is filled per channel. */
+int p25fe_slice_dev(p25fe_t *h, const float *d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
+                    uint64_t abs_bb0, const p25fe_anchor_t *d_anchor_in, uint8_t *d_dibits, size_t dibit_stride,
+                    int64_t *d_sync_pos, uint64_t *d_sync_dibit, size_t sync_stride, p25fe_result_t *d_result,
+                    void *stream);
+
+/* stages 1-7 from a fresh stream state over a resident capture (BASELINE.json config 2/4). */
+int p25fe_run_dev(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n, uint8_t *d_dibits,
+                  size_t dibit_stride, p25fe_result_t *d_result, void *stream);
+
+/* Time-sharded capture (BASELINE.json config 5): shard = owned range [abs0, abs0 + n) with
+ * n_hist >= p25fe_shard_halo() samples of left context in memory (or n_hist == abs0 for the
+ * first shard).  Pass 1 demodulates, detects frame syncs and fills d_result[c] with the
+ * shard summary (first_event, n_dibits_after_first, anchor_out) assuming no carry-in.  The
+ * caller exchanges summaries (all_gather of a few bytes), resolves each shard's carry-in
+ * anchor with p25fe_shard_resolve on the host, then pass 2 slices. */
+size_t p25fe_shard_halo(void);
+int p25fe_shard_pass1(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
+                      uint64_t abs0, p25fe_result_t *d_result, void *stream);
+int p25fe_shard_pass2(p25fe_t *h, const p25fe_anchor_t *d_anchor_in, uint8_t *d_dibits, size_t dibit_stride,
+                      p25fe_result_t *d_result, void *stream);
+/* Host-side combine: summaries[r] for r = 0..n_shards-1 in time order (one channel) ->
+ * anchor_in[r] and dibit_offset[r]. Pure integer/struct logic, no device work. */
+int p25fe_shard_resolve(const p25fe_result_t *summaries, const uint64_t *shard_bb0, const uint64_t *shard_bb_n,
+                        size_t n_shards, p25fe_anchor_t *anchor_in, uint64_t *dibit_offset);
+
+/* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1/2 record HIP
+ * events on the caller's stream around each kernel (K1 front end, K2 sync, K3 scan, K4 slice).
+ * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel
+ * and the number of calls since the last read (at most the last 64 calls are kept). */
+int p25fe_profile_enable(p25fe_t *h, int on);
+int p25fe_profile_read(p25fe_t *h, double ms[4], uint64_t *n_calls);
+
+/* Number of baseband samples produced by n input samples starting at absolute index abs0. */
+size_t p25fe_n_baseband(uint64_t abs0, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P25FE_H */

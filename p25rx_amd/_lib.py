@@ -1,0 +1,114 @@
+"""ctypes binding of libp25fe.so (the C ABI of include/p25fe.h).
+
+The library is the product: if it is missing or no gfx950 device is present every call
+fails loudly -- there is no Python/NumPy compute fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libp25fe.so")
+MAX_TAPS = 64
+ABI_VERSION = 1
+FMT_CF32, FMT_U8 = 0, 1
+
+OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_channels", C.c_int32),
+                ("n_decim_taps", C.c_int32), ("n_chan_taps", C.c_int32),
+                ("decim_taps", C.c_float * MAX_TAPS), ("chan_taps", C.c_float * MAX_TAPS)]
+
+
+class Anchor(C.Structure):
+    _fields_ = [("s", C.c_int64), ("hi", C.c_float), ("mid", C.c_float), ("lo", C.c_float), ("valid", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_baseband", C.c_uint64), ("n_dibits", C.c_uint64), ("n_sync", C.c_uint64),
+                ("anchor_out", Anchor), ("first_event", C.c_int64), ("n_dibits_after_first", C.c_uint64)]
+
+
+ANCHOR_DTYPE = np.dtype([("s", "<i8"), ("hi", "<f4"), ("mid", "<f4"), ("lo", "<f4"), ("valid", "<i4")])
+RESULT_DTYPE = np.dtype([("n_baseband", "<u8"), ("n_dibits", "<u8"), ("n_sync", "<u8"), ("anchor_out", ANCHOR_DTYPE),
+                         ("first_event", "<i8"), ("n_dibits_after_first", "<u8")])
+assert ANCHOR_DTYPE.itemsize == C.sizeof(Anchor) and RESULT_DTYPE.itemsize == C.sizeof(Result)
+
+# every symbol include/p25fe.h declares (tests check the library exports exactly these)
+SYMBOLS = [
+    "p25fe_default_config", "p25fe_create", "p25fe_destroy", "p25fe_strerror", "p25fe_last_hip_error",
+    "p25fe_demod_u8", "p25fe_demod_cf32", "p25fe_slice", "p25fe_run_u8", "p25fe_run_cf32", "p25fe_resync",
+    "p25fe_reset", "p25fe_state_size", "p25fe_state_export", "p25fe_state_import", "p25fe_demod_dev",
+    "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
+    "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
+]
+
+
+class P25feError(RuntimeError):
+    def __init__(self, status, msg, hip=0):
+        super().__init__("p25fe: %s (status %d%s)" % (msg, status, ", hipError %d" % hip if hip else ""))
+        self.status = status
+        self.hip = hip
+
+
+_LIB = None
+
+
+def load():
+    """Load libp25fe.so.  Raises if it has not been built -- never substitutes another path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libp25fe.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C p25rx_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+    psz = C.POINTER(sz)
+    L.p25fe_default_config.argtypes = [C.POINTER(Config)]
+    L.p25fe_default_config.restype = None
+    L.p25fe_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.p25fe_destroy.argtypes = [vp]
+    L.p25fe_destroy.restype = None
+    L.p25fe_strerror.argtypes = [C.c_int]
+    L.p25fe_strerror.restype = C.c_char_p
+    L.p25fe_last_hip_error.argtypes = [vp]
+    L.p25fe_demod_u8.argtypes = [vp, vp, sz, vp, sz, psz, vp]
+    L.p25fe_demod_cf32.argtypes = [vp, vp, sz, vp, sz, psz, vp]
+    L.p25fe_slice.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp]
+    L.p25fe_run_u8.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.p25fe_run_cf32.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.p25fe_resync.argtypes = [vp]
+    L.p25fe_reset.argtypes = [vp]
+    L.p25fe_state_size.argtypes = [vp, psz]
+    L.p25fe_state_export.argtypes = [vp, vp, sz, psz]
+    L.p25fe_state_import.argtypes = [vp, vp, sz]
+    L.p25fe_demod_dev.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, sz, vp, vp]
+    L.p25fe_slice_dev.argtypes = [vp, vp, sz, sz, sz, u64, vp, vp, sz, vp, vp, sz, vp, vp]
+    L.p25fe_run_dev.argtypes = [vp, vp, C.c_int, sz, sz, vp, sz, vp, vp]
+    L.p25fe_shard_halo.argtypes = []
+    L.p25fe_shard_halo.restype = sz
+    L.p25fe_shard_pass1.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, vp]
+    L.p25fe_shard_pass2.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.p25fe_profile_enable.argtypes = [vp, C.c_int]
+    L.p25fe_profile_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
+    L.p25fe_n_baseband.argtypes = [u64, sz]
+    L.p25fe_n_baseband.restype = sz
+    _LIB = L
+    return L
+
+
+def default_config():
+    cfg = Config()
+    load().p25fe_default_config(C.byref(cfg))
+    return cfg
+
+
+def check(L, h, rc):
+    if rc != OK:
+        hip = L.p25fe_last_hip_error(h) if (h and rc == ERR_HIP) else 0
+        raise P25feError(rc, L.p25fe_strerror(rc).decode(), hip)

@@ -1,0 +1,708 @@
+// p25fe_api.hip -- host side of the C ABI declared in include/p25fe.h.
+//
+// Owns device scratch and the stream state that DemodTask / MessageReceiver keep in their
+// structs (src/demod.rs:25-40, src/recv.rs:47), and launches the kernels of p25fe_kernels.hip.
+// No CPU compute path exists here: every entry point either runs the HIP kernels or fails.
+#include "p25fe_kernels.hip"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+using namespace p25k;
+
+namespace {
+
+constexpr size_t HISTPAD = 288;      // >= HIST_IQ (284), multiple of 8: keeps 16-B alignment for u8 and cf32
+constexpr size_t BBPAD = 256;        // >= HIST_BB (241), multiple of 4
+constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 1568
+constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+inline size_t fmt_bytes(int fmt) { return fmt == P25FE_FMT_CF32 ? 8 : 2; }
+
+}  // namespace
+
+struct p25fe {
+    p25fe_config_t cfg;
+    int C = 1;
+    int last_hip = 0;
+    int n_cu = 256;
+    Taps taps;
+    hipStream_t stream = nullptr;          // for the host-pointer calls
+
+    // scratch
+    DevBuf iq_stage, bb_buf, events, recs, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    // stream state (per channel, channel-major in the device buffers)
+    uint64_t abs_iq = 0;                   // IQ samples consumed
+    int fmt_locked = -1;
+    DevBuf hist_iq;                        // [C][HISTPAD] raw samples
+    uint64_t abs_bb = 0;                   // baseband samples consumed by the slicer
+    DevBuf tail_bb;                        // [C][BBPAD] floats
+    std::vector<p25fe_anchor_t> anchor;    // [C]
+    std::vector<uint64_t> total_dibits;    // [C]
+    int64_t min_e = 0;
+    // profiling ring: PROF_RING calls x 5 events (before K1, after K1, K2, K3, K4)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    uint64_t prof_calls = 0;
+    int prof_slot = -1;                    // slot being recorded by the current call
+    // shard context between pass1 and pass2
+    size_t sh_nbb = 0, sh_bb_stride = 0;
+    uint64_t sh_abs_bb0 = 0;
+    size_t sh_hist_bb = 0;
+};
+
+constexpr int PROF_RING = 64;
+
+#define HIPCHK(h, expr)                                                        \
+    do {                                                                       \
+        hipError_t e__ = (expr);                                               \
+        if (e__ != hipSuccess) { (h)->last_hip = (int)e__; return P25FE_ERR_HIP; } \
+    } while (0)
+
+extern "C" {
+
+void p25fe_default_config(p25fe_config_t* cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->abi_version = P25FE_ABI_VERSION;
+    cfg->device = 0;
+    cfg->n_channels = 1;
+    cfg->n_decim_taps = P25FE_T1;
+    cfg->n_chan_taps = P25FE_T2;
+    memcpy(cfg->decim_taps, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
+    memcpy(cfg->chan_taps, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
+}
+
+const char* p25fe_strerror(int status)
+{
+    switch (status) {
+    case P25FE_OK: return "ok";
+    case P25FE_ERR_ARG: return "invalid argument";
+    case P25FE_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+    case P25FE_ERR_HIP: return "HIP runtime error";
+    case P25FE_ERR_CAPACITY: return "output buffer too small";
+    case P25FE_ERR_FORMAT: return "sample format changed within a stream";
+    case P25FE_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+int p25fe_last_hip_error(const p25fe_t* h) { return h ? h->last_hip : 0; }
+
+size_t p25fe_n_baseband(uint64_t abs0, size_t n)
+{
+    const size_t o0 = (size_t)((4 + 5 - abs0 % 5) % 5);
+    return n > o0 ? (n - o0 - 1) / 5 + 1 : 0;
+}
+
+size_t p25fe_shard_halo(void) { return SHARD_HALO; }
+
+static int state_alloc(p25fe_t* h)
+{
+    const size_t C = (size_t)h->C;
+    HIPCHK(h, h->hist_iq.ensure(C * HISTPAD * 8));
+    HIPCHK(h, h->tail_bb.ensure(C * BBPAD * sizeof(float)));
+    HIPCHK(h, h->anchors.ensure(C * sizeof(p25fe_anchor_t)));
+    HIPCHK(h, h->results.ensure(C * sizeof(p25fe_result_t)));
+    HIPCHK(h, h->power_out.ensure(C * sizeof(float)));
+    return P25FE_OK;
+}
+
+int p25fe_reset(p25fe_t* h)
+{
+    if (!h) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->abs_iq = 0;
+    h->fmt_locked = -1;
+    h->abs_bb = 0;
+    h->min_e = 0;
+    h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0});
+    h->total_dibits.assign((size_t)h->C, 0);
+    HIPCHK(h, hipMemsetAsync(h->hist_iq.p, 0, (size_t)h->C * HISTPAD * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->tail_bb.p, 0, (size_t)h->C * BBPAD * sizeof(float), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return P25FE_OK;
+}
+
+int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
+{
+    if (!cfg || !out) return P25FE_ERR_ARG;
+    *out = nullptr;
+    if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_decim_taps < 1 ||
+        cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_T2)
+        return P25FE_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return P25FE_ERR_NO_DEVICE;
+    if (hipSetDevice(cfg->device) != hipSuccess) return P25FE_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return P25FE_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return P25FE_ERR_NO_DEVICE;   // code object is gfx950 only
+
+    p25fe_t* h = new (std::nothrow) p25fe;
+    if (!h) return P25FE_ERR_NOMEM;
+    h->cfg = *cfg;
+    h->C = cfg->n_channels;
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    memset(&h->taps, 0, sizeof h->taps);                 // zero padding at the old end is bit-neutral
+    memcpy(h->taps.dec, cfg->decim_taps, sizeof(float) * (size_t)cfg->n_decim_taps);
+    memcpy(h->taps.ch, cfg->chan_taps, sizeof(float) * (size_t)cfg->n_chan_taps);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return P25FE_ERR_HIP; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return P25FE_ERR_HIP; }
+    int rc = state_alloc(h);
+    if (rc == P25FE_OK) rc = p25fe_reset(h);
+    if (rc != P25FE_OK) { p25fe_destroy(h); return rc; }
+    *out = h;
+    return P25FE_OK;
+}
+
+void p25fe_destroy(p25fe_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->outs, &h->power_partial, &h->power_out,
+                      &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------
+// profiling hook
+// --------------------------------------------------------------------------------------------
+static void prof_begin(p25fe_t* h) { h->prof_slot = h->prof_on ? (int)(h->prof_calls++ % PROF_RING) : -1; }
+static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
+{
+    if (h->prof_slot >= 0) (void)hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st);
+}
+
+// --------------------------------------------------------------------------------------------
+// internal launchers
+// --------------------------------------------------------------------------------------------
+static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
+                           uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
+                           hipStream_t st)
+{
+    if (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) return P25FE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_x) & 15u) != 0) return P25FE_ERR_ARG;     // 16-B vector loads
+    if (h->C > 1 && (ch_stride % (fmt == P25FE_FMT_CF32 ? 2 : 8)) != 0) return P25FE_ERR_ARG;
+    const size_t n_out = p25fe_n_baseband(abs0, n);
+    const long total = (long)n_out - m_begin;
+    if (total <= 0) {
+        if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0, sizeof(float) * (size_t)h->C, st));
+        return P25FE_OK;
+    }
+    // segments: one round of resident workgroups (2 per CU by LDS) when the range is large, so no tail
+    // round; P25FE_WGS_PER_CU overrides for experiments.
+    static const long wgs_per_cu = [] { const char* e = getenv("P25FE_WGS_PER_CU"); long v = e ? atol(e) : 2; return v > 0 ? v : 2; }();
+    const long target_wgs = (long)h->n_cu * wgs_per_cu;
+    long per_ch = target_wgs / h->C;
+    if (per_ch < 1) per_ch = 1;
+    long subs = ((total + per_ch - 1) / per_ch + HALO_D + SUB - 1) / SUB;
+    if (subs < 1) subs = 1;
+    if (subs > 8192) subs = 8192;
+    const long seg_len = (long)(SUB - HALO_D) + (subs - 1) * (long)SUB;
+    const long n_seg = (total + seg_len - 1) / seg_len;
+
+    K1Args a;
+    a.x = d_x;
+    a.ch_stride = (long)ch_stride;
+    a.n_hist = (long)n_hist;
+    a.n_new = (long)n;
+    a.o0 = (int)((4 + 5 - abs0 % 5) % 5);
+    a.bb = d_bb;
+    a.bb_stride = (long)bb_stride;
+    a.n_out = (long)n_out;
+    a.subs_per_seg = (int)subs;
+    a.m_begin = m_begin;
+    a.power_partial = nullptr;
+    if (d_power_dbm) {
+        HIPCHK(h, h->power_partial.ensure(sizeof(float) * (size_t)h->C * (size_t)n_seg));
+        a.power_partial = h->power_partial.as<float>();
+    }
+    dim3 grid((unsigned)n_seg, (unsigned)h->C);
+    if (fmt == P25FE_FMT_CF32)
+        hipLaunchKernelGGL(k_frontend<P25FE_FMT_CF32>, grid, dim3(NT), K1_LDS_BYTES, st, a, h->taps);
+    else
+        hipLaunchKernelGGL(k_frontend<P25FE_FMT_U8>, grid, dim3(NT), K1_LDS_BYTES, st, a, h->taps);
+    HIPCHK(h, hipGetLastError());
+    if (d_power_dbm) {
+        hipLaunchKernelGGL(k_power_finish, dim3((unsigned)h->C), dim3(256), 0, st, a.power_partial, (int)n_seg,
+                           (long)n_out, d_power_dbm);
+        HIPCHK(h, hipGetLastError());
+    }
+    return P25FE_OK;
+}
+
+static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
+{
+    const size_t C = (size_t)h->C;
+    const size_t n_tiles = (n_bb + TB - 1) / TB;
+    HIPCHK(h, h->events.ensure(C * round_up(n_bb + 8, 16)));
+    HIPCHK(h, h->recs.ensure(C * (n_tiles + 1) * sizeof(TileRec)));
+    HIPCHK(h, h->outs.ensure(C * (n_tiles + 1) * sizeof(ScanOut)));
+    return P25FE_OK;
+}
+
+static int launch_sync(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
+                       uint64_t abs_bb0, int64_t min_e, hipStream_t st)
+{
+    const size_t n_tiles = (n_bb + TB - 1) / TB;
+    SyncArgs s;
+    s.bb = d_bb; s.bb_stride = (long)bb_stride; s.n_hist = (long)n_hist_bb; s.n = (long)n_bb; s.abs0 = (long)abs_bb0;
+    s.n_tiles = (int)n_tiles;
+    s.events = h->events.as<uint8_t>();
+    s.ev_stride = (long)round_up(n_bb + 8, 16);
+    s.recs = h->recs.as<TileRec>();
+    s.min_e = min_e;
+    hipLaunchKernelGGL(k_sync, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, s);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
+                             uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits,
+                             size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
+                             p25fe_result_t* d_result, bool do_slice, hipStream_t st)
+{
+    const size_t n_tiles = (n_bb + TB - 1) / TB;
+    ScanArgs c;
+    c.recs = h->recs.as<TileRec>(); c.outs = h->outs.as<ScanOut>(); c.n_tiles = (int)n_tiles; c.n = (long)n_bb;
+    c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result; c.n_baseband = n_bb;
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)h->C), dim3(1024), 0, st, c);
+    HIPCHK(h, hipGetLastError());
+    prof_mark(h, 3, st);
+    if (!do_slice) { prof_mark(h, 4, st); return P25FE_OK; }
+    SliceArgs l;
+    l.bb = d_bb; l.bb_stride = (long)bb_stride; l.n_hist = (long)n_hist_bb; l.n = (long)n_bb; l.abs0 = (long)abs_bb0;
+    l.n_tiles = (int)n_tiles; l.events = h->events.as<uint8_t>(); l.ev_stride = (long)round_up(n_bb + 8, 16);
+    l.outs = h->outs.as<ScanOut>(); l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
+    l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
+    l.sync_stride = (long)sync_stride;
+    hipLaunchKernelGGL(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, l);
+    HIPCHK(h, hipGetLastError());
+    prof_mark(h, 4, st);
+    return P25FE_OK;
+}
+
+static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
+                     uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, int64_t min_e, uint8_t* d_dibits,
+                     size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
+                     p25fe_result_t* d_result, hipStream_t st)
+{
+    if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
+        return launch_scan_slice(h, d_bb, bb_stride, n_hist_bb, 0, abs_bb0, d_anchor_in, d_dibits, dibit_stride,
+                                 nullptr, nullptr, 0, d_result, false, st);
+    int rc = ensure_slice_scratch(h, n_bb);
+    if (rc) return rc;
+    rc = launch_sync(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, min_e, st);
+    if (rc) return rc;
+    prof_mark(h, 2, st);
+    return launch_scan_slice(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, d_anchor_in, d_dibits, dibit_stride,
+                             d_sync_pos, d_sync_dibit, sync_stride, d_result, true, st);
+}
+
+extern "C" {
+
+// --------------------------------------------------------------------------------------------
+// device-resident ranges
+// --------------------------------------------------------------------------------------------
+int p25fe_demod_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                    float* d_bb, size_t bb_stride, float* d_power_dbm, void* stream)
+{
+    if (!h || !d_iq || !d_bb) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, 0, d_bb, bb_stride, d_power_dbm,
+                           (hipStream_t)stream);
+}
+
+int p25fe_slice_dev(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb, uint64_t abs_bb0,
+                    const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos,
+                    uint64_t* d_sync_dibit, size_t sync_stride, p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_bb || !d_dibits || !d_result) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return dev_slice(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, d_anchor_in, 0, d_dibits, dibit_stride, d_sync_pos,
+                     d_sync_dibit, sync_stride, d_result, (hipStream_t)stream);
+}
+
+int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
+                  size_t dibit_stride, p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n_bb = p25fe_n_baseband(0, n);
+    const size_t bb_stride = round_up(n_bb + 4, 4);
+    HIPCHK(h, h->bb_buf.ensure((size_t)h->C * bb_stride * sizeof(float)));
+    int rc = ensure_slice_scratch(h, n_bb);
+    if (rc) return rc;
+    prof_begin(h);
+    prof_mark(h, 0, st);
+    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, 0, h->bb_buf.as<float>(), bb_stride, nullptr, st);
+    if (rc) return rc;
+    prof_mark(h, 1, st);
+    rc = dev_slice(h, h->bb_buf.as<float>(), bb_stride, 0, n_bb, 0, nullptr, 0, d_dibits, dibit_stride, nullptr,
+                   nullptr, 0, d_result, st);
+    h->prof_slot = -1;
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------------
+// time shards
+// --------------------------------------------------------------------------------------------
+int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                      p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_iq || !d_result) return P25FE_ERR_ARG;
+    if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n_bb = p25fe_n_baseband(abs0, n);
+    const uint64_t abs_bb0 = p25fe_n_baseband(0, (size_t)abs0);      // baseband samples before this shard
+    const size_t bb_stride = round_up(BBPAD + n_bb + 4, 4);
+    HIPCHK(h, h->bb_buf.ensure((size_t)h->C * bb_stride * sizeof(float)));
+    int rc = ensure_slice_scratch(h, n_bb);
+    if (rc) return rc;
+    float* bb0 = h->bb_buf.as<float>() + BBPAD;
+    const size_t hist_bb = abs_bb0 < BBPAD ? (size_t)abs_bb0 : BBPAD;
+    prof_begin(h);
+    prof_mark(h, 0, st);
+    rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)hist_bb, bb0, bb_stride, nullptr, st);
+    if (rc) return rc;
+    prof_mark(h, 1, st);
+    rc = launch_sync(h, bb0, bb_stride, hist_bb, n_bb, abs_bb0, 0, st);
+    if (rc) return rc;
+    prof_mark(h, 2, st);
+    h->sh_nbb = n_bb; h->sh_bb_stride = bb_stride; h->sh_abs_bb0 = abs_bb0; h->sh_hist_bb = hist_bb;
+    rc = launch_scan_slice(h, bb0, bb_stride, hist_bb, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                           d_result, false, st);
+    h->prof_slot = -1;
+    return rc;
+}
+
+int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride,
+                      p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_dibits || !d_result || h->sh_nbb == 0) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    float* bb0 = h->bb_buf.as<float>() + BBPAD;
+    return launch_scan_slice(h, bb0, h->sh_bb_stride, h->sh_hist_bb, h->sh_nbb, h->sh_abs_bb0, d_anchor_in, d_dibits,
+                             dibit_stride, nullptr, nullptr, 0, d_result, true, (hipStream_t)stream);
+}
+
+int p25fe_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
+                        size_t n_shards, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
+{
+    if (!summaries || !shard_bb0 || !shard_bb_n || !anchor_in || !dibit_offset) return P25FE_ERR_ARG;
+    p25fe_anchor_t cur = {0, 0.f, 0.f, 0.f, 0};
+    uint64_t off = 0;
+    for (size_t r = 0; r < n_shards; ++r) {
+        anchor_in[r] = cur;
+        dibit_offset[r] = off;
+        const long lo = (long)shard_bb0[r], hi = (long)(shard_bb0[r] + shard_bb_n[r]);
+        const long pre_hi = summaries[r].first_event >= 0 ? (long)summaries[r].first_event : hi;
+        const uint64_t pre = cur.valid ? (uint64_t)count_instants(cur.s, lo, pre_hi) : 0;
+        off += pre + (summaries[r].first_event >= 0 ? summaries[r].n_dibits_after_first : 0);
+        if (summaries[r].first_event >= 0) cur = summaries[r].anchor_out;
+    }
+    return P25FE_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// streaming with host buffers
+// --------------------------------------------------------------------------------------------
+// Stage [history | new] per channel on the device, run K1, roll the history.
+static int stream_demod(p25fe_t* h, const void* iq, int fmt, size_t n, float* d_bb_out, size_t bb_stride,
+                        float* d_power, size_t* n_out)
+{
+    if (h->fmt_locked >= 0 && h->fmt_locked != fmt && h->abs_iq > 0) return P25FE_ERR_FORMAT;
+    h->fmt_locked = fmt;
+    const size_t C = (size_t)h->C, eb = fmt_bytes(fmt);
+    const size_t stride = HISTPAD + round_up(n, 8) + 8;              // samples, multiple of 8
+    HIPCHK(h, h->iq_stage.ensure(C * stride * eb));
+    char* stage = h->iq_stage.as<char>();
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpy2DAsync(stage, stride * eb, h->hist_iq.p, HISTPAD * eb, HISTPAD * eb, C,
+                               hipMemcpyDeviceToDevice, st));
+    if (n)
+        HIPCHK(h, hipMemcpy2DAsync(stage + HISTPAD * eb, stride * eb, iq, n * eb, n * eb, C, hipMemcpyHostToDevice, st));
+    const size_t n_hist = h->abs_iq < HISTPAD ? (size_t)h->abs_iq : HISTPAD;
+    const size_t nb = p25fe_n_baseband(h->abs_iq, n);
+    int rc = launch_frontend(h, stage + HISTPAD * eb, fmt, stride, n_hist, n, h->abs_iq, 0, d_bb_out, bb_stride,
+                             d_power, st);
+    if (rc) return rc;
+    // new history = last HISTPAD samples of [history | new]
+    HIPCHK(h, hipMemcpy2DAsync(h->hist_iq.p, HISTPAD * eb, stage + n * eb, stride * eb, HISTPAD * eb, C,
+                               hipMemcpyDeviceToDevice, st));
+    h->abs_iq += n;
+    *n_out = nb;
+    return P25FE_OK;
+}
+
+static int demod_host(p25fe_t* h, const void* iq, int fmt, size_t n, float* bb, size_t bb_cap, size_t* n_out,
+                      float* power_dbm)
+{
+    if (!h || (!iq && n) || !bb || !n_out) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t nb = p25fe_n_baseband(h->abs_iq, n);
+    if (nb > bb_cap) return P25FE_ERR_CAPACITY;
+    const size_t C = (size_t)h->C;
+    const size_t bb_stride = round_up(nb + 4, 4);
+    HIPCHK(h, h->bb_buf.ensure(C * bb_stride * sizeof(float)));
+    size_t got = 0;
+    int rc = stream_demod(h, iq, fmt, n, h->bb_buf.as<float>(), bb_stride, power_dbm ? h->power_out.as<float>() : nullptr,
+                          &got);
+    if (rc) return rc;
+    if (got)
+        HIPCHK(h, hipMemcpy2DAsync(bb, bb_cap * sizeof(float), h->bb_buf.p, bb_stride * sizeof(float),
+                                   got * sizeof(float), C, hipMemcpyDeviceToHost, h->stream));
+    if (power_dbm)
+        HIPCHK(h, hipMemcpyAsync(power_dbm, h->power_out.p, sizeof(float) * C, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_out = got;
+    return P25FE_OK;
+}
+
+int p25fe_demod_u8(p25fe_t* h, const uint8_t* iq, size_t n_bytes, float* bb, size_t bb_cap, size_t* n_out,
+                   float* power_dbm)
+{
+    if (n_bytes & 1) return P25FE_ERR_ARG;
+    return demod_host(h, iq, P25FE_FMT_U8, n_bytes / 2, bb, bb_cap, n_out, power_dbm);
+}
+
+int p25fe_demod_cf32(p25fe_t* h, const float* iq, size_t n_samples, float* bb, size_t bb_cap, size_t* n_out,
+                     float* power_dbm)
+{
+    return demod_host(h, iq, P25FE_FMT_CF32, n_samples, bb, bb_cap, n_out, power_dbm);
+}
+
+// Slice n_bb new baseband samples that already sit at bb_buf + BBPAD (per channel, stride bb_stride);
+// the tail of the previous call is copied in front of them.  Copies results to the host.
+static int stream_slice_staged(p25fe_t* h, size_t n_bb, size_t bb_stride, uint8_t* dibits, size_t cap, size_t* n_dibits,
+                               int64_t* sync_pos, uint64_t* sync_dibit, size_t sync_cap, size_t* n_sync)
+{
+    const size_t C = (size_t)h->C;
+    hipStream_t st = h->stream;
+    float* base = h->bb_buf.as<float>();
+    HIPCHK(h, hipMemcpy2DAsync(base, bb_stride * sizeof(float), h->tail_bb.p, BBPAD * sizeof(float),
+                               BBPAD * sizeof(float), C, hipMemcpyDeviceToDevice, st));
+    const size_t max_d = n_bb / SPS + 2;
+    const size_t dstride = round_up(max_d, 16);
+    HIPCHK(h, h->dibits.ensure(C * dstride));
+    const size_t sstride = sync_cap;
+    if (sync_cap) {
+        HIPCHK(h, h->sync_pos.ensure(C * sstride * sizeof(int64_t)));
+        HIPCHK(h, h->sync_dibit.ensure(C * sstride * sizeof(uint64_t)));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->anchors.p, h->anchor.data(), sizeof(p25fe_anchor_t) * C, hipMemcpyHostToDevice, st));
+    const size_t hist = h->abs_bb < BBPAD ? (size_t)h->abs_bb : BBPAD;
+    int rc = dev_slice(h, base + BBPAD, bb_stride, hist, n_bb, h->abs_bb, h->anchors.as<p25fe_anchor_t>(), h->min_e,
+                       h->dibits.as<uint8_t>(), dstride, sync_cap ? h->sync_pos.as<int64_t>() : nullptr,
+                       sync_cap ? h->sync_dibit.as<uint64_t>() : nullptr, sstride, h->results.as<p25fe_result_t>(), st);
+    if (rc) return rc;
+    std::vector<p25fe_result_t> res(C);
+    HIPCHK(h, hipMemcpyAsync(res.data(), h->results.p, sizeof(p25fe_result_t) * C, hipMemcpyDeviceToHost, st));
+    // roll the tail: last BBPAD samples of [tail | new]
+    HIPCHK(h, hipMemcpy2DAsync(h->tail_bb.p, BBPAD * sizeof(float), base + n_bb, bb_stride * sizeof(float),
+                               BBPAD * sizeof(float), C, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (size_t c = 0; c < C; ++c) {
+        if (res[c].n_dibits)
+            HIPCHK(h, hipMemcpyAsync(dibits + c * cap, h->dibits.as<uint8_t>() + c * dstride, res[c].n_dibits,
+                                     hipMemcpyDeviceToHost, st));
+        const size_t ns = res[c].n_sync < sync_cap ? (size_t)res[c].n_sync : sync_cap;
+        if (ns && sync_pos)
+            HIPCHK(h, hipMemcpyAsync(sync_pos + c * sync_cap, h->sync_pos.as<int64_t>() + c * sstride,
+                                     ns * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        if (ns && sync_dibit)
+            HIPCHK(h, hipMemcpyAsync(sync_dibit + c * sync_cap, h->sync_dibit.as<uint64_t>() + c * sstride,
+                                     ns * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (size_t c = 0; c < C; ++c) {
+        const size_t ns = res[c].n_sync < sync_cap ? (size_t)res[c].n_sync : sync_cap;
+        if (sync_dibit)
+            for (size_t k = 0; k < ns; ++k) sync_dibit[c * sync_cap + k] += h->total_dibits[c];
+        n_dibits[c] = (size_t)res[c].n_dibits;
+        if (n_sync) n_sync[c] = (size_t)res[c].n_sync;
+        h->anchor[c] = res[c].anchor_out;
+        h->total_dibits[c] += res[c].n_dibits;
+    }
+    h->abs_bb += n_bb;
+    return P25FE_OK;
+}
+
+int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits, int64_t* sync_pos,
+                uint64_t* sync_dibit, size_t sync_cap, size_t* n_sync)
+{
+    if (!h || (!bb && n) || !dibits || !n_dibits) return P25FE_ERR_ARG;
+    if ((sync_pos || sync_dibit) && !(sync_pos && sync_dibit)) return P25FE_ERR_ARG;
+    if (!sync_pos) sync_cap = 0;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t C = (size_t)h->C;
+    if (n == 0) { for (size_t c = 0; c < C; ++c) { n_dibits[c] = 0; if (n_sync) n_sync[c] = 0; } return P25FE_OK; }
+    if (cap < n / SPS + 1) return P25FE_ERR_CAPACITY;               // worst case, checked before any state moves
+    const size_t bb_stride = round_up(BBPAD + n + 4, 4);
+    HIPCHK(h, h->bb_buf.ensure(C * bb_stride * sizeof(float)));
+    HIPCHK(h, hipMemcpy2DAsync(h->bb_buf.as<float>() + BBPAD, bb_stride * sizeof(float), bb, n * sizeof(float),
+                               n * sizeof(float), C, hipMemcpyHostToDevice, h->stream));
+    return stream_slice_staged(h, n, bb_stride, dibits, cap, n_dibits, sync_pos, sync_dibit, sync_cap, n_sync);
+}
+
+static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits)
+{
+    if (!h || (!iq && n) || !dibits || !n_dibits) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t C = (size_t)h->C;
+    const size_t nb = p25fe_n_baseband(h->abs_iq, n);
+    if (cap < nb / SPS + 1) return P25FE_ERR_CAPACITY;              // worst case, checked before any state moves
+    const size_t bb_stride = round_up(BBPAD + nb + 4, 4);
+    HIPCHK(h, h->bb_buf.ensure(C * bb_stride * sizeof(float)));
+    size_t got = 0;
+    int rc = stream_demod(h, iq, fmt, n, h->bb_buf.as<float>() + BBPAD, bb_stride, nullptr, &got);
+    if (rc) return rc;
+    if (got == 0) { for (size_t c = 0; c < C; ++c) n_dibits[c] = 0; return P25FE_OK; }
+    return stream_slice_staged(h, got, bb_stride, dibits, cap, n_dibits, nullptr, nullptr, 0, nullptr);
+}
+
+int p25fe_run_u8(p25fe_t* h, const uint8_t* iq, size_t n_bytes, uint8_t* dibits, size_t cap, size_t* n_dibits)
+{
+    if (n_bytes & 1) return P25FE_ERR_ARG;
+    return run_host(h, iq, P25FE_FMT_U8, n_bytes / 2, dibits, cap, n_dibits);
+}
+
+int p25fe_run_cf32(p25fe_t* h, const float* iq, size_t n_samples, uint8_t* dibits, size_t cap, size_t* n_dibits)
+{
+    return run_host(h, iq, P25FE_FMT_CF32, n_samples, dibits, cap, n_dibits);
+}
+
+int p25fe_profile_enable(p25fe_t* h, int on)
+{
+    if (!h) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (on && h->prof_ev.empty()) {
+        h->prof_ev.resize((size_t)PROF_RING * 5);
+        for (auto& e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
+    }
+    h->prof_on = on != 0;
+    h->prof_calls = 0;
+    return P25FE_OK;
+}
+
+int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
+{
+    if (!h || !ms) return P25FE_ERR_ARG;
+    for (int k = 0; k < 4; ++k) ms[k] = 0.0;
+    const uint64_t calls = h->prof_calls;
+    const uint64_t kept = calls < (uint64_t)PROF_RING ? calls : (uint64_t)PROF_RING;
+    for (uint64_t s = 0; s < kept; ++s) {
+        HIPCHK(h, hipEventSynchronize(h->prof_ev[s * 5 + 4]));
+        for (int k = 0; k < 4; ++k) {
+            float t = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&t, h->prof_ev[s * 5 + k], h->prof_ev[s * 5 + k + 1]));
+            ms[k] += t;
+        }
+    }
+    if (n_calls) *n_calls = kept;
+    h->prof_calls = 0;
+    return P25FE_OK;
+}
+
+int p25fe_resync(p25fe_t* h)
+{
+    if (!h) return P25FE_ERR_ARG;
+    for (auto& a : h->anchor) a.valid = 0;
+    h->min_e = (int64_t)h->abs_bb + 1;      // a detection decided before the resync must not come back (SPEC 3.8)
+    return P25FE_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// state blob: header | hist_iq raw | tail_bb | anchors | totals
+// --------------------------------------------------------------------------------------------
+struct StateHeader {
+    uint32_t magic, abi;
+    int32_t n_channels, fmt_locked;
+    uint64_t abs_iq, abs_bb;
+    int64_t min_e;
+};
+
+int p25fe_state_size(const p25fe_t* h, size_t* n)
+{
+    if (!h || !n) return P25FE_ERR_ARG;
+    const size_t C = (size_t)h->C;
+    *n = sizeof(StateHeader) + C * HISTPAD * 8 + C * BBPAD * sizeof(float) + C * sizeof(p25fe_anchor_t) + C * sizeof(uint64_t);
+    return P25FE_OK;
+}
+
+int p25fe_state_export(const p25fe_t* hc, void* buf, size_t cap, size_t* n)
+{
+    p25fe_t* h = const_cast<p25fe_t*>(hc);
+    size_t need = 0;
+    if (!h || !buf || p25fe_state_size(h, &need)) return P25FE_ERR_ARG;
+    if (n) *n = need;
+    if (cap < need) return P25FE_ERR_CAPACITY;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t C = (size_t)h->C;
+    char* p = static_cast<char*>(buf);
+    StateHeader hd = {STATE_MAGIC, P25FE_ABI_VERSION, h->C, h->fmt_locked, h->abs_iq, h->abs_bb, h->min_e};
+    memcpy(p, &hd, sizeof hd); p += sizeof hd;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(p, h->hist_iq.p, C * HISTPAD * 8, hipMemcpyDeviceToHost)); p += C * HISTPAD * 8;
+    HIPCHK(h, hipMemcpy(p, h->tail_bb.p, C * BBPAD * sizeof(float), hipMemcpyDeviceToHost)); p += C * BBPAD * sizeof(float);
+    memcpy(p, h->anchor.data(), C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);
+    memcpy(p, h->total_dibits.data(), C * sizeof(uint64_t));
+    return P25FE_OK;
+}
+
+int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
+{
+    size_t need = 0;
+    if (!h || !buf || p25fe_state_size(h, &need) || n < need) return P25FE_ERR_ARG;
+    const char* p = static_cast<const char*>(buf);
+    StateHeader hd;
+    memcpy(&hd, p, sizeof hd); p += sizeof hd;
+    if (hd.magic != STATE_MAGIC || hd.abi != P25FE_ABI_VERSION || hd.n_channels != h->C) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t C = (size_t)h->C;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->hist_iq.p, p, C * HISTPAD * 8, hipMemcpyHostToDevice)); p += C * HISTPAD * 8;
+    HIPCHK(h, hipMemcpy(h->tail_bb.p, p, C * BBPAD * sizeof(float), hipMemcpyHostToDevice)); p += C * BBPAD * sizeof(float);
+    memcpy(h->anchor.data(), p, C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);
+    memcpy(h->total_dibits.data(), p, C * sizeof(uint64_t));
+    h->fmt_locked = hd.fmt_locked; h->abs_iq = hd.abs_iq; h->abs_bb = hd.abs_bb; h->min_e = hd.min_e;
+    return P25FE_OK;
+}
+
+}  // extern "C"

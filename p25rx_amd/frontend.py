@@ -1,0 +1,250 @@
+"""Handle-level Python view of the C ABI (include/p25fe.h).
+
+`FrontEnd` owns one p25fe_t.  Host-buffer methods take/return NumPy arrays and mirror the
+per-chunk bodies of DemodTask::run (src/demod.rs:70-117) and RecvTask::run
+(src/recv.rs:148-150).  `*_dev` methods take torch CUDA tensors -- torch supplies device
+memory and streams only; all arithmetic happens in libp25fe.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FMT_CF32, FMT_U8, RESULT_DTYPE, ANCHOR_DTYPE
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FrontEnd:
+    def __init__(self, n_channels=1, device=0, decim_taps=None, chan_taps=None):
+        self.L = _lib.load()
+        cfg = _lib.default_config()
+        cfg.device = device
+        cfg.n_channels = n_channels
+        if decim_taps is not None:
+            cfg.n_decim_taps = len(decim_taps)
+            for i, v in enumerate(decim_taps):
+                cfg.decim_taps[i] = v
+        if chan_taps is not None:
+            cfg.n_chan_taps = len(chan_taps)
+            for i, v in enumerate(chan_taps):
+                cfg.chan_taps[i] = v
+        self.cfg = cfg
+        self.C = n_channels
+        self.device = device
+        self.h = C.c_void_p()
+        _lib.check(self.L, None, self.L.p25fe_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.p25fe_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        _lib.check(self.L, self.h, rc)
+
+    # ---- streaming, host buffers -------------------------------------------------------------
+    def _demod(self, fn, arr, n_units, n_samples, want_power):
+        cap = n_samples // 5 + 2
+        bb = np.empty((self.C, cap), dtype=np.float32)
+        n_out = C.c_size_t(0)
+        pw = np.zeros(self.C, dtype=np.float32)
+        self._chk(fn(self.h, _p(arr), n_units, _p(bb), cap, C.byref(n_out), _p(pw) if want_power else None))
+        out = bb[:, :n_out.value]
+        out = out[0].copy() if self.C == 1 else out.copy()
+        if want_power:
+            return out, (float(pw[0]) if self.C == 1 else pw)
+        return out
+
+    def demod_u8(self, data, want_power=False):
+        """One DemodTask::run loop body on interleaved u8 I/Q; data shape [n_bytes] or [C, n_bytes]."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(self.C, -1)
+        return self._demod(self.L.p25fe_demod_u8, data, data.shape[1], data.shape[1] // 2, want_power)
+
+    def demod_cf32(self, iq, want_power=False):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(self.C, -1)
+        return self._demod(self.L.p25fe_demod_cf32, iq, iq.shape[1], iq.shape[1], want_power)
+
+    def slice(self, bb, sync_cap=None):
+        """RecvTask sample loop on baseband; returns (dibits, sync_pos, sync_dibit) (lists per channel if C > 1)."""
+        bb = np.ascontiguousarray(bb, dtype=np.float32).reshape(self.C, -1)
+        n = bb.shape[1]
+        cap = n // 10 + 2
+        scap = sync_cap if sync_cap is not None else n // 6 + 2
+        dib = np.empty((self.C, cap), dtype=np.uint8)
+        spos = np.empty((self.C, scap), dtype=np.int64)
+        sdib = np.empty((self.C, scap), dtype=np.uint64)
+        nd = (C.c_size_t * self.C)()
+        ns = (C.c_size_t * self.C)()
+        self._chk(self.L.p25fe_slice(self.h, _p(bb), n, _p(dib), cap, nd, _p(spos), _p(sdib), scap, ns))
+        outs = [(dib[c, :nd[c]].copy(), spos[c, :min(ns[c], scap)].copy(), sdib[c, :min(ns[c], scap)].copy())
+                for c in range(self.C)]
+        return outs[0] if self.C == 1 else outs
+
+    def _run(self, fn, arr, n_units, n_samples):
+        cap = n_samples // 50 + 4
+        dib = np.empty((self.C, cap), dtype=np.uint8)
+        nd = (C.c_size_t * self.C)()
+        self._chk(fn(self.h, _p(arr), n_units, _p(dib), cap, nd))
+        outs = [dib[c, :nd[c]].copy() for c in range(self.C)]
+        return outs[0] if self.C == 1 else outs
+
+    def run_u8(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(self.C, -1)
+        return self._run(self.L.p25fe_run_u8, data, data.shape[1], data.shape[1] // 2)
+
+    def run_cf32(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(self.C, -1)
+        return self._run(self.L.p25fe_run_cf32, iq, iq.shape[1], iq.shape[1])
+
+    def resync(self):
+        self._chk(self.L.p25fe_resync(self.h))
+
+    def reset(self):
+        self._chk(self.L.p25fe_reset(self.h))
+
+    def state_export(self):
+        n = C.c_size_t(0)
+        self._chk(self.L.p25fe_state_size(self.h, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        self._chk(self.L.p25fe_state_export(self.h, _p(buf), buf.size, C.byref(n)))
+        return buf
+
+    def state_import(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(self.L.p25fe_state_import(self.h, _p(blob), blob.size))
+
+    # ---- device-resident ranges (torch tensors as plumbing) -------------------------------------
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _fmt_of(t):
+        import torch
+        if t.dtype == torch.float32:
+            return FMT_CF32, t.shape[-2] if t.dim() == 3 else t.shape[0]
+        if t.dtype == torch.uint8:
+            return FMT_U8, t.shape[-2] if t.dim() == 3 else t.shape[0]
+        raise TypeError("IQ tensor must be float32 [C, n, 2] or uint8 [C, n, 2]")
+
+    def _iq_view(self, iq):
+        """iq: [n, 2] or [C, n, 2] contiguous per channel; returns (fmt, n, ch_stride)."""
+        import torch
+        assert iq.is_cuda and iq.shape[-1] == 2
+        if iq.dim() == 2:
+            iq = iq.unsqueeze(0)
+        assert iq.shape[0] == self.C and iq.stride(2) == 1 and iq.stride(1) == 2
+        fmt = FMT_CF32 if iq.dtype == torch.float32 else FMT_U8
+        if iq.dtype not in (torch.float32, torch.uint8):
+            raise TypeError("IQ tensor must be float32 or uint8")
+        return fmt, iq.shape[1], (iq.stride(0) // 2 if self.C > 1 else iq.shape[1])
+
+    def run_dev(self, iq, dibits=None, result=None):
+        """Fresh-stream IQ -> dibits on device.  Returns (dibits[C, cap] uint8 cuda, result uint8 tensor)."""
+        import torch
+        fmt, n, stride = self._iq_view(iq)
+        cap = (n // 50 + 64 + 15) // 16 * 16
+        if dibits is None:
+            dibits = torch.empty((self.C, cap), dtype=torch.uint8, device=iq.device)
+        if result is None:
+            result = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=iq.device)
+        self._chk(self.L.p25fe_run_dev(self.h, C.c_void_p(iq.data_ptr()), fmt, stride, n, C.c_void_p(dibits.data_ptr()),
+                                       dibits.stride(0), C.c_void_p(result.data_ptr()), self._stream()))
+        return dibits, result
+
+    def demod_dev(self, iq, n_hist=0, abs0=0, bb=None, want_power=False, offset=0):
+        """stages 1-5 on a device range; `offset` = index of the first owned sample inside `iq` (>= n_hist)."""
+        import torch
+        fmt, n_total, stride = self._iq_view(iq)
+        n = n_total - offset
+        nb = self.L.p25fe_n_baseband(abs0, n)
+        if bb is None:
+            bb = torch.empty((self.C, (nb + 7) // 4 * 4), dtype=torch.float32, device=iq.device)
+        pw = torch.empty(self.C, dtype=torch.float32, device=iq.device) if want_power else None
+        ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
+        self._chk(self.L.p25fe_demod_dev(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n, abs0,
+                                         C.c_void_p(bb.data_ptr()), bb.stride(0),
+                                         C.c_void_p(pw.data_ptr()) if want_power else None, self._stream()))
+        return (bb, nb, pw) if want_power else (bb, nb)
+
+    def slice_dev(self, bb, n_bb, n_hist_bb=0, abs_bb0=0, anchor_in=None, offset=0, sync_cap=0):
+        import torch
+        dev = bb.device
+        if bb.dim() == 1:
+            bb = bb.unsqueeze(0)
+        cap = (n_bb // 10 + 64 + 15) // 16 * 16
+        dib = torch.empty((self.C, cap), dtype=torch.uint8, device=dev)
+        res = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        spos = torch.empty((self.C, max(sync_cap, 1)), dtype=torch.int64, device=dev)
+        sdib = torch.empty((self.C, max(sync_cap, 1)), dtype=torch.int64, device=dev)
+        a_in = None
+        if anchor_in is not None:
+            a_in = torch.from_numpy(np.frombuffer(np.asarray(anchor_in, dtype=ANCHOR_DTYPE).tobytes(), dtype=np.uint8).copy()).to(dev)
+        self._chk(self.L.p25fe_slice_dev(self.h, C.c_void_p(bb.data_ptr() + 4 * offset), bb.stride(0), n_hist_bb, n_bb,
+                                         abs_bb0, C.c_void_p(a_in.data_ptr()) if a_in is not None else None,
+                                         C.c_void_p(dib.data_ptr()), dib.stride(0),
+                                         C.c_void_p(spos.data_ptr()) if sync_cap else None,
+                                         C.c_void_p(sdib.data_ptr()) if sync_cap else None, sync_cap,
+                                         C.c_void_p(res.data_ptr()), self._stream()))
+        return dib, res, spos, sdib
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.p25fe_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> (ms per kernel [K1 front end, K2 sync, K3 scan, K4 slice] summed over calls, n_calls)."""
+        ms = (C.c_double * 4)()
+        n = C.c_uint64(0)
+        self._chk(self.L.p25fe_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return [ms[i] for i in range(4)], n.value
+
+    def shard_halo(self):
+        return self.L.p25fe_shard_halo()
+
+    def shard_pass1(self, iq, offset, n_hist, abs0, result=None):
+        import torch
+        fmt, n_total, stride = self._iq_view(iq)
+        n = n_total - offset
+        if result is None:
+            result = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=iq.device)
+        ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
+        self._chk(self.L.p25fe_shard_pass1(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n, abs0,
+                                           C.c_void_p(result.data_ptr()), self._stream()))
+        return result
+
+    def shard_pass2(self, anchor_in, n_bb, device, result=None, dibits=None):
+        import torch
+        cap = (n_bb // 10 + 64 + 15) // 16 * 16
+        dib = dibits if dibits is not None else torch.empty((self.C, cap), dtype=torch.uint8, device=device)
+        if result is None:
+            result = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device)
+        a_in = torch.from_numpy(np.frombuffer(np.asarray(anchor_in, dtype=ANCHOR_DTYPE).tobytes(), dtype=np.uint8).copy()).to(device)
+        self._chk(self.L.p25fe_shard_pass2(self.h, C.c_void_p(a_in.data_ptr()), C.c_void_p(dib.data_ptr()), dib.stride(0),
+                                           C.c_void_p(result.data_ptr()), self._stream()))
+        return dib, result
+
+    def shard_resolve(self, summaries, bb0, bbn):
+        """Host combine of per-shard summaries (np structured RESULT_DTYPE, time order) -> (anchor_in, dibit_offset)."""
+        summaries = np.ascontiguousarray(summaries, dtype=RESULT_DTYPE)
+        bb0 = np.ascontiguousarray(bb0, dtype=np.uint64)
+        bbn = np.ascontiguousarray(bbn, dtype=np.uint64)
+        n = len(summaries)
+        anc = np.zeros(n, dtype=ANCHOR_DTYPE)
+        off = np.zeros(n, dtype=np.uint64)
+        self._chk(self.L.p25fe_shard_resolve(_p(summaries), _p(bb0), _p(bbn), n, _p(anc), _p(off)))
+        return anc, off
+
+
+def parse_results(t):
+    """uint8 result tensor [C, sizeof(p25fe_result_t)] -> NumPy structured array (syncs the stream)."""
+    return np.frombuffer(t.cpu().numpy().tobytes(), dtype=RESULT_DTYPE).copy()
+
+
+def n_baseband(abs0, n):
+    return _lib.load().p25fe_n_baseband(abs0, n)

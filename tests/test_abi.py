@@ -1,0 +1,92 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every symbol include/p25fe.h declares,
+and its host-only entry points behave (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from p25rx_amd import _lib
+    return _lib
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "p25fe.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(p25fe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (p25fe_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+
+
+def test_default_config_matches_spec(lib, spec):
+    cfg = lib.default_config()
+    assert cfg.abi_version == 1 and cfg.n_channels == 1
+    assert cfg.n_decim_taps == spec["t1"] and cfg.n_chan_taps == spec["t2"]
+    assert np.array_equal(np.array(cfg.decim_taps[:spec["t1"]], dtype=np.float32), np.array(spec["decim_taps"], dtype=np.float32))
+    assert np.array_equal(np.array(cfg.chan_taps[:spec["t2"]], dtype=np.float32), np.array(spec["chan_taps"], dtype=np.float32))
+
+
+def test_spec_files_regenerate_bit_for_bit():
+    before = {p: open(os.path.join(ROOT, p)).read() for p in ("include/p25fe_spec.h", "tests/golden/spec.json")}
+    subprocess.check_call(["python", os.path.join(ROOT, "tools", "gen_spec.py")], stdout=subprocess.DEVNULL)
+    for p, txt in before.items():
+        assert open(os.path.join(ROOT, p)).read() == txt, p
+
+
+def test_n_baseband_matches_reference_chunking(lib):
+    """16384-sample chunks alternate 3276/3277 outputs (src/demod.rs:87-90)."""
+    L = lib.load()
+    tot, lens = 0, []
+    for _ in range(10):
+        lens.append(L.p25fe_n_baseband(tot, 16384))
+        tot += 16384
+    assert set(lens) == {3276, 3277} and sum(lens) == L.p25fe_n_baseband(0, tot) == tot // 5
+    assert L.p25fe_n_baseband(0, 4) == 0 and L.p25fe_n_baseband(0, 5) == 1 and L.p25fe_n_baseband(3, 2) == 1
+
+
+def test_no_device_fails_loudly(lib):
+    """Without a GPU the product refuses to run: no CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from p25rx_amd.frontend import FrontEnd
+    with pytest.raises(lib.P25feError) as e:
+        FrontEnd()
+    assert e.value.status == lib.ERR_NO_DEVICE
+
+
+def test_shard_resolve_host_logic(lib):
+    """p25fe_shard_resolve is pure host logic: carry the latest anchor, count pre-sync dibits in closed form."""
+    L = lib.load()
+    R, A = lib.RESULT_DTYPE, lib.ANCHOR_DTYPE
+    summ = np.zeros(4, dtype=R)
+    bb0 = np.array([0, 1000, 2000, 3000], dtype=np.uint64)
+    bbn = np.array([1000, 1000, 1000, 1000], dtype=np.uint64)
+    # shard 0: first event takes effect at 308 (s = 302), 69 dibits after it; shard 1: no sync; shard 2: re-anchors
+    summ[0]["first_event"], summ[0]["n_dibits_after_first"] = 308, 69
+    summ[0]["anchor_out"] = (302, 0.2, 0.0, -0.2, 1)
+    summ[1]["first_event"] = -1
+    summ[2]["first_event"], summ[2]["n_dibits_after_first"] = 2509, 49
+    summ[2]["anchor_out"] = (2503, 0.3, 0.1, -0.1, 1)
+    summ[3]["first_event"] = -1
+    anc = np.zeros(4, dtype=A)
+    off = np.zeros(4, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, p(anc), p(off)) == 0
+    assert anc["valid"].tolist() == [0, 1, 1, 1] and anc["s"].tolist()[1:] == [302, 302, 2503]
+    inst = lambda s, lo, hi: len([n for n in range(lo, hi) if n > s and (n - s) % 10 == 0])
+    exp1 = 69
+    exp2 = exp1 + inst(302, 1000, 2000)
+    exp3 = exp2 + inst(302, 2000, 2509) + 49
+    assert off.tolist() == [0, exp1, exp2, exp3]
