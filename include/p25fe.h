@@ -88,7 +88,7 @@ typedef struct p25fe_result {
     uint64_t n_dibits;                   /* dibits produced */
     uint64_t n_sync;                     /* frame-sync detections */
     p25fe_anchor_t anchor_out;           /* anchor after the range */
-    int64_t first_event;                 /* baseband index where the range's first own detection takes effect, -1 if none */
+    int64_t first_event;                 /* baseband index at which the range's first own detection is decided (s + W), -1 if none */
     uint64_t n_dibits_after_first;       /* dibits governed by the range's own detections */
 } p25fe_result_t;
 

@@ -65,6 +65,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libp25fe.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C p25rx_amd/csrc` (there is no CPU fallback)")
+    # torch (plumbing: device memory, streams, RCCL) bundles its own libamdhip64.so.7.  Import it FIRST so
+    # that libp25fe.so's NEEDED libamdhip64.so.7 binds to the runtime torch uses: two HIP runtimes in one
+    # process do not share devices or pointers.  A host without torch binds to /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     psz = C.POINTER(sz)

@@ -17,7 +17,7 @@ using namespace p25k;
 namespace {
 
 constexpr size_t HISTPAD = 288;      // >= HIST_IQ (284), multiple of 8: keeps 16-B alignment for u8 and cf32
-constexpr size_t BBPAD = 256;        // >= HIST_BB (241), multiple of 4
+constexpr size_t BBPAD = 256;        // >= HIST_BB (240), multiple of 4
 constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 1568
 constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
 
@@ -61,7 +61,6 @@ struct p25fe {
     DevBuf tail_bb;                        // [C][BBPAD] floats
     std::vector<p25fe_anchor_t> anchor;    // [C]
     std::vector<uint64_t> total_dibits;    // [C]
-    int64_t min_e = 0;
     // profiling ring: PROF_RING calls x 5 events (before K1, after K1, K2, K3, K4)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -138,7 +137,6 @@ int p25fe_reset(p25fe_t* h)
     h->abs_iq = 0;
     h->fmt_locked = -1;
     h->abs_bb = 0;
-    h->min_e = 0;
     h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0});
     h->total_dibits.assign((size_t)h->C, 0);
     HIPCHK(h, hipMemsetAsync(h->hist_iq.p, 0, (size_t)h->C * HISTPAD * 8, h->stream));
@@ -276,7 +274,7 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
 }
 
 static int launch_sync(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
-                       uint64_t abs_bb0, int64_t min_e, hipStream_t st)
+                       uint64_t abs_bb0, hipStream_t st)
 {
     const size_t n_tiles = (n_bb + TB - 1) / TB;
     SyncArgs s;
@@ -285,7 +283,6 @@ static int launch_sync(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n
     s.events = h->events.as<uint8_t>();
     s.ev_stride = (long)round_up(n_bb + 8, 16);
     s.recs = h->recs.as<TileRec>();
-    s.min_e = min_e;
     hipLaunchKernelGGL(k_sync, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, s);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
@@ -317,7 +314,7 @@ static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, si
 }
 
 static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
-                     uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, int64_t min_e, uint8_t* d_dibits,
+                     uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits,
                      size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
                      p25fe_result_t* d_result, hipStream_t st)
 {
@@ -326,7 +323,7 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
                                  nullptr, nullptr, 0, d_result, false, st);
     int rc = ensure_slice_scratch(h, n_bb);
     if (rc) return rc;
-    rc = launch_sync(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, min_e, st);
+    rc = launch_sync(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, st);
     if (rc) return rc;
     prof_mark(h, 2, st);
     return launch_scan_slice(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, d_anchor_in, d_dibits, dibit_stride,
@@ -353,7 +350,7 @@ int p25fe_slice_dev(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hi
 {
     if (!h || !d_bb || !d_dibits || !d_result) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    return dev_slice(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, d_anchor_in, 0, d_dibits, dibit_stride, d_sync_pos,
+    return dev_slice(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, d_anchor_in, d_dibits, dibit_stride, d_sync_pos,
                      d_sync_dibit, sync_stride, d_result, (hipStream_t)stream);
 }
 
@@ -373,7 +370,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, 0, h->bb_buf.as<float>(), bb_stride, nullptr, st);
     if (rc) return rc;
     prof_mark(h, 1, st);
-    rc = dev_slice(h, h->bb_buf.as<float>(), bb_stride, 0, n_bb, 0, nullptr, 0, d_dibits, dibit_stride, nullptr,
+    rc = dev_slice(h, h->bb_buf.as<float>(), bb_stride, 0, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr,
                    nullptr, 0, d_result, st);
     h->prof_slot = -1;
     return rc;
@@ -402,7 +399,7 @@ int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, s
     rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)hist_bb, bb0, bb_stride, nullptr, st);
     if (rc) return rc;
     prof_mark(h, 1, st);
-    rc = launch_sync(h, bb0, bb_stride, hist_bb, n_bb, abs_bb0, 0, st);
+    rc = launch_sync(h, bb0, bb_stride, hist_bb, n_bb, abs_bb0, st);
     if (rc) return rc;
     prof_mark(h, 2, st);
     h->sh_nbb = n_bb; h->sh_bb_stride = bb_stride; h->sh_abs_bb0 = abs_bb0; h->sh_hist_bb = hist_bb;
@@ -432,7 +429,7 @@ int p25fe_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_b
         anchor_in[r] = cur;
         dibit_offset[r] = off;
         const long lo = (long)shard_bb0[r], hi = (long)(shard_bb0[r] + shard_bb_n[r]);
-        const long pre_hi = summaries[r].first_event >= 0 ? (long)summaries[r].first_event : hi;
+        const long pre_hi = summaries[r].first_event >= 0 ? (long)summaries[r].first_event + 1 : hi;
         const uint64_t pre = cur.valid ? (uint64_t)count_instants(cur.s, lo, pre_hi) : 0;
         off += pre + (summaries[r].first_event >= 0 ? summaries[r].n_dibits_after_first : 0);
         if (summaries[r].first_event >= 0) cur = summaries[r].anchor_out;
@@ -528,7 +525,7 @@ static int stream_slice_staged(p25fe_t* h, size_t n_bb, size_t bb_stride, uint8_
     }
     HIPCHK(h, hipMemcpyAsync(h->anchors.p, h->anchor.data(), sizeof(p25fe_anchor_t) * C, hipMemcpyHostToDevice, st));
     const size_t hist = h->abs_bb < BBPAD ? (size_t)h->abs_bb : BBPAD;
-    int rc = dev_slice(h, base + BBPAD, bb_stride, hist, n_bb, h->abs_bb, h->anchors.as<p25fe_anchor_t>(), h->min_e,
+    int rc = dev_slice(h, base + BBPAD, bb_stride, hist, n_bb, h->abs_bb, h->anchors.as<p25fe_anchor_t>(),
                        h->dibits.as<uint8_t>(), dstride, sync_cap ? h->sync_pos.as<int64_t>() : nullptr,
                        sync_cap ? h->sync_dibit.as<uint64_t>() : nullptr, sstride, h->results.as<p25fe_result_t>(), st);
     if (rc) return rc;
@@ -644,7 +641,6 @@ int p25fe_resync(p25fe_t* h)
 {
     if (!h) return P25FE_ERR_ARG;
     for (auto& a : h->anchor) a.valid = 0;
-    h->min_e = (int64_t)h->abs_bb + 1;      // a detection decided before the resync must not come back (SPEC 3.8)
     return P25FE_OK;
 }
 
@@ -655,7 +651,6 @@ struct StateHeader {
     uint32_t magic, abi;
     int32_t n_channels, fmt_locked;
     uint64_t abs_iq, abs_bb;
-    int64_t min_e;
 };
 
 int p25fe_state_size(const p25fe_t* h, size_t* n)
@@ -676,7 +671,7 @@ int p25fe_state_export(const p25fe_t* hc, void* buf, size_t cap, size_t* n)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
     char* p = static_cast<char*>(buf);
-    StateHeader hd = {STATE_MAGIC, P25FE_ABI_VERSION, h->C, h->fmt_locked, h->abs_iq, h->abs_bb, h->min_e};
+    StateHeader hd = {STATE_MAGIC, P25FE_ABI_VERSION, h->C, h->fmt_locked, h->abs_iq, h->abs_bb};
     memcpy(p, &hd, sizeof hd); p += sizeof hd;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(p, h->hist_iq.p, C * HISTPAD * 8, hipMemcpyDeviceToHost)); p += C * HISTPAD * 8;
@@ -701,7 +696,7 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
     HIPCHK(h, hipMemcpy(h->tail_bb.p, p, C * BBPAD * sizeof(float), hipMemcpyHostToDevice)); p += C * BBPAD * sizeof(float);
     memcpy(h->anchor.data(), p, C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);
     memcpy(h->total_dibits.data(), p, C * sizeof(uint64_t));
-    h->fmt_locked = hd.fmt_locked; h->abs_iq = hd.abs_iq; h->abs_bb = hd.abs_bb; h->min_e = hd.min_e;
+    h->fmt_locked = hd.fmt_locked; h->abs_iq = hd.abs_iq; h->abs_bb = hd.abs_bb;
     return P25FE_OK;
 }
 

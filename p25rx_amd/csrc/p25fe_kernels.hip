@@ -355,7 +355,8 @@ __global__ void k_power_finish(const float* partial, int n_partial, long n, floa
 // ------------------------------------------------------------------------------------------
 // K2..K4: symbol receiver as a scan (SPEC 3.6-3.8)
 //
-// A detection at s (sync word's last symbol) takes effect at e = s + W + 1: instant n is
+// A detection at s (sync word's last symbol) is DECIDED at e = s + W (the peak window is complete)
+// and governs instants n > e: instant n is
 // governed by the detection with the latest e <= n.  Tiles own the EVENTS whose e falls in
 // them, so every dependency points left.
 // ------------------------------------------------------------------------------------------
@@ -364,16 +365,16 @@ constexpr int SPS = P25FE_SPS;
 constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
 constexpr int TB = 2048;                                     // baseband samples per tile
 constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
-constexpr int HIST_BB = SYNC_SPAN + 2 * W + 1;               // 241: left context of a tile
+constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
 constexpr int BT_N = TB + HIST_BB + 3;                       // LDS baseband tile (+pad)
 constexpr int CT_N = TB + 2 * W + 2;                         // c[] for s in [a-2W-1, a+TB-W-1) plus peak lookahead
 
 struct TileRec {            // per (channel, tile) summary written by K2
-    long first_event;       // absolute index where the tile's first event takes effect, -1 if none
+    long first_event;       // absolute decision index e = s + W of the tile's first event, -1 if none
     long last_s;            // s of the tile's last event (absolute), valid if first_event >= 0
     float hi, mid, lo;      // thresholds of the last event
     int n_events;
-    long post_count;        // instants in [first_event, tile_end) under the tile's own events
+    long post_count;        // instants in (first_event, tile_end) under the tile's own events
 };
 
 struct ScanOut {            // per (channel, tile) carry-in written by K3
@@ -475,14 +476,13 @@ struct SyncArgs {
     uint8_t* events;        // [ch][n] event flags (e-indexed)
     long ev_stride;
     TileRec* recs;          // [ch][n_tiles]
-    long min_e;             // events taking effect before this absolute index are dropped (resync)
 };
 
 // K2: correlate, peak-pick, flag events, summarise the tile.
 __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
 {
     __shared__ float BT[BT_N];          // BT[k] = b[t0 - HIST_BB + k]
-    __shared__ float CT[CT_N];          // CT[k] = c[t0 - 2W - 1 + k]
+    __shared__ float CT[CT_N];          // CT[k] = c[t0 - 2W + k]
     __shared__ uint8_t CAND[CT_N];
     __shared__ long shl[8];
     __shared__ int shi[8];
@@ -495,9 +495,9 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     for (int k = tid; k < BT_N; k += NT) BT[k] = bb_at(bbp, a.n_hist, a.n, t0 - HIST_BB + k);
     __syncthreads();
 
-    // c[s], cand[s] for s = t0 - 2W - 1 + k, k in [0, TB + 2W): needs b[s - 230 .. s]
+    // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s]
     for (int k = tid; k < TB + 2 * W; k += NT) {
-        // s = t0 - 2W - 1 + k  ->  BT index of b[s] = s - (t0 - HIST_BB) = k + HIST_BB - 2W - 1 = k + SYNC_SPAN
+        // s = t0 - 2W + k  ->  BT index of b[s] = s - (t0 - HIST_BB) = k + HIST_BB - 2W = k + SYNC_SPAN
         const int is = k + SYNC_SPAN;
         float c = 0.f, e = 0.f;
 #pragma unroll
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     }
     __syncthreads();
 
-    // event at local e-index i (sample t0 + i) <=> detection at s = t0 + i - W - 1 -> CT index k = i + W.
+    // event at local index i (decided when sample t0 + i arrives) <=> detection at s = t0 + i - W -> CT index k = i + W.
     // s must lie inside the stream so far: s >= -n_hist (older samples read as zero anyway) and the peak
     // window s + W = t0 + i - 1 < n is guaranteed by i < tn.
     long my_last = -1;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
         const int i = tid * VPT + u;
         const int k = i + W;
         bool det = false;
-        if (i < tn && CAND[k] && a.abs0 + t0 + i >= a.min_e) {
+        if (i < tn && CAND[k]) {
             const float cm = CT[k];
             det = true;
 #pragma unroll
@@ -554,11 +554,11 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
         if (i < tn) {
-            if (evl[u]) cur = t0 + i;
-            if (cur >= 0) {
-                const long s = cur - W - 1;             // local index of the anchor
+            if (cur >= 0) {                             // events decided BEFORE this sample govern it
+                const long s = cur - W;                 // local index of the anchor
                 if ((t0 + i - s) % SPS == 0) ++cnt;     // t0 + i > s always
             }
+            if (evl[u]) cur = t0 + i;
         }
     }
     int total_cnt, total_ev;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
         r.post_count = total_cnt;
         r.last_s = -1; r.hi = r.mid = r.lo = 0.f;
         if (last_ev >= 0) {
-            const long s = last_ev - W - 1;                     // local
+            const long s = last_ev - W;                         // local
             float hi, mid, lo;
             sync_thresholds(BT, (int)(s - (t0 - HIST_BB)), hi, mid, lo);
             r.last_s = s + a.abs0; r.hi = hi; r.mid = mid; r.lo = lo;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         const long tlo = a.abs0 + (long)i * TB;
         long thi = tlo + TB;
         if (thi > a.abs0 + a.n) thi = a.abs0 + a.n;
-        const long pre_hi = recs[i].first_event >= 0 ? recs[i].first_event : thi;
+        const long pre_hi = recs[i].first_event >= 0 ? recs[i].first_event + 1 : thi;   // instant AT e is still the old anchor's
         const unsigned long long pre = o.valid ? (unsigned long long)count_instants(o.anchor_s, tlo, pre_hi) : 0ull;
         o.dibit_off = my_cnt;          // relative to my chunk for now
         o.event_off = my_ev;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
         // dibits after the first event = total - (dibits before tile f) - (pre-count of tile f)
         const ScanOut of = outs[f];
         const long tlo = a.abs0 + f * TB;
-        const unsigned long long pre = of.valid ? (unsigned long long)count_instants(of.anchor_s, tlo, recs[f].first_event) : 0ull;
+        const unsigned long long pre = of.valid ? (unsigned long long)count_instants(of.anchor_s, tlo, recs[f].first_event + 1) : 0ull;
         a.result[ch].first_event = recs[f].first_event;
         a.result[ch].n_dibits_after_first = sh_cnt[1023] - of.dibit_off - pre;
     }
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
             my_last = i;
             ++my_ev;
             float hi, mid, lo;
-            sync_thresholds(BT, i - W - 1 + HIST_BB, hi, mid, lo);
+            sync_thresholds(BT, i - W + HIST_BB, hi, mid, lo);
             THI[i] = hi; TMID[i] = mid; TLO[i] = lo;
         }
     }
@@ -759,11 +759,11 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
         if (i < tn) {
-            if (evl[u]) cur = i;
             bool is = false;
-            if (cur >= 0) is = ((i - (cur - W - 1)) % SPS) == 0;
+            if (cur >= 0) is = ((i - (cur - W)) % SPS) == 0;
             else if (co.valid) is = ((a.abs0 + t0 + i - co.anchor_s) % SPS) == 0;
             if (is) { ++cnt; inst |= 1u << u; }
+            if (evl[u]) cur = i;
         }
     }
     int total;
@@ -776,22 +776,22 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
         if (i < tn) {
-            if (evl[u]) {
-                if (a.sync_pos && (long)(co.event_off + evrank) < a.sync_stride) {
-                    a.sync_pos[(size_t)ch * a.sync_stride + co.event_off + evrank] = a.abs0 + t0 + i - W - 1;
-                    // dibits emitted for instants <= s + W = this index - 1  -> rank so far (instant at i itself comes after)
-                    a.sync_dibit[(size_t)ch * a.sync_stride + co.event_off + evrank] = co.dibit_off + rank;
-                }
-                ++evrank;
-            }
-            // NOTE: an instant at index i is governed by events with e <= i, i.e. including an event AT i.
-            if (evl[u]) cur = i;
+            // the instant at index i (if any) is governed by events decided before i
             if ((inst >> u) & 1u) {
                 float hi, mid, lo;
                 if (cur >= 0) { hi = THI[cur]; mid = TMID[cur]; lo = TLO[cur]; }
                 else { hi = co.hi; mid = co.mid; lo = co.lo; }
                 const float v = BT[i + HIST_BB];
                 out[rank++] = v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
+            }
+            if (evl[u]) {
+                if (a.sync_pos && (long)(co.event_off + evrank) < a.sync_stride) {
+                    a.sync_pos[(size_t)ch * a.sync_stride + co.event_off + evrank] = a.abs0 + t0 + i - W;
+                    // index of the first dibit this detection governs = dibits for instants <= i
+                    a.sync_dibit[(size_t)ch * a.sync_stride + co.event_off + evrank] = co.dibit_off + rank;
+                }
+                ++evrank;
+                cur = i;
             }
         }
     }

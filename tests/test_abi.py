@@ -73,11 +73,11 @@ def test_shard_resolve_host_logic(lib):
     summ = np.zeros(4, dtype=R)
     bb0 = np.array([0, 1000, 2000, 3000], dtype=np.uint64)
     bbn = np.array([1000, 1000, 1000, 1000], dtype=np.uint64)
-    # shard 0: first event takes effect at 308 (s = 302), 69 dibits after it; shard 1: no sync; shard 2: re-anchors
-    summ[0]["first_event"], summ[0]["n_dibits_after_first"] = 308, 69
+    # shard 0: first event decided at 307 (s = 302), 69 dibits after it; shard 1: no sync; shard 2: re-anchors
+    summ[0]["first_event"], summ[0]["n_dibits_after_first"] = 307, 69
     summ[0]["anchor_out"] = (302, 0.2, 0.0, -0.2, 1)
     summ[1]["first_event"] = -1
-    summ[2]["first_event"], summ[2]["n_dibits_after_first"] = 2509, 49
+    summ[2]["first_event"], summ[2]["n_dibits_after_first"] = 2508, 49
     summ[2]["anchor_out"] = (2503, 0.3, 0.1, -0.1, 1)
     summ[3]["first_event"] = -1
     anc = np.zeros(4, dtype=A)

@@ -108,7 +108,9 @@ def test_power_dbm(O, FE, c4fm_1s):
         assert abs(pa - pb) < 1e-3
     x = (0.25 * np.exp(1j * np.linspace(0, 900, 16384))).astype(np.complex64)
     _, p = FE().demod_cf32(x, want_power=True)
-    assert abs(p - (30 + 20 * np.log10(0.25))) < 0.05
+    _, po = O.Demod().feed_cf32(x, want_power=True)
+    assert abs(p - po) < 1e-3
+    assert abs(p - (30 + 20 * np.log10(0.25))) < 0.3      # 2.1 kHz tone: passband droop + start-up transient
 
 
 def test_slice_ragged_chunks_and_sync_events(O, FE, c4fm_1s):
