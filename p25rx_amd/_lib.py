@@ -72,7 +72,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(os.environ.get("P25FE_LIB", LIB_PATH))      # P25FE_LIB: measurement builds (tools/ablate.sh) only
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     psz = C.POINTER(sz)
     L.p25fe_default_config.argtypes = [C.POINTER(Config)]

@@ -49,6 +49,10 @@ struct p25fe {
     int last_hip = 0;
     int n_cu = 256;
     Taps taps;
+    int k1_nt = 64;                        // K1 workgroup size (64: one wave per workgroup, barrier-free)
+    int k1_p = 5;                          // FIR outputs per thread
+    bool default_taps = true;              // taps == p25fe_spec.h tables bit for bit -> immediate-coefficient kernels
+    DevBuf d_taps;                         // device copy for the generic kernels
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
     // scratch
@@ -169,12 +173,35 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     memcpy(h->taps.dec, cfg->decim_taps, sizeof(float) * (size_t)cfg->n_decim_taps);
     memcpy(h->taps.ch, cfg->chan_taps, sizeof(float) * (size_t)cfg->n_chan_taps);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return P25FE_ERR_HIP; }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_LDS_BYTES);
-    if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); delete h; return P25FE_ERR_HIP; }
+    Taps def;
+    memset(&def, 0, sizeof def);
+    memcpy(def.dec, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
+    memcpy(def.ch, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
+    h->default_taps = memcmp(&def, &h->taps, sizeof def) == 0;
+    hipError_t e = hipSuccess;
+    {
+        const char* ev = getenv("P25FE_K1_NT");
+        const int nt = ev ? atoi(ev) : 64;
+        h->k1_nt = (nt == 256 || nt == 128) ? nt : 64;
+        const char* pv = getenv("P25FE_K1_P");
+        h->k1_p = (pv && atoi(pv) == 3) ? 3 : 5;
+    }
+    auto set_lds = [&](const void* f, size_t bytes) {
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    };
+#define P25FE_FOR_K1(NTK, PK)                                                                                       \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);    \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);   \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);      \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);
+    P25FE_FOR_K1(64, 5)
+    P25FE_FOR_K1(64, 3)
+    P25FE_FOR_K1(128, 5)
+    P25FE_FOR_K1(256, 5)
+#undef P25FE_FOR_K1
+    if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
+    if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); h->d_taps.release(); delete h; return P25FE_ERR_HIP; }
     int rc = state_alloc(h);
     if (rc == P25FE_OK) rc = p25fe_reset(h);
     if (rc != P25FE_OK) { p25fe_destroy(h); return rc; }
@@ -188,7 +215,7 @@ void p25fe_destroy(p25fe_t* h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->outs, &h->power_partial, &h->power_out,
-                      &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb};
+                      &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
@@ -221,16 +248,19 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0, sizeof(float) * (size_t)h->C, st));
         return P25FE_OK;
     }
-    // segments: one round of resident workgroups (2 per CU by LDS) when the range is large, so no tail
-    // round; P25FE_WGS_PER_CU overrides for experiments.
-    static const long wgs_per_cu = [] { const char* e = getenv("P25FE_WGS_PER_CU"); long v = e ? atol(e) : 2; return v > 0 ? v : 2; }();
+    // segments: one round of resident workgroups when the range is large (LDS admits 2 x 256-thread,
+    // 4 x 128 or 8 x 64-thread workgroups per CU), so there is no tail round; P25FE_WGS_PER_CU overrides.
+    const int nt = h->k1_nt, pk = (nt == 64) ? h->k1_p : 5;
+    const long sub = (long)nt * pk;
+    static const long wgs_env = [] { const char* e = getenv("P25FE_WGS_PER_CU"); return e ? atol(e) : 0L; }();
+    const long wgs_per_cu = wgs_env > 0 ? wgs_env : (pk == 3 ? 12 : 2 * (256 / nt));
     const long target_wgs = (long)h->n_cu * wgs_per_cu;
     long per_ch = target_wgs / h->C;
     if (per_ch < 1) per_ch = 1;
-    long subs = ((total + per_ch - 1) / per_ch + HALO_D + SUB - 1) / SUB;
+    long subs = ((total + per_ch - 1) / per_ch + HALO_D + sub - 1) / sub;
     if (subs < 1) subs = 1;
-    if (subs > 8192) subs = 8192;
-    const long seg_len = (long)(SUB - HALO_D) + (subs - 1) * (long)SUB;
+    if (subs > 32768) subs = 32768;
+    const long seg_len = (sub - HALO_D) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;
 
     K1Args a;
@@ -250,10 +280,23 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         a.power_partial = h->power_partial.as<float>();
     }
     dim3 grid((unsigned)n_seg, (unsigned)h->C);
-    if (fmt == P25FE_FMT_CF32)
-        hipLaunchKernelGGL(k_frontend<P25FE_FMT_CF32>, grid, dim3(NT), K1_LDS_BYTES, st, a, h->taps);
-    else
-        hipLaunchKernelGGL(k_frontend<P25FE_FMT_U8>, grid, dim3(NT), K1_LDS_BYTES, st, a, h->taps);
+    const Taps* dt = h->d_taps.as<Taps>();
+#define P25FE_LAUNCH_K1(NTK, PK)                                                                                          \
+    do {                                                                                                                  \
+        const size_t lds = Geo<NTK, PK>::LDS_BYTES;                                                                       \
+        if (fmt == P25FE_FMT_CF32) {                                                                                      \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);  \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);                 \
+        } else {                                                                                                          \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);    \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);                   \
+        }                                                                                                                 \
+    } while (0)
+    if (nt == 256) P25FE_LAUNCH_K1(256, 5);
+    else if (nt == 128) P25FE_LAUNCH_K1(128, 5);
+    else if (pk == 3) P25FE_LAUNCH_K1(64, 3);
+    else P25FE_LAUNCH_K1(64, 5);
+#undef P25FE_LAUNCH_K1
     HIPCHK(h, hipGetLastError());
     if (d_power_dbm) {
         hipLaunchKernelGGL(k_power_finish, dim3((unsigned)h->C), dim3(256), 0, st, a.power_partial, (int)n_seg,

@@ -22,29 +22,34 @@
 namespace p25k {
 
 // ------------------------------------------------------------------------------------------
-// geometry of K1
+// geometry of K1, parametrised by the workgroup size NTK (64 = one wave per workgroup: no
+// s_barrier at all, eight independent waves per CU interleave their phases freely)
 // ------------------------------------------------------------------------------------------
-constexpr int NT = 256;                      // threads per workgroup (4 waves)
-constexpr int P = 5;                         // consecutive FIR outputs per thread (odd: conflict-free ds_read_b64)
-constexpr int SUB = NT * P;                  // 1280 decimated samples per sub-tile
 constexpr int DEC = P25FE_DECIM;
 constexpr int T1 = P25FE_T1;
 constexpr int T2 = P25FE_T2;
 constexpr int BOX = P25FE_BOXCAR;
 constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9])
 constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50
-constexpr int XWIN = DEC * SUB + (T1 - DEC); // 6426 input samples feed one sub-tile of d
-constexpr int XPAD = 8;                      // alignment slack of the vector loader
-constexpr int XIN_N = XWIN + XPAD + 6;       // 6440 (even)
-constexpr int D_N = (T2 - 1) + SUB;          // 1320: [40 carry | 1280]
-constexpr int Y_N = 2 + SUB;                 // [2 carry (1 used) | 1280], keeps 16-B alignment
-constexpr int F_N = 12 + SUB;                // [12 carry (9 used) | 1280]
-constexpr int F_CARRY = 12;
-constexpr int Y_CARRY = 2;
-constexpr int D_CARRY = T2 - 1;
-constexpr size_t K1_LDS_BYTES = sizeof(float2) * (XIN_N + D_N + Y_N) + sizeof(float) * F_N;
+constexpr int F_CARRY = 12;                  // fm carry (9 used)
+constexpr int Y_CARRY = 2;                   // y carry (1 used), keeps 16-B alignment
+constexpr int D_CARRY = T2 - 1;              // d carry
 // history (input samples before the first owned one) needed for exact results
 constexpr int HIST_IQ = DEC * HALO_D + (T1 - 1) + (DEC - 1);   // 284
+
+// PK = consecutive FIR outputs per thread (odd: lane stride 2*5*PK / 2*PK dwords -> conflict-free ds_read_b64)
+template <int NTK, int PK> struct Geo {
+    static constexpr int NT = NTK;
+    static constexpr int P = PK;
+    static constexpr int SUB = NTK * PK;                  // decimated samples per sub-tile
+    static constexpr int XWIN = DEC * SUB + (T1 - DEC);   // input samples feeding one sub-tile of d
+    static constexpr int XIN_N = 8 + (XWIN + 8 + 7) / 8 * 8;   // 8 spare entries in front + window + loader slack
+    static constexpr int D_N = D_CARRY + SUB;
+    static constexpr int Y_N = Y_CARRY + SUB;
+    static constexpr int F_N = F_CARRY + SUB;
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (XIN_N + D_N + Y_N) + sizeof(float) * (F_N + T1 + T2 + 3);
+    static constexpr int WAVES_PER_SIMD = PK <= 3 ? 3 : 2;   // register budget the kernel is compiled for
+};
 
 struct Taps {
     float dec[T1];
@@ -80,99 +85,85 @@ __device__ __forceinline__ float fm_discriminate(float2 s, float2 prev)
     return spec_atan2f(im, re) * P25FE_FM_GAIN;
 }
 
+// One complex sample from LDS as a single ds_read_b64.  The volatile 64-bit access keeps the compiler from
+// pairing neighbouring reads into ds_read2_b64, which moves 16 B per lane at HALF the LDS rate of two
+// ds_read_b64 (MI355X_MICROARCH.md LDS table: 8 vs 2+2 cycles per wave-instruction).
+__device__ __forceinline__ float2 lds_read_c(const float2* p)
+{
+#ifdef P25FE_LDS_READ2
+    return *p;
+#else
+    typedef const volatile unsigned long long __attribute__((address_space(3))) * lds_u64_ptr;
+    const unsigned long long u = *((lds_u64_ptr)p);                 // generic -> LDS address space: stays a DS op
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+#endif
+}
+
 // SPEC 3.1: rtlsdr_iq LUT value as arithmetic (src/demod.rs:82-84)
 __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((float)b, P25FE_U8_SCALE, -1.0f); }
 
 // ------------------------------------------------------------------------------------------
-// window loader: global -> registers, 16 B per lane per load, zero outside [-n_hist, n_new)
+// window loader: global -> registers, one 16-B vector per lane per load.
+//
+// Every load is unconditional and branch-free: the vector index is clamped into the range of
+// vectors that contain at least one valid sample, and samples outside [-n_hist, n_new) are
+// zeroed when the registers are written to LDS (only in boundary sub-tiles; interior ones skip
+// the masking).  A clamped vector is 16-B aligned and shares its 16 bytes with a valid sample,
+// so it can never touch an unmapped page.  (An earlier version had a second, element-wise path
+// for straddling vectors; two paths writing the same VGPRs made the compiler put
+// s_waitcnt vmcnt(0) in front of every load, serialising 13 HBM round trips per sub-tile.)
 // ------------------------------------------------------------------------------------------
-template <int FMT> struct Loader;
-
-template <> struct Loader<P25FE_FMT_CF32> {
-    static constexpr int SPV = 2;                                   // samples per 16-B vector
-    static constexpr int NV = (XWIN + SPV + SPV * NT - 1) / (SPV * NT);   // vectors per thread: 13
-    float4 v[NV];
-    // base: pointer to owned sample 0 of this channel; first: index of the first window sample
-    __device__ __forceinline__ void load(const void* base, long first, long n_hist, long n_new, int tid)
-    {
-        const float4* p = reinterpret_cast<const float4*>(base);
-        const long first_al = first & ~1L;                          // floor to even (two's complement)
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const long i0 = first_al + 2L * (tid + j * NT);         // even sample index
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 >= -n_hist && i0 + 1 < n_new) {
-                r = p[i0 >> 1];                                     // arithmetic shift: works for negative even i0
-            } else if (i0 + 1 >= -n_hist && i0 < n_new) {           // straddles a boundary: element-wise
-                const float2* q = reinterpret_cast<const float2*>(base);
-                if (i0 >= -n_hist && i0 < n_new) { float2 a = q[i0]; r.x = a.x; r.y = a.y; }
-                if (i0 + 1 >= -n_hist && i0 + 1 < n_new) { float2 a = q[i0 + 1]; r.z = a.x; r.w = a.y; }
-            }
-            v[j] = r;
-        }
-    }
-    // XIN[k] must hold sample first + k; vector j of thread tid holds samples first_al + 2*(tid + j*NT) + {0,1}
-    __device__ __forceinline__ void store(float2* XIN, long first, int tid) const
-    {
-        const int sh = (int)(first & 1L);                           // 0 or 1
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int k = 2 * (tid + j * NT) - sh;
-            if (k >= 0 && k < XIN_N) XIN[k] = make_float2(v[j].x, v[j].y);
-            if (k + 1 >= 0 && k + 1 < XIN_N) XIN[k + 1] = make_float2(v[j].z, v[j].w);
-        }
-    }
-};
-
-template <> struct Loader<P25FE_FMT_U8> {
-    static constexpr int SPV = 8;                                   // 8 byte pairs per 16-B vector
-    static constexpr int NV = (XWIN + SPV + SPV * NT - 1) / (SPV * NT);   // 4
+template <int FMT, int NTK, int PK> struct Loader {
+    using G = Geo<NTK, PK>;
+    static constexpr int LOG_SPV = FMT == P25FE_FMT_CF32 ? 1 : 3;   // samples per 16-B vector: 2 (cf32) or 8 (u8 pairs)
+    static constexpr int SPV = 1 << LOG_SPV;
+    static constexpr int NV = (G::XWIN + SPV + SPV * NTK - 1) / (SPV * NTK);   // vectors per thread: 13 / 4
     uint4 v[NV];
-    unsigned valid[NV];                                             // bit e: sample e of the vector is inside the stream
-    __device__ __forceinline__ void load(const void* base, long first, long n_hist, long n_new, int tid)
+
+    // base: pointer to owned sample 0 of this channel; first: index of the first window sample
+    // i_last: last sample index this workgroup will ever need (loads past it collapse onto one cached vector)
+    __device__ __forceinline__ void load(const void* base, long first, long n_hist, long n_new, long i_last, int tid)
     {
         const uint4* p = reinterpret_cast<const uint4*>(base);
-        const long first_al = first & ~7L;
+        const long vfirst = (first >> LOG_SPV) + tid;               // floor division (arithmetic shift)
+        const long vlo = (-n_hist) >> LOG_SPV;                      // vector holding sample -n_hist
+        const long last = i_last < n_new - 1 ? i_last : n_new - 1;
+        const long vhi = last >> LOG_SPV;                           // vector holding the last useful sample
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const long i0 = first_al + 8L * (tid + j * NT);
-            uint4 r = make_uint4(0u, 0u, 0u, 0u);
-            unsigned m = 0u;
-            if (i0 >= -n_hist && i0 + 7 < n_new) {
-                r = p[i0 >> 3];
-                m = 0xffu;
-            } else if (i0 + 7 >= -n_hist && i0 < n_new) {           // straddles a boundary: element-wise
-                const uint16_t* q = reinterpret_cast<const uint16_t*>(base);
-                unsigned w[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const long i = i0 + e;
-                    const bool ok = (i >= -n_hist && i < n_new);
-                    w[e] = ok ? (unsigned)q[i] : 0u;
-                    m |= (ok ? 1u : 0u) << e;
-                }
-                r.x = w[0] | (w[1] << 16);
-                r.y = w[2] | (w[3] << 16);
-                r.z = w[4] | (w[5] << 16);
-                r.w = w[6] | (w[7] << 16);
-            }
-            v[j] = r;
-            valid[j] = m;
+            long vi = vfirst + (long)j * NTK;
+            vi = vi < vlo ? vlo : vi;
+            vi = vi > vhi ? vhi : vi;
+            v[j] = p[vi];
         }
     }
-    __device__ __forceinline__ void store(float2* XIN, long first, int tid) const
+
+    // XIN[k] must hold sample first + k; vector j of thread tid holds samples SPV * (vfirst + j * NTK) + e
+    __device__ __forceinline__ void store(float2* XIN, long first, long n_hist, long n_new, int tid) const
     {
-        const int sh = (int)(first & 7L);
+        const long first_al = (first >> LOG_SPV) << LOG_SPV;
+        const int sh = (int)(first - first_al);                     // 0 .. SPV-1
+        float2* XS = XIN - sh;                                      // XIN is preceded by SPV spare entries
+        const bool interior = first_al >= -n_hist && first_al + (long)NV * SPV * NTK <= n_new;   // uniform
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 8 * (tid + j * NT) + e - sh;
-                const unsigned pair = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                float2 s = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
-                if (!((valid[j] >> e) & 1u)) s = make_float2(0.f, 0.f);
-                if (k >= 0 && k < XIN_N) XIN[k] = s;
+            for (int e = 0; e < SPV; ++e) {
+                const int k = SPV * (tid + j * NTK) + e;             // always inside the XIN allocation
+                float2 s;
+                if (FMT == P25FE_FMT_CF32) {
+                    s = make_float2(__uint_as_float(w[2 * (e & 1)]), __uint_as_float(w[2 * (e & 1) + 1]));
+                } else {
+                    const unsigned pair = (w[(e >> 1) & 3] >> (16 * (e & 1))) & 0xffffu;
+                    s = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
+                }
+                if (!interior) {
+                    const long i = first_al + SPV * (long)(tid + j * NTK) + e;
+                    if (i < -n_hist || i >= n_new) s = make_float2(0.f, 0.f);
+                }
+                // only the last round of vectors can run past the window: everything else is stored unconditionally
+                if (j < NV - 1 || k < G::XIN_N - 8) XS[k] = s;
             }
         }
     }
@@ -201,16 +192,42 @@ struct K1Args {
     float* power_partial;   // nullable: [n_channels][gridDim.x] partial sums of |y|^2
 };
 
-template <int FMT>
-__global__ __launch_bounds__(NT, 2) void k_frontend(K1Args a, Taps taps)
+// Phase boundary inside a workgroup.  With NTK == 64 the workgroup is one wave: LDS operations of
+// one wave execute in order, so only the compiler must be kept from reordering across the
+// boundary and the hardware barrier disappears.
+template <int NTK> __device__ __forceinline__ void phase_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* XIN = reinterpret_cast<float2*>(smem);
-    float2* D = XIN + XIN_N;
-    float2* Y = D + D_N;
-    float* F = reinterpret_cast<float*>(Y + Y_N);
+    if (NTK > 64) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
 
+// CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
+// registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
+template <int FMT, bool CT, int NTK, int PK>
+__global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+{
+    using G = Geo<NTK, PK>;
+    constexpr int SUB = G::SUB;
+    constexpr int P = PK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* XIN = reinterpret_cast<float2*>(smem) + 8;              // 8 spare entries in front (loader shift)
+    float2* D = reinterpret_cast<float2*>(smem) + G::XIN_N;
+    float2* Y = D + G::D_N;
+    float* F = reinterpret_cast<float*>(Y + G::Y_N);
+    float* TAPS = F + G::F_N;                                       // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
+    if (!CT) {
+        for (int k = tid; k < T1; k += NTK) TAPS[k] = gtaps->dec[k];
+        for (int k = tid; k < T2; k += NTK) TAPS[T1 + k] = gtaps->ch[k];
+    }
+    auto tap_dec = [&](int k) -> float { return CT ? P25FE_DEFAULT_DECIM_TAPS[k] : TAPS[k]; };
+    auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
+
     const long seg_len = (long)(SUB - HALO_D) + (long)(a.subs_per_seg - 1) * SUB;
     const long m_seg0 = a.m_begin + (long)blockIdx.x * seg_len;
     if (m_seg0 >= a.n_out) return;
@@ -220,23 +237,43 @@ __global__ __launch_bounds__(NT, 2) void k_frontend(K1Args a, Taps taps)
     float* bb = a.bb + (size_t)ch * a.bb_stride;
 
     // zero the carries (their garbage would only reach never-stored outputs, but keep it tidy)
-    if (tid < D_CARRY) D[tid] = make_float2(0.f, 0.f);
+    for (int k = tid; k < D_CARRY; k += NTK) D[k] = make_float2(0.f, 0.f);
     if (tid < Y_CARRY) Y[tid] = make_float2(0.f, 0.f);
     if (tid < F_CARRY) F[tid] = 0.f;
 
-    Loader<FMT> ld;
+    Loader<FMT, NTK, PK> ld;
     long dlo = m_seg0 - HALO_D;                                    // first d index of this sub-tile
-    ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, tid);
+    const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
+    ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid);
     float pw = 0.f;
+    // Outputs are kept in registers for one sub-tile and stored at the top of the next one, BEFORE the
+    // prefetch loads are issued: vmcnt counts loads and stores in one in-order queue, so stores issued
+    // after the prefetch would force the wait at the top of the loop to drain them too (measured: the
+    // loop then ran at the HBM write round-trip per sub-tile).
+    float outv[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) outv[q] = 0.f;
+    long out_lo = m_seg0 - 2 * (long)SUB;                           // nothing in range yet
+    auto flush_outputs = [&]() {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const long m = out_lo + tid + q * NTK;
+            if (m >= m_seg0 && m < m_seg1) bb[m] = outv[q];
+        }
+    };
 
     for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB) {
         if (dlo >= m_seg1) break;                                  // uniform
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[k] = x[first + k]
-        ld.store(XIN, first, tid);
-        __syncthreads();
-        if (it + 1 < a.subs_per_seg && dlo + SUB < m_seg1)
-            ld.load(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, tid);
+        ld.store(XIN, first, a.n_hist, a.n_new, tid);
+        phase_sync<NTK>();
+        flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
+        // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
+        ld.load(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid);
 
+#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
+        continue;
+#endif
         // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Thread: d[dlo + 5 tid + p], p = 0..4.
         // Output p needs x[first + 5(5 tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[25 tid + 5p + 30 - k].
         {
@@ -246,21 +283,24 @@ __global__ __launch_bounds__(NT, 2) void k_frontend(K1Args a, Taps taps)
             for (int p = 0; p < P; ++p) acc[p] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int j = DEC * (P - 1) + T1 - 1; j >= 0; --j) {    // newest to oldest => tap order 0..T1-1
-                const float2 s = w[j];
+                const float2 s = lds_read_c(w + j);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = DEC * p + (T1 - 1) - j;
                     if (k >= 0 && k < T1) {
-                        acc[p].x = __builtin_fmaf(taps.dec[k], s.x, acc[p].x);
-                        acc[p].y = __builtin_fmaf(taps.dec[k], s.y, acc[p].y);
+                        acc[p].x = __builtin_fmaf(tap_dec(k), s.x, acc[p].x);
+                        acc[p].y = __builtin_fmaf(tap_dec(k), s.y, acc[p].y);
                     }
                 }
             }
 #pragma unroll
             for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = acc[p];
         }
-        __syncthreads();
+        phase_sync<NTK>();
 
+#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
+        continue;
+#endif
         // ---- stage 3: channel FIR (src/demod.rs:93). Thread: y[dlo + 5 tid + p] from D[5 tid + p + 40 - k].
         {
             const float2* w = D + P * tid;
@@ -269,13 +309,13 @@ __global__ __launch_bounds__(NT, 2) void k_frontend(K1Args a, Taps taps)
             for (int p = 0; p < P; ++p) acc[p] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int j = (P - 1) + T2 - 1; j >= 0; --j) {
-                const float2 s = w[j];
+                const float2 s = lds_read_c(w + j);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
                     if (k >= 0 && k < T2) {
-                        acc[p].x = __builtin_fmaf(taps.ch[k], s.x, acc[p].x);
-                        acc[p].y = __builtin_fmaf(taps.ch[k], s.y, acc[p].y);
+                        acc[p].x = __builtin_fmaf(tap_ch(k), s.x, acc[p].x);
+                        acc[p].y = __builtin_fmaf(tap_ch(k), s.y, acc[p].y);
                     }
                 }
             }
@@ -289,45 +329,52 @@ __global__ __launch_bounds__(NT, 2) void k_frontend(K1Args a, Taps taps)
                 }
             }
         }
-        __syncthreads();
+        phase_sync<NTK>();
 
+#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 3
+        continue;
+#endif
         // ---- stage 4: FM discriminator (src/demod.rs:109-111), one output per thread per pass
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const int i = tid + q * NT;
+            const int i = tid + q * NTK;
             F[F_CARRY + i] = fm_discriminate(Y[Y_CARRY + i], Y[Y_CARRY + i - 1]);
         }
-        __syncthreads();
+        phase_sync<NTK>();
 
-        // ---- stage 5: boxcar (src/demod.rs:114) + coalesced store of the owned outputs
+    #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
+        continue;
+#endif
+        // ---- stage 5: boxcar (src/demod.rs:114); lane-consecutive outputs -> coalesced stores (deferred)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const int i = tid + q * NT;
+            const int i = tid + q * NTK;
             const float* f = F + F_CARRY + i;
             float acc = f[0];
 #pragma unroll
             for (int j = 1; j < BOX; ++j) acc = acc + f[-j];
-            const long m = dlo + i;
-            if (m >= m_seg0 && m < m_seg1) bb[m] = acc * P25FE_BOXCAR_SCALE;
+            outv[q] = acc * P25FE_BOXCAR_SCALE;
         }
-        __syncthreads();
+        out_lo = dlo;
+        phase_sync<NTK>();
 
         // ---- carry context to the next sub-tile
-        if (tid < D_CARRY) D[tid] = D[SUB + tid];
+        for (int k = tid; k < D_CARRY; k += NTK) D[k] = D[SUB + k];
         if (tid < Y_CARRY) Y[tid] = Y[SUB + tid];
         if (tid < F_CARRY) F[tid] = F[SUB + tid];
-        // ordered before their next use by the barrier that follows the next XIN store
+        // ordered before their next use by the phase boundary that follows the next XIN store
     }
+    flush_outputs();
 
     if (a.power_partial) {
         // block reduction of the |y|^2 partials (tree; tolerance vs the sequential fold is in the tests)
-        __syncthreads();
+        phase_sync<NTK>();
         float* red = F;
         red[tid] = pw;
-        __syncthreads();
-        for (int s = NT / 2; s > 0; s >>= 1) {
+        phase_sync<NTK>();
+        for (int s = NTK / 2; s > 0; s >>= 1) {
             if (tid < s) red[tid] = red[tid] + red[tid + s];
-            __syncthreads();
+            phase_sync<NTK>();
         }
         if (tid == 0) a.power_partial[(size_t)ch * gridDim.x + blockIdx.x] = red[0];
     }
@@ -364,6 +411,7 @@ constexpr int W = P25FE_PEAK_W;
 constexpr int SPS = P25FE_SPS;
 constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
 constexpr int TB = 2048;                                     // baseband samples per tile
+constexpr int NT = 256;                                      // threads per workgroup in K2 / K4
 constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
 constexpr int BT_N = TB + HIST_BB + 3;                       // LDS baseband tile (+pad)

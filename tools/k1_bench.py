@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the kernels on random IQ (within-process A/B across env settings is done by the caller).
+usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|run] [channels=1] [fmt=cf32|u8]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from p25rx_amd.frontend import FrontEnd
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+mode = sys.argv[3] if len(sys.argv) > 3 else "k1"
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+fmt = sys.argv[5] if len(sys.argv) > 5 else "cf32"
+n = int(secs * 240000) // 8 * 8
+dev = torch.device("cuda", 0)
+if fmt == "cf32":
+    iq = torch.randn((C, n, 2), dtype=torch.float32, device=dev) * 0.3
+else:
+    iq = torch.randint(0, 256, (C, n, 2), dtype=torch.uint8, device=dev)
+fe = FrontEnd(n_channels=C)
+bb = None
+def step():
+    global bb
+    if mode == "k1":
+        bb, nb = fe.demod_dev(iq, bb=bb)
+    else:
+        fe.run_dev(iq)
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+for e0, e1 in ev:          # back-to-back launches, no host sync in between (steady-state clocks)
+    e0.record(); step(); e1.record()
+torch.cuda.synchronize()
+ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+med, mn, p90 = ts[len(ts) // 2], ts[0], ts[int(len(ts) * 0.9)]
+bps = 8.8 if fmt == "cf32" else 2.8
+tag = " ".join("%s=%s" % (k[6:], os.path.basename(v)) for k, v in sorted(os.environ.items()) if k.startswith("P25FE_"))
+print("%-6s C=%d n=%d %s [%s]: med %.4f min %.4f p90 %.4f ms -> %.1f Gsamples/s, %.0f GB/s"
+      % (mode, C, n, fmt, tag, med, mn, p90, C * n / med / 1e6, C * n * bps / med / 1e6))
