@@ -49,14 +49,13 @@ struct p25fe {
     int last_hip = 0;
     int n_cu = 256;
     Taps taps;
-    int k1_nt = 64;                        // K1 workgroup size (64: one wave per workgroup, barrier-free)
     int k1_p = 5;                          // FIR outputs per thread
     bool default_taps = true;              // taps == p25fe_spec.h tables bit for bit -> immediate-coefficient kernels
     DevBuf d_taps;                         // device copy for the generic kernels
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
     // scratch
-    DevBuf iq_stage, bb_buf, events, recs, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    DevBuf iq_stage, bb_buf, events, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
@@ -180,24 +179,20 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     h->default_taps = memcmp(&def, &h->taps, sizeof def) == 0;
     hipError_t e = hipSuccess;
     {
-        const char* ev = getenv("P25FE_K1_NT");
-        const int nt = ev ? atoi(ev) : 64;
-        h->k1_nt = (nt == 256 || nt == 128) ? nt : 64;
-        const char* pv = getenv("P25FE_K1_P");
+        const char* pv = getenv("P25FE_K1_P");            // tuning knob: FIR outputs per lane (5 default, 3)
         h->k1_p = (pv && atoi(pv) == 3) ? 3 : 5;
     }
     auto set_lds = [&](const void* f, size_t bytes) {
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     };
-#define P25FE_FOR_K1(NTK, PK)                                                                                       \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);    \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);   \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);      \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, NTK, PK>), Geo<NTK, PK>::LDS_BYTES);
-    P25FE_FOR_K1(64, 5)
-    P25FE_FOR_K1(64, 3)
-    P25FE_FOR_K1(128, 5)
-    P25FE_FOR_K1(256, 5)
+#define P25FE_FOR_K1(PK)                                                                                  \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK>), Geo<PK>::LDS_BYTES);    \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK>), Geo<PK>::LDS_BYTES);   \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK>), Geo<PK>::LDS_BYTES);      \
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK>), Geo<PK>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_scan), K3_LDS_BYTES);
+    P25FE_FOR_K1(5)
+    P25FE_FOR_K1(3)
 #undef P25FE_FOR_K1
     if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
@@ -214,7 +209,7 @@ void p25fe_destroy(p25fe_t* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->outs, &h->power_partial, &h->power_out,
+    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
                       &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
@@ -248,12 +243,12 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0, sizeof(float) * (size_t)h->C, st));
         return P25FE_OK;
     }
-    // segments: one round of resident workgroups when the range is large (LDS admits 2 x 256-thread,
-    // 4 x 128 or 8 x 64-thread workgroups per CU), so there is no tail round; P25FE_WGS_PER_CU overrides.
-    const int nt = h->k1_nt, pk = (nt == 64) ? h->k1_p : 5;
-    const long sub = (long)nt * pk;
+    // segments: one round of resident one-wave workgroups when the range is large (LDS admits 9 per CU at
+    // PK = 5, VGPRs 8), so there is no tail round; P25FE_WGS_PER_CU overrides for experiments.
+    const int pk = h->k1_p;
+    const long sub = (long)WV * pk;
     static const long wgs_env = [] { const char* e = getenv("P25FE_WGS_PER_CU"); return e ? atol(e) : 0L; }();
-    const long wgs_per_cu = wgs_env > 0 ? wgs_env : (pk == 3 ? 12 : 2 * (256 / nt));
+    const long wgs_per_cu = wgs_env > 0 ? wgs_env : (pk == 3 ? 14 : 9);     // LDS-limited residency
     const long target_wgs = (long)h->n_cu * wgs_per_cu;
     long per_ch = target_wgs / h->C;
     if (per_ch < 1) per_ch = 1;
@@ -281,21 +276,19 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     }
     dim3 grid((unsigned)n_seg, (unsigned)h->C);
     const Taps* dt = h->d_taps.as<Taps>();
-#define P25FE_LAUNCH_K1(NTK, PK)                                                                                          \
+#define P25FE_LAUNCH_K1(PK)                                                                                               \
     do {                                                                                                                  \
-        const size_t lds = Geo<NTK, PK>::LDS_BYTES;                                                                       \
+        const size_t lds = Geo<PK>::LDS_BYTES;                                                                            \
         if (fmt == P25FE_FMT_CF32) {                                                                                      \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);  \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);                 \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK>), grid, dim3(WV), lds, st, a, dt);  \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK>), grid, dim3(WV), lds, st, a, dt);                 \
         } else {                                                                                                          \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);    \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, NTK, PK>), grid, dim3(NTK), lds, st, a, dt);                   \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, PK>), grid, dim3(WV), lds, st, a, dt);    \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK>), grid, dim3(WV), lds, st, a, dt);                   \
         }                                                                                                                 \
     } while (0)
-    if (nt == 256) P25FE_LAUNCH_K1(256, 5);
-    else if (nt == 128) P25FE_LAUNCH_K1(128, 5);
-    else if (pk == 3) P25FE_LAUNCH_K1(64, 3);
-    else P25FE_LAUNCH_K1(64, 5);
+    if (pk == 3) P25FE_LAUNCH_K1(3);
+    else P25FE_LAUNCH_K1(5);
 #undef P25FE_LAUNCH_K1
     HIPCHK(h, hipGetLastError());
     if (d_power_dbm) {
@@ -312,6 +305,7 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
     const size_t n_tiles = (n_bb + TB - 1) / TB;
     HIPCHK(h, h->events.ensure(C * round_up(n_bb + 8, 16)));
     HIPCHK(h, h->recs.ensure(C * (n_tiles + 1) * sizeof(TileRec)));
+    HIPCHK(h, h->tsum.ensure(C * (n_tiles + 1) * sizeof(unsigned long long)));
     HIPCHK(h, h->outs.ensure(C * (n_tiles + 1) * sizeof(ScanOut)));
     return P25FE_OK;
 }
@@ -326,6 +320,7 @@ static int launch_sync(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n
     s.events = h->events.as<uint8_t>();
     s.ev_stride = (long)round_up(n_bb + 8, 16);
     s.recs = h->recs.as<TileRec>();
+    s.tsum = h->tsum.as<unsigned long long>();
     hipLaunchKernelGGL(k_sync, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, s);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
@@ -338,16 +333,16 @@ static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, si
 {
     const size_t n_tiles = (n_bb + TB - 1) / TB;
     ScanArgs c;
-    c.recs = h->recs.as<TileRec>(); c.outs = h->outs.as<ScanOut>(); c.n_tiles = (int)n_tiles; c.n = (long)n_bb;
+    c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>(); c.n_tiles = (int)n_tiles; c.n = (long)n_bb;
     c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result; c.n_baseband = n_bb;
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)h->C), dim3(1024), 0, st, c);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)h->C), dim3(NT3), K3_LDS_BYTES, st, c);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 3, st);
     if (!do_slice) { prof_mark(h, 4, st); return P25FE_OK; }
     SliceArgs l;
     l.bb = d_bb; l.bb_stride = (long)bb_stride; l.n_hist = (long)n_hist_bb; l.n = (long)n_bb; l.abs0 = (long)abs_bb0;
     l.n_tiles = (int)n_tiles; l.events = h->events.as<uint8_t>(); l.ev_stride = (long)round_up(n_bb + 8, 16);
-    l.outs = h->outs.as<ScanOut>(); l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
+    l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.anchor_in = d_anchor_in; l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
     hipLaunchKernelGGL(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, l);

@@ -22,33 +22,31 @@
 namespace p25k {
 
 // ------------------------------------------------------------------------------------------
-// geometry of K1, parametrised by the workgroup size NTK (64 = one wave per workgroup: no
-// s_barrier at all, eight independent waves per CU interleave their phases freely)
+// geometry of K1.  A workgroup is ONE wave (64 lanes): no s_barrier anywhere, and the CU's resident
+// waves (2-3 per SIMD) run their load / FIR / FM phases out of step with each other, which is what
+// overlaps HBM latency, LDS traffic and VALU work.
 // ------------------------------------------------------------------------------------------
+constexpr int WV = 64;                       // lanes per workgroup
 constexpr int DEC = P25FE_DECIM;
 constexpr int T1 = P25FE_T1;
 constexpr int T2 = P25FE_T2;
 constexpr int BOX = P25FE_BOXCAR;
 constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9])
 constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50
-constexpr int F_CARRY = 12;                  // fm carry (9 used)
-constexpr int Y_CARRY = 2;                   // y carry (1 used), keeps 16-B alignment
-constexpr int D_CARRY = T2 - 1;              // d carry
+constexpr int D_CARRY = T2 - 1;              // d carried between sub-tiles
 // history (input samples before the first owned one) needed for exact results
 constexpr int HIST_IQ = DEC * HALO_D + (T1 - 1) + (DEC - 1);   // 284
 
-// PK = consecutive FIR outputs per thread (odd: lane stride 2*5*PK / 2*PK dwords -> conflict-free ds_read_b64)
-template <int NTK, int PK> struct Geo {
-    static constexpr int NT = NTK;
+// PK = consecutive FIR outputs per lane (odd: lane stride 2*5*PK / 2*PK dwords -> conflict-free ds_read_b64)
+template <int PK> struct Geo {
     static constexpr int P = PK;
-    static constexpr int SUB = NTK * PK;                  // decimated samples per sub-tile
+    static constexpr int SUB = WV * PK;                   // decimated samples per sub-tile (320 for PK = 5)
     static constexpr int XWIN = DEC * SUB + (T1 - DEC);   // input samples feeding one sub-tile of d
     static constexpr int XIN_N = 8 + (XWIN + 8 + 7) / 8 * 8;   // 8 spare entries in front + window + loader slack
     static constexpr int D_N = D_CARRY + SUB;
-    static constexpr int Y_N = Y_CARRY + SUB;
-    static constexpr int F_N = F_CARRY + SUB;
-    static constexpr size_t LDS_BYTES = sizeof(float2) * (XIN_N + D_N + Y_N) + sizeof(float) * (F_N + T1 + T2 + 3);
-    static constexpr int WAVES_PER_SIMD = PK <= 3 ? 3 : 2;   // register budget the kernel is compiled for
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (XIN_N + D_N) + sizeof(float) * (SUB + T1 + T2 + 3);
+    static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
+    static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 3;   // register budget the kernel is compiled for (128 / 168 VGPRs)
 };
 
 struct Taps {
@@ -90,13 +88,29 @@ __device__ __forceinline__ float fm_discriminate(float2 s, float2 prev)
 // ds_read_b64 (MI355X_MICROARCH.md LDS table: 8 vs 2+2 cycles per wave-instruction).
 __device__ __forceinline__ float2 lds_read_c(const float2* p)
 {
-#ifdef P25FE_LDS_READ2
-    return *p;
-#else
     typedef const volatile unsigned long long __attribute__((address_space(3))) * lds_u64_ptr;
     const unsigned long long u = *((lds_u64_ptr)p);                 // generic -> LDS address space: stays a DS op
     return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-#endif
+}
+
+// Value held by lane-1 of the wave; lane 0 receives `lane0` (DPP wave_shr:1 -- one VALU op, no LDS).
+__device__ __forceinline__ float wave_shr1(float v, float lane0)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+// Wave-uniform copy of lane L's value (v_readlane_b32 -> SGPR).
+template <int L> __device__ __forceinline__ float lane_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L));
+}
+
+// Phase boundary inside the one-wave workgroup: LDS operations of one wave execute in order, so only
+// the compiler has to be kept from moving accesses across the boundary.
+__device__ __forceinline__ void phase_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // SPEC 3.1: rtlsdr_iq LUT value as arithmetic (src/demod.rs:82-84)
@@ -113,44 +127,48 @@ __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((
 // for straddling vectors; two paths writing the same VGPRs made the compiler put
 // s_waitcnt vmcnt(0) in front of every load, serialising 13 HBM round trips per sub-tile.)
 // ------------------------------------------------------------------------------------------
-template <int FMT, int NTK, int PK> struct Loader {
-    using G = Geo<NTK, PK>;
+template <int FMT, int PK> struct Loader {
+    using G = Geo<PK>;
     static constexpr int LOG_SPV = FMT == P25FE_FMT_CF32 ? 1 : 3;   // samples per 16-B vector: 2 (cf32) or 8 (u8 pairs)
     static constexpr int SPV = 1 << LOG_SPV;
-    static constexpr int NV = (G::XWIN + SPV + SPV * NTK - 1) / (SPV * NTK);   // vectors per thread: 13 / 4
+    static constexpr int NV = (G::XWIN + SPV + SPV * WV - 1) / (SPV * WV);   // vectors per lane: 13 / 4 for PK = 5
     uint4 v[NV];
 
-    // base: pointer to owned sample 0 of this channel; first: index of the first window sample
+    // base: pointer to owned sample 0 of this channel; first: index of the first window sample;
     // i_last: last sample index this workgroup will ever need (loads past it collapse onto one cached vector)
     __device__ __forceinline__ void load(const void* base, long first, long n_hist, long n_new, long i_last, int tid)
     {
-        const uint4* p = reinterpret_cast<const uint4*>(base);
-        const long vfirst = (first >> LOG_SPV) + tid;               // floor division (arithmetic shift)
-        const long vlo = (-n_hist) >> LOG_SPV;                      // vector holding sample -n_hist
+        const long v0 = first >> LOG_SPV;                           // floor division (arithmetic shift), uniform
+        const uint4* q = reinterpret_cast<const uint4*>(base) + v0; // uniform base of the window
         const long last = i_last < n_new - 1 ? i_last : n_new - 1;
-        const long vhi = last >> LOG_SPV;                           // vector holding the last useful sample
+        // clamp range relative to the window, saturated to 32 bits: one v_med3_i32 per vector
+        long lo = ((-n_hist) >> LOG_SPV) - v0;                      // vector holding sample -n_hist
+        long hi = (last >> LOG_SPV) - v0;                           // vector holding the last useful sample
+        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
+        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
+        const int lo32 = (int)lo, hi32 = (int)hi;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            long vi = vfirst + (long)j * NTK;
-            vi = vi < vlo ? vlo : vi;
-            vi = vi > vhi ? vhi : vi;
-            v[j] = p[vi];
+            int r = tid + j * WV;
+            r = r < lo32 ? lo32 : r;
+            r = r > hi32 ? hi32 : r;
+            v[j] = q[r];
         }
     }
 
-    // XIN[k] must hold sample first + k; vector j of thread tid holds samples SPV * (vfirst + j * NTK) + e
+    // XIN[k] must hold sample first + k; vector j of lane tid holds samples SPV * (vfirst + j * WV) + e
     __device__ __forceinline__ void store(float2* XIN, long first, long n_hist, long n_new, int tid) const
     {
         const long first_al = (first >> LOG_SPV) << LOG_SPV;
         const int sh = (int)(first - first_al);                     // 0 .. SPV-1
-        float2* XS = XIN - sh;                                      // XIN is preceded by SPV spare entries
-        const bool interior = first_al >= -n_hist && first_al + (long)NV * SPV * NTK <= n_new;   // uniform
+        float2* XS = XIN - sh;                                      // XIN is preceded by 8 spare entries
+        const bool interior = first_al >= -n_hist && first_al + (long)NV * SPV * WV <= n_new;   // uniform
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
             for (int e = 0; e < SPV; ++e) {
-                const int k = SPV * (tid + j * NTK) + e;             // always inside the XIN allocation
+                const int k = SPV * (tid + j * WV) + e;
                 float2 s;
                 if (FMT == P25FE_FMT_CF32) {
                     s = make_float2(__uint_as_float(w[2 * (e & 1)]), __uint_as_float(w[2 * (e & 1) + 1]));
@@ -159,7 +177,7 @@ template <int FMT, int NTK, int PK> struct Loader {
                     s = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
                 }
                 if (!interior) {
-                    const long i = first_al + SPV * (long)(tid + j * NTK) + e;
+                    const long i = first_al + SPV * (long)(tid + j * WV) + e;
                     if (i < -n_hist || i >= n_new) s = make_float2(0.f, 0.f);
                 }
                 // only the last round of vectors can run past the window: everything else is stored unconditionally
@@ -170,10 +188,16 @@ template <int FMT, int NTK, int PK> struct Loader {
 };
 
 // ------------------------------------------------------------------------------------------
-// K1: fused front end.  One workgroup walks `subs_per_seg` consecutive sub-tiles of one channel;
-// FIR / FM / boxcar context is carried in LDS between sub-tiles, so the (T2-1)+10 sample halo is
-// recomputed once per segment only.  The next sub-tile's input window is prefetched into
-// registers while the current one is processed.
+// K1: fused front end.  One wave walks `subs_per_seg` consecutive sub-tiles of one channel.
+//   * the next sub-tile's input window is prefetched into registers while the current one is
+//     processed; it reaches LDS (time-linear cf32) at the top of the next iteration;
+//   * both FIRs are register-tiled: a lane computes PK consecutive outputs from one sliding
+//     window of ds_read_b64 (tap order and single accumulator as SPEC 3.2 prescribes);
+//   * FM discriminator and boxcar never touch LDS: a lane has its own PK channel outputs in
+//     registers and gets its left neighbours' values with DPP wave_shr:1; what crosses a sub-tile
+//     boundary is carried in SGPRs (v_readlane of lanes 63, 62, ...);
+//   * the d history ((T2-1) samples) is carried in LDS, so the filter halo is recomputed once
+//     per segment only.
 //
 // Local indexing: owned input sample i in [0, n_new); output m' in [0, n_out) is produced by
 // input i = o0 + 5 m' (o0 = first decimation instant inside the owned range, SPEC 3.2).
@@ -192,38 +216,24 @@ struct K1Args {
     float* power_partial;   // nullable: [n_channels][gridDim.x] partial sums of |y|^2
 };
 
-// Phase boundary inside a workgroup.  With NTK == 64 the workgroup is one wave: LDS operations of
-// one wave execute in order, so only the compiler must be kept from reordering across the
-// boundary and the hardware barrier disappears.
-template <int NTK> __device__ __forceinline__ void phase_sync()
-{
-    if (NTK > 64) {
-        __syncthreads();
-    } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
 // registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
-template <int FMT, bool CT, int NTK, int PK>
-__global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+template <int FMT, bool CT, int PK>
+__global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
-    using G = Geo<NTK, PK>;
+    using G = Geo<PK>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
+    constexpr int NBACK = G::NBACK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* XIN = reinterpret_cast<float2*>(smem) + 8;              // 8 spare entries in front (loader shift)
-    float2* D = reinterpret_cast<float2*>(smem) + G::XIN_N;
-    float2* Y = D + G::D_N;
-    float* F = reinterpret_cast<float*>(Y + G::Y_N);
-    float* TAPS = F + G::F_N;                                       // [T1 | T2], only when !CT
+    float2* D = reinterpret_cast<float2*>(smem) + G::XIN_N;        // [D_CARRY | SUB]
+    float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose
+    float* TAPS = OUT + SUB;                                        // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
     if (!CT) {
-        for (int k = tid; k < T1; k += NTK) TAPS[k] = gtaps->dec[k];
-        for (int k = tid; k < T2; k += NTK) TAPS[T1 + k] = gtaps->ch[k];
+        for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
+        for (int k = tid; k < T2; k += WV) TAPS[T1 + k] = gtaps->ch[k];
     }
     auto tap_dec = [&](int k) -> float { return CT ? P25FE_DEFAULT_DECIM_TAPS[k] : TAPS[k]; };
     auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
@@ -236,16 +246,24 @@ __global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_fronten
     const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)ch * a.ch_stride * (FMT == P25FE_FMT_CF32 ? 8 : 2);
     float* bb = a.bb + (size_t)ch * a.bb_stride;
 
-    // zero the carries (their garbage would only reach never-stored outputs, but keep it tidy)
-    for (int k = tid; k < D_CARRY; k += NTK) D[k] = make_float2(0.f, 0.f);
-    if (tid < Y_CARRY) Y[tid] = make_float2(0.f, 0.f);
-    if (tid < F_CARRY) F[tid] = 0.f;
+    // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
+    for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
 
-    Loader<FMT, NTK, PK> ld;
+    Loader<FMT, PK> ld;
     long dlo = m_seg0 - HALO_D;                                    // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
     ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid);
     float pw = 0.f;
+
+    // context carried across sub-tiles in wave-uniform registers: the last channel output and the
+    // fm values of the last NBACK lanes of the previous sub-tile
+    float2 y_carry = make_float2(0.f, 0.f);
+    float f_carry[NBACK][P];
+#pragma unroll
+    for (int b = 0; b < NBACK; ++b)
+#pragma unroll
+        for (int p = 0; p < P; ++p) f_carry[b][p] = 0.f;
+
     // Outputs are kept in registers for one sub-tile and stored at the top of the next one, BEFORE the
     // prefetch loads are issued: vmcnt counts loads and stores in one in-order queue, so stores issued
     // after the prefetch would force the wait at the top of the loop to drain them too (measured: the
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_fronten
     auto flush_outputs = [&]() {
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const long m = out_lo + tid + q * NTK;
+            const long m = out_lo + tid + q * WV;
             if (m >= m_seg0 && m < m_seg1) bb[m] = outv[q];
         }
     };
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_fronten
         if (dlo >= m_seg1) break;                                  // uniform
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[k] = x[first + k]
         ld.store(XIN, first, a.n_hist, a.n_new, tid);
-        phase_sync<NTK>();
+        phase_sync();
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
         ld.load(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid);
@@ -274,8 +292,8 @@ __global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_fronten
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
         continue;
 #endif
-        // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Thread: d[dlo + 5 tid + p], p = 0..4.
-        // Output p needs x[first + 5(5 tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[25 tid + 5p + 30 - k].
+        // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Lane: d[dlo + P tid + p], p = 0..P-1.
+        // Output p needs x[first + 5(P tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[5 P tid + 5p + 30 - k].
         {
             const float2* w = XIN + (DEC * P) * tid;
             float2 acc[P];
@@ -296,17 +314,17 @@ __global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_fronten
 #pragma unroll
             for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = acc[p];
         }
-        phase_sync<NTK>();
+        phase_sync();
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
         continue;
 #endif
-        // ---- stage 3: channel FIR (src/demod.rs:93). Thread: y[dlo + 5 tid + p] from D[5 tid + p + 40 - k].
+        // ---- stage 3: channel FIR (src/demod.rs:93). Lane: y[dlo + P tid + p] from D[P tid + p + 40 - k].
+        float2 y[P];
         {
             const float2* w = D + P * tid;
-            float2 acc[P];
 #pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = make_float2(0.f, 0.f);
+            for (int p = 0; p < P; ++p) y[p] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int j = (P - 1) + T2 - 1; j >= 0; --j) {
                 const float2 s = lds_read_c(w + j);
@@ -314,69 +332,94 @@ __global__ __launch_bounds__(NTK, (Geo<NTK, PK>::WAVES_PER_SIMD)) void k_fronten
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
                     if (k >= 0 && k < T2) {
-                        acc[p].x = __builtin_fmaf(tap_ch(k), s.x, acc[p].x);
-                        acc[p].y = __builtin_fmaf(tap_ch(k), s.y, acc[p].y);
+                        y[p].x = __builtin_fmaf(tap_ch(k), s.x, y[p].x);
+                        y[p].y = __builtin_fmaf(tap_ch(k), s.y, y[p].y);
                     }
                 }
             }
+            if (a.power_partial) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                Y[Y_CARRY + P * tid + p] = acc[p];
-                const long m = dlo + P * tid + p;
-                if (a.power_partial && m >= m_seg0 && m < m_seg1 && m >= 0) {
-                    const float q0 = acc[p].x * acc[p].x, q1 = acc[p].y * acc[p].y;
-                    pw = pw + (q0 + q1);
+                for (int p = 0; p < P; ++p) {
+                    const long m = dlo + P * tid + p;
+                    if (m >= m_seg0 && m < m_seg1 && m >= 0) {
+                        const float q0 = y[p].x * y[p].x, q1 = y[p].y * y[p].y;
+                        pw = pw + (q0 + q1);
+                    }
                 }
             }
         }
-        phase_sync<NTK>();
+        phase_sync();                                               // all reads of D done before its carry is rewritten
+        // carry the d history to the next sub-tile (ordered before its next use by the next phase boundaries)
+        for (int k = tid; k < D_CARRY; k += WV) D[k] = D[SUB + k];
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 3
         continue;
 #endif
-        // ---- stage 4: FM discriminator (src/demod.rs:109-111), one output per thread per pass
+        // ---- stage 4: FM discriminator (src/demod.rs:109-111) on the lane's own P outputs; the sample before
+        // the first one comes from lane-1 (DPP), for lane 0 from the previous sub-tile (SGPR carry)
+        float f[P];
+        {
+            float2 yprev;
+            yprev.x = wave_shr1(y[P - 1].x, y_carry.x);
+            yprev.y = wave_shr1(y[P - 1].y, y_carry.y);
+            f[0] = fm_discriminate(y[0], yprev);
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = tid + q * NTK;
-            F[F_CARRY + i] = fm_discriminate(Y[Y_CARRY + i], Y[Y_CARRY + i - 1]);
+            for (int p = 1; p < P; ++p) f[p] = fm_discriminate(y[p], y[p - 1]);
+            y_carry.x = lane_bcast<WV - 1>(y[P - 1].x);
+            y_carry.y = lane_bcast<WV - 1>(y[P - 1].y);
         }
-        phase_sync<NTK>();
 
-    #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
+#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
+        asm volatile("" ::"v"(f[0]), "v"(f[P - 1]));
         continue;
 #endif
-        // ---- stage 5: boxcar (src/demod.rs:114); lane-consecutive outputs -> coalesced stores (deferred)
+        // ---- stage 5: boxcar (src/demod.rs:114): b[m] = (fm[m] + fm[m-1] + ... + fm[m-9]) / 10, newest first.
+        // fm[P tid + p - j] lives in this lane (q = p - j >= 0) or in lane - b, b = ceil(-q / P): prevf[b-1][q + b P].
+        {
+            float prevf[NBACK][P];
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int i = tid + q * NTK;
-            const float* f = F + F_CARRY + i;
-            float acc = f[0];
+            for (int p = 0; p < P; ++p) prevf[0][p] = wave_shr1(f[p], f_carry[0][p]);
 #pragma unroll
-            for (int j = 1; j < BOX; ++j) acc = acc + f[-j];
-            outv[q] = acc * P25FE_BOXCAR_SCALE;
+            for (int b = 1; b < NBACK; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p) prevf[b][p] = wave_shr1(prevf[b - 1][p], f_carry[b][p]);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float acc = f[p];
+#pragma unroll
+                for (int j = 1; j < BOX; ++j) {
+                    const int q = p - j;
+                    if (q >= 0) {
+                        acc = acc + f[q];
+                    } else {
+                        const int b = (-q + P - 1) / P;             // 1 .. NBACK
+                        acc = acc + prevf[b - 1][q + b * P];
+                    }
+                }
+                OUT[P * tid + p] = acc * P25FE_BOXCAR_SCALE;        // lane stride P dwords (odd): conflict-free
+            }
+            // next sub-tile's lane 0 / 1 / ... read these: lane 63 is one lane back, lane 62 two, ...
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (NBACK >= 3) f_carry[2][p] = lane_bcast<WV - 3>(f[p]);
+                if (NBACK >= 2) f_carry[1][p] = lane_bcast<WV - 2>(f[p]);
+                f_carry[0][p] = lane_bcast<WV - 1>(f[p]);
+            }
         }
+        phase_sync();
+        // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
+#pragma unroll
+        for (int q = 0; q < P; ++q) outv[q] = OUT[tid + q * WV];
         out_lo = dlo;
-        phase_sync<NTK>();
-
-        // ---- carry context to the next sub-tile
-        for (int k = tid; k < D_CARRY; k += NTK) D[k] = D[SUB + k];
-        if (tid < Y_CARRY) Y[tid] = Y[SUB + tid];
-        if (tid < F_CARRY) F[tid] = F[SUB + tid];
-        // ordered before their next use by the phase boundary that follows the next XIN store
+        phase_sync();
     }
     flush_outputs();
 
     if (a.power_partial) {
-        // block reduction of the |y|^2 partials (tree; tolerance vs the sequential fold is in the tests)
-        phase_sync<NTK>();
-        float* red = F;
-        red[tid] = pw;
-        phase_sync<NTK>();
-        for (int s = NTK / 2; s > 0; s >>= 1) {
-            if (tid < s) red[tid] = red[tid] + red[tid + s];
-            phase_sync<NTK>();
-        }
-        if (tid == 0) a.power_partial[(size_t)ch * gridDim.x + blockIdx.x] = red[0];
+        // wave reduction of the |y|^2 partials (tree; tolerance vs the sequential fold is in the tests)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) pw = pw + __shfl_down(pw, d, 64);
+        if (tid == 0) a.power_partial[(size_t)ch * gridDim.x + blockIdx.x] = pw;
     }
 }
 
@@ -414,7 +457,8 @@ constexpr int TB = 2048;                                     // baseband samples
 constexpr int NT = 256;                                      // threads per workgroup in K2 / K4
 constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
-constexpr int BT_N = TB + HIST_BB + 3;                       // LDS baseband tile (+pad)
+constexpr int CQ = 9;                                        // symbol-spaced correlation outputs per thread (K2)
+constexpr int BT_N = 10 * CQ * 25 + 10 * (CQ + 23) + 16;     // LDS baseband tile incl. the register-tiling overrun (2586)
 constexpr int CT_N = TB + 2 * W + 2;                         // c[] for s in [a-2W-1, a+TB-W-1) plus peak lookahead
 
 struct TileRec {            // per (channel, tile) summary written by K2
@@ -425,12 +469,19 @@ struct TileRec {            // per (channel, tile) summary written by K2
     long post_count;        // instants in (first_event, tile_end) under the tile's own events
 };
 
+// Packed per-tile summary for the scan (one coalesced 8-byte word per tile):
+//   bits  0..11  first_off + 1   (0: the tile has no event)      bits 12..23  last_off + 1
+//   bits 24..35  n_events                                          bits 36..47  post_count
+__host__ __device__ inline unsigned long long pack_tsum(int first_off, int last_off, int n_events, int post_count)
+{
+    return (unsigned long long)(first_off + 1) | ((unsigned long long)(last_off + 1) << 12) |
+           ((unsigned long long)n_events << 24) | ((unsigned long long)post_count << 36);
+}
+
 struct ScanOut {            // per (channel, tile) carry-in written by K3
-    long anchor_s;
-    float hi, mid, lo;
-    int valid;
+    int src;                        // tile whose last event is this tile's carry-in anchor; -1: the range's anchor_in
+    unsigned event_off;             // events of the range before this tile
     unsigned long long dibit_off;   // dibits of the range before this tile
-    unsigned long long event_off;   // events of the range before this tile
 };
 
 __device__ __forceinline__ float bb_at(const float* bbp, long n_hist, long n, long i)
@@ -524,6 +575,7 @@ struct SyncArgs {
     uint8_t* events;        // [ch][n] event flags (e-indexed)
     long ev_stride;
     TileRec* recs;          // [ch][n_tiles]
+    unsigned long long* tsum;   // [ch][n_tiles] packed summaries for K3
 };
 
 // K2: correlate, peak-pick, flag events, summarise the tile.
@@ -543,19 +595,31 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     for (int k = tid; k < BT_N; k += NT) BT[k] = bb_at(bbp, a.n_hist, a.n, t0 - HIST_BB + k);
     __syncthreads();
 
-    // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s]
-    for (int k = tid; k < TB + 2 * W; k += NT) {
-        // s = t0 - 2W + k  ->  BT index of b[s] = s - (t0 - HIST_BB) = k + HIST_BB - 2W = k + SYNC_SPAN
-        const int is = k + SYNC_SPAN;
-        float c = 0.f, e = 0.f;
+    // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s] = BT[k + 10 j], j = 0..23.
+    // Register tiling over symbol-spaced positions: a thread takes one sample phase r = k % 10 and CQ
+    // consecutive symbol slots, so its CQ outputs share a sliding window of CQ + 23 LDS reads (3.6 reads per
+    // output instead of 24); each output keeps its own accumulators in tap order j = 0..23 (SPEC 3.6).
+    if (tid < 250) {
+        const int r = tid % SPS, qb = tid / SPS;
+        const int base = SPS * CQ * qb + r;                     // k of the thread's first output
+        float w[CQ + P25FE_SYNC_DIBITS - 1];
 #pragma unroll
-        for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-            const float v = BT[is - SPS * (P25FE_SYNC_DIBITS - 1 - j)];
-            c = ((P25FE_SYNC_SIGN_MASK >> j) & 1u) ? c + v : c - v;
-            e = __builtin_fmaf(v, v, e);
+        for (int m = 0; m < CQ + P25FE_SYNC_DIBITS - 1; ++m) w[m] = BT[base + SPS * m];
+#pragma unroll
+        for (int i = 0; i < CQ; ++i) {
+            const int k = base + SPS * i;
+            float c = 0.f, e = 0.f;
+#pragma unroll
+            for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
+                const float v = w[i + j];
+                c = ((P25FE_SYNC_SIGN_MASK >> j) & 1u) ? c + v : c - v;
+                e = __builtin_fmaf(v, v, e);
+            }
+            if (k < TB + 2 * W) {
+                CT[k] = c;
+                CAND[k] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
+            }
         }
-        CT[k] = c;
-        CAND[k] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
     }
     __syncthreads();
 
@@ -596,17 +660,17 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
 
     // latest own event before each thread's first sample, then count instants under own events
     const long incoming = block_excl_max(my_last, shl, tid);
-    long cur = incoming;        // local e-position of the governing event, -1: carry-in (unknown here)
+    int cur = incoming >= 0 ? (int)(incoming - t0) : -1;   // tile-local index of the governing event, -1: carry-in (unknown here)
     int cnt = 0;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
-        if (i < tn) {
+        if (i < (int)tn) {
             if (cur >= 0) {                             // events decided BEFORE this sample govern it
-                const long s = cur - W;                 // local index of the anchor
-                if ((t0 + i - s) % SPS == 0) ++cnt;     // t0 + i > s always
+                const unsigned dist = (unsigned)(i - (cur - W));   // > 0: distance to the anchor
+                if (dist % (unsigned)SPS == 0u) ++cnt;
             }
-            if (evl[u]) cur = t0 + i;
+            if (evl[u]) cur = i;
         }
     }
     int total_cnt, total_ev;
@@ -637,11 +701,14 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
             r.last_s = s + a.abs0; r.hi = hi; r.mid = mid; r.lo = lo;
         }
         a.recs[(size_t)ch * a.n_tiles + tile] = r;
+        a.tsum[(size_t)ch * a.n_tiles + tile] =
+            first_ev >= 0 ? pack_tsum((int)(first_ev - t0), (int)(last_ev - t0), total_ev, total_cnt) : 0ull;
     }
 }
 
 struct ScanArgs {
     const TileRec* recs;
+    const unsigned long long* tsum;
     ScanOut* outs;
     int n_tiles;
     long n;                 // owned samples per channel
@@ -651,98 +718,188 @@ struct ScanArgs {
     unsigned long long n_baseband;      // to report
 };
 
-// K3: one workgroup per channel.  Exclusive "latest anchor" scan over tiles, then dibit/event offsets.
-__global__ __launch_bounds__(1024) void k_scan(ScanArgs a)
+constexpr int NT3 = 1024;
+
+// 1024-thread inclusive scans: wave shuffles, then the 16 wave totals through LDS.
+__device__ __forceinline__ long block_incl_max1024(long v, long* sh, int tid, long& total)
 {
-    __shared__ long sh_src[1024];
-    __shared__ unsigned long long sh_cnt[1024];
-    __shared__ unsigned long long sh_ev[1024];
+    const int lane = tid & 63, wv = tid >> 6;
+    long inc = wave_incl_max(v, lane);
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    long carry = -1, tot = -1;
+#pragma unroll
+    for (int k = 0; k < NT3 / 64; ++k) {
+        const long t = sh[k];
+        if (k < wv) carry = t > carry ? t : carry;
+        tot = t > tot ? t : tot;
+    }
+    __syncthreads();
+    total = tot;
+    return inc > carry ? inc : carry;
+}
+__device__ __forceinline__ unsigned long long wave_incl_sum64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long block_incl_sum1024(unsigned long long v, unsigned long long* sh, int tid,
+                                                                  unsigned long long& total)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long inc = wave_incl_sum64(v, lane);
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    unsigned long long carry = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT3 / 64; ++k) {
+        const unsigned long long t = sh[k];
+        if (k < wv) carry += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return inc + carry;
+}
+
+constexpr int K3_CHUNK = 16384;                                  // tiles staged in LDS at a time (128 KB)
+constexpr size_t K3_LDS_BYTES = sizeof(unsigned long long) * K3_CHUNK;
+
+// K3: one workgroup per channel.  The packed tile summaries are staged in LDS (coalesced loads, all in
+// flight at once); every thread then walks a contiguous run of tiles, with two block scans per chunk
+// (latest event tile; dibit / event counts).  Chunks carry (anchor, counts) forward in registers.
+__global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    unsigned long long* TS = reinterpret_cast<unsigned long long*>(smem3);
+    __shared__ long shl[NT3 / 64];
+    __shared__ unsigned long long shu[NT3 / 64];
+    __shared__ unsigned long long first_info[2];      // [0] = first event tile + 1, [1] = dibits before its first event
+    __shared__ long excl_tmp[NT3 / 64];
     const int tid = threadIdx.x, ch = blockIdx.x;
     const TileRec* recs = a.recs + (size_t)ch * a.n_tiles;
+    const unsigned long long* tsum = a.tsum + (size_t)ch * a.n_tiles;
     ScanOut* outs = a.outs + (size_t)ch * a.n_tiles;
-    const int per = (a.n_tiles + 1023) / 1024;
-    const int i0 = tid * per, i1 = (i0 + per < a.n_tiles) ? i0 + per : a.n_tiles;
-
-    // pass A: index of the latest tile with an event, exclusive over tiles
-    long last = -1;
-    for (int i = i0; i < i1; ++i) if (recs[i].first_event >= 0) last = i;
-    sh_src[tid] = last;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {               // Hillis-Steele inclusive max
-        long v = sh_src[tid];
-        if (tid >= d) { const long o = sh_src[tid - d]; v = o > v ? o : v; }
-        __syncthreads();
-        sh_src[tid] = v;
-        __syncthreads();
-    }
-    long src = tid > 0 ? sh_src[tid - 1] : -1;         // latest event tile before my chunk
     p25fe_anchor_t ain;
     ain.valid = 0; ain.s = 0; ain.hi = ain.mid = ain.lo = 0.f;
     if (a.anchor_in) ain = a.anchor_in[ch];
+    if (tid == 0) { first_info[0] = 0; first_info[1] = 0; }
 
-    // pass B: per-tile carry-in anchor and counts
-    unsigned long long my_cnt = 0, my_ev = 0;
-    for (int i = i0; i < i1; ++i) {
-        ScanOut o;
-        if (src >= 0) { o.valid = 1; o.anchor_s = recs[src].last_s; o.hi = recs[src].hi; o.mid = recs[src].mid; o.lo = recs[src].lo; }
-        else { o.valid = ain.valid; o.anchor_s = ain.s; o.hi = ain.hi; o.mid = ain.mid; o.lo = ain.lo; }
-        const long tlo = a.abs0 + (long)i * TB;
-        long thi = tlo + TB;
-        if (thi > a.abs0 + a.n) thi = a.abs0 + a.n;
-        const long pre_hi = recs[i].first_event >= 0 ? recs[i].first_event + 1 : thi;   // instant AT e is still the old anchor's
-        const unsigned long long pre = o.valid ? (unsigned long long)count_instants(o.anchor_s, tlo, pre_hi) : 0ull;
-        o.dibit_off = my_cnt;          // relative to my chunk for now
-        o.event_off = my_ev;
-        outs[i] = o;
-        my_cnt += pre + (unsigned long long)recs[i].post_count;
-        my_ev += (unsigned long long)recs[i].n_events;
-        if (recs[i].first_event >= 0) src = i;
+    // uniform carries across chunks
+    long carry_src = -1;                       // latest event tile so far (absolute tile index)
+    long carry_s = ain.s;                      // its anchor position
+    bool carry_valid = ain.valid != 0;
+    unsigned long long carry_cnt = 0, carry_ev = 0;
+
+    for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
+        const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
+        __syncthreads();
+        for (int k = tid; k < cn; k += NT3) TS[k] = tsum[c0 + k];
+        __syncthreads();
+        const int per = (cn + NT3 - 1) / NT3;
+        const int k0 = tid * per, k1 = (k0 + per < cn) ? k0 + per : cn;
+
+        // pass 1: latest event tile inside my run -> block exclusive max
+        long last = -1;
+        for (int k = k0; k < k1; ++k) if (TS[k] & 0xfffu) last = k;
+        long tot_max;
+        const long incl = block_incl_max1024(last, shl, tid, tot_max);
+        long excl = __shfl_up(incl, 1, 64);
+        if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
+        __syncthreads();
+        if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
+        __syncthreads();
+
+        // pass 2: counts of my run under the running anchor
+        auto anchor_of = [&](long src, long& s_out, bool& v_out) {   // src: chunk-local tile index or -1
+            if (src >= 0) {
+                s_out = a.abs0 + (long)(c0 + src) * TB + (long)((TS[src] >> 12) & 0xfffu) - 1 - W;
+                v_out = true;
+            } else {
+                s_out = carry_s;
+                v_out = carry_valid;
+            }
+        };
+        auto pre_of = [&](int k, unsigned long long u, long s, bool v) -> unsigned long long {
+            const long tlo = a.abs0 + (long)(c0 + k) * TB;
+            long thi = tlo + TB;
+            if (thi > a.abs0 + a.n) thi = a.abs0 + a.n;
+            const int first1 = (int)(u & 0xfffu);
+            const long pre_hi = first1 ? tlo + first1 : thi;        // instant AT the event index is still the old anchor's
+            return v ? (unsigned long long)count_instants(s, tlo, pre_hi) : 0ull;
+        };
+        unsigned long long my_cnt = 0, my_ev = 0;
+        {
+            long src = excl;
+            for (int k = k0; k < k1; ++k) {
+                const unsigned long long u = TS[k];
+                long s; bool v;
+                anchor_of(src, s, v);
+                my_cnt += pre_of(k, u, s, v) + ((u >> 36) & 0xfffu);
+                my_ev += (u >> 24) & 0xfffu;
+                if (u & 0xfffu) src = k;
+            }
+        }
+        unsigned long long tot_cnt, tot_ev;
+        const unsigned long long icnt = block_incl_sum1024(my_cnt, shu, tid, tot_cnt);
+        const unsigned long long iev = block_incl_sum1024(my_ev, shu, tid, tot_ev);
+
+        // pass 3: write the per-tile carry-ins
+        {
+            long src = excl;
+            unsigned long long dc = carry_cnt + icnt - my_cnt, ec = carry_ev + iev - my_ev;
+            for (int k = k0; k < k1; ++k) {
+                const unsigned long long u = TS[k];
+                long s; bool v;
+                anchor_of(src, s, v);
+                const unsigned long long pre = pre_of(k, u, s, v);
+                ScanOut o;
+                o.src = src >= 0 ? (int)(c0 + src) : (int)carry_src;
+                o.event_off = (unsigned)ec;
+                o.dibit_off = dc;
+                outs[c0 + k] = o;
+                if ((u & 0xfffu) && src < 0 && carry_src < 0) {    // the range's first event
+                    first_info[0] = (unsigned long long)(c0 + k) + 1;
+                    first_info[1] = dc + pre;
+                }
+                dc += pre + ((u >> 36) & 0xfffu);
+                ec += (u >> 24) & 0xfffu;
+                if (u & 0xfffu) src = k;
+            }
+        }
+        // carries for the next chunk (uniform: every thread computes the same values)
+        if (tot_max >= 0) {
+            carry_s = a.abs0 + (long)(c0 + tot_max) * TB + (long)((TS[tot_max] >> 12) & 0xfffu) - 1 - W;
+            carry_valid = true;
+            carry_src = c0 + tot_max;
+        }
+        carry_cnt += tot_cnt;
+        carry_ev += tot_ev;
     }
-    sh_cnt[tid] = my_cnt;
-    sh_ev[tid] = my_ev;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        unsigned long long v = sh_cnt[tid], w = sh_ev[tid];
-        if (tid >= d) { v += sh_cnt[tid - d]; w += sh_ev[tid - d]; }
-        __syncthreads();
-        sh_cnt[tid] = v; sh_ev[tid] = w;
-        __syncthreads();
-    }
-    const unsigned long long base_cnt = tid > 0 ? sh_cnt[tid - 1] : 0ull;
-    const unsigned long long base_ev = tid > 0 ? sh_ev[tid - 1] : 0ull;
-    for (int i = i0; i < i1; ++i) { outs[i].dibit_off += base_cnt; outs[i].event_off += base_ev; }
-
-    if (tid == 1023) {
+    if (tid == 0) {
         p25fe_result_t r;
         r.n_baseband = a.n_baseband;
-        r.n_dibits = sh_cnt[1023];
-        r.n_sync = sh_ev[1023];
-        const long lt = sh_src[1023];
-        if (lt >= 0) { r.anchor_out.valid = 1; r.anchor_out.s = recs[lt].last_s; r.anchor_out.hi = recs[lt].hi; r.anchor_out.mid = recs[lt].mid; r.anchor_out.lo = recs[lt].lo; }
-        else r.anchor_out = ain;
-        // summary for time-sharding: first own event and the dibits governed by own events
-        long fe = -1; unsigned long long after = 0;
-        r.first_event = fe; r.n_dibits_after_first = after;
+        r.n_dibits = carry_cnt;
+        r.n_sync = carry_ev;
+        if (carry_src >= 0) {
+            const TileRec t = recs[carry_src];
+            r.anchor_out.valid = 1; r.anchor_out.s = t.last_s; r.anchor_out.hi = t.hi; r.anchor_out.mid = t.mid; r.anchor_out.lo = t.lo;
+        } else {
+            r.anchor_out = ain;
+        }
+        r.first_event = -1;
+        r.n_dibits_after_first = 0;
+        if (first_info[0]) {
+            const long f = (long)first_info[0] - 1;
+            r.first_event = recs[f].first_event;
+            r.n_dibits_after_first = carry_cnt - first_info[1];
+        }
         a.result[ch] = r;
-    }
-    // first_event / n_dibits_after_first: first tile with an event (min-reduce), then suffix counts
-    __syncthreads();
-    long ft = 0x7fffffffffffffffL;
-    for (int i = i0; i < i1; ++i) if (recs[i].first_event >= 0) { ft = i; break; }
-    sh_src[tid] = ft;
-    __syncthreads();
-    for (int d = 512; d > 0; d >>= 1) {
-        if (tid < d) { const long o = sh_src[tid + d]; if (o < sh_src[tid]) sh_src[tid] = o; }
-        __syncthreads();
-    }
-    if (tid == 0 && sh_src[0] != 0x7fffffffffffffffL) {
-        const long f = sh_src[0];
-        // dibits after the first event = total - (dibits before tile f) - (pre-count of tile f)
-        const ScanOut of = outs[f];
-        const long tlo = a.abs0 + f * TB;
-        const unsigned long long pre = of.valid ? (unsigned long long)count_instants(of.anchor_s, tlo, recs[f].first_event + 1) : 0ull;
-        a.result[ch].first_event = recs[f].first_event;
-        a.result[ch].n_dibits_after_first = sh_cnt[1023] - of.dibit_off - pre;
     }
 }
 
@@ -756,6 +913,8 @@ struct SliceArgs {
     const uint8_t* events;
     long ev_stride;
     const ScanOut* outs;
+    const TileRec* recs;
+    const p25fe_anchor_t* anchor_in;    // nullable
     uint8_t* dibits;            // [ch][dibit_stride]
     long dibit_stride;
     int64_t* sync_pos;          // nullable
@@ -763,53 +922,71 @@ struct SliceArgs {
     long sync_stride;
 };
 
-// K4: slice the anchored symbol instants of one tile.
+// K4: slice the anchored symbol instants of one tile.  No LDS tile: a thread reads its own 8 samples and
+// 8 event flags straight from global memory (both were just written and are L2 / MALL resident).
 __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
 {
-    __shared__ float BT[BT_N];
-    __shared__ float THI[TB], TMID[TB], TLO[TB];
     __shared__ long shl[8];
     __shared__ int shi[8];
     const int tid = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
     const long t0 = (long)tile * TB;
     const float* bbp = a.bb + (size_t)ch * a.bb_stride;
     const long tn = (a.n - t0 < TB) ? a.n - t0 : TB;
-    const ScanOut co = a.outs[(size_t)ch * a.n_tiles + tile];
-
-    for (int k = tid; k < BT_N; k += NT) BT[k] = bb_at(bbp, a.n_hist, a.n, t0 - HIST_BB + k);
-    uint8_t evl[VPT];
-    {
-        const uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0;
-#pragma unroll
-        for (int u = 0; u < VPT; ++u) evl[u] = (tid * VPT + u < tn) ? evp[tid * VPT + u] : 0;
+    const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
+    struct { long anchor_s; float hi, mid, lo; int valid; unsigned long long dibit_off; unsigned event_off; } co;
+    co.dibit_off = so.dibit_off; co.event_off = so.event_off;
+    if (so.src >= 0) {
+        const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
+        co.anchor_s = t.last_s; co.hi = t.hi; co.mid = t.mid; co.lo = t.lo; co.valid = 1;
+    } else if (a.anchor_in) {
+        const p25fe_anchor_t ai = a.anchor_in[ch];
+        co.anchor_s = ai.s; co.hi = ai.hi; co.mid = ai.mid; co.lo = ai.lo; co.valid = ai.valid;
+    } else {
+        co.anchor_s = 0; co.hi = co.mid = co.lo = 0.f; co.valid = 0;
     }
-    __syncthreads();
+
+    uint8_t evl[VPT];
+    float bv[VPT];
+    {
+        const uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0 + tid * VPT;
+        const float* bp = bbp + t0 + tid * VPT;
+        const bool full = tid * VPT + VPT <= tn;
+        if (full && ((a.ev_stride & 7) == 0)) {
+            const uint2 pk = *reinterpret_cast<const uint2*>(evp);
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) evl[u] = (uint8_t)(((u < 4 ? pk.x : pk.y) >> (8 * (u & 3))) & 0xffu);
+        } else {
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) evl[u] = (tid * VPT + u < tn) ? evp[u] : 0;
+        }
+        if (full && ((reinterpret_cast<uintptr_t>(bp) & 15u) == 0)) {
+            const float4 b0 = reinterpret_cast<const float4*>(bp)[0], b1 = reinterpret_cast<const float4*>(bp)[1];
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) bv[u] = (tid * VPT + u < tn) ? bp[u] : 0.f;
+        }
+    }
 
     long my_last = -1;
     int my_ev = 0;
 #pragma unroll
-    for (int u = 0; u < VPT; ++u) {
-        const int i = tid * VPT + u;
-        if (evl[u]) {
-            my_last = i;
-            ++my_ev;
-            float hi, mid, lo;
-            sync_thresholds(BT, i - W + HIST_BB, hi, mid, lo);
-            THI[i] = hi; TMID[i] = mid; TLO[i] = lo;
-        }
-    }
-    const long incoming = block_excl_max(my_last, shl, tid);     // includes a barrier: thresholds visible
+    for (int u = 0; u < VPT; ++u)
+        if (evl[u]) { my_last = tid * VPT + u; ++my_ev; }
+    const long incoming = block_excl_max(my_last, shl, tid);
     // walk my 8 samples: count, then rank, then emit
-    long cur = incoming;
+    int cur = (int)incoming;
     int cnt = 0;
     unsigned inst = 0;
+    // distance of my first sample to the carry-in anchor, mod 10 (one 64-bit modulo per thread, then 32-bit)
+    const unsigned cph = co.valid ? (unsigned)((a.abs0 + t0 + (long)tid * VPT - co.anchor_s) % SPS) : 0u;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
-        if (i < tn) {
+        if (i < (int)tn) {
             bool is = false;
-            if (cur >= 0) is = ((i - (cur - W)) % SPS) == 0;
-            else if (co.valid) is = ((a.abs0 + t0 + i - co.anchor_s) % SPS) == 0;
+            if (cur >= 0) is = ((unsigned)(i - (cur - W)) % (unsigned)SPS) == 0u;
+            else if (co.valid) is = ((cph + (unsigned)u) % (unsigned)SPS) == 0u;
             if (is) { ++cnt; inst |= 1u << u; }
             if (evl[u]) cur = i;
         }
@@ -819,17 +996,35 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     int evtotal;
     int evrank = block_excl_sum(my_ev, shi, tid, evtotal);
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + co.dibit_off;
-    cur = incoming;
+    cur = (int)incoming;
+    int thr_for = -2;                      // tile-local anchor whose thresholds are cached in hi / mid / lo
+    float hi = co.hi, mid = co.mid, lo = co.lo;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
-        if (i < tn) {
+        if (i < (int)tn) {
             // the instant at index i (if any) is governed by events decided before i
             if ((inst >> u) & 1u) {
-                float hi, mid, lo;
-                if (cur >= 0) { hi = THI[cur]; mid = TMID[cur]; lo = TLO[cur]; }
-                else { hi = co.hi; mid = co.mid; lo = co.lo; }
-                const float v = BT[i + HIST_BB];
+                if (cur >= 0 && cur != thr_for) {
+                    // thresholds of an in-tile anchor: same arithmetic as K2 (same bits), from global memory;
+                    // in-tile events are rare, so this beats staging the tile and its 240-sample halo in LDS
+                    const long s = t0 + cur - W;               // local index of the sync word's last symbol
+                    float Pp = 0.f, Nn = 0.f;
+#pragma unroll
+                    for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
+                        const float v = bb_at(bbp, a.n_hist, a.n, s - SPS * (P25FE_SYNC_DIBITS - 1 - j));
+                        if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
+                    }
+                    Pp = Pp * P25FE_SYNC_INV_NPOS;
+                    Nn = Nn * P25FE_SYNC_INV_NNEG;
+                    mid = (Pp + Nn) * 0.5f;
+                    const float span = (Pp - Nn) * 0.5f;
+                    const float d = span * P25FE_SLICE_FRAC;
+                    hi = mid + d;
+                    lo = mid - d;
+                    thr_for = cur;
+                }
+                const float v = bv[u];
                 out[rank++] = v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
             }
             if (evl[u]) {
