@@ -98,35 +98,12 @@ def main():
         def step():
             fe.run_dev(iq, dibits=dibits, result=result)
     else:
+        from p25rx_amd.sharding import TimeShard
+        ts = TimeShard(fe, rank, world, n, dist)
         summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-        counts = torch.zeros(world, dtype=torch.int64, device=dev)
-        my_count = torch.zeros(1, dtype=torch.int64, device=dev)
-        bb0s = [n_baseband(0, r * n) for r in range(world)]
-        bbns = [n_baseband(r * n, n) for r in range(world)]
-        halo_src = buf[halo + n - halo:]                           # my last `halo` samples -> right neighbour
 
         def step():
-            # 1. filter-state overlap: last `halo` IQ samples to rank+1 (xGMI point-to-point)
-            ops = []
-            if rank + 1 < world:
-                ops.append(dist.P2POp(dist.isend, halo_src, rank + 1))
-            if rank > 0:
-                ops.append(dist.P2POp(dist.irecv, buf[:halo], rank - 1))
-            for w in dist.batch_isend_irecv(ops) if ops else []:
-                w.wait()
-            # 2. pass 1 on the owned range with left context
-            h = halo if rank > 0 else 0
-            fe.shard_pass1(buf[halo - h:], offset=h, n_hist=h, abs0=abs0, result=result)
-            # 3. exchange the shard summaries, resolve the symbol-timing carry
-            dist.all_gather_into_tensor(summ_all.view(-1), result.view(-1))
-            summ = np.frombuffer(summ_all.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
-            anc, off = fe.shard_resolve(summ, bb0s, bbns)
-            # 4. pass 2: slice under the resolved carry-in
-            fe.shard_pass2(anc[rank:rank + 1], bbn, dev, result=result, dibits=dibits)
-            # 5. reduced dibit stream: counts to everyone (the dibits stay sharded in HBM; rank 0 can
-            #    fetch them with a gather of sum(counts) bytes -- 2.9 MB per shard)
-            my_count[0] = int(off[rank])
-            dist.all_gather_into_tensor(counts, my_count)
+            ts.step(buf, result, summ_all, dibits)
 
     for _ in range(args.warmup):
         step()

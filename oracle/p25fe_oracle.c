@@ -18,7 +18,7 @@
  * It is pinned instead against (i) an independent fp64 numpy/scipy model, (ii) physical
  * known-answer tests and (iii) the known symbols of a seeded C4FM modulator (tests/).
  *
- * Arithmetic contract (docs/SPEC.md section 3): fp32 throughout, every multiply-add that the
+ * Arithmetic contract (docs/SPEC.md section 2): fp32 throughout, every multiply-add that the
  * spec writes as fma() is one fused operation, nothing else may be contracted or
  * re-associated: build with -ffp-contract=off, no -ffast-math.
  */
@@ -302,7 +302,7 @@ float p25o_atan2f(const p25o_config *c, float y, float x) { return spec_atan2f(c
  * Symbol receiver: the front half of p25::message::receiver::MessageReceiver::feed(f32)
  * (src/recv.rs:207, src/replay.rs:44) down to the point where a dibit exists, and
  * MessageReceiver::resync (src/recv.rs:136, 179).  The p25 crate is not available, so the
- * rule is build-defined (SPEC 3.6-3.8):
+ * rule is build-defined (SPEC 3.7-3.8):
  *   c[n]   = sum_j sign_j * b[n - 10 (23 - j)]          (frame-sync correlation, 24 taps)
  *   e[n]   = sum_j b[n - 10 (23 - j)]^2
  *   cand   = c > 0 && e >= e_min && c*c >= 24*0.85 * e   (normalised correlation >= ~0.92)

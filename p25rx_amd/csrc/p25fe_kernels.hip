@@ -73,7 +73,7 @@ __device__ __forceinline__ float spec_atan2f(float y, float x)
     return r;
 }
 
-// SPEC 3.3: FM discriminator, angle of s * conj(prev) times fs / (2 pi dev)   (src/demod.rs:54, 110)
+// SPEC 3.4: FM discriminator, angle of s * conj(prev) times fs / (2 pi dev)   (src/demod.rs:54, 110)
 __device__ __forceinline__ float fm_discriminate(float2 s, float2 prev)
 {
     const float t = s.y * prev.y;
@@ -443,7 +443,7 @@ __global__ void k_power_finish(const float* partial, int n_partial, long n, floa
 }
 
 // ------------------------------------------------------------------------------------------
-// K2..K4: symbol receiver as a scan (SPEC 3.6-3.8)
+// K2..K4: symbol receiver as a scan (SPEC 3.7-3.8)
 //
 // A detection at s (sync word's last symbol) is DECIDED at e = s + W (the peak window is complete)
 // and governs instants n > e: instant n is
@@ -489,7 +489,7 @@ __device__ __forceinline__ float bb_at(const float* bbp, long n_hist, long n, lo
     return (i >= -n_hist && i < n) ? bbp[i] : 0.0f;
 }
 
-// thresholds from the sync word ending at local LDS index `is` (SPEC 3.7)
+// thresholds from the sync word ending at local LDS index `is` (SPEC 3.8)
 __device__ __forceinline__ void sync_thresholds(const float* BT, int is, float& hi, float& mid, float& lo)
 {
     float Pp = 0.f, Nn = 0.f;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s] = BT[k + 10 j], j = 0..23.
     // Register tiling over symbol-spaced positions: a thread takes one sample phase r = k % 10 and CQ
     // consecutive symbol slots, so its CQ outputs share a sliding window of CQ + 23 LDS reads (3.6 reads per
-    // output instead of 24); each output keeps its own accumulators in tap order j = 0..23 (SPEC 3.6).
+    // output instead of 24); each output keeps its own accumulators in tap order j = 0..23 (SPEC 3.7).
     if (tid < 250) {
         const int r = tid % SPS, qb = tid / SPS;
         const int base = SPS * CQ * qb + r;                     // k of the thread's first output

@@ -90,3 +90,16 @@ def test_shard_resolve_host_logic(lib):
     exp2 = exp1 + inst(302, 1000, 2000)
     exp3 = exp2 + inst(302, 2000, 2509) + 49
     assert off.tolist() == [0, exp1, exp2, exp3]
+
+
+def test_cpp_host_driver_built_and_fails_loudly_without_gpu(lib, tmp_path):
+    """The C++ DemodTask/RecvTask mirror links only the C ABI; without a device it aborts (reference: panic = abort)."""
+    import torch
+    exe = os.path.join(ROOT, "build", "p25fe_replay")
+    assert os.path.exists(exe)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    src = tmp_path / "x.u8"
+    src.write_bytes(bytes(64))
+    r = subprocess.run([exe, "u8", str(src), str(tmp_path / "o")], capture_output=True)
+    assert r.returncode != 0 and b"no usable HIP device" in r.stderr

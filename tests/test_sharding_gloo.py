@@ -1,0 +1,134 @@
+"""world_size-2 CPU test (gloo) of the time-shard orchestration in p25rx_amd/sharding.py.
+
+The GPU kernels cannot run here, so the per-shard compute is a TEST DOUBLE built on the CPU oracle
+(OracleShardFE below); what is under test is the product's N > 1 logic: the halo exchange, the
+all-gather of shard summaries, p25fe_shard_resolve (real C-ABI host function) and the resulting
+carry-in / dibit offsets.  The concatenated shard outputs must equal one oracle pass over the capture.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+N_PER_RANK = 96000        # 0.4 s per rank
+WORLD = 2
+
+
+class OracleShardFE:
+    """Test double with the shard_* surface of p25rx_amd.frontend.FrontEnd, computed by the oracle."""
+
+    def __init__(self):
+        from oracle import oracle as O
+        from p25rx_amd import _lib
+        self.O, self._lib = O, _lib
+        self.W = O.load_spec()["sync_peak_w"]
+
+    def shard_halo(self):
+        return self._lib.load().p25fe_shard_halo()
+
+    def shard_pass1(self, view, offset, n_hist, abs0, result=None):
+        import torch
+        from p25rx_amd.frontend import n_baseband
+        O = self.O
+        x = view.numpy().view(np.complex64).reshape(-1)
+        pad = (abs0 - n_hist) % 5                                   # keep the absolute 5:1 grid (src/demod.rs:87-90)
+        bb_all = O.Demod().feed_cf32(np.concatenate([np.zeros(pad, np.complex64), x]))
+        nb = n_baseband(abs0, len(x) - offset)
+        self.bb0 = n_baseband(0, abs0)
+        self.bb = bb_all[len(bb_all) - nb:]
+        hist = bb_all[max(0, len(bb_all) - nb - 256):len(bb_all) - nb]
+        r = O.Recv()
+        r.feed(hist)
+        r.resync()                                                  # events decided before the shard belong to the previous one
+        dib, spos, sdib = r.feed(self.bb)
+        base = self.bb0 - len(hist)                                 # absolute index of hist[0]
+        self.own = (dib, spos + base)
+        st = r.state()
+        summ = np.zeros(1, dtype=self._lib.RESULT_DTYPE)
+        summ["n_baseband"] = nb
+        summ["first_event"] = -1
+        if len(spos):
+            summ["first_event"] = spos[0] + base + self.W
+            summ["n_dibits_after_first"] = len(dib)
+            summ["anchor_out"] = (st["s"] + base, st["hi"], st["mid"], st["lo"], 1)
+        out = torch.from_numpy(np.frombuffer(summ.tobytes(), dtype=np.uint8).copy()).view(1, -1)
+        if result is not None:
+            result.copy_(out)
+            return result
+        return out
+
+    def shard_resolve(self, summaries, bb0, bbn):
+        import ctypes as C
+        L = self._lib.load()
+        summaries = np.ascontiguousarray(summaries, dtype=self._lib.RESULT_DTYPE)
+        bb0 = np.ascontiguousarray(bb0, dtype=np.uint64)
+        bbn = np.ascontiguousarray(bbn, dtype=np.uint64)
+        n = len(summaries)
+        anc = np.zeros(n, dtype=self._lib.ANCHOR_DTYPE)
+        off = np.zeros(n, dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert L.p25fe_shard_resolve(p(summaries), p(bb0), p(bbn), n, p(anc), p(off)) == 0
+        return anc, off
+
+    def shard_pass2(self, anchor_in, n_bb, device, result=None, dibits=None):
+        a = anchor_in[0]
+        dib, spos = self.own
+        pre = np.zeros(0, np.uint8)
+        if a["valid"]:
+            hi_idx = (spos[0] + self.W) if len(spos) else self.bb0 + len(self.bb) - 1   # instants <= first decision index
+            n = np.arange(self.bb0, hi_idx + 1)
+            n = n[(n > a["s"]) & ((n - a["s"]) % 10 == 0)]
+            v = self.bb[n - self.bb0]
+            pre = np.where(v >= a["hi"], 1, np.where(v >= a["mid"], 0, np.where(v >= a["lo"], 2, 3))).astype(np.uint8)
+        self.out = np.concatenate([pre, dib])
+        return None, None
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from p25rx_amd import c4fm
+    from p25rx_amd.sharding import TimeShard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        iq, _, _ = c4fm.synth(world * N_PER_RANK / 240000.0, seed=77, snr_db=22.0, frame_dibits=700)
+        fe = OracleShardFE()
+        ts = TimeShard(fe, rank, world, N_PER_RANK, dist)
+        buf = ts.alloc(torch, "cpu", torch.float32)
+        mine = iq[rank * N_PER_RANK:(rank + 1) * N_PER_RANK]
+        buf[ts.halo:] = torch.from_numpy(mine.view(np.float32).reshape(-1, 2))
+        result = torch.zeros((1, fe._lib.RESULT_DTYPE.itemsize), dtype=torch.uint8)
+        summ_all = torch.zeros((world, fe._lib.RESULT_DTYPE.itemsize), dtype=torch.uint8)
+        off, summ = ts.step(buf, result, summ_all, None)
+        if rank > 0:                                            # halo really is the left neighbour's tail
+            left = iq[rank * N_PER_RANK - ts.halo:rank * N_PER_RANK]
+            assert np.array_equal(buf[:ts.halo].numpy().view(np.complex64).reshape(-1), left)
+        q.put((rank, off, fe.out, O.run_cf32(iq) if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_time_shards_world2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=150) for _ in range(WORLD)])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    ref = got[0][3]
+    outs = [g[2] for g in got]
+    assert got[0][1] == 0 and got[1][1] == len(outs[0])         # dibit offsets from p25fe_shard_resolve
+    assert np.array_equal(np.concatenate(outs), ref[:sum(len(o) for o in outs)])
+    assert abs(len(ref) - sum(len(o) for o in outs)) <= 1
