@@ -243,17 +243,14 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0, sizeof(float) * (size_t)h->C, st));
         return P25FE_OK;
     }
-    // segments: one round of resident one-wave workgroups when the range is large (LDS admits 9 per CU at
-    // PK = 5, VGPRs 8), so there is no tail round; P25FE_WGS_PER_CU overrides for experiments.
+    // Segments are SHORT: two sub-tiles per one-wave workgroup.  Measured on config 2 (profiles/): one long
+    // segment per resident wave (44 sub-tiles, no tail round) ran K1 in 0.305 ms, 2 sub-tiles per workgroup in
+    // 0.232 ms -- neighbouring workgroups then stream neighbouring DRAM pages and the dispatcher balances the CUs,
+    // which outweighs recomputing the 50-sample filter halo once per 590 outputs (8 %).  P25FE_SUBS overrides.
     const int pk = h->k1_p;
     const long sub = (long)WV * pk;
-    static const long wgs_env = [] { const char* e = getenv("P25FE_WGS_PER_CU"); return e ? atol(e) : 0L; }();
-    const long wgs_per_cu = wgs_env > 0 ? wgs_env : (pk == 3 ? 14 : 9);     // LDS-limited residency
-    const long target_wgs = (long)h->n_cu * wgs_per_cu;
-    long per_ch = target_wgs / h->C;
-    if (per_ch < 1) per_ch = 1;
-    long subs = ((total + per_ch - 1) / per_ch + HALO_D + sub - 1) / sub;
-    if (subs < 1) subs = 1;
+    static const long subs_env = [] { const char* e = getenv("P25FE_SUBS"); return e ? atol(e) : 0L; }();
+    long subs = subs_env > 0 ? subs_env : 2;
     if (subs > 32768) subs = 32768;
     const long seg_len = (sub - HALO_D) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;

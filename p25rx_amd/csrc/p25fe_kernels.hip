@@ -46,7 +46,7 @@ template <int PK> struct Geo {
     static constexpr int D_N = D_CARRY + SUB;
     static constexpr size_t LDS_BYTES = sizeof(float2) * (XIN_N + D_N) + sizeof(float) * (SUB + T1 + T2 + 3);
     static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
-    static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 3;   // register budget the kernel is compiled for (128 / 168 VGPRs)
+    static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
 
 struct Taps {
@@ -152,6 +152,11 @@ template <int FMT, int PK> struct Loader {
             int r = tid + j * WV;
             r = r < lo32 ? lo32 : r;
             r = r > hi32 ? hi32 : r;
+#if defined(P25FE_ABLATE) && P25FE_ABLATE == 6     // measurement build: every window load hits one cached vector row
+            r = tid;
+            v[j] = reinterpret_cast<const uint4*>(base)[r];
+            continue;
+#endif
             v[j] = q[r];
         }
     }
@@ -271,12 +276,14 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     float outv[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) outv[q] = 0.f;
-    long out_lo = m_seg0 - 2 * (long)SUB;                           // nothing in range yet
+    int out_rel = -2 * SUB;                                         // out_lo - m_seg0; nothing in range yet
+    const int seg_n = (int)(m_seg1 - m_seg0);
+    float* const bb_seg = bb + m_seg0;
     auto flush_outputs = [&]() {
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            const long m = out_lo + tid + q * WV;
-            if (m >= m_seg0 && m < m_seg1) bb[m] = outv[q];
+            const int r = out_rel + tid + q * WV;                   // output index relative to the segment start
+            if (r >= 0 && r < seg_n) bb_seg[r] = outv[q];
         }
     };
 
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
 #pragma unroll
         for (int q = 0; q < P; ++q) outv[q] = OUT[tid + q * WV];
-        out_lo = dlo;
+        out_rel = (int)(dlo - m_seg0);
         phase_sync();
     }
     flush_outputs();

@@ -4,7 +4,7 @@
 set -e
 ROOT=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $ROOT/build/abl
-for n in 1 2 3 4; do
+for n in 1 2 3 4 6; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC \
      -fhip-fp32-correctly-rounded-divide-sqrt -DP25FE_ABLATE=$n -I$ROOT/include -shared \
      -o $ROOT/build/abl/libp25fe_abl$n.so $ROOT/p25rx_amd/csrc/p25fe_api.hip
