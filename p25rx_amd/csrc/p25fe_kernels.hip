@@ -821,34 +821,49 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
         __syncthreads();
 
-        // pass 2: counts of my run under the running anchor
-        auto anchor_of = [&](long src, long& s_out, bool& v_out) {   // src: chunk-local tile index or -1
+        // passes 2 and 3 walk the run with the anchor expressed as a PHASE: ph = (tile_start - s) mod 10, so the
+        // closed-form instant counts are 32-bit (a tile has 2048 samples); the only 64-bit modulo is the one that
+        // brings a carry-in anchor from before this chunk into the run.
+        auto phase_at = [&](int k, long src, bool& v) -> unsigned {   // phase of tile k's start under anchor `src`
             if (src >= 0) {
-                s_out = a.abs0 + (long)(c0 + src) * TB + (long)((TS[src] >> 12) & 0xfffu) - 1 - W;
-                v_out = true;
-            } else {
-                s_out = carry_s;
-                v_out = carry_valid;
+                v = true;
+                const int last_off = (int)((TS[src] >> 12) & 0xfffu) - 1;
+                const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TB - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
+                return dist % (unsigned)SPS;
             }
-        };
-        auto pre_of = [&](int k, unsigned long long u, long s, bool v) -> unsigned long long {
+            v = carry_valid;
+            if (!carry_valid) return 0u;
             const long tlo = a.abs0 + (long)(c0 + k) * TB;
-            long thi = tlo + TB;
-            if (thi > a.abs0 + a.n) thi = a.abs0 + a.n;
-            const int first1 = (int)(u & 0xfffu);
-            const long pre_hi = first1 ? tlo + first1 : thi;        // instant AT the event index is still the old anchor's
-            return v ? (unsigned long long)count_instants(s, tlo, pre_hi) : 0ull;
+            return (unsigned)((tlo - carry_s) % SPS);
+        };
+        auto count32 = [&](unsigned ph, int len) -> unsigned {        // n in [0, len): (ph + n) % 10 == 0, n + dist > 0 holds
+            const int f = (int)((SPS - ph) % (unsigned)SPS);          // first instant offset
+            return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
+        };
+        auto tile_len = [&](int k) -> int {
+            const long tlo = a.abs0 + (long)(c0 + k) * TB;
+            const long rem = a.abs0 + a.n - tlo;
+            return rem < TB ? (int)rem : TB;
         };
         unsigned long long my_cnt = 0, my_ev = 0;
         {
             long src = excl;
+            bool v;
+            unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
+            if (!(k0 < k1)) v = false;
             for (int k = k0; k < k1; ++k) {
                 const unsigned long long u = TS[k];
-                long s; bool v;
-                anchor_of(src, s, v);
-                my_cnt += pre_of(k, u, s, v) + ((u >> 36) & 0xfffu);
+                const int first1 = (int)(u & 0xfffu);
+                const int len = first1 ? first1 : tile_len(k);        // instant AT the event index is still the old anchor's
+                my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> 36) & 0xfffu);
                 my_ev += (u >> 24) & 0xfffu;
-                if (u & 0xfffu) src = k;
+                if (first1) {
+                    src = k; v = true;
+                    const int last_off = (int)((u >> 12) & 0xfffu) - 1;
+                    ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;     // next tile's start under the new anchor
+                } else {
+                    ph = (ph + (unsigned)TB) % (unsigned)SPS;
+                }
             }
         }
         unsigned long long tot_cnt, tot_ev;
@@ -858,24 +873,33 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         // pass 3: write the per-tile carry-ins
         {
             long src = excl;
+            bool v;
+            unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
+            if (!(k0 < k1)) v = false;
             unsigned long long dc = carry_cnt + icnt - my_cnt, ec = carry_ev + iev - my_ev;
             for (int k = k0; k < k1; ++k) {
                 const unsigned long long u = TS[k];
-                long s; bool v;
-                anchor_of(src, s, v);
-                const unsigned long long pre = pre_of(k, u, s, v);
+                const int first1 = (int)(u & 0xfffu);
+                const int len = first1 ? first1 : tile_len(k);
+                const unsigned pre = v ? count32(ph, len) : 0u;
                 ScanOut o;
                 o.src = src >= 0 ? (int)(c0 + src) : (int)carry_src;
                 o.event_off = (unsigned)ec;
                 o.dibit_off = dc;
                 outs[c0 + k] = o;
-                if ((u & 0xfffu) && src < 0 && carry_src < 0) {    // the range's first event
+                if (first1 && src < 0 && carry_src < 0) {           // the range's first event
                     first_info[0] = (unsigned long long)(c0 + k) + 1;
                     first_info[1] = dc + pre;
                 }
-                dc += pre + ((u >> 36) & 0xfffu);
+                dc += pre + (unsigned)((u >> 36) & 0xfffu);
                 ec += (u >> 24) & 0xfffu;
-                if (u & 0xfffu) src = k;
+                if (first1) {
+                    src = k; v = true;
+                    const int last_off = (int)((u >> 12) & 0xfffu) - 1;
+                    ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;
+                } else {
+                    ph = (ph + (unsigned)TB) % (unsigned)SPS;
+                }
             }
         }
         // carries for the next chunk (uniform: every thread computes the same values)
@@ -986,7 +1010,9 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     int cnt = 0;
     unsigned inst = 0;
     // distance of my first sample to the carry-in anchor, mod 10 (one 64-bit modulo per thread, then 32-bit)
-    const unsigned cph = co.valid ? (unsigned)((a.abs0 + t0 + (long)tid * VPT - co.anchor_s) % SPS) : 0u;
+    // (wave-uniform 64-bit modulo once, then 32-bit per thread)
+    const unsigned base_ph = co.valid ? (unsigned)((a.abs0 + t0 - co.anchor_s) % SPS) : 0u;
+    const unsigned cph = (base_ph + (unsigned)(tid * VPT)) % (unsigned)SPS;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int i = tid * VPT + u;
