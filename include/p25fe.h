@@ -146,6 +146,14 @@ int p25fe_state_import(p25fe_t *h, const void *buf, size_t n);
 int p25fe_demod_dev(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                     uint64_t abs0, float *d_bb, size_t bb_stride, float *d_power_dbm, void *stream);
 
+/* Stage 0 of BASELINE.json config 3 (2.4 Msps front end; the reference is fixed at 240 ksps, src/consts.rs:11):
+ * 10:1 decimating FIR, cf32 @ 2.4 Msps -> cf32 @ 240 ksps, P25FE_T0 taps of p25fe_spec.h.  Same range
+ * conventions as p25fe_demod_dev; writes p25fe_n_predecim(abs0, n) complex samples per channel to d_out
+ * (+ c * out_stride complex samples).  Feed d_out to p25fe_run_dev / p25fe_demod_dev. */
+int p25fe_predecim_dev(p25fe_t *h, const float *d_iq, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                       float *d_out, size_t out_stride, void *stream);
+size_t p25fe_n_predecim(uint64_t abs0, size_t n);
+
 /* stages 6-7 on device baseband.  d_bb points at the first owned sample; n_hist_bb valid
  * samples precede it; abs_bb0 is its absolute index; d_anchor_in (nullable = no lock) is the
  * carry-in per channel.  d_result[c] is filled per channel. */

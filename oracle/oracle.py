@@ -89,6 +89,11 @@ def _bind(lib):
     lib.p25o_recv_feed.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp, vp, sz, C.POINTER(sz)]
     lib.p25o_recv_state.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_float * 3), C.POINTER(C.c_uint64)]
+    lib.p25o_predecim_create.restype = vp
+    lib.p25o_predecim_create.argtypes = [vp, C.c_int, C.c_int]
+    lib.p25o_predecim_destroy.argtypes = [vp]
+    lib.p25o_predecim_feed.restype = sz
+    lib.p25o_predecim_feed.argtypes = [vp, vp, sz, vp]
     lib.p25o_run_cf32.restype = C.c_int64
     lib.p25o_run_cf32.argtypes = [C.POINTER(Config), vp, sz, vp, sz]
     lib.p25o_has_fma.restype = C.c_int
@@ -150,6 +155,28 @@ class Demod:
         bb = np.empty(cap, dtype=np.float32)
         n = self.L.p25o_demod_cf32_stages(self.h, _ptr(iq), iq.size, _ptr(ch), _ptr(fm), _ptr(bb))
         return ch[:n].copy(), fm[:n].copy(), bb[:n].copy()
+
+
+class PreDecim:
+    """Stage 0 of config 3: 2.4 Msps -> 240 ksps, 10:1 decimating FIR (no reference counterpart)."""
+
+    def __init__(self, spec=None, libpath=None):
+        self.L = lib(libpath)
+        s = spec or load_spec()
+        taps = np.array(s["pre_taps"], dtype=np.float32)
+        self.decim = s["pre_decim"]
+        self.h = self.L.p25o_predecim_create(_ptr(taps), len(taps), self.decim)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.p25o_predecim_destroy(self.h)
+            self.h = None
+
+    def feed(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        out = np.empty(iq.size // self.decim + 2, dtype=np.complex64)
+        n = self.L.p25o_predecim_feed(self.h, _ptr(iq), iq.size, _ptr(out))
+        return out[:n].copy()
 
 
 class Recv:

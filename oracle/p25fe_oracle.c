@@ -27,7 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define P25O_MAX_TAPS 64
+#define P25O_MAX_TAPS 64          /* config arrays */
+#define P25O_FIR_CAP 128          /* capacity of one FIR object (the 80-tap pre-decimator is the longest) */
 #define P25O_ATAN_NCOEF 8
 #define P25O_SYNC_DIBITS 24
 
@@ -70,8 +71,8 @@ static void build_iq_lut(cf32 *lut, float scale)
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     int ntaps, pos;
-    float taps[P25O_MAX_TAPS];
-    cf32 hist[2 * P25O_MAX_TAPS];
+    float taps[P25O_FIR_CAP];
+    cf32 hist[2 * P25O_FIR_CAP];
 } fir_c;
 
 static void fir_init(fir_c *f, const float *taps, int ntaps)
@@ -205,6 +206,40 @@ static size_t decim_in_place(p25o_demod *d, cf32 *buf, size_t n)
         if (++d->decim_phase == d->cfg.decim) {
             d->decim_phase = 0;
             buf[len++] = fir_eval(&d->decim);
+        }
+    }
+    return len;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 0 of BASELINE.json config 3 (2.4 Msps front end): 10:1 decimating FIR to 240 ksps in front of
+ * DemodTask.  The reference has no such stage (SDR_SAMPLE_RATE is a fixed 240000, src/consts.rs:11); it is
+ * built like static_decimate::Decimator (filter, keep every N-th, phase persists) with SPEC 3.0's taps:
+ * output m is produced by input n = 10 m + 9, acc from +0, tap 0 on the newest sample.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { fir_c fir; int phase, decim; } p25o_predecim;
+
+p25o_predecim *p25o_predecim_create(const float *taps, int ntaps, int decim)
+{
+    if (ntaps > P25O_FIR_CAP) return NULL;
+    p25o_predecim *p = calloc(1, sizeof *p);
+    fir_init(&p->fir, taps, ntaps);
+    p->decim = decim;
+    return p;
+}
+
+void p25o_predecim_destroy(p25o_predecim *p) { free(p); }
+
+size_t p25o_predecim_feed(p25o_predecim *p, const float *iq, size_t n, float *out)
+{
+    const cf32 *x = (const cf32 *)iq;
+    cf32 *y = (cf32 *)out;
+    size_t len = 0;
+    for (size_t i = 0; i < n; i++) {
+        fir_push(&p->fir, x[i]);
+        if (++p->phase == p->decim) {
+            p->phase = 0;
+            y[len++] = fir_eval(&p->fir);
         }
     }
     return len;

@@ -379,6 +379,30 @@ int p25fe_demod_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, siz
                            (hipStream_t)stream);
 }
 
+size_t p25fe_n_predecim(uint64_t abs0, size_t n)
+{
+    const size_t o0 = (size_t)((PD - 1 + PD - abs0 % PD) % PD);
+    return n > o0 ? (n - o0 - 1) / PD + 1 : 0;
+}
+
+int p25fe_predecim_dev(p25fe_t* h, const float* d_iq, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                       float* d_out, size_t out_stride, void* stream)
+{
+    if (!h || !d_iq || !d_out) return P25FE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) != 0 || (h->C > 1 && (ch_stride & 1))) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t n_out = p25fe_n_predecim(abs0, n);
+    if (n_out == 0) return P25FE_OK;
+    K0Args a;
+    a.x = d_iq; a.ch_stride = (long)ch_stride; a.n_hist = (long)n_hist; a.n_new = (long)n;
+    a.o0 = (int)((PD - 1 + PD - abs0 % PD) % PD);
+    a.y = d_out; a.y_stride = (long)out_stride; a.n_out = (long)n_out;
+    dim3 grid((unsigned)((n_out + K0_TILE - 1) / K0_TILE), (unsigned)h->C);
+    hipLaunchKernelGGL(k_predecim, grid, dim3(K0_NT), 0, (hipStream_t)stream, a);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
 int p25fe_slice_dev(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb, uint64_t abs_bb0,
                     const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos,
                     uint64_t* d_sync_dibit, size_t sync_stride, p25fe_result_t* d_result, void* stream)

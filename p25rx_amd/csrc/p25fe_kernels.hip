@@ -430,6 +430,75 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K0: stage 0 of BASELINE.json config 3 -- 10:1 decimating FIR, 2.4 Msps cf32 -> 240 ksps cf32, T0 = 80 taps
+// (SPEC 3.0; no reference counterpart: src/consts.rs:11 fixes 240 ksps).  A 256-thread workgroup produces 512
+// outputs from 5190 inputs staged in LDS in POLYPHASE layout X[r][j] = x[base + 10 j + r]: output i then reads
+// X[9 - k%10][i + 7 - k/10] for tap k, i.e. consecutive lanes read consecutive complex samples (conflict-free
+// ds_read_b64) while the taps stay compile-time immediates in tap order 0..79 with one accumulator.
+// Algorithmic bytes: 8 B read + 0.8 B written per input sample.
+// ------------------------------------------------------------------------------------------
+constexpr int PD = P25FE_PRE_DECIM;          // 10
+constexpr int T0 = P25FE_T0;                 // 80
+constexpr int K0_NT = 256;
+constexpr int K0_TILE = 512;                 // outputs per workgroup
+constexpr int K0_HALO = T0 - PD;             // 70 input samples of left context
+constexpr int K0_NIN = PD * K0_TILE + K0_HALO;      // 5190
+constexpr int K0_JP = K0_NIN / PD + 2;       // 521 entries per phase row (odd: spreads the staging writes)
+constexpr int HIST_PRE = K0_HALO + PD - 1;   // 79: history needed for exact results
+
+struct K0Args {
+    const float* x;         // owned sample 0 of channel 0 (cf32 @ 2.4 Msps), 16-B aligned
+    long ch_stride;         // samples
+    long n_hist, n_new;
+    int o0;                 // first decimation instant inside the owned range, 0..9
+    float* y;               // cf32 out @ 240 ksps, channel 0
+    long y_stride;          // samples
+    long n_out;
+};
+
+__global__ __launch_bounds__(K0_NT) void k_predecim(K0Args a)
+{
+    __shared__ float2 X[PD * K0_JP];
+    const int tid = threadIdx.x, ch = blockIdx.y;
+    const long m0 = (long)blockIdx.x * K0_TILE;
+    const float* xb = a.x + 2 * (size_t)ch * a.ch_stride;
+    float2* yb = reinterpret_cast<float2*>(a.y) + (size_t)ch * a.y_stride;
+    const long base = (long)a.o0 + PD * m0 - (T0 - 1);             // input index of window position 0 (output m is fed by input o0 + 10 m)
+    // stage: 16-B vectors (2 samples), clamped index, out-of-stream samples zeroed (same scheme as K1's loader)
+    const long v0 = base >> 1;
+    const int sh = (int)(base - (v0 << 1));                 // 0 or 1
+    const long vlo = (-a.n_hist) >> 1, vhi = (a.n_new - 1) >> 1;
+    const float4* q = reinterpret_cast<const float4*>(xb);
+    for (int r = tid; r < (K0_NIN + 2 + 1) / 2; r += K0_NT) {
+        long vi = v0 + r;
+        vi = vi < vlo ? vlo : vi;
+        vi = vi > vhi ? vhi : vi;
+        const float4 v = q[vi];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const long i = ((v0 + r) << 1) + e;             // input sample index
+            const int k = 2 * r + e - sh;                   // position in the window
+            float2 s = e ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+            if (i < -a.n_hist || i >= a.n_new) s = make_float2(0.f, 0.f);
+            if (k >= 0 && k < K0_NIN) X[(k % PD) * K0_JP + k / PD] = s;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < K0_TILE / K0_NT; ++o) {
+        const int i = tid + o * K0_NT;
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < T0; ++k) {
+            const float2 s = lds_read_c(&X[(PD - 1 - k % PD) * K0_JP + i + (T0 / PD - 1) - k / PD]);
+            acc.x = __builtin_fmaf(P25FE_DEFAULT_PRE_TAPS[k], s.x, acc.x);
+            acc.y = __builtin_fmaf(P25FE_DEFAULT_PRE_TAPS[k], s.y, acc.y);
+        }
+        if (m0 + i < a.n_out) yb[m0 + i] = acc;
+    }
+}
+
 // finish power_dbm (src/demod.rs:123-134): 30 + 10 log10( (sum / N) / R ), R = 1
 __global__ void k_power_finish(const float* partial, int n_partial, long n, float* out_dbm)
 {

@@ -173,6 +173,19 @@ class FrontEnd:
                                          C.c_void_p(pw.data_ptr()) if want_power else None, self._stream()))
         return (bb, nb, pw) if want_power else (bb, nb)
 
+    def predecim_dev(self, iq, n_hist=0, abs0=0, offset=0, out=None):
+        """Stage 0 (config 3): cf32 @ 2.4 Msps [n, 2] or [C, n, 2] -> cf32 @ 240 ksps [C, n_out, 2] on device."""
+        import torch
+        fmt, n_total, stride = self._iq_view(iq)
+        assert fmt == FMT_CF32
+        n = n_total - offset
+        no = self.L.p25fe_n_predecim(abs0, n)
+        if out is None:
+            out = torch.empty((self.C, (no + 3) // 2 * 2, 2), dtype=torch.float32, device=iq.device)
+        self._chk(self.L.p25fe_predecim_dev(self.h, C.c_void_p(iq.data_ptr() + 8 * offset), stride, n_hist, n, abs0,
+                                            C.c_void_p(out.data_ptr()), out.stride(0) // 2, self._stream()))
+        return out, no
+
     def slice_dev(self, bb, n_bb, n_hist_bb=0, abs_bb0=0, anchor_in=None, offset=0, sync_cap=0):
         import torch
         dev = bb.device

@@ -185,3 +185,16 @@ def test_golden_fixture_matches():
     assert np.array_equal(spos, g["sync_pos"])
     with open(os.path.join(GOLDEN, "spec.json")) as f:
         assert json.load(f)["t1"] == 31
+
+
+def test_predecim_fp64_and_chunking(spec):
+    """Stage 0 (config 3, no reference counterpart): 10:1 decimating FIR vs scipy fp64; chunk invariance."""
+    rng = np.random.default_rng(0)
+    x = ((rng.standard_normal(60001) + 1j * rng.standard_normal(60001)) * 0.3).astype(np.complex64)
+    y = O.PreDecim().feed(x)
+    ref = signal.lfilter(np.array(spec["pre_taps"], dtype=np.float64), 1.0, x.astype(np.complex128))[9::10]
+    assert len(y) == len(ref) == 6000
+    assert np.abs(y - ref).max() < 3e-7
+    p = O.PreDecim()
+    parts = [p.feed(x[o:o + 777]) for o in range(0, len(x), 777)]
+    assert np.array_equal(np.concatenate(parts), y)

@@ -19,6 +19,8 @@ decimator  : T1 = 31 taps, Kaiser(beta=7.0)-windowed sinc, cutoff 12 kHz at fs =
              unity DC gain.  Anti-alias for the 5:1 rate change of src/demod.rs:50.
 channel    : T2 = 41 taps, Kaiser(beta=5.0)-windowed sinc, cutoff 6.25 kHz at fs = 48 kHz,
              unity DC gain.  "Channel-select lowpass" of src/demod.rs:28-29.
+pre-decim  : T0 = 80 taps, Kaiser(beta=7.0)-windowed sinc, cutoff 60 kHz at fs = 2.4 MHz, unity DC
+             gain: the 10:1 stage of BASELINE.json config 3 (2.4 Msps front end; no reference counterpart).
 atan       : odd polynomial t*(c0 + c1 t^2 + ... + c7 t^14) ~ atan(t) on [0, 1], weighted
              least squares on 4096 Chebyshev nodes, coefficients rounded to fp32.
 fm gain    : fs / (2 pi dev) with fs = 48000, dev = 5000 (src/demod.rs:54).
@@ -33,6 +35,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 T1, T2 = 31, 41
+T0, PRE_DECIM, FS_WIDE = 80, 10, 2400000.0
 FS_IN, FS_BB = 240000.0, 48000.0
 DECIM = 5
 SPS = 10                      # baseband samples per symbol (48000 / 4800)
@@ -81,6 +84,7 @@ def hexf(x):
 def main():
     dec = kaiser_sinc(T1, 12000.0, FS_IN, 7.0)
     chan = kaiser_sinc(T2, 6250.0, FS_BB, 5.0)
+    pre = kaiser_sinc(T0, 60000.0, FS_WIDE, 7.0)
     atc = atan_coeffs()
     fm_gain = np.float32(FS_BB / (2.0 * np.pi * 5000.0))
     syms = sync_symbols()
@@ -96,6 +100,7 @@ def main():
         "decim": DECIM, "sps": SPS, "t1": T1, "t2": T2,
         "decim_taps": [float(x) for x in dec],
         "chan_taps": [float(x) for x in chan],
+        "pre_decim": PRE_DECIM, "t0": T0, "pre_taps": [float(x) for x in pre],
         "atan_coeffs": [float(x) for x in atc],
         "fm_gain": float(fm_gain),
         "u8_scale": float(np.float32(2.0 / 255.0)),
@@ -130,6 +135,8 @@ def main():
     h.append("#define P25FE_T1 %d               /* decimator taps */\n" % T1)
     h.append("#define P25FE_T2 %d               /* channel filter taps */\n" % T2)
     h.append("#define P25FE_BOXCAR %d           /* src/demod.rs:52 */\n" % 10)
+    h.append("#define P25FE_PRE_DECIM %d        /* 2.4 Msps -> 240 ksps (BASELINE.json config 3) */\n" % PRE_DECIM)
+    h.append("#define P25FE_T0 %d               /* pre-decimator taps */\n" % T0)
     h.append("#define P25FE_ATAN_NCOEF %d\n" % len(atc))
     h.append("#define P25FE_SYNC_DIBITS %d\n" % SYNC_DIBITS)
     h.append("#define P25FE_SYNC_SPAN %d        /* (24-1)*10 baseband samples */\n" % ((SYNC_DIBITS - 1) * SPS))
@@ -149,6 +156,8 @@ def main():
     h.append("\n")
     h.append(arr("P25FE_DEFAULT_CHAN_TAPS", list(chan)))
     h.append("\n")
+    h.append(arr("P25FE_DEFAULT_PRE_TAPS", list(pre)))
+    h.append("\n")
     h.append(arr("P25FE_ATAN_COEFFS", list(atc)))
     h.append("\n#endif /* P25FE_SPEC_H */\n")
     os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
@@ -162,6 +171,7 @@ def main():
                 for f in freqs]
     print("decim taps sum", float(dec.astype(np.float64).sum()))
     print("decim resp dB @ 0,6.25k,12k,24k,41k,48k:", np.round(resp(dec, FS_IN, [0, 6250, 12000, 24000, 41000, 48000]), 2))
+    print("pre   resp dB @ 0,12k,24k,41k,120k,199k,240k:", np.round(resp(pre, FS_WIDE, [0, 12000, 24000, 41000, 120000, 199000, 240000]), 2))
     print("chan  resp dB @ 0,3k,5k,6.25k,9k,12.5k:", np.round(resp(chan, FS_BB, [0, 3000, 5000, 6250, 9000, 12500]), 2))
     t = np.linspace(0, 1, 200001)
     p = np.zeros_like(t)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the kernels on random IQ (within-process A/B across env settings is done by the caller).
-usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|run] [channels=1] [fmt=cf32|u8]"""
+usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|run] [channels=1] [fmt=cf32|u8]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,8 @@ def step():
     global bb
     if mode == "k1":
         bb, nb = fe.demod_dev(iq, bb=bb)
+    elif mode == "k0":                      # config 3 stage 0: the buffer is read as a 2.4 Msps capture
+        bb, nb = fe.predecim_dev(iq, out=bb)
     else:
         fe.run_dev(iq)
 for _ in range(5):
