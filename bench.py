@@ -8,7 +8,7 @@ resident capture: BASELINE.json configs[1], 1 channel x 600 s of synthetic C4FM 
 N > 1 (one rank per GPU, RCCL): BASELINE.json configs[4]'s structure -- one long capture cut
 into N contiguous 600 s time shards (weak scaling).  Each step exchanges the filter halo with
 the left neighbour (send/recv), runs pass 1, all-gathers the 56-byte shard summaries, resolves
-the symbol-timing carry, runs pass 2 and gathers the dibit counts.
+the symbol-timing carry on the device and runs pass 2 -- no host synchronisation inside a step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
 dominant kernel (K1) from HIP events recorded inside the library on the launch stream, and
@@ -100,10 +100,11 @@ def main():
     else:
         from p25rx_amd.sharding import TimeShard
         ts = TimeShard(fe, rank, world, n, dist)
+        ts.setup_device(torch, dev)
         summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
 
         def step():
-            ts.step(buf, result, summ_all, dibits)
+            ts.step_device(buf, result, summ_all, dibits)
 
     for _ in range(args.warmup):
         step()

@@ -182,6 +182,12 @@ int p25fe_shard_pass2(p25fe_t *h, const p25fe_anchor_t *d_anchor_in, uint8_t *d_
 int p25fe_shard_resolve(const p25fe_result_t *summaries, const uint64_t *shard_bb0, const uint64_t *shard_bb_n,
                         size_t n_shards, p25fe_anchor_t *anchor_in, uint64_t *dibit_offset);
 
+/* Same combine on the device (one tiny kernel, no host synchronisation): all arrays are device pointers, e.g. the
+ * all-gathered summaries; writes n_shards anchors / offsets; pass d_anchor_in + rank to p25fe_shard_pass2. */
+int p25fe_shard_resolve_dev(p25fe_t *h, const p25fe_result_t *d_summaries, const uint64_t *d_shard_bb0,
+                            const uint64_t *d_shard_bb_n, size_t n_shards, p25fe_anchor_t *d_anchor_in,
+                            uint64_t *d_dibit_offset, void *stream);
+
 /* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1/2 record HIP
  * events on the caller's stream around each kernel (K1 front end, K2 sync, K3 scan, K4 slice).
  * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel

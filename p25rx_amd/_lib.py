@@ -44,7 +44,7 @@ SYMBOLS = [
     "p25fe_reset", "p25fe_state_size", "p25fe_state_export", "p25fe_state_import", "p25fe_demod_dev",
     "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
-    "p25fe_predecim_dev", "p25fe_n_predecim",
+    "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev",
 ]
 
 
@@ -102,6 +102,7 @@ def load():
     L.p25fe_shard_pass1.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, vp]
     L.p25fe_shard_pass2.argtypes = [vp, vp, vp, sz, vp, vp]
     L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.p25fe_shard_resolve_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_profile_enable.argtypes = [vp, C.c_int]
     L.p25fe_profile_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
     L.p25fe_predecim_dev.argtypes = [vp, vp, sz, sz, sz, u64, vp, sz, vp]

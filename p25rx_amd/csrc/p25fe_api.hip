@@ -482,17 +482,19 @@ int p25fe_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_b
                         size_t n_shards, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {
     if (!summaries || !shard_bb0 || !shard_bb_n || !anchor_in || !dibit_offset) return P25FE_ERR_ARG;
-    p25fe_anchor_t cur = {0, 0.f, 0.f, 0.f, 0};
-    uint64_t off = 0;
-    for (size_t r = 0; r < n_shards; ++r) {
-        anchor_in[r] = cur;
-        dibit_offset[r] = off;
-        const long lo = (long)shard_bb0[r], hi = (long)(shard_bb0[r] + shard_bb_n[r]);
-        const long pre_hi = summaries[r].first_event >= 0 ? (long)summaries[r].first_event + 1 : hi;
-        const uint64_t pre = cur.valid ? (uint64_t)count_instants(cur.s, lo, pre_hi) : 0;
-        off += pre + (summaries[r].first_event >= 0 ? summaries[r].n_dibits_after_first : 0);
-        if (summaries[r].first_event >= 0) cur = summaries[r].anchor_out;
-    }
+    shard_resolve_impl(summaries, shard_bb0, shard_bb_n, (int)n_shards, anchor_in, dibit_offset);
+    return P25FE_OK;
+}
+
+int p25fe_shard_resolve_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const uint64_t* d_shard_bb0,
+                            const uint64_t* d_shard_bb_n, size_t n_shards, p25fe_anchor_t* d_anchor_in,
+                            uint64_t* d_dibit_offset, void* stream)
+{
+    if (!h || !d_summaries || !d_shard_bb0 || !d_shard_bb_n || !d_anchor_in || !d_dibit_offset) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_summaries, d_shard_bb0, d_shard_bb_n,
+                       (int)n_shards, d_anchor_in, d_dibit_offset);
+    HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
 

@@ -1142,4 +1142,33 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     }
 }
 
+// Carry resolution across time shards (BASELINE.json config 5): the same "latest anchor wins" rule as K3, one level
+// up.  summaries[r] were produced assuming no carry-in; shard r's carry-in is the anchor_out of the latest earlier
+// shard that has an event of its own, and its dibit offset adds the closed-form count of instants that the carry-in
+// governs before the shard's first own event.  Shared by the host entry point and the one-thread device kernel.
+__host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summaries, const uint64_t* shard_bb0,
+                                                    const uint64_t* shard_bb_n, int n_shards, p25fe_anchor_t* anchor_in,
+                                                    uint64_t* dibit_offset)
+{
+    p25fe_anchor_t cur;
+    cur.s = 0; cur.hi = cur.mid = cur.lo = 0.f; cur.valid = 0;
+    uint64_t off = 0;
+    for (int r = 0; r < n_shards; ++r) {
+        anchor_in[r] = cur;
+        dibit_offset[r] = off;
+        const long lo = (long)shard_bb0[r], hi = (long)(shard_bb0[r] + shard_bb_n[r]);
+        const long pre_hi = summaries[r].first_event >= 0 ? (long)summaries[r].first_event + 1 : hi;
+        const uint64_t pre = cur.valid ? (uint64_t)count_instants(cur.s, lo, pre_hi) : 0;
+        off += pre + (summaries[r].first_event >= 0 ? summaries[r].n_dibits_after_first : 0);
+        if (summaries[r].first_event >= 0) cur = summaries[r].anchor_out;
+    }
+}
+
+__global__ void k_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
+                                int n_shards, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        shard_resolve_impl(summaries, shard_bb0, shard_bb_n, n_shards, anchor_in, dibit_offset);
+}
+
 }  // namespace p25k

@@ -231,13 +231,31 @@ class FrontEnd:
                                            C.c_void_p(result.data_ptr()), self._stream()))
         return result
 
+    def shard_resolve_dev(self, summ_all, d_bb0, d_bbn, anchors=None, offsets=None):
+        """Device-side combine: summ_all uint8 [n_shards, sizeof(result)], d_bb0 / d_bbn int64 device tensors.
+        Returns (anchors uint8 [n_shards, sizeof(anchor)], offsets int64 [n_shards]) without synchronising."""
+        import torch
+        n = summ_all.shape[0]
+        if anchors is None:
+            anchors = torch.empty((n, ANCHOR_DTYPE.itemsize), dtype=torch.uint8, device=summ_all.device)
+        if offsets is None:
+            offsets = torch.empty(n, dtype=torch.int64, device=summ_all.device)
+        self._chk(self.L.p25fe_shard_resolve_dev(self.h, C.c_void_p(summ_all.data_ptr()), C.c_void_p(d_bb0.data_ptr()),
+                                                 C.c_void_p(d_bbn.data_ptr()), n, C.c_void_p(anchors.data_ptr()),
+                                                 C.c_void_p(offsets.data_ptr()), self._stream()))
+        return anchors, offsets
+
     def shard_pass2(self, anchor_in, n_bb, device, result=None, dibits=None):
+        """anchor_in: NumPy structured anchor(s) (host) or a uint8 device tensor holding one p25fe_anchor_t per channel."""
         import torch
         cap = (n_bb // 10 + 64 + 15) // 16 * 16
         dib = dibits if dibits is not None else torch.empty((self.C, cap), dtype=torch.uint8, device=device)
         if result is None:
             result = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=device)
-        a_in = torch.from_numpy(np.frombuffer(np.asarray(anchor_in, dtype=ANCHOR_DTYPE).tobytes(), dtype=np.uint8).copy()).to(device)
+        if isinstance(anchor_in, torch.Tensor):
+            a_in = anchor_in
+        else:
+            a_in = torch.from_numpy(np.frombuffer(np.asarray(anchor_in, dtype=ANCHOR_DTYPE).tobytes(), dtype=np.uint8).copy()).to(device)
         self._chk(self.L.p25fe_shard_pass2(self.h, C.c_void_p(a_in.data_ptr()), C.c_void_p(dib.data_ptr()), dib.stride(0),
                                            C.c_void_p(result.data_ptr()), self._stream()))
         return dib, result

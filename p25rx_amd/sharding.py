@@ -74,3 +74,24 @@ class TimeShard:
         summ, anchors, offsets = self.exchange_summaries(result, summ_all)
         self.pass2(anchors, buf.device, result, dibits)
         return int(offsets[self.rank]), summ
+
+    # ---- same step without any host synchronisation: the carry is resolved by a one-thread kernel ----------
+    def setup_device(self, torch, device):
+        self.d_bb0 = torch.tensor(self.bb0, dtype=torch.int64, device=device)
+        self.d_bbn = torch.tensor(self.bbn, dtype=torch.int64, device=device)
+        self.d_anchors = self.d_offsets = None
+
+    def step_device(self, buf, result, summ_all, dibits):
+        """exchange_halo -> pass 1 -> all_gather -> k_shard_resolve -> pass 2, all enqueued on the current stream.
+        Returns the device tensor of per-shard dibit offsets (read it after the timed region)."""
+        self.exchange_halo(buf)
+        self.pass1(buf, result)
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(summ_all.view(-1), result.view(-1))
+        else:
+            summ_all.copy_(result)
+        self.d_anchors, self.d_offsets = self.fe.shard_resolve_dev(summ_all, self.d_bb0, self.d_bbn, self.d_anchors,
+                                                                   self.d_offsets)
+        self.fe.shard_pass2(self.d_anchors[self.rank:self.rank + 1], self.bbn[self.rank], buf.device, result=result,
+                            dibits=dibits)
+        return self.d_offsets

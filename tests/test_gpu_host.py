@@ -84,3 +84,26 @@ def test_scan_spans_several_lds_chunks():
     assert np.array_equal(sd[0, :len(spos)].cpu().numpy().astype(np.uint64), sdib)
     st = r.state()
     assert int(rr["anchor_out"]["s"]) == st["s"] and float(rr["anchor_out"]["hi"]) == np.float32(st["hi"])
+
+
+def test_timeshard_step_device_world1(c4fm_1s):
+    """The N > 1 bench path (TimeShard.step_device) degenerates to one shard at world = 1: same dibits as run_dev."""
+    import torch
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    from p25rx_amd.sharding import TimeShard
+    iq = c4fm_1s[0]
+    n = len(iq) // 8 * 8
+    fe = FrontEnd()
+    ts = TimeShard(fe, 0, 1, n, None)
+    ts.setup_device(torch, "cuda")
+    buf = ts.alloc(torch, "cuda", torch.float32)
+    buf[ts.halo:] = torch.from_numpy(iq[:n].view(np.float32).reshape(-1, 2)).cuda()
+    result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    summ_all = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    dibits = torch.empty((1, n // 50 + 64), dtype=torch.uint8, device="cuda")
+    off = ts.step_device(buf, result, summ_all, dibits)
+    nd = int(parse_results(result)[0]["n_dibits"])
+    ref, rres = FrontEnd().run_dev(buf[ts.halo:])
+    assert nd == int(parse_results(rres)[0]["n_dibits"]) and int(off[0]) == 0
+    assert torch.equal(dibits[0, :nd], ref[0, :nd])

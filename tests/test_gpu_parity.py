@@ -249,6 +249,19 @@ def test_time_shards_equal_single_pass(O, FE):
         assert off[r] == sum(len(x) for x in out)
         out.append(dib[0, :k].cpu().numpy())
     assert np.array_equal(np.concatenate(out), ref)
+    # the same combine on the device (no host sync), and pass 2 fed with the device anchors
+    summ_t = torch.from_numpy(np.frombuffer(np.array(summ).tobytes(), dtype=np.uint8).copy()).view(len(summ), -1).cuda()
+    # (pass 2 above overwrote nothing the summaries depend on: they were parsed before)
+    d_bb0 = torch.tensor(bb0, dtype=torch.int64, device="cuda")
+    d_bbn = torch.tensor(bbn, dtype=torch.int64, device="cuda")
+    d_anc, d_off = fe.shard_resolve_dev(summ_t, d_bb0, d_bbn)
+    assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), off)
+    assert d_anc.cpu().numpy().tobytes() == anc.tobytes()
+    out2 = []
+    for r in range(len(cuts) - 1):
+        dib, res = fes[r].shard_pass2(d_anc[r:r + 1], bbn[r], t.device)
+        out2.append(dib[0, :int(parse_results(res)[0]["n_dibits"])].cpu().numpy())
+    assert np.array_equal(np.concatenate(out2), ref)
 
 
 def test_custom_taps_zero_padded(O, FE, c4fm_1s):
