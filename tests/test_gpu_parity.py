@@ -329,3 +329,26 @@ def test_config3_wideband_predecimator(O, FE):
     first = len([m for m in range(len(x240)) if 10 * m + 9 < off])   # outputs produced before the range
     assert np.array_equal(y2[0, :no2].cpu().numpy().view(np.uint32),
                           x240[first:first + no2].view(np.float32).reshape(-1, 2).view(np.uint32))
+
+
+def test_config4_256_channels(O, FE):
+    """BASELINE.json config 4 shape: 256 independent channels, channel-major, one launch per kernel; every
+    channel must equal its own oracle run (distinct seeds, SNRs, frequency and timing offsets)."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    Cn, secs = 256, 0.2
+    iqs = []
+    for c in range(Cn):
+        iq, _, _ = c4fm.synth(secs, seed=500 + c, snr_db=12.0 + (c % 20), freq_offset_hz=20.0 * (c % 11) - 100.0,
+                              timing_offset=c % 50, frame_dibits=300 + 7 * (c % 13))
+        iqs.append(iq)
+    arr = np.stack(iqs)
+    t = torch.from_numpy(arr.view(np.float32).reshape(Cn, -1, 2)).cuda()
+    fe = FE(n_channels=Cn)
+    dib, res = fe.run_dev(t)
+    r = parse_results(res)
+    for c in range(Cn):
+        ref = O.run_cf32(iqs[c])
+        assert int(r["n_dibits"][c]) == len(ref), c
+        assert np.array_equal(dib[c, :len(ref)].cpu().numpy(), ref), c
