@@ -614,16 +614,21 @@ __device__ __forceinline__ int wave_incl_sum(int v, int lane)
     return v;
 }
 
-// Block-wide exclusive scans over per-thread (last event position, count).  scratch: >= 8 longs + 8 ints.
-__device__ __forceinline__ long block_excl_max(long v, long* sh, int tid)
+// Block-wide exclusive scans over per-thread (last event index inside the tile, count).  scratch: >= 8 ints.
+__device__ __forceinline__ int block_excl_max(int v, int* sh, int tid)
 {
     const int lane = tid & 63, wv = tid >> 6;
-    const long inc = wave_incl_max(v, lane);
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = o > inc ? o : inc;
+    }
     if (lane == 63) sh[wv] = inc;
     __syncthreads();
-    long prev = __shfl_up(inc, 1, 64);
+    int prev = __shfl_up(inc, 1, 64);
     if (lane == 0) prev = -1;
-    long carry = -1;
+    int carry = -1;
     for (int k = 0; k < wv; ++k) carry = sh[k] > carry ? sh[k] : carry;
     __syncthreads();
     return prev > carry ? prev : carry;
@@ -659,8 +664,8 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
 {
     __shared__ float BT[BT_N];          // BT[k] = b[t0 - HIST_BB + k]
     __shared__ float CT[CT_N];          // CT[k] = c[t0 - 2W + k]
-    __shared__ uint8_t CAND[CT_N];
-    __shared__ long shl[8];
+    __shared__ __attribute__((aligned(8))) uint8_t CAND[CT_N + 16];   // flag of position k at CAND[k - W + 8]: sample i's flag at the 8-aligned CAND[i + 8]
+    __shared__ int shl[8];
     __shared__ int shi[8];
 
     const int tid = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
@@ -668,7 +673,12 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     const float* bbp = a.bb + (size_t)ch * a.bb_stride;
     const long tn = (a.n - t0 < TB) ? a.n - t0 : TB;            // samples in this tile
 
-    for (int k = tid; k < BT_N; k += NT) BT[k] = bb_at(bbp, a.n_hist, a.n, t0 - HIST_BB + k);
+    if (t0 - HIST_BB >= -a.n_hist && t0 - HIST_BB + BT_N <= a.n) {      // uniform: interior tile, no bounds checks
+        const float* src = bbp + (t0 - HIST_BB);
+        for (int k = tid; k < BT_N; k += NT) BT[k] = src[k];
+    } else {
+        for (int k = tid; k < BT_N; k += NT) BT[k] = bb_at(bbp, a.n_hist, a.n, t0 - HIST_BB + k);
+    }
     __syncthreads();
 
     // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s] = BT[k + 10 j], j = 0..23.
@@ -693,7 +703,7 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
             }
             if (k < TB + 2 * W) {
                 CT[k] = c;
-                CAND[k] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
+                CAND[k - W + 8] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
             }
         }
     }
@@ -701,23 +711,30 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
 
     // event at local index i (decided when sample t0 + i arrives) <=> detection at s = t0 + i - W -> CT index k = i + W.
     // s must lie inside the stream so far: s >= -n_hist (older samples read as zero anyway) and the peak
-    // window s + W = t0 + i - 1 < n is guaranteed by i < tn.
-    long my_last = -1;
+    // window s + W = t0 + i - 1 < n is guaranteed by i < tn.  CAND is stored shifted so that a thread's 8
+    // flags are one aligned 8-byte LDS read; no candidate among them (the common case) skips the peak test.
+    int my_last = -1;                                  // tile-local index of my last event
     int my_ev = 0;
     uint8_t evl[VPT];
 #pragma unroll
-    for (int u = 0; u < VPT; ++u) {
-        const int i = tid * VPT + u;
-        const int k = i + W;
-        bool det = false;
-        if (i < tn && CAND[k]) {
-            const float cm = CT[k];
-            det = true;
+    for (int u = 0; u < VPT; ++u) evl[u] = 0;
+    {
+        const uint2 cm8 = *reinterpret_cast<const uint2*>(&CAND[tid * VPT + 8]);        // flags of samples tid*8 .. tid*8+7
+        if ((cm8.x | cm8.y) != 0u) {
 #pragma unroll
-            for (int d = 1; d <= W; ++d) det = det && (cm > CT[k - d]) && (cm >= CT[k + d]);
+            for (int u = 0; u < VPT; ++u) {
+                const int i = tid * VPT + u;
+                const int k = i + W;
+                const bool cand = (((u < 4 ? cm8.x : cm8.y) >> (8 * (u & 3))) & 0xffu) != 0u;
+                if (i < (int)tn && cand) {
+                    const float cm = CT[k];
+                    bool det = true;
+#pragma unroll
+                    for (int d = 1; d <= W; ++d) det = det && (cm > CT[k - d]) && (cm >= CT[k + d]);
+                    if (det) { evl[u] = 1; my_last = i; ++my_ev; }
+                }
+            }
         }
-        evl[u] = det;
-        if (det) { my_last = t0 + i; ++my_ev; }
     }
     if (a.events) {
         uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0;
@@ -735,50 +752,61 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     }
 
     // latest own event before each thread's first sample, then count instants under own events
-    const long incoming = block_excl_max(my_last, shl, tid);
-    int cur = incoming >= 0 ? (int)(incoming - t0) : -1;   // tile-local index of the governing event, -1: carry-in (unknown here)
+    const int incoming = block_excl_max(my_last, shl, tid);
+    int cur = incoming;                                 // tile-local index of the governing event, -1: carry-in (unknown here)
     int cnt = 0;
+    if (my_ev == 0) {
+        // common case: no event inside my 8 samples -> at most one instant (8 < 10), closed form
+        if (cur >= 0) {
+            const int i0 = tid * VPT;
+            const int navail = (int)tn - i0 < VPT ? (int)tn - i0 : VPT;
+            const unsigned ph = (unsigned)(i0 - (cur - W)) % (unsigned)SPS;
+            const int f = (int)((SPS - ph) % (unsigned)SPS);
+            cnt = f < navail ? 1 : 0;
+        }
+    } else {
 #pragma unroll
-    for (int u = 0; u < VPT; ++u) {
-        const int i = tid * VPT + u;
-        if (i < (int)tn) {
-            if (cur >= 0) {                             // events decided BEFORE this sample govern it
-                const unsigned dist = (unsigned)(i - (cur - W));   // > 0: distance to the anchor
-                if (dist % (unsigned)SPS == 0u) ++cnt;
+        for (int u = 0; u < VPT; ++u) {
+            const int i = tid * VPT + u;
+            if (i < (int)tn) {
+                if (cur >= 0) {                             // events decided BEFORE this sample govern it
+                    const unsigned dist = (unsigned)(i - (cur - W));   // > 0: distance to the anchor
+                    if (dist % (unsigned)SPS == 0u) ++cnt;
+                }
+                if (evl[u]) cur = i;
             }
-            if (evl[u]) cur = i;
         }
     }
-    int total_cnt, total_ev;
-    block_excl_sum(cnt, shi, tid, total_cnt);
-    block_excl_sum(my_ev, shi, tid, total_ev);
+    int total_packed;
+    block_excl_sum(cnt | (my_ev << 16), shi, tid, total_packed);   // instants low half, events high half
+    const int total_cnt = total_packed & 0xffff, total_ev = total_packed >> 16;
     // first / last event of the tile
-    __shared__ long first_ev, last_ev;
+    __shared__ int first_ev, last_ev;                           // tile-local indices
     if (tid == 0) first_ev = -1;
     if (tid == NT - 1) last_ev = incoming > my_last ? incoming : my_last;
     __syncthreads();
     if (my_last >= 0 && incoming < 0) {                        // the one thread whose event has none before it
-        long f = -1;
+        int f = -1;
 #pragma unroll
-        for (int u = VPT - 1; u >= 0; --u) if (evl[u]) f = t0 + tid * VPT + u;
+        for (int u = VPT - 1; u >= 0; --u) if (evl[u]) f = tid * VPT + u;
         first_ev = f;
     }
     __syncthreads();
     if (tid == 0) {
         TileRec r;
-        r.first_event = first_ev >= 0 ? first_ev + a.abs0 : -1;
+        r.first_event = first_ev >= 0 ? a.abs0 + t0 + first_ev : -1;
         r.n_events = total_ev;
         r.post_count = total_cnt;
         r.last_s = -1; r.hi = r.mid = r.lo = 0.f;
         if (last_ev >= 0) {
-            const long s = last_ev - W;                         // local
+            const int s = last_ev - W;                          // tile-local
             float hi, mid, lo;
-            sync_thresholds(BT, (int)(s - (t0 - HIST_BB)), hi, mid, lo);
-            r.last_s = s + a.abs0; r.hi = hi; r.mid = mid; r.lo = lo;
+            sync_thresholds(BT, s + HIST_BB, hi, mid, lo);
+            r.last_s = a.abs0 + t0 + s; r.hi = hi; r.mid = mid; r.lo = lo;
         }
         a.recs[(size_t)ch * a.n_tiles + tile] = r;
         a.tsum[(size_t)ch * a.n_tiles + tile] =
-            first_ev >= 0 ? pack_tsum((int)(first_ev - t0), (int)(last_ev - t0), total_ev, total_cnt) : 0ull;
+            first_ev >= 0 ? pack_tsum(first_ev, last_ev, total_ev, total_cnt) : 0ull;
     }
 }
 
@@ -1026,7 +1054,7 @@ struct SliceArgs {
 // 8 event flags straight from global memory (both were just written and are L2 / MALL resident).
 __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
 {
-    __shared__ long shl[8];
+    __shared__ int shl[8];
     __shared__ int shi[8];
     const int tid = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
     const long t0 = (long)tile * TB;
@@ -1068,37 +1096,50 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
         }
     }
 
-    long my_last = -1;
+    int my_last = -1;
     int my_ev = 0;
 #pragma unroll
     for (int u = 0; u < VPT; ++u)
         if (evl[u]) { my_last = tid * VPT + u; ++my_ev; }
-    const long incoming = block_excl_max(my_last, shl, tid);
+    const int incoming = block_excl_max(my_last, shl, tid);
     // walk my 8 samples: count, then rank, then emit
-    int cur = (int)incoming;
+    int cur = incoming;
     int cnt = 0;
     unsigned inst = 0;
     // distance of my first sample to the carry-in anchor, mod 10 (one 64-bit modulo per thread, then 32-bit)
     // (wave-uniform 64-bit modulo once, then 32-bit per thread)
     const unsigned base_ph = co.valid ? (unsigned)((a.abs0 + t0 - co.anchor_s) % SPS) : 0u;
     const unsigned cph = (base_ph + (unsigned)(tid * VPT)) % (unsigned)SPS;
+    if (my_ev == 0) {
+        // common case: no event inside my 8 samples -> one governing anchor, and since 8 < 10 at most ONE instant
+        const int i0 = tid * VPT;
+        const int navail = (int)tn - i0 < VPT ? (int)tn - i0 : VPT;
+        unsigned ph = 0u;
+        bool gov = false;
+        if (cur >= 0) { ph = (unsigned)(i0 - (cur - W)) % (unsigned)SPS; gov = true; }
+        else if (co.valid) { ph = cph; gov = true; }
+        const int f = (int)((SPS - ph) % (unsigned)SPS);        // offset of the first instant at or after i0
+        if (gov && f < navail) { cnt = 1; inst = 1u << f; }
+    } else {
 #pragma unroll
-    for (int u = 0; u < VPT; ++u) {
-        const int i = tid * VPT + u;
-        if (i < (int)tn) {
-            bool is = false;
-            if (cur >= 0) is = ((unsigned)(i - (cur - W)) % (unsigned)SPS) == 0u;
-            else if (co.valid) is = ((cph + (unsigned)u) % (unsigned)SPS) == 0u;
-            if (is) { ++cnt; inst |= 1u << u; }
-            if (evl[u]) cur = i;
+        for (int u = 0; u < VPT; ++u) {
+            const int i = tid * VPT + u;
+            if (i < (int)tn) {
+                bool is = false;
+                if (cur >= 0) is = ((unsigned)(i - (cur - W)) % (unsigned)SPS) == 0u;
+                else if (co.valid) is = ((cph + (unsigned)u) % (unsigned)SPS) == 0u;
+                if (is) { ++cnt; inst |= 1u << u; }
+                if (evl[u]) cur = i;
+            }
         }
     }
+    // one block scan for both ranks: instants in the low half, events in the high half (each <= 2048 per tile)
     int total;
-    int rank = block_excl_sum(cnt, shi, tid, total);
-    int evtotal;
-    int evrank = block_excl_sum(my_ev, shi, tid, evtotal);
+    const int packed = block_excl_sum(cnt | (my_ev << 16), shi, tid, total);
+    int rank = packed & 0xffff;
+    int evrank = packed >> 16;
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + co.dibit_off;
-    cur = (int)incoming;
+    cur = incoming;
     int thr_for = -2;                      // tile-local anchor whose thresholds are cached in hi / mid / lo
     float hi = co.hi, mid = co.mid, lo = co.lo;
 #pragma unroll
