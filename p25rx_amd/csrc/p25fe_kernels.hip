@@ -530,11 +530,12 @@ constexpr int W = P25FE_PEAK_W;
 constexpr int SPS = P25FE_SPS;
 constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
 constexpr int TB = 2048;                                     // baseband samples per tile
-constexpr int NT = 256;                                      // threads per workgroup in K2 / K4
+constexpr int NT = 256;                                      // threads per workgroup in K2 / K4 (512 x 4096-sample tiles measured slower)
 constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
 constexpr int CQ = 9;                                        // symbol-spaced correlation outputs per thread (K2)
-constexpr int BT_N = 10 * CQ * 25 + 10 * (CQ + 23) + 16;     // LDS baseband tile incl. the register-tiling overrun (2586)
+constexpr int CORR_T = (TB + 2 * W + SPS * CQ - 1) / (SPS * CQ) * SPS;   // threads busy in the correlation (10 phases x slot blocks): 460
+constexpr int BT_N = SPS * CQ * (CORR_T / SPS) + SPS * (CQ + 23) + 16;    // LDS baseband tile incl. the register-tiling overrun
 constexpr int CT_N = TB + 2 * W + 2;                         // c[] for s in [a-2W-1, a+TB-W-1) plus peak lookahead
 
 struct TileRec {            // per (channel, tile) summary written by K2
@@ -546,12 +547,14 @@ struct TileRec {            // per (channel, tile) summary written by K2
 };
 
 // Packed per-tile summary for the scan (one coalesced 8-byte word per tile):
-//   bits  0..11  first_off + 1   (0: the tile has no event)      bits 12..23  last_off + 1
-//   bits 24..35  n_events                                          bits 36..47  post_count
+//   bits  0..12  first_off + 1   (0: the tile has no event)      bits 13..25  last_off + 1
+//   bits 26..38  n_events                                          bits 39..51  post_count
+constexpr int TS_BITS = 13;                                  // TB + 1 <= 2^13
+constexpr unsigned long long TS_MASK = (1ull << TS_BITS) - 1;
 __host__ __device__ inline unsigned long long pack_tsum(int first_off, int last_off, int n_events, int post_count)
 {
-    return (unsigned long long)(first_off + 1) | ((unsigned long long)(last_off + 1) << 12) |
-           ((unsigned long long)n_events << 24) | ((unsigned long long)post_count << 36);
+    return (unsigned long long)(first_off + 1) | ((unsigned long long)(last_off + 1) << TS_BITS) |
+           ((unsigned long long)n_events << (2 * TS_BITS)) | ((unsigned long long)post_count << (3 * TS_BITS));
 }
 
 struct ScanOut {            // per (channel, tile) carry-in written by K3
@@ -641,7 +644,9 @@ __device__ __forceinline__ int block_excl_sum(int v, int* sh, int tid, int& tota
     __syncthreads();
     int carry = 0;
     for (int k = 0; k < wv; ++k) carry += sh[k];
-    total = sh[0] + sh[1] + sh[2] + sh[3];
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) total += sh[k];
     __syncthreads();
     return carry + inc - v;
 }
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     // Register tiling over symbol-spaced positions: a thread takes one sample phase r = k % 10 and CQ
     // consecutive symbol slots, so its CQ outputs share a sliding window of CQ + 23 LDS reads (3.6 reads per
     // output instead of 24); each output keeps its own accumulators in tap order j = 0..23 (SPEC 3.7).
-    if (tid < 250) {
+    if (tid < CORR_T) {
         const int r = tid % SPS, qb = tid / SPS;
         const int base = SPS * CQ * qb + r;                     // k of the thread's first output
         float w[CQ + P25FE_SYNC_DIBITS - 1];
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
 
         // pass 1: latest event tile inside my run -> block exclusive max
         long last = -1;
-        for (int k = k0; k < k1; ++k) if (TS[k] & 0xfffu) last = k;
+        for (int k = k0; k < k1; ++k) if (TS[k] & TS_MASK) last = k;
         long tot_max;
         const long incl = block_incl_max1024(last, shl, tid, tot_max);
         long excl = __shfl_up(incl, 1, 64);
@@ -924,7 +929,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         auto phase_at = [&](int k, long src, bool& v) -> unsigned {   // phase of tile k's start under anchor `src`
             if (src >= 0) {
                 v = true;
-                const int last_off = (int)((TS[src] >> 12) & 0xfffu) - 1;
+                const int last_off = (int)((TS[src] >> TS_BITS) & TS_MASK) - 1;
                 const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TB - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
                 return dist % (unsigned)SPS;
             }
@@ -950,13 +955,13 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
             if (!(k0 < k1)) v = false;
             for (int k = k0; k < k1; ++k) {
                 const unsigned long long u = TS[k];
-                const int first1 = (int)(u & 0xfffu);
+                const int first1 = (int)(u & TS_MASK);
                 const int len = first1 ? first1 : tile_len(k);        // instant AT the event index is still the old anchor's
-                my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> 36) & 0xfffu);
-                my_ev += (u >> 24) & 0xfffu;
+                my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
+                my_ev += (u >> (2 * TS_BITS)) & TS_MASK;
                 if (first1) {
                     src = k; v = true;
-                    const int last_off = (int)((u >> 12) & 0xfffu) - 1;
+                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
                     ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;     // next tile's start under the new anchor
                 } else {
                     ph = (ph + (unsigned)TB) % (unsigned)SPS;
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
             unsigned long long dc = carry_cnt + icnt - my_cnt, ec = carry_ev + iev - my_ev;
             for (int k = k0; k < k1; ++k) {
                 const unsigned long long u = TS[k];
-                const int first1 = (int)(u & 0xfffu);
+                const int first1 = (int)(u & TS_MASK);
                 const int len = first1 ? first1 : tile_len(k);
                 const unsigned pre = v ? count32(ph, len) : 0u;
                 ScanOut o;
@@ -988,11 +993,11 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
                     first_info[0] = (unsigned long long)(c0 + k) + 1;
                     first_info[1] = dc + pre;
                 }
-                dc += pre + (unsigned)((u >> 36) & 0xfffu);
-                ec += (u >> 24) & 0xfffu;
+                dc += pre + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
+                ec += (u >> (2 * TS_BITS)) & TS_MASK;
                 if (first1) {
                     src = k; v = true;
-                    const int last_off = (int)((u >> 12) & 0xfffu) - 1;
+                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
                     ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;
                 } else {
                     ph = (ph + (unsigned)TB) % (unsigned)SPS;
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         }
         // carries for the next chunk (uniform: every thread computes the same values)
         if (tot_max >= 0) {
-            carry_s = a.abs0 + (long)(c0 + tot_max) * TB + (long)((TS[tot_max] >> 12) & 0xfffu) - 1 - W;
+            carry_s = a.abs0 + (long)(c0 + tot_max) * TB + (long)((TS[tot_max] >> TS_BITS) & TS_MASK) - 1 - W;
             carry_valid = true;
             carry_src = c0 + tot_max;
         }

@@ -63,15 +63,15 @@ def test_cpp_replay_driver(tmp_path, c4fm_1s, mode):
 
 
 def test_scan_spans_several_lds_chunks():
-    """K3 stages 16384 tile summaries in LDS at a time: 40 M baseband samples = 19532 tiles cross a chunk boundary."""
+    """K3 stages 16384 tile summaries in LDS at a time: 70 M baseband samples = 34180 tiles cross a chunk boundary."""
     import torch
     from oracle import oracle as O
     from p25rx_amd import c4fm
     from p25rx_amd.frontend import FrontEnd, parse_results
     iq, _, _ = c4fm.synth(2.0, seed=9, snr_db=25.0, frame_dibits=1100)
     bb1 = O.Demod().feed_cf32(iq)[200:]                      # start mid-stream so the tiling repeats irregularly
-    reps = 40_000_000 // len(bb1) + 1
-    bb = np.tile(bb1, reps)[:40_000_000]
+    reps = 70_000_000 // len(bb1) + 1
+    bb = np.tile(bb1, reps)[:70_000_000]
     r = O.Recv()
     dib, spos, sdib = r.feed(bb)
     t = torch.from_numpy(bb).cuda()
