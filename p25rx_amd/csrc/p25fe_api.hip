@@ -55,7 +55,7 @@ struct p25fe {
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
     // scratch
-    DevBuf iq_stage, bb_buf, events, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    DevBuf iq_stage, bb_buf, events, recs, tsum, outs, aggs, carries, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
@@ -190,7 +190,6 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK>), Geo<PK>::LDS_BYTES);   \
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK>), Geo<PK>::LDS_BYTES);      \
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK>), Geo<PK>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_scan), K3_LDS_BYTES);
     P25FE_FOR_K1(5)
     P25FE_FOR_K1(3)
 #undef P25FE_FOR_K1
@@ -209,7 +208,7 @@ void p25fe_destroy(p25fe_t* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
+    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->tsum, &h->outs, &h->aggs, &h->carries, &h->power_partial, &h->power_out,
                       &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
@@ -303,6 +302,9 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
     HIPCHK(h, h->events.ensure(C * round_up(n_bb + 8, 16)));
     HIPCHK(h, h->recs.ensure(C * (n_tiles + 1) * sizeof(TileRec)));
     HIPCHK(h, h->tsum.ensure(C * (n_tiles + 1) * sizeof(unsigned long long)));
+    const size_t n_groups = (n_tiles + K3_GROUP - 1) / K3_GROUP + 1;
+    HIPCHK(h, h->aggs.ensure(C * n_groups * sizeof(GroupAgg)));
+    HIPCHK(h, h->carries.ensure(C * n_groups * sizeof(GroupCarry)));
     HIPCHK(h, h->outs.ensure(C * (n_tiles + 1) * sizeof(ScanOut)));
     return P25FE_OK;
 }
@@ -332,14 +334,22 @@ static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, si
     ScanArgs c;
     c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>(); c.n_tiles = (int)n_tiles; c.n = (long)n_bb;
     c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result; c.n_baseband = n_bb;
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)h->C), dim3(NT3), K3_LDS_BYTES, st, c);
+    const size_t n_groups = (n_tiles + K3_GROUP - 1) / K3_GROUP;
+    c.aggs = h->aggs.as<GroupAgg>(); c.carries = h->carries.as<GroupCarry>(); c.n_groups = (int)n_groups;
+    c.n_channels = h->C;
+    if (n_groups) {
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)n_groups, (unsigned)h->C), dim3(NT3), 0, st, c);
+        HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_scan_groups, dim3((unsigned)((h->C + 63) / 64)), dim3(64), 0, st, c);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 3, st);
     if (!do_slice) { prof_mark(h, 4, st); return P25FE_OK; }
     SliceArgs l;
     l.bb = d_bb; l.bb_stride = (long)bb_stride; l.n_hist = (long)n_hist_bb; l.n = (long)n_bb; l.abs0 = (long)abs_bb0;
     l.n_tiles = (int)n_tiles; l.events = h->events.as<uint8_t>(); l.ev_stride = (long)round_up(n_bb + 8, 16);
-    l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.anchor_in = d_anchor_in; l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
+    l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.carries = h->carries.as<GroupCarry>();
+    l.n_groups = (int)n_groups; l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
     hipLaunchKernelGGL(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, l);

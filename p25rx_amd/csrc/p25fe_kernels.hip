@@ -529,8 +529,8 @@ __global__ void k_power_finish(const float* partial, int n_partial, long n, floa
 constexpr int W = P25FE_PEAK_W;
 constexpr int SPS = P25FE_SPS;
 constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
-constexpr int TB = 2048;                                     // baseband samples per tile
-constexpr int NT = 256;                                      // threads per workgroup in K2 / K4 (512 x 4096-sample tiles measured slower)
+constexpr int TB = 1024;                                     // baseband samples per tile
+constexpr int NT = 128;                                      // threads per workgroup in K2 / K4 (256 x 2048 and 512 x 4096 measured slower)
 constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
 constexpr int CQ = 9;                                        // symbol-spaced correlation outputs per thread (K2)
@@ -815,11 +815,34 @@ __global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
     }
 }
 
+// The scan over tiles is two-level so that it does not run on a single CU: K3a scans groups of K3_GROUP tiles in
+// parallel (one workgroup each, no carry-in), K3b walks the (few) group aggregates and hands every group its carry,
+// K4 adds the group carry to the group-local values.
+struct GroupAgg {           // per (channel, group), written by K3a
+    int first_tile;         // absolute index of the group's first tile with an event, -1 if none
+    int last_tile;          // ... last tile with an event
+    long first_event;       // absolute decision index of the group's first event
+    unsigned long long cnt_after_first;   // dibits governed by the group's own events
+    unsigned long long n_events;
+};
+struct GroupCarry {         // per (channel, group), written by K3b
+    long anchor_s;          // anchor in force at the group's first sample
+    float hi, mid, lo;
+    int valid;
+    unsigned long long dibit_base;         // dibits of the range before the group
+    unsigned long long base_after_first;   // dibit_base + dibits before the group's first own event
+    unsigned long long event_base;         // events of the range before the group
+};
+
 struct ScanArgs {
     const TileRec* recs;
     const unsigned long long* tsum;
-    ScanOut* outs;
+    ScanOut* outs;          // group-local: src absolute or -1, offsets relative to the group's first own event / start
+    GroupAgg* aggs;         // [ch][n_groups]
+    GroupCarry* carries;    // [ch][n_groups]
     int n_tiles;
+    int n_groups;
+    int n_channels;
     long n;                 // owned samples per channel
     long abs0;
     const p25fe_anchor_t* anchor_in;    // nullable, [ch]
@@ -875,165 +898,172 @@ __device__ __forceinline__ unsigned long long block_incl_sum1024(unsigned long l
     return inc + carry;
 }
 
-constexpr int K3_CHUNK = 16384;                                  // tiles staged in LDS at a time (128 KB)
-constexpr size_t K3_LDS_BYTES = sizeof(unsigned long long) * K3_CHUNK;
+constexpr int K3_GROUP = 2048;                                   // tiles per K3a workgroup (2 per thread, 16 KB of LDS)
 
-// K3: one workgroup per channel.  The packed tile summaries are staged in LDS (coalesced loads, all in
-// flight at once); every thread then walks a contiguous run of tiles, with two block scans per chunk
-// (latest event tile; dibit / event counts).  Chunks carry (anchor, counts) forward in registers.
+// K3a: one workgroup per (group of K3_GROUP tiles, channel), no carry-in.  The packed tile summaries are staged in
+// LDS; every thread walks a contiguous run of tiles; two block scans (latest event tile; dibit / event counts).
 __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem3[];
-    unsigned long long* TS = reinterpret_cast<unsigned long long*>(smem3);
+    __shared__ unsigned long long TS[K3_GROUP];
     __shared__ long shl[NT3 / 64];
     __shared__ unsigned long long shu[NT3 / 64];
-    __shared__ unsigned long long first_info[2];      // [0] = first event tile + 1, [1] = dibits before its first event
     __shared__ long excl_tmp[NT3 / 64];
-    const int tid = threadIdx.x, ch = blockIdx.x;
-    const TileRec* recs = a.recs + (size_t)ch * a.n_tiles;
+    const int tid = threadIdx.x, grp = blockIdx.x, ch = blockIdx.y;
     const unsigned long long* tsum = a.tsum + (size_t)ch * a.n_tiles;
     ScanOut* outs = a.outs + (size_t)ch * a.n_tiles;
-    p25fe_anchor_t ain;
-    ain.valid = 0; ain.s = 0; ain.hi = ain.mid = ain.lo = 0.f;
-    if (a.anchor_in) ain = a.anchor_in[ch];
-    if (tid == 0) { first_info[0] = 0; first_info[1] = 0; }
+    const int c0 = grp * K3_GROUP;
+    const int cn = (a.n_tiles - c0 < K3_GROUP) ? a.n_tiles - c0 : K3_GROUP;
 
-    // uniform carries across chunks
-    long carry_src = -1;                       // latest event tile so far (absolute tile index)
-    long carry_s = ain.s;                      // its anchor position
-    bool carry_valid = ain.valid != 0;
-    unsigned long long carry_cnt = 0, carry_ev = 0;
+    for (int k = tid; k < cn; k += NT3) TS[k] = tsum[c0 + k];
+    __syncthreads();
+    const int per = (cn + NT3 - 1) / NT3;
+    const int k0 = tid * per, k1 = (k0 + per < cn) ? k0 + per : cn;
 
-    for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
-        const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
-        __syncthreads();
-        for (int k = tid; k < cn; k += NT3) TS[k] = tsum[c0 + k];
-        __syncthreads();
-        const int per = (cn + NT3 - 1) / NT3;
-        const int k0 = tid * per, k1 = (k0 + per < cn) ? k0 + per : cn;
+    // pass 1: latest event tile inside my run -> block exclusive max
+    long last = -1;
+    for (int k = k0; k < k1; ++k) if (TS[k] & TS_MASK) last = k;
+    long tot_max;
+    const long incl = block_incl_max1024(last, shl, tid, tot_max);
+    long excl = __shfl_up(incl, 1, 64);
+    if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
+    __syncthreads();
+    if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
+    __syncthreads();
 
-        // pass 1: latest event tile inside my run -> block exclusive max
-        long last = -1;
-        for (int k = k0; k < k1; ++k) if (TS[k] & TS_MASK) last = k;
-        long tot_max;
-        const long incl = block_incl_max1024(last, shl, tid, tot_max);
-        long excl = __shfl_up(incl, 1, 64);
-        if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
-        __syncthreads();
-        if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
-        __syncthreads();
-
-        // passes 2 and 3 walk the run with the anchor expressed as a PHASE: ph = (tile_start - s) mod 10, so the
-        // closed-form instant counts are 32-bit (a tile has 2048 samples); the only 64-bit modulo is the one that
-        // brings a carry-in anchor from before this chunk into the run.
-        auto phase_at = [&](int k, long src, bool& v) -> unsigned {   // phase of tile k's start under anchor `src`
-            if (src >= 0) {
-                v = true;
-                const int last_off = (int)((TS[src] >> TS_BITS) & TS_MASK) - 1;
-                const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TB - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
-                return dist % (unsigned)SPS;
-            }
-            v = carry_valid;
-            if (!carry_valid) return 0u;
-            const long tlo = a.abs0 + (long)(c0 + k) * TB;
-            return (unsigned)((tlo - carry_s) % SPS);
-        };
-        auto count32 = [&](unsigned ph, int len) -> unsigned {        // n in [0, len): (ph + n) % 10 == 0, n + dist > 0 holds
-            const int f = (int)((SPS - ph) % (unsigned)SPS);          // first instant offset
-            return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
-        };
-        auto tile_len = [&](int k) -> int {
-            const long tlo = a.abs0 + (long)(c0 + k) * TB;
-            const long rem = a.abs0 + a.n - tlo;
-            return rem < TB ? (int)rem : TB;
-        };
-        unsigned long long my_cnt = 0, my_ev = 0;
-        {
-            long src = excl;
-            bool v;
-            unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
-            if (!(k0 < k1)) v = false;
-            for (int k = k0; k < k1; ++k) {
-                const unsigned long long u = TS[k];
-                const int first1 = (int)(u & TS_MASK);
-                const int len = first1 ? first1 : tile_len(k);        // instant AT the event index is still the old anchor's
-                my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
-                my_ev += (u >> (2 * TS_BITS)) & TS_MASK;
-                if (first1) {
-                    src = k; v = true;
-                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
-                    ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;     // next tile's start under the new anchor
-                } else {
-                    ph = (ph + (unsigned)TB) % (unsigned)SPS;
-                }
+    // passes 2 and 3 walk the run with the anchor expressed as a PHASE: ph = (tile_start - s) mod 10, so the
+    // closed-form instant counts are 32-bit.  Tiles before the group's first event (src < 0) are governed by the
+    // group's carry-in, which is not known here: they contribute nothing and K4 adds their part from GroupCarry.
+    auto phase_at = [&](int k, long src, bool& v) -> unsigned {   // phase of tile k's start under anchor `src`
+        v = src >= 0;
+        if (!v) return 0u;
+        const int last_off = (int)((TS[src] >> TS_BITS) & TS_MASK) - 1;
+        const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TB - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
+        return dist % (unsigned)SPS;
+    };
+    auto count32 = [&](unsigned ph, int len) -> unsigned {        // n in [0, len): (ph + n) % 10 == 0
+        const int f = (int)((SPS - ph) % (unsigned)SPS);          // first instant offset
+        return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
+    };
+    auto tile_len = [&](int k) -> int {
+        const long rem = a.n - (long)(c0 + k) * TB;
+        return rem < TB ? (int)rem : TB;
+    };
+    unsigned long long my_cnt = 0, my_ev = 0;
+    {
+        long src = excl;
+        bool v = false;
+        unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
+        for (int k = k0; k < k1; ++k) {
+            const unsigned long long u = TS[k];
+            const int first1 = (int)(u & TS_MASK);
+            const int len = first1 ? first1 : tile_len(k);        // instant AT the event index is still the old anchor's
+            my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
+            my_ev += (u >> (2 * TS_BITS)) & TS_MASK;
+            if (first1) {
+                src = k; v = true;
+                const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
+                ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;     // next tile's start under the new anchor
+            } else {
+                ph = (ph + (unsigned)TB) % (unsigned)SPS;
             }
         }
-        unsigned long long tot_cnt, tot_ev;
-        const unsigned long long icnt = block_incl_sum1024(my_cnt, shu, tid, tot_cnt);
-        const unsigned long long iev = block_incl_sum1024(my_ev, shu, tid, tot_ev);
+    }
+    unsigned long long tot_cnt, tot_ev;
+    const unsigned long long icnt = block_incl_sum1024(my_cnt, shu, tid, tot_cnt);
+    const unsigned long long iev = block_incl_sum1024(my_ev, shu, tid, tot_ev);
 
-        // pass 3: write the per-tile carry-ins
-        {
-            long src = excl;
-            bool v;
-            unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
-            if (!(k0 < k1)) v = false;
-            unsigned long long dc = carry_cnt + icnt - my_cnt, ec = carry_ev + iev - my_ev;
-            for (int k = k0; k < k1; ++k) {
-                const unsigned long long u = TS[k];
-                const int first1 = (int)(u & TS_MASK);
-                const int len = first1 ? first1 : tile_len(k);
-                const unsigned pre = v ? count32(ph, len) : 0u;
-                ScanOut o;
-                o.src = src >= 0 ? (int)(c0 + src) : (int)carry_src;
-                o.event_off = (unsigned)ec;
-                o.dibit_off = dc;
-                outs[c0 + k] = o;
-                if (first1 && src < 0 && carry_src < 0) {           // the range's first event
-                    first_info[0] = (unsigned long long)(c0 + k) + 1;
-                    first_info[1] = dc + pre;
-                }
-                dc += pre + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
-                ec += (u >> (2 * TS_BITS)) & TS_MASK;
-                if (first1) {
-                    src = k; v = true;
-                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
-                    ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;
-                } else {
-                    ph = (ph + (unsigned)TB) % (unsigned)SPS;
-                }
+    // pass 3: write the per-tile group-local carry-ins
+    {
+        long src = excl;
+        bool v = false;
+        unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
+        unsigned long long dc = icnt - my_cnt, ec = iev - my_ev;
+        for (int k = k0; k < k1; ++k) {
+            const unsigned long long u = TS[k];
+            const int first1 = (int)(u & TS_MASK);
+            const int len = first1 ? first1 : tile_len(k);
+            const unsigned pre = v ? count32(ph, len) : 0u;
+            ScanOut o;
+            o.src = src >= 0 ? (int)(c0 + src) : -1;
+            o.event_off = (unsigned)ec;
+            o.dibit_off = dc;
+            outs[c0 + k] = o;
+            dc += pre + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
+            ec += (u >> (2 * TS_BITS)) & TS_MASK;
+            if (first1) {
+                src = k; v = true;
+                const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
+                ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;
+            } else {
+                ph = (ph + (unsigned)TB) % (unsigned)SPS;
             }
         }
-        // carries for the next chunk (uniform: every thread computes the same values)
-        if (tot_max >= 0) {
-            carry_s = a.abs0 + (long)(c0 + tot_max) * TB + (long)((TS[tot_max] >> TS_BITS) & TS_MASK) - 1 - W;
-            carry_valid = true;
-            carry_src = c0 + tot_max;
-        }
-        carry_cnt += tot_cnt;
-        carry_ev += tot_ev;
+    }
+    // group aggregate: first / last event tile (min over first-event holders = the thread with excl < 0 and an event)
+    __shared__ int first_tile_sh;
+    if (tid == 0) first_tile_sh = -1;
+    __syncthreads();
+    if (last >= 0 && excl < 0) {
+        int f = -1;
+        for (int k = k1 - 1; k >= k0; --k) if (TS[k] & TS_MASK) f = k;
+        first_tile_sh = f;
     }
     __syncthreads();
     if (tid == 0) {
-        p25fe_result_t r;
-        r.n_baseband = a.n_baseband;
-        r.n_dibits = carry_cnt;
-        r.n_sync = carry_ev;
-        if (carry_src >= 0) {
-            const TileRec t = recs[carry_src];
-            r.anchor_out.valid = 1; r.anchor_out.s = t.last_s; r.anchor_out.hi = t.hi; r.anchor_out.mid = t.mid; r.anchor_out.lo = t.lo;
-        } else {
-            r.anchor_out = ain;
-        }
-        r.first_event = -1;
-        r.n_dibits_after_first = 0;
-        if (first_info[0]) {
-            const long f = (long)first_info[0] - 1;
-            r.first_event = recs[f].first_event;
-            r.n_dibits_after_first = carry_cnt - first_info[1];
-        }
-        a.result[ch] = r;
+        GroupAgg g;
+        g.first_tile = first_tile_sh >= 0 ? c0 + first_tile_sh : -1;
+        g.last_tile = tot_max >= 0 ? c0 + (int)tot_max : -1;
+        g.first_event = -1;
+        if (first_tile_sh >= 0)
+            g.first_event = a.abs0 + (long)(c0 + first_tile_sh) * TB + (long)(TS[first_tile_sh] & TS_MASK) - 1;
+        g.cnt_after_first = tot_cnt;
+        g.n_events = tot_ev;
+        a.aggs[(size_t)ch * a.n_groups + grp] = g;
     }
+}
+
+// K3b: one thread per channel walks the group aggregates (a 1-hour capture has ~80 groups) and hands every group its
+// carry-in anchor and bases; also writes the range summary.
+__global__ void k_scan_groups(ScanArgs a)
+{
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.n_channels) return;
+    const TileRec* recs = a.recs + (size_t)ch * a.n_tiles;
+    p25fe_anchor_t A;
+    A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
+    if (a.anchor_in) A = a.anchor_in[ch];
+    unsigned long long B = 0, E = 0, base_first = 0;
+    long first_event = -1;
+    for (int g = 0; g < a.n_groups; ++g) {
+        const GroupAgg ag = a.aggs[(size_t)ch * a.n_groups + g];
+        const long lo = a.abs0 + (long)g * K3_GROUP * TB;
+        long hi = lo + (long)K3_GROUP * TB;
+        if (hi > a.abs0 + a.n) hi = a.abs0 + a.n;
+        GroupCarry c;
+        c.anchor_s = A.s; c.hi = A.hi; c.mid = A.mid; c.lo = A.lo; c.valid = A.valid;
+        c.dibit_base = B;
+        c.event_base = E;
+        const long pre_hi = ag.first_tile >= 0 ? ag.first_event + 1 : hi;
+        const unsigned long long lead = A.valid ? (unsigned long long)count_instants(A.s, lo, pre_hi) : 0ull;
+        c.base_after_first = B + lead;
+        a.carries[(size_t)ch * a.n_groups + g] = c;
+        B += lead;
+        if (ag.first_tile >= 0) {
+            if (first_event < 0) { first_event = ag.first_event; base_first = B; }
+            B += ag.cnt_after_first;
+            const TileRec t = recs[ag.last_tile];
+            A.valid = 1; A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo;
+        }
+        E += ag.n_events;
+    }
+    p25fe_result_t r;
+    r.n_baseband = a.n_baseband;
+    r.n_dibits = B;
+    r.n_sync = E;
+    r.anchor_out = A;
+    r.first_event = first_event;
+    r.n_dibits_after_first = first_event >= 0 ? B - base_first : 0;
+    a.result[ch] = r;
 }
 
 struct SliceArgs {
@@ -1047,7 +1077,8 @@ struct SliceArgs {
     long ev_stride;
     const ScanOut* outs;
     const TileRec* recs;
-    const p25fe_anchor_t* anchor_in;    // nullable
+    const GroupCarry* carries;          // [ch][n_groups]
+    int n_groups;
     uint8_t* dibits;            // [ch][dibit_stride]
     long dibit_stride;
     int64_t* sync_pos;          // nullable
@@ -1066,16 +1097,17 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     const float* bbp = a.bb + (size_t)ch * a.bb_stride;
     const long tn = (a.n - t0 < TB) ? a.n - t0 : TB;
     const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
+    const GroupCarry gc = a.carries[(size_t)ch * a.n_groups + tile / K3_GROUP];
     struct { long anchor_s; float hi, mid, lo; int valid; unsigned long long dibit_off; unsigned event_off; } co;
-    co.dibit_off = so.dibit_off; co.event_off = so.event_off;
-    if (so.src >= 0) {
+    co.event_off = (unsigned)(gc.event_base + so.event_off);
+    if (so.src >= 0) {                                   // an event of this group governs the tile's start
         const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
         co.anchor_s = t.last_s; co.hi = t.hi; co.mid = t.mid; co.lo = t.lo; co.valid = 1;
-    } else if (a.anchor_in) {
-        const p25fe_anchor_t ai = a.anchor_in[ch];
-        co.anchor_s = ai.s; co.hi = ai.hi; co.mid = ai.mid; co.lo = ai.lo; co.valid = ai.valid;
-    } else {
-        co.anchor_s = 0; co.hi = co.mid = co.lo = 0.f; co.valid = 0;
+        co.dibit_off = gc.base_after_first + so.dibit_off;
+    } else {                                             // the group's carry-in governs it: closed-form count so far
+        co.anchor_s = gc.anchor_s; co.hi = gc.hi; co.mid = gc.mid; co.lo = gc.lo; co.valid = gc.valid;
+        const long glo = a.abs0 + (long)(tile / K3_GROUP) * K3_GROUP * TB;
+        co.dibit_off = gc.dibit_base + (gc.valid ? (unsigned long long)count_instants(gc.anchor_s, glo, a.abs0 + t0) : 0ull);
     }
 
     uint8_t evl[VPT];
