@@ -352,3 +352,58 @@ def test_config4_256_channels(O, FE):
         ref = O.run_cf32(iqs[c])
         assert int(r["n_dibits"][c]) == len(ref), c
         assert np.array_equal(dib[c, :len(ref)].cpu().numpy(), ref), c
+
+
+def test_fuzz_ranges_and_alignment(O, FE, c4fm_1s):
+    """Randomised device ranges: any (offset, n_hist, length) on the 16-B grid reproduces the oracle stream exactly,
+    for cf32 and u8; unaligned pointers and bad strides are rejected with P25FE_ERR_ARG, never silently mis-read."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd._lib import P25feError, ERR_ARG
+    iq = c4fm_1s[0][:150000]
+    ref = O.Demod().feed_cf32(iq)
+    u8 = c4fm.to_u8(iq)
+    ref8 = O.Demod().feed_u8(u8)
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    t8 = torch.from_numpy(u8.reshape(-1, 2)).cuda()
+    rng = np.random.default_rng(42)
+    fe = FE()
+    for trial in range(24):
+        use8 = trial % 2 == 1
+        g = 8 if use8 else 2
+        off = int(rng.integers(150, 60000)) // g * g
+        n = int(rng.integers(1, 80000))
+        n = min(n, len(iq) - off)
+        n_hist = int(rng.choice([288, 300, 1000, off]))
+        n_hist = min(n_hist, off)
+        src, rr = (t8, ref8) if use8 else (t, ref)
+        bb, nb = fe.demod_dev(src[:off + n], n_hist=n_hist, abs0=off, offset=off)
+        first = len([m for m in range(off // 5 - 1, off // 5 + 2) if 5 * m + 4 < off]) + max(off // 5 - 1, 0)
+        got = bb[0, :nb].cpu().numpy()
+        # outputs produced by inputs inside [off, off + n): exact provided the history covers the filter memory
+        assert np.array_equal(bits(got), bits(rr[first:first + nb])), (trial, off, n, n_hist)
+    with pytest.raises(P25feError) as e:
+        fe.demod_dev(t[1:], n_hist=0, abs0=0)                      # owned sample 0 at an 8-byte, not 16-byte, address
+    assert e.value.status == ERR_ARG
+    fe3 = FE(n_channels=3)
+    with pytest.raises(P25feError):
+        bad = torch.zeros((3, 1001, 2), dtype=torch.float32, device="cuda")   # odd channel stride
+        fe3.demod_dev(bad)
+
+
+def test_tiny_and_empty_inputs(O, FE):
+    """Empty, 1-sample and sub-filter-length inputs through every host entry point."""
+    fe = FE()
+    assert len(fe.demod_cf32(np.zeros(0, np.complex64))) == 0
+    assert len(fe.run_cf32(np.zeros(0, np.complex64))) == 0
+    d, sp, sd = fe.slice(np.zeros(0, np.float32))
+    assert len(d) == 0 and len(sp) == 0
+    x = (np.arange(1, 41) * (0.01 + 0.02j)).astype(np.complex64)
+    od, fe2 = O.Demod(), FE()
+    for k in range(0, 40, 3):
+        assert np.array_equal(bits(fe2.demod_cf32(x[k:k + 3])), bits(od.feed_cf32(x[k:k + 3])))
+    orc, fe3 = O.Recv(), FE()
+    b = np.linspace(-0.4, 0.4, 77).astype(np.float32)
+    for k in range(77):
+        a1, a2 = fe3.slice(b[k:k + 1]), orc.feed(b[k:k + 1])
+        assert all(np.array_equal(p, q) for p, q in zip(a1, a2))
