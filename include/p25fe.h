@@ -188,6 +188,25 @@ int p25fe_shard_resolve_dev(p25fe_t *h, const p25fe_result_t *d_summaries, const
                             const uint64_t *d_shard_bb_n, size_t n_shards, p25fe_anchor_t *d_anchor_in,
                             uint64_t *d_dibit_offset, void *stream);
 
+/* Network identifier that follows each frame sync (next row after the dibits, SURVEY.md section 8f: what
+ * p25::MessageReceiver reports as MessageEvent::PacketNID, src/recv.rs:216-222, consumed by
+ * ReceiverPolicy::handle_nid, src/policy.rs:92).  64 bits = BCH(63,16,23) code word (NAC 12 bits, DUID 4 bits)
+ * + 1 extra bit, 32 dibits after the sync word with a status symbol interleaved (docs/SPEC.md 3.9). */
+typedef struct p25fe_nid {
+    uint64_t raw;                        /* received 64 bits, first transmitted bit in bit 63 */
+    int64_t sync_pos;                    /* copied from the sync event (0 if d_sync_pos is null) */
+    uint16_t nac;                        /* network access code of the nearest code word */
+    uint8_t duid;                        /* data unit id */
+    uint8_t n_errors;                    /* Hamming distance to that code word */
+    int32_t valid;                       /* 1 decoded (<= 11 bit errors), 0 undecodable, -1 dibit stream ends inside the NID */
+} p25fe_nid_t;
+
+/* d_dibits / n_dibits: one channel's dibit stream (as written by p25fe_run_dev / p25fe_slice_dev); d_sync_dibit[k]:
+ * index of the first dibit after sync word k (the sync_dibit output of p25fe_slice_dev); d_sync_pos nullable.
+ * Writes n_sync records.  All device pointers; enqueued on `stream`. */
+int p25fe_nid_dev(p25fe_t *h, const uint8_t *d_dibits, size_t n_dibits, const uint64_t *d_sync_dibit,
+                  const int64_t *d_sync_pos, size_t n_sync, p25fe_nid_t *d_out, void *stream);
+
 /* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1/2 record HIP
  * events on the caller's stream around each kernel (K1 front end, K2 sync, K3 scan, K4 slice).
  * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel

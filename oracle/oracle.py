@@ -94,6 +94,8 @@ def _bind(lib):
     lib.p25o_predecim_destroy.argtypes = [vp]
     lib.p25o_predecim_feed.restype = sz
     lib.p25o_predecim_feed.argtypes = [vp, vp, sz, vp]
+    lib.p25o_nid_decode.restype = sz
+    lib.p25o_nid_decode.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp]
     lib.p25o_run_cf32.restype = C.c_int64
     lib.p25o_run_cf32.argtypes = [C.POINTER(Config), vp, sz, vp, sz]
     lib.p25o_has_fma.restype = C.c_int
@@ -214,6 +216,23 @@ class Recv:
         thr = (C.c_float * 3)()
         self.L.p25o_recv_state(self.h, C.byref(t), C.byref(v), C.byref(s), C.byref(thr), C.byref(nd))
         return dict(t=t.value, valid=bool(v.value), s=s.value, hi=thr[0], mid=thr[1], lo=thr[2], n_dibits=nd.value)
+
+
+NID_DTYPE = np.dtype([("raw", "<u8"), ("sync_pos", "<i8"), ("nac", "<u2"), ("duid", "u1"), ("n_errors", "u1"),
+                      ("valid", "<i4")])
+
+
+def nid_decode(dibits, sync_dibit, sync_pos=None, spec=None):
+    """Network identifiers that follow the given sync events (SPEC 3.9); returns a NID_DTYPE array."""
+    s = spec or load_spec()
+    rows = np.array(s["nid_rows"], dtype=np.uint64)
+    dibits = np.ascontiguousarray(dibits, dtype=np.uint8)
+    sync_dibit = np.ascontiguousarray(sync_dibit, dtype=np.uint64)
+    sp = None if sync_pos is None else np.ascontiguousarray(sync_pos, dtype=np.int64)
+    out = np.zeros(len(sync_dibit), dtype=NID_DTYPE)
+    lib().p25o_nid_decode(_ptr(rows), s["nid_t"], _ptr(dibits), dibits.size, _ptr(sync_dibit),
+                          _ptr(sp) if sp is not None else None, len(sync_dibit), _ptr(out))
+    return out
 
 
 def power_dbm(samples, resistance=1.0):

@@ -472,4 +472,59 @@ int64_t p25o_run_cf32(const p25o_config *cfg, const float *iq, size_t n, uint8_t
     return rc ? rc : (int64_t)total;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Network identifier after the frame sync (what MessageReceiver reports as
+ * MessageEvent::PacketNID, src/recv.rs:216-222, and policy.handle_nid consumes, src/policy.rs:92).
+ * TIA-102.BAAA: 64 bits = BCH(63,16,23) code word (NAC 12 bits, DUID 4 bits, 47 parity bits) + 1 extra bit,
+ * sent as 32 dibits right after the 24-dibit frame sync with one status symbol interleaved at dibit 35
+ * counted from the start of the frame sync (= 11 dibits into the NID).  Decoding (SPEC 3.9): the code word
+ * nearest in Hamming distance among all 65536 (smallest data word on ties), valid iff distance <= t = 11 --
+ * the same result as a bounded-distance BCH decoder.  `rows` are the generator-matrix rows of p25fe_spec.h.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t raw;        /* the 64 received bits, first transmitted bit in bit 63 */
+    int64_t sync_pos;    /* copied from the sync event */
+    uint16_t nac;
+    uint8_t duid;
+    uint8_t n_errors;    /* Hamming distance to the chosen code word (saturated at 255) */
+    int32_t valid;       /* 1: decoded, 0: more than t errors, -1: the dibit stream ends inside the NID */
+} p25o_nid;
+
+size_t p25o_nid_decode(const uint64_t *rows, int t, const uint8_t *dibits, size_t n_dibits, const uint64_t *sync_dibit,
+                       const int64_t *sync_pos, size_t n_sync, p25o_nid *out)
+{
+    uint64_t lo[256], hi[256];                 /* code word of data = (h << 8) | l is hi[h] ^ lo[l] */
+    for (int v = 0; v < 256; v++) {
+        uint64_t a = 0, b = 0;
+        for (int i = 0; i < 8; i++)
+            if (v & (1 << i)) { a ^= rows[i]; b ^= rows[8 + i]; }
+        lo[v] = a; hi[v] = b;
+    }
+    for (size_t k = 0; k < n_sync; k++) {
+        p25o_nid r;
+        memset(&r, 0, sizeof r);
+        r.sync_pos = sync_pos ? sync_pos[k] : 0;
+        const uint64_t D = sync_dibit[k];
+        if (D + 33 > n_dibits) { r.valid = -1; out[k] = r; continue; }
+        uint64_t raw = 0;
+        for (int j = 0; j < 33; j++) {
+            if (j == 11) continue;             /* status symbol */
+            raw = (raw << 2) | (uint64_t)(dibits[D + j] & 3u);
+        }
+        r.raw = raw;
+        const uint64_t cw = raw >> 1;
+        int best = 64; unsigned bd = 0;
+        for (unsigned d = 0; d < 65536u; d++) {
+            const int dist = __builtin_popcountll((hi[d >> 8] ^ lo[d & 255u]) ^ cw);
+            if (dist < best) { best = dist; bd = d; }
+        }
+        r.nac = (uint16_t)(bd >> 4);
+        r.duid = (uint8_t)(bd & 15u);
+        r.n_errors = (uint8_t)(best > 255 ? 255 : best);
+        r.valid = best <= t ? 1 : 0;
+        out[k] = r;
+    }
+    return n_sync;
+}
+
 int p25o_has_fma(void) { return __builtin_cpu_supports("fma"); }

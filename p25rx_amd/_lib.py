@@ -35,6 +35,9 @@ class Result(C.Structure):
 ANCHOR_DTYPE = np.dtype([("s", "<i8"), ("hi", "<f4"), ("mid", "<f4"), ("lo", "<f4"), ("valid", "<i4")])
 RESULT_DTYPE = np.dtype([("n_baseband", "<u8"), ("n_dibits", "<u8"), ("n_sync", "<u8"), ("anchor_out", ANCHOR_DTYPE),
                          ("first_event", "<i8"), ("n_dibits_after_first", "<u8")])
+NID_DTYPE = np.dtype([("raw", "<u8"), ("sync_pos", "<i8"), ("nac", "<u2"), ("duid", "u1"), ("n_errors", "u1"),
+                      ("valid", "<i4")])
+assert NID_DTYPE.itemsize == 24
 assert ANCHOR_DTYPE.itemsize == C.sizeof(Anchor) and RESULT_DTYPE.itemsize == C.sizeof(Result)
 
 # every symbol include/p25fe.h declares (tests check the library exports exactly these)
@@ -44,7 +47,7 @@ SYMBOLS = [
     "p25fe_reset", "p25fe_state_size", "p25fe_state_export", "p25fe_state_import", "p25fe_demod_dev",
     "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
-    "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev",
+    "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
 ]
 
 
@@ -103,6 +106,7 @@ def load():
     L.p25fe_shard_pass2.argtypes = [vp, vp, vp, sz, vp, vp]
     L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, vp, vp]
     L.p25fe_shard_resolve_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+    L.p25fe_nid_dev.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
     L.p25fe_profile_enable.argtypes = [vp, C.c_int]
     L.p25fe_profile_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
     L.p25fe_predecim_dev.argtypes = [vp, vp, sz, sz, sz, u64, vp, sz, vp]

@@ -52,12 +52,37 @@ def tx_filter(span_symbols=8, sps=SPS_IQ, alpha=0.2):
     return h
 
 
-def make_dibits(n_dibits, seed, frame_dibits=864):
+NID_GEN_POLY = int("6331141367235453", 8)      # BCH(63,16,23), TIA-102.BAAA (verified in tools/gen_spec.py)
+
+
+def nid_word(nac, duid):
+    """64-bit NID: systematic BCH(63,16) code word of (nac << 4 | duid) followed by one extra (even parity) bit."""
+    m = ((nac & 0xFFF) << 4 | (duid & 0xF)) << 47
+    r, db = m, NID_GEN_POLY.bit_length()
+    while r.bit_length() >= db:
+        r ^= NID_GEN_POLY << (r.bit_length() - db)
+    cw = m | r
+    return (cw << 1) | (bin(cw).count("1") & 1)
+
+
+def nid_dibits(nac, duid, status=2):
+    """The 33 dibits that follow a frame sync: 32 NID dibits with the status symbol at position 11."""
+    w = nid_word(nac, duid)
+    d = [(w >> (62 - 2 * i)) & 3 for i in range(32)]
+    return np.array(d[:11] + [status] + d[11:], dtype=np.uint8)
+
+
+def make_dibits(n_dibits, seed, frame_dibits=864, nid=None):
+    """PRNG dibits with the frame-sync word every `frame_dibits`; nid = callable(frame_index) -> (nac, duid) puts a
+    valid network identifier (with its status symbol) after every sync word."""
     rng = np.random.Generator(np.random.PCG64(seed))
     d = rng.integers(0, 4, size=n_dibits, dtype=np.uint8)
     fs = sync_dibits()
-    for start in range(0, n_dibits - SYNC_DIBITS + 1, frame_dibits):
+    for f, start in enumerate(range(0, n_dibits - SYNC_DIBITS + 1, frame_dibits)):
         d[start:start + SYNC_DIBITS] = fs
+        if nid is not None and start + SYNC_DIBITS + 33 <= n_dibits:
+            nac, duid = nid(f)
+            d[start + SYNC_DIBITS:start + SYNC_DIBITS + 33] = nid_dibits(nac, duid)
     return d
 
 
@@ -88,12 +113,12 @@ def modulate(dibits, snr_db=30.0, seed=0, freq_offset_hz=0.0, amplitude=0.5, tim
     return iq.astype(np.complex64), {"symbol_center_iq": centers, "n_symbols": nsym}
 
 
-def synth(seconds=1.0, seed=1, snr_db=30.0, frame_dibits=864, **kw):
+def synth(seconds=1.0, seed=1, snr_db=30.0, frame_dibits=864, nid=None, **kw):
     """`seconds` of C4FM IQ at 240 ksps (BASELINE.json config 1/2 shape).  Returns iq, dibits, info."""
     n_iq = int(round(seconds * FS_IQ))
     lead = kw.pop("lead_symbols", 4)
     nsym = n_iq // SPS_IQ - 2 * lead
-    d = make_dibits(nsym, seed, frame_dibits)
+    d = make_dibits(nsym, seed, frame_dibits, nid=nid)
     iq, info = modulate(d, snr_db=snr_db, seed=seed, lead_symbols=lead, **kw)
     return iq[:n_iq], d, info
 

@@ -676,6 +676,19 @@ int p25fe_run_cf32(p25fe_t* h, const float* iq, size_t n_samples, uint8_t* dibit
     return run_host(h, iq, P25FE_FMT_CF32, n_samples, dibits, cap, n_dibits);
 }
 
+int p25fe_nid_dev(p25fe_t* h, const uint8_t* d_dibits, size_t n_dibits, const uint64_t* d_sync_dibit,
+                  const int64_t* d_sync_pos, size_t n_sync, p25fe_nid_t* d_out, void* stream)
+{
+    if (!h || !d_dibits || !d_sync_dibit || !d_out) return P25FE_ERR_ARG;
+    if (n_sync == 0) return P25FE_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_nid, dim3((unsigned)n_sync), dim3(256), 0, (hipStream_t)stream, d_dibits,
+                       (unsigned long long)n_dibits, reinterpret_cast<const unsigned long long*>(d_sync_dibit),
+                       reinterpret_cast<const long*>(d_sync_pos), d_out);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
 int p25fe_profile_enable(p25fe_t* h, int on)
 {
     if (!h) return P25FE_ERR_ARG;

@@ -1220,6 +1220,65 @@ __global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K5: network identifier after each frame sync (MessageEvent::PacketNID, src/recv.rs:216-222).
+// One workgroup per sync event gathers the 32 NID dibits (status symbol at +11 skipped) and finds the nearest of the
+// 65536 BCH(63,16,23) code words by exhaustive Hamming search (256 per thread, two 256-entry XOR tables in LDS) --
+// equivalent to a bounded-distance decoder when at most t = 11 bits are wrong, and embarrassingly parallel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nid(const uint8_t* dibits, unsigned long long n_dibits, const unsigned long long* sync_dibit,
+                                             const long* sync_pos, p25fe_nid_t* out)
+{
+    __shared__ unsigned long long LO[256], HI[256];
+    __shared__ unsigned long long raw_sh;
+    __shared__ unsigned best_sh[4];
+    const int tid = threadIdx.x, k = blockIdx.x;
+    {
+        unsigned long long a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (tid & (1 << i)) { a ^= P25FE_NID_ROWS[i]; b ^= P25FE_NID_ROWS[8 + i]; }
+        LO[tid] = a; HI[tid] = b;
+    }
+    const unsigned long long D = sync_dibit[k];
+    const bool have = D + 33 <= n_dibits;
+    if (tid == 0) {
+        unsigned long long raw = 0;
+        if (have)
+            for (int j = 0; j < 33; ++j)
+                if (j != 11) raw = (raw << 2) | (unsigned long long)(dibits[D + j] & 3u);
+        raw_sh = raw;
+    }
+    __syncthreads();
+    const unsigned long long cw = raw_sh >> 1;
+    unsigned best = 0xffffffffu;                                // (distance << 16) | data : min = nearest, smallest data on ties
+    for (unsigned d = (unsigned)tid; d < 65536u; d += 256u) {
+        const unsigned dist = (unsigned)__popcll((HI[d >> 8] ^ LO[d & 255u]) ^ cw);
+        const unsigned key = (dist << 16) | d;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = __shfl_down(best, o, 64);
+        best = v < best ? v : best;
+    }
+    if ((tid & 63) == 0) best_sh[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned b = best_sh[0];
+        for (int w = 1; w < 4; ++w) b = best_sh[w] < b ? best_sh[w] : b;
+        p25fe_nid_t r;
+        r.raw = have ? raw_sh : 0ull;
+        r.sync_pos = sync_pos ? sync_pos[k] : 0;
+        const unsigned data = b & 0xffffu, dist = b >> 16;
+        r.nac = have ? (uint16_t)(data >> 4) : 0;
+        r.duid = have ? (uint8_t)(data & 15u) : 0;
+        r.n_errors = have ? (uint8_t)dist : 0;
+        r.valid = have ? (dist <= P25FE_NID_T ? 1 : 0) : -1;
+        out[k] = r;
+    }
+}
+
 // Carry resolution across time shards (BASELINE.json config 5): the same "latest anchor wins" rule as K3, one level
 // up.  summaries[r] were produced assuming no carry-in; shard r's carry-in is the anchor_out of the latest earlier
 // shard that has an event of its own, and its dibit offset adds the closed-form count of instants that the carry-in

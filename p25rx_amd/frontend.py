@@ -207,6 +207,17 @@ class FrontEnd:
                                          C.c_void_p(res.data_ptr()), self._stream()))
         return dib, res, spos, sdib
 
+    def nid_dev(self, dibits, n_dibits, sync_dibit, sync_pos=None, n_sync=None):
+        """Network identifiers after the sync events of ONE channel: dibits uint8 [>= n_dibits], sync_dibit int64/uint64
+        [n_sync] (device tensors) -> uint8 tensor [n_sync, 24] (view with _lib.NID_DTYPE after .cpu())."""
+        import torch
+        n_sync = int(sync_dibit.numel() if n_sync is None else n_sync)
+        out = torch.empty((max(n_sync, 1), 24), dtype=torch.uint8, device=dibits.device)
+        self._chk(self.L.p25fe_nid_dev(self.h, C.c_void_p(dibits.data_ptr()), int(n_dibits), C.c_void_p(sync_dibit.data_ptr()),
+                                       C.c_void_p(sync_pos.data_ptr()) if sync_pos is not None else None, n_sync,
+                                       C.c_void_p(out.data_ptr()), self._stream()))
+        return out[:n_sync]
+
     def profile_enable(self, on=True):
         self._chk(self.L.p25fe_profile_enable(self.h, 1 if on else 0))
 

@@ -24,6 +24,9 @@ pre-decim  : T0 = 80 taps, Kaiser(beta=7.0)-windowed sinc, cutoff 60 kHz at fs =
 atan       : odd polynomial t*(c0 + c1 t^2 + ... + c7 t^14) ~ atan(t) on [0, 1], weighted
              least squares on 4096 Chebyshev nodes, coefficients rounded to fp32.
 fm gain    : fs / (2 pi dev) with fs = 48000, dev = 5000 (src/demod.rs:54).
+nid        : network identifier that follows the frame sync: 16 data bits (NAC 12, DUID 4) in a BCH(63,16,23)
+             code word + 1 extra bit; generator polynomial 6331141367235453 (octal, TIA-102.BAAA).  This script
+             verifies that g(x) has degree 47, divides x^63 + 1 and gives minimum weight 23 (it refuses otherwise).
 sync       : P25 frame sync word 0x5575F5FF77FF (TIA-102.BAAA), dibit 01 -> +3, 11 -> -3.
 """
 import json
@@ -41,6 +44,7 @@ DECIM = 5
 SPS = 10                      # baseband samples per symbol (48000 / 4800)
 SYNC_WORD = 0x5575F5FF77FF    # 48 bits, 24 dibits
 SYNC_DIBITS = 24
+NID_GEN_POLY = int("6331141367235453", 8)
 
 
 def kaiser_sinc(ntaps, cutoff_hz, fs, beta):
@@ -77,6 +81,33 @@ def sync_symbols():
     return syms
 
 
+def gf2_mod(a, b):
+    db = b.bit_length()
+    while a.bit_length() >= db:
+        a ^= b << (a.bit_length() - db)
+    return a
+
+
+def nid_encode(data16):
+    """Systematic BCH(63,16): 16 data bits, then the remainder of data * x^47 modulo g(x)."""
+    m = data16 << 47
+    return m | gf2_mod(m, NID_GEN_POLY)
+
+
+def check_nid_code():
+    assert NID_GEN_POLY.bit_length() - 1 == 47
+    assert gf2_mod((1 << 63) | 1, NID_GEN_POLY) == 0
+    rows = [nid_encode(1 << i) for i in range(16)]
+    cw, prev, minw = 0, 0, 64
+    for i in range(1, 1 << 16):
+        gray = i ^ (i >> 1)
+        cw ^= rows[(gray ^ prev).bit_length() - 1]
+        prev = gray
+        minw = min(minw, bin(cw).count("1"))
+    assert minw == 23, minw
+    return rows
+
+
 def hexf(x):
     return float(np.float32(x)).hex() + "f"
 
@@ -89,6 +120,7 @@ def main():
     fm_gain = np.float32(FS_BB / (2.0 * np.pi * 5000.0))
     syms = sync_symbols()
     assert all(abs(s) == 3 for s in syms)
+    nid_rows = check_nid_code()
     sync_sign_mask = 0
     for j, s in enumerate(syms):           # bit j set <=> symbol j (oldest first) is +3
         if s > 0:
@@ -114,6 +146,7 @@ def main():
         "sync_peak_w": 5,
         "slice_frac": float(np.float32(2.0 / 3.0)),
         "pi": float(np.float32(np.pi)), "half_pi": float(np.float32(np.pi / 2.0)),
+        "nid_gen_poly": NID_GEN_POLY, "nid_rows": nid_rows, "nid_t": 11, "nid_status_pos": 35,
     }
 
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -151,7 +184,13 @@ def main():
     h.append("#define P25FE_FM_GAIN %s       /* 48000 / (2 pi 5000); src/demod.rs:54 */\n" % hexf(fm_gain))
     h.append("#define P25FE_U8_SCALE %s      /* 2/255 */\n" % hexf(spec["u8_scale"]))
     h.append("#define P25FE_BOXCAR_SCALE %s  /* 1/10 */\n" % hexf(spec["boxcar_scale"]))
-    h.append("#define P25FE_PI %s\n#define P25FE_HALF_PI %s\n\n" % (hexf(spec["pi"]), hexf(spec["half_pi"])))
+    h.append("#define P25FE_PI %s\n#define P25FE_HALF_PI %s\n" % (hexf(spec["pi"]), hexf(spec["half_pi"])))
+    h.append("#define P25FE_NID_GEN_POLY 0x%xULL   /* octal 6331141367235453: BCH(63,16,23), TIA-102.BAAA */\n" % NID_GEN_POLY)
+    h.append("#define P25FE_NID_T 11                /* correctable bit errors */\n")
+    h.append("#define P25FE_NID_DIBITS 32           /* 64 bits = 63-bit code word + 1 extra bit */\n")
+    h.append("#define P25FE_NID_STATUS_POS 35       /* dibit index (from the start of the frame sync) of the status symbol inside the NID */\n\n")
+    h.append("/* rows of the systematic generator matrix: code word of data bit i (bit 62 = first transmitted bit) */\n")
+    h.append("static const unsigned long long P25FE_NID_ROWS[16] = {\n    " + ",\n    ".join("0x%016xULL" % r for r in nid_rows) + "\n};\n\n")
     h.append(arr("P25FE_DEFAULT_DECIM_TAPS", list(dec)))
     h.append("\n")
     h.append(arr("P25FE_DEFAULT_CHAN_TAPS", list(chan)))
