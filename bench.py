@@ -68,6 +68,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("P25FE_BENCH_ONE_GPU"):        # test hook: every rank on GPU 0 (only useful where RCCL allows it)
+        local = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
