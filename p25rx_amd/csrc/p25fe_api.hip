@@ -407,8 +407,9 @@ int p25fe_predecim_dev(p25fe_t* h, const float* d_iq, size_t ch_stride, size_t n
     a.x = d_iq; a.ch_stride = (long)ch_stride; a.n_hist = (long)n_hist; a.n_new = (long)n;
     a.o0 = (int)((PD - 1 + PD - abs0 % PD) % PD);
     a.y = d_out; a.y_stride = (long)out_stride; a.n_out = (long)n_out;
-    dim3 grid((unsigned)((n_out + K0_TILE - 1) / K0_TILE), (unsigned)h->C);
-    hipLaunchKernelGGL(k_predecim, grid, dim3(K0_NT), 0, (hipStream_t)stream, a);
+    const size_t per_wg = (size_t)K0_SUB * K0_SUBS;
+    dim3 grid((unsigned)((n_out + per_wg - 1) / per_wg), (unsigned)h->C);
+    hipLaunchKernelGGL(k_predecim, grid, dim3(WV), 0, (hipStream_t)stream, a);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }

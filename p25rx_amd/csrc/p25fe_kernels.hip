@@ -432,19 +432,30 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
 
 // ------------------------------------------------------------------------------------------
 // K0: stage 0 of BASELINE.json config 3 -- 10:1 decimating FIR, 2.4 Msps cf32 -> 240 ksps cf32, T0 = 80 taps
-// (SPEC 3.0; no reference counterpart: src/consts.rs:11 fixes 240 ksps).  A 256-thread workgroup produces 512
-// outputs from 5190 inputs staged in LDS in POLYPHASE layout X[r][j] = x[base + 10 j + r]: output i then reads
-// X[9 - k%10][i + 7 - k/10] for tap k, i.e. consecutive lanes read consecutive complex samples (conflict-free
-// ds_read_b64) while the taps stay compile-time immediates in tap order 0..79 with one accumulator.
+// (SPEC 3.0; no reference counterpart: src/consts.rs:11 fixes 240 ksps).  Same construction as K1: one wave per
+// workgroup, next window prefetched into registers, outputs stored one iteration late.  The 1990-sample window of
+// a 192-output sub-tile is staged in LDS in POLYPHASE layout X[r][j] = x[base + 10 j + r]; a lane computes 3
+// consecutive outputs i = 3 lane + p: tap k = 10 q + r' needs X[9 - r'][3 lane + u] with u = p + 7 - q, so walking
+// u = 9..0 and loading the ten phases of column 3 lane + u feeds up to three accumulators, each in tap order
+// 0..79 (lane stride 3 complex = 6 dwords: conflict-free ds_read_b64; 100 reads for 240 packed FMAs).
+// A pure FIR carries no state between sub-tiles: the 70-sample left context is simply part of every window.
 // Algorithmic bytes: 8 B read + 0.8 B written per input sample.
 // ------------------------------------------------------------------------------------------
 constexpr int PD = P25FE_PRE_DECIM;          // 10
 constexpr int T0 = P25FE_T0;                 // 80
-constexpr int K0_NT = 256;
-constexpr int K0_TILE = 512;                 // outputs per workgroup (256 measured 6 % slower)
+constexpr int K0_P = 3;                      // outputs per lane (odd)
+constexpr int K0_SUB = WV * K0_P;            // 192 outputs per sub-tile
+#ifndef P25FE_K0_SUBS
+#define P25FE_K0_SUBS 2
+#endif
+#ifndef P25FE_K0_WPS
+#define P25FE_K0_WPS 2
+#endif
+constexpr int K0_SUBS = P25FE_K0_SUBS;       // sub-tiles per workgroup (prefetch pipeline depth)
 constexpr int K0_HALO = T0 - PD;             // 70 input samples of left context
-constexpr int K0_NIN = PD * K0_TILE + K0_HALO;      // 5190
-constexpr int K0_JP = K0_NIN / PD + 2;       // 521 entries per phase row (odd: spreads the staging writes)
+constexpr int K0_NIN = PD * K0_SUB + K0_HALO;       // 1990 window positions
+constexpr int K0_JP = K0_NIN / PD + 2;       // 201 entries per phase row (odd: spreads the staging writes)
+constexpr int K0_NV = (K0_NIN + 2 + 2 * WV - 1) / (2 * WV);   // 16-B vectors per lane: 16
 constexpr int HIST_PRE = K0_HALO + PD - 1;   // 79: history needed for exact results
 
 struct K0Args {
@@ -457,46 +468,111 @@ struct K0Args {
     long n_out;
 };
 
-__global__ __launch_bounds__(K0_NT) void k_predecim(K0Args a)
+__global__ __launch_bounds__(WV, P25FE_K0_WPS) void k_predecim(K0Args a)
 {
     __shared__ float2 X[PD * K0_JP];
+    __shared__ float2 OUT[K0_SUB];
     const int tid = threadIdx.x, ch = blockIdx.y;
-    const long m0 = (long)blockIdx.x * K0_TILE;
-    const float* xb = a.x + 2 * (size_t)ch * a.ch_stride;
+    const long m_wg0 = (long)blockIdx.x * (K0_SUB * K0_SUBS);
+    const uint4* xb = reinterpret_cast<const uint4*>(a.x + 2 * (size_t)ch * a.ch_stride);
     float2* yb = reinterpret_cast<float2*>(a.y) + (size_t)ch * a.y_stride;
-    const long base = (long)a.o0 + PD * m0 - (T0 - 1);             // input index of window position 0 (output m is fed by input o0 + 10 m)
-    // stage: 16-B vectors (2 samples), clamped index, out-of-stream samples zeroed (same scheme as K1's loader)
-    const long v0 = base >> 1;
-    const int sh = (int)(base - (v0 << 1));                 // 0 or 1
-    const long vlo = (-a.n_hist) >> 1, vhi = (a.n_new - 1) >> 1;
-    const float4* q = reinterpret_cast<const float4*>(xb);
-    for (int r = tid; r < (K0_NIN + 2 + 1) / 2; r += K0_NT) {
-        long vi = v0 + r;
-        vi = vi < vlo ? vlo : vi;
-        vi = vi > vhi ? vhi : vi;
-        const float4 v = q[vi];
+
+    const long wg_last = (long)a.o0 + PD * (m_wg0 + (long)(K0_SUBS - 1) * K0_SUB) - (T0 - 1);   // base of the last window
+    uint4 v[K0_NV];
+    // window of the sub-tile whose first output is m0: positions k = 0 .. K0_NIN-1 are inputs base + k
+    auto load = [&](long m0) {
+        const long base = (long)a.o0 + PD * m0 - (T0 - 1);
+        const long v0 = base >> 1;
+        long lo = ((-a.n_hist) >> 1) - v0, hi = ((a.n_new - 1) >> 1) - v0;
+        const long seg_hi = ((wg_last + K0_NIN) >> 1) - v0;         // prefetch past the segment re-reads its last vector
+        hi = hi < seg_hi ? hi : seg_hi;
+        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
+        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
+        const int lo32 = (int)lo, hi32 = (int)hi;
+        const uint4* q = xb + v0;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const long i = ((v0 + r) << 1) + e;             // input sample index
-            const int k = 2 * r + e - sh;                   // position in the window
-            float2 s = e ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-            if (i < -a.n_hist || i >= a.n_new) s = make_float2(0.f, 0.f);
-            if (k >= 0 && k < K0_NIN) X[(k % PD) * K0_JP + k / PD] = s;
+        for (int j = 0; j < K0_NV; ++j) {
+            int r = tid + j * WV;
+            r = r < lo32 ? lo32 : r;
+            r = r > hi32 ? hi32 : r;
+            v[j] = q[r];
         }
-    }
-    __syncthreads();
+    };
+    auto stage = [&](long m0) {
+        const long base = (long)a.o0 + PD * m0 - (T0 - 1);
+        const long v0 = base >> 1;
+        const int sh = (int)(base - (v0 << 1));                     // 0 or 1
+        const bool interior = (v0 << 1) >= -a.n_hist && (v0 << 1) + 2L * K0_NV * WV <= a.n_new;   // uniform
 #pragma unroll
-    for (int o = 0; o < K0_TILE / K0_NT; ++o) {
-        const int i = tid + o * K0_NT;
-        float2 acc = make_float2(0.f, 0.f);
+        for (int j = 0; j < K0_NV; ++j) {
+            const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-        for (int k = 0; k < T0; ++k) {
-            const float2 s = lds_read_c(&X[(PD - 1 - k % PD) * K0_JP + i + (T0 / PD - 1) - k / PD]);
-            acc.x = __builtin_fmaf(P25FE_DEFAULT_PRE_TAPS[k], s.x, acc.x);
-            acc.y = __builtin_fmaf(P25FE_DEFAULT_PRE_TAPS[k], s.y, acc.y);
+            for (int e = 0; e < 2; ++e) {
+                const int k = 2 * (tid + j * WV) + e - sh;          // window position
+                float2 s2 = make_float2(__uint_as_float(w[2 * e]), __uint_as_float(w[2 * e + 1]));
+                if (!interior) {
+                    const long i = ((v0 + tid + (long)j * WV) << 1) + e;
+                    if (i < -a.n_hist || i >= a.n_new) s2 = make_float2(0.f, 0.f);
+                }
+                if (k >= 0 && k < K0_NIN) X[((unsigned)k % PD) * K0_JP + (unsigned)k / PD] = s2;
+            }
         }
-        if (m0 + i < a.n_out) yb[m0 + i] = acc;
+    };
+
+    float2 outv[K0_P];
+#pragma unroll
+    for (int q = 0; q < K0_P; ++q) outv[q] = make_float2(0.f, 0.f);
+    long out_m0 = -1;                                               // sub-tile whose outputs sit in outv (-1: none)
+    auto flush = [&]() {
+        if (out_m0 >= 0) {
+#pragma unroll
+            for (int q = 0; q < K0_P; ++q) {
+                const long m = out_m0 + tid + q * WV;
+                if (m < a.n_out) yb[m] = outv[q];
+            }
+        }
+    };
+
+    load(m_wg0);
+#pragma unroll 1
+    for (int it = 0; it < K0_SUBS; ++it) {
+        const long m0 = m_wg0 + (long)it * K0_SUB;
+        if (m0 >= a.n_out) break;                                   // uniform
+        stage(m0);
+        phase_sync();
+        flush();                                                    // stores before the prefetch (single in-order vmcnt queue)
+        load(m0 + K0_SUB);                                          // unconditional; clamped past the stream
+        float2 acc[K0_P];
+#pragma unroll
+        for (int p = 0; p < K0_P; ++p) acc[p] = make_float2(0.f, 0.f);
+        const float2* col = X + K0_P * tid;
+#pragma unroll
+        for (int u = K0_P - 1 + T0 / PD - 1; u >= 0; --u) {        // u = 9 .. 0
+            float2 ph[PD];
+#pragma unroll
+            for (int r = 0; r < PD; ++r) ph[r] = lds_read_c(col + r * K0_JP + u);
+#pragma unroll
+            for (int p = 0; p < K0_P; ++p) {
+                const int q = p + (T0 / PD - 1) - u;                // tap block 10 q .. 10 q + 9
+                if (q >= 0 && q < T0 / PD) {
+#pragma unroll
+                    for (int rr = 0; rr < PD; ++rr) {
+                        const float h = P25FE_DEFAULT_PRE_TAPS[PD * q + rr];
+                        acc[p].x = __builtin_fmaf(h, ph[PD - 1 - rr].x, acc[p].x);
+                        acc[p].y = __builtin_fmaf(h, ph[PD - 1 - rr].y, acc[p].y);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < K0_P; ++p) OUT[K0_P * tid + p] = acc[p];
+        phase_sync();
+#pragma unroll
+        for (int q = 0; q < K0_P; ++q) outv[q] = OUT[tid + q * WV];
+        out_m0 = m0;
+        phase_sync();
     }
+    flush();
 }
 
 // finish power_dbm (src/demod.rs:123-134): 30 + 10 log10( (sum / N) / R ), R = 1
