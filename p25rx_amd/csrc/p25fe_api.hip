@@ -320,7 +320,7 @@ static int launch_sync(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n
     s.ev_stride = (long)round_up(n_bb + 8, 16);
     s.recs = h->recs.as<TileRec>();
     s.tsum = h->tsum.as<unsigned long long>();
-    hipLaunchKernelGGL(k_sync, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, s);
+    hipLaunchKernelGGL(k_sync, dim3((unsigned)((n_tiles + K2_SUBS - 1) / K2_SUBS), (unsigned)h->C), dim3(WV), 0, st, s);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }

@@ -609,10 +609,6 @@ constexpr int TB = 1024;                                     // baseband samples
 constexpr int NT = 128;                                      // threads per workgroup in K2 / K4 (256 x 2048 and 512 x 4096 measured slower)
 constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
-constexpr int CQ = 9;                                        // symbol-spaced correlation outputs per thread (K2)
-constexpr int CORR_T = (TB + 2 * W + SPS * CQ - 1) / (SPS * CQ) * SPS;   // threads busy in the correlation (10 phases x slot blocks): 460
-constexpr int BT_N = SPS * CQ * (CORR_T / SPS) + SPS * (CQ + 23) + 16;    // LDS baseband tile incl. the register-tiling overrun
-constexpr int CT_N = TB + 2 * W + 2;                         // c[] for s in [a-2W-1, a+TB-W-1) plus peak lookahead
 
 struct TileRec {            // per (channel, tile) summary written by K2
     long first_event;       // absolute decision index e = s + W of the tile's first event, -1 if none
@@ -740,154 +736,240 @@ struct SyncArgs {
     unsigned long long* tsum;   // [ch][n_tiles] packed summaries for K3
 };
 
-// K2: correlate, peak-pick, flag events, summarise the tile.
-__global__ __launch_bounds__(NT) void k_sync(SyncArgs a)
+// K2: correlate, peak-pick, flag events, summarise the tile.  Built like K1: one wave per workgroup (no s_barrier,
+// wave-level scans only), K2_SUBS consecutive tiles per workgroup with the next tile's window prefetched into
+// registers (16-B loads) while the current one is correlated.
+//   correlation: lanes 0..59 = 10 sample phases x 6 slot blocks; a lane produces K2_CQ = 18 symbol-spaced outputs
+//   from a sliding window of 41 LDS reads (2.3 reads per output instead of 24), each output with its own
+//   accumulators in tap order j = 0..23 (SPEC 3.7);
+//   peak pick / instant count: a lane owns 16 consecutive samples (<= 2 symbol instants without an event inside).
+#ifndef P25FE_K2_SUBS
+#define P25FE_K2_SUBS 2
+#endif
+constexpr int K2_SUBS = P25FE_K2_SUBS;
+constexpr int K2_CQ = 18;
+constexpr int K2_LANES = SPS * 6;                                // 60 lanes busy in the correlation
+constexpr int K2_NC = TB + 2 * W;                                // c[] positions a tile needs: 1034
+constexpr int K2_VPL = TB / WV;                                  // 16 samples per lane
+constexpr int K2_NV = 6;                                         // 16-B vectors per lane: window of 1310 (+3 shift) floats
+constexpr int K2_BT = 4 * WV * K2_NV;                            // 1536 floats of LDS (every vector has a slot)
+static_assert(SPS * K2_CQ * (K2_LANES / SPS) >= K2_NC, "correlation lanes must cover the tile");
+static_assert(SPS * K2_CQ * (K2_LANES / SPS - 1) + SPS - 1 + SPS * (K2_CQ + P25FE_SYNC_DIBITS - 2) + 3 < K2_BT, "window fits");
+static_assert(K2_VPL > SPS && K2_VPL <= 2 * SPS, "instant count closed form assumes 1..2 instants per lane");
+
+__device__ __forceinline__ int wave_incl_max_i(int v, int lane)
 {
-    __shared__ float BT[BT_N];          // BT[k] = b[t0 - HIST_BB + k]
-    __shared__ float CT[CT_N];          // CT[k] = c[t0 - 2W + k]
-    __shared__ __attribute__((aligned(8))) uint8_t CAND[CT_N + 16];   // flag of position k at CAND[k - W + 8]: sample i's flag at the 8-aligned CAND[i + 8]
-    __shared__ int shl[8];
-    __shared__ int shi[8];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
 
-    const int tid = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
-    const long t0 = (long)tile * TB;                            // local index of the tile's first sample
+__global__ __launch_bounds__(WV, 3) void k_sync(SyncArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float BT[K2_BT];      // BT[k] = b[t0 - HIST_BB + k]
+    __shared__ float CT[K2_NC + 2];                               // CT[k] = c[t0 - 2W + k]
+    __shared__ __attribute__((aligned(8))) uint8_t CAND[K2_NC + 16];   // flag of position k at CAND[k - W + 8]: sample i's flag at the 8-aligned CAND[i + 8]
+
+    const int lane = threadIdx.x, ch = blockIdx.y;
     const float* bbp = a.bb + (size_t)ch * a.bb_stride;
-    const long tn = (a.n - t0 < TB) ? a.n - t0 : TB;            // samples in this tile
+    const long A = (long)(reinterpret_cast<uintptr_t>(bbp) >> 2);          // float address of owned sample 0
+    const float4* vec0 = reinterpret_cast<const float4*>(reinterpret_cast<uintptr_t>(bbp) & ~(uintptr_t)15);
+    const long Av = A >> 2;                                                // vector address of vec0 (the vector holding sample 0)
+    const long vlo = ((A - a.n_hist) >> 2) - Av, vhi = ((A + a.n - 1) >> 2) - Av;   // loadable vectors (relative)
 
-    if (t0 - HIST_BB >= -a.n_hist && t0 - HIST_BB + BT_N <= a.n) {      // uniform: interior tile, no bounds checks
-        const float* src = bbp + (t0 - HIST_BB);
-        for (int k = tid; k < BT_N; k += NT) BT[k] = src[k];
-    } else {
-        for (int k = tid; k < BT_N; k += NT) BT[k] = bb_at(bbp, a.n_hist, a.n, t0 - HIST_BB + k);
-    }
-    __syncthreads();
-
-    // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s] = BT[k + 10 j], j = 0..23.
-    // Register tiling over symbol-spaced positions: a thread takes one sample phase r = k % 10 and CQ
-    // consecutive symbol slots, so its CQ outputs share a sliding window of CQ + 23 LDS reads (3.6 reads per
-    // output instead of 24); each output keeps its own accumulators in tap order j = 0..23 (SPEC 3.7).
-    if (tid < CORR_T) {
-        const int r = tid % SPS, qb = tid / SPS;
-        const int base = SPS * CQ * qb + r;                     // k of the thread's first output
-        float w[CQ + P25FE_SYNC_DIBITS - 1];
+    float4 v[K2_NV];
+    auto load = [&](int tile) {
+        const long P = A + (long)tile * TB - HIST_BB;                      // float address of BT[0]
+        const long V0 = (P >> 2) - Av;
+        long lo = vlo - V0, hi = vhi - V0;
+        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
+        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
+        const int lo32 = (int)lo, hi32 = (int)hi;
+        const float4* q = vec0 + V0;
 #pragma unroll
-        for (int m = 0; m < CQ + P25FE_SYNC_DIBITS - 1; ++m) w[m] = BT[base + SPS * m];
-#pragma unroll
-        for (int i = 0; i < CQ; ++i) {
-            const int k = base + SPS * i;
-            float c = 0.f, e = 0.f;
-#pragma unroll
-            for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-                const float v = w[i + j];
-                c = ((P25FE_SYNC_SIGN_MASK >> j) & 1u) ? c + v : c - v;
-                e = __builtin_fmaf(v, v, e);
-            }
-            if (k < TB + 2 * W) {
-                CT[k] = c;
-                CAND[k - W + 8] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
-            }
+        for (int j = 0; j < K2_NV; ++j) {
+            int r = lane + j * WV;
+            r = r < lo32 ? lo32 : r;
+            r = r > hi32 ? hi32 : r;
+            v[j] = q[r];
         }
-    }
-    __syncthreads();
-
-    // event at local index i (decided when sample t0 + i arrives) <=> detection at s = t0 + i - W -> CT index k = i + W.
-    // s must lie inside the stream so far: s >= -n_hist (older samples read as zero anyway) and the peak
-    // window s + W = t0 + i - 1 < n is guaranteed by i < tn.  CAND is stored shifted so that a thread's 8
-    // flags are one aligned 8-byte LDS read; no candidate among them (the common case) skips the peak test.
-    int my_last = -1;                                  // tile-local index of my last event
-    int my_ev = 0;
-    uint8_t evl[VPT];
+    };
+    auto stage = [&](int tile) {
+        const long t0 = (long)tile * TB;
+        const long P = A + t0 - HIST_BB;
+        const int sh = (int)(P & 3);
+        const bool fast = sh == 0 && t0 - HIST_BB >= -a.n_hist && t0 - HIST_BB + K2_BT <= a.n;   // uniform
+        if (fast) {
 #pragma unroll
-    for (int u = 0; u < VPT; ++u) evl[u] = 0;
-    {
-        const uint2 cm8 = *reinterpret_cast<const uint2*>(&CAND[tid * VPT + 8]);        // flags of samples tid*8 .. tid*8+7
-        if ((cm8.x | cm8.y) != 0u) {
-#pragma unroll
-            for (int u = 0; u < VPT; ++u) {
-                const int i = tid * VPT + u;
-                const int k = i + W;
-                const bool cand = (((u < 4 ? cm8.x : cm8.y) >> (8 * (u & 3))) & 0xffu) != 0u;
-                if (i < (int)tn && cand) {
-                    const float cm = CT[k];
-                    bool det = true;
-#pragma unroll
-                    for (int d = 1; d <= W; ++d) det = det && (cm > CT[k - d]) && (cm >= CT[k + d]);
-                    if (det) { evl[u] = 1; my_last = i; ++my_ev; }
-                }
-            }
-        }
-    }
-    if (a.events) {
-        uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0;
-        // 8 consecutive bytes per thread: one 8-byte store when aligned (t0 multiple of 2048, stride multiple of 8)
-        if (tid * VPT + VPT <= tn && ((a.ev_stride & 7) == 0)) {
-            uint2 pk;
-            pk.x = evl[0] | (evl[1] << 8) | (evl[2] << 16) | ((unsigned)evl[3] << 24);
-            pk.y = evl[4] | (evl[5] << 8) | (evl[6] << 16) | ((unsigned)evl[7] << 24);
-            *reinterpret_cast<uint2*>(evp + tid * VPT) = pk;
+            for (int j = 0; j < K2_NV; ++j) *reinterpret_cast<float4*>(&BT[4 * (lane + j * WV)]) = v[j];
         } else {
 #pragma unroll
-            for (int u = 0; u < VPT; ++u)
-                if (tid * VPT + u < tn) evp[tid * VPT + u] = evl[u];
-        }
-    }
-
-    // latest own event before each thread's first sample, then count instants under own events
-    const int incoming = block_excl_max(my_last, shl, tid);
-    int cur = incoming;                                 // tile-local index of the governing event, -1: carry-in (unknown here)
-    int cnt = 0;
-    if (my_ev == 0) {
-        // common case: no event inside my 8 samples -> at most one instant (8 < 10), closed form
-        if (cur >= 0) {
-            const int i0 = tid * VPT;
-            const int navail = (int)tn - i0 < VPT ? (int)tn - i0 : VPT;
-            const unsigned ph = (unsigned)(i0 - (cur - W)) % (unsigned)SPS;
-            const int f = (int)((SPS - ph) % (unsigned)SPS);
-            cnt = f < navail ? 1 : 0;
-        }
-    } else {
+            for (int j = 0; j < K2_NV; ++j) {
+                const float w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-        for (int u = 0; u < VPT; ++u) {
-            const int i = tid * VPT + u;
-            if (i < (int)tn) {
-                if (cur >= 0) {                             // events decided BEFORE this sample govern it
-                    const unsigned dist = (unsigned)(i - (cur - W));   // > 0: distance to the anchor
-                    if (dist % (unsigned)SPS == 0u) ++cnt;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * (lane + j * WV) + e - sh;
+                    const long i = t0 - HIST_BB + k;
+                    if (k >= 0 && k < K2_BT) BT[k] = (i >= -a.n_hist && i < a.n) ? w4[e] : 0.0f;
                 }
-                if (evl[u]) cur = i;
             }
         }
-    }
-    int total_packed;
-    block_excl_sum(cnt | (my_ev << 16), shi, tid, total_packed);   // instants low half, events high half
-    const int total_cnt = total_packed & 0xffff, total_ev = total_packed >> 16;
-    // first / last event of the tile
-    __shared__ int first_ev, last_ev;                           // tile-local indices
-    if (tid == 0) first_ev = -1;
-    if (tid == NT - 1) last_ev = incoming > my_last ? incoming : my_last;
-    __syncthreads();
-    if (my_last >= 0 && incoming < 0) {                        // the one thread whose event has none before it
-        int f = -1;
-#pragma unroll
-        for (int u = VPT - 1; u >= 0; --u) if (evl[u]) f = tid * VPT + u;
-        first_ev = f;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        TileRec r;
-        r.first_event = first_ev >= 0 ? a.abs0 + t0 + first_ev : -1;
-        r.n_events = total_ev;
-        r.post_count = total_cnt;
-        r.last_s = -1; r.hi = r.mid = r.lo = 0.f;
-        if (last_ev >= 0) {
-            const int s = last_ev - W;                          // tile-local
-            float hi, mid, lo;
-            sync_thresholds(BT, s + HIST_BB, hi, mid, lo);
-            r.last_s = a.abs0 + t0 + s; r.hi = hi; r.mid = mid; r.lo = lo;
+    };
+
+    const int tile_first = blockIdx.x * K2_SUBS;
+    load(tile_first);
+#pragma unroll 1
+    for (int it = 0; it < K2_SUBS; ++it) {
+        const int tile = tile_first + it;
+        if (tile >= a.n_tiles) break;                               // uniform
+        const long t0 = (long)tile * TB;                            // local index of the tile's first sample
+        const int tn = (a.n - t0 < TB) ? (int)(a.n - t0) : TB;      // samples in this tile
+        stage(tile);
+        phase_sync();
+        {
+            const int nxt = tile + 1 < a.n_tiles ? tile + 1 : tile; // unconditional prefetch (clamped: re-reads this tile)
+            load(it + 1 < K2_SUBS ? nxt : tile);
         }
-        a.recs[(size_t)ch * a.n_tiles + tile] = r;
-        a.tsum[(size_t)ch * a.n_tiles + tile] =
-            first_ev >= 0 ? pack_tsum(first_ev, last_ev, total_ev, total_cnt) : 0ull;
+#if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 1   // measurement builds only: stop after the LDS staging
+        if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = BT[tile % K2_BT] == 123.f ? 1ull : 0ull;
+        phase_sync();
+        continue;
+#endif
+
+        // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s] = BT[k + 10 j], j = 0..23.
+        if (lane < K2_LANES) {
+            const int r = lane % SPS, qb = lane / SPS;
+            const int base = SPS * K2_CQ * qb + r;                  // k of the lane's first output
+            float w[K2_CQ + P25FE_SYNC_DIBITS - 1];
+#pragma unroll
+            for (int m = 0; m < K2_CQ + P25FE_SYNC_DIBITS - 1; ++m) w[m] = BT[base + SPS * m];
+#pragma unroll
+            for (int i = 0; i < K2_CQ; ++i) {
+                const int k = base + SPS * i;
+                float c = 0.f, e = 0.f;
+#pragma unroll
+                for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
+                    const float x = w[i + j];
+                    c = ((P25FE_SYNC_SIGN_MASK >> j) & 1u) ? c + x : c - x;
+                    e = __builtin_fmaf(x, x, e);
+                }
+                if (k < K2_NC) {
+                    CT[k] = c;
+                    CAND[k - W + 8] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
+                }
+            }
+        }
+        phase_sync();
+#if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 2   // stop after the correlation
+        if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = (CT[tile % K2_NC] == 123.f || CAND[tile % K2_NC]) ? 1ull : 0ull;
+        phase_sync();
+        continue;
+#endif
+
+        // event at local index i (decided when sample t0 + i arrives) <=> detection at s = t0 + i - W -> CT index
+        // k = i + W.  The peak window s + W = t0 + i - 1 < n is guaranteed by i < tn.  CAND is stored shifted so that
+        // a lane's 16 flags are two aligned 8-byte LDS reads; no candidate among them (the common case) skips the test.
+        int my_last = -1, my_first = -1, my_ev = 0;
+        unsigned evw[4] = {0u, 0u, 0u, 0u};                         // 16 event flags, one byte each
+        {
+            const uint2 c0 = *reinterpret_cast<const uint2*>(&CAND[lane * K2_VPL + 8]);
+            const uint2 c1 = *reinterpret_cast<const uint2*>(&CAND[lane * K2_VPL + 16]);
+            const unsigned cw[4] = {c0.x, c0.y, c1.x, c1.y};
+            if ((c0.x | c0.y | c1.x | c1.y) != 0u) {
+#pragma unroll
+                for (int u = 0; u < K2_VPL; ++u) {
+                    const int i = lane * K2_VPL + u;
+                    const int k = i + W;
+                    const bool cand = ((cw[u >> 2] >> (8 * (u & 3))) & 0xffu) != 0u;
+                    if (i < tn && cand) {
+                        const float cm = CT[k];
+                        bool det = true;
+#pragma unroll
+                        for (int d = 1; d <= W; ++d) det = det && (cm > CT[k - d]) && (cm >= CT[k + d]);
+                        if (det) {
+                            evw[u >> 2] |= 1u << (8 * (u & 3));
+                            if (my_first < 0) my_first = i;
+                            my_last = i; ++my_ev;
+                        }
+                    }
+                }
+            }
+        }
+        if (a.events) {
+            uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0;
+            if (lane * K2_VPL + K2_VPL <= tn && ((a.ev_stride & 15) == 0)) {
+                *reinterpret_cast<uint4*>(evp + lane * K2_VPL) = make_uint4(evw[0], evw[1], evw[2], evw[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < K2_VPL; ++u)
+                    if (lane * K2_VPL + u < tn) evp[lane * K2_VPL + u] = (uint8_t)((evw[u >> 2] >> (8 * (u & 3))) & 1u);
+            }
+        }
+#if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 3   // stop after peak pick + event flags
+        if (my_last == 12345) a.tsum[(size_t)ch * a.n_tiles + tile] = 1ull;
+        phase_sync();
+        continue;
+#endif
+
+        // latest own event before each lane's first sample, then count instants under own events
+        const int incl = wave_incl_max_i(my_last, lane);
+        int incoming = __shfl_up(incl, 1, 64);
+        if (lane == 0) incoming = -1;
+        int cur = incoming;                                         // tile-local index of the governing event, -1: carry-in (unknown here)
+        int cnt = 0;
+        const int i0 = lane * K2_VPL;
+        if (my_ev == 0) {
+            // common case: no event inside my 16 samples -> one or two instants, closed form
+            if (cur >= 0) {
+                const int navail = tn - i0 < K2_VPL ? tn - i0 : K2_VPL;
+                const unsigned ph = (unsigned)(i0 - (cur - W)) % (unsigned)SPS;
+                const int f = (int)((SPS - ph) % (unsigned)SPS);
+                cnt = (f < navail ? 1 : 0) + (f + SPS < navail ? 1 : 0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < K2_VPL; ++u) {
+                const int i = i0 + u;
+                if (i < tn) {
+                    if (cur >= 0) {                                 // events decided BEFORE this sample govern it
+                        const unsigned dist = (unsigned)(i - (cur - W));   // > 0: distance to the anchor
+                        if (dist % (unsigned)SPS == 0u) ++cnt;
+                    }
+                    if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) cur = i;
+                }
+            }
+        }
+        const int total_packed = wave_sum_i(cnt | (my_ev << 16));   // instants low half, events high half
+        const int total_cnt = total_packed & 0xffff, total_ev = total_packed >> 16;
+        const int last_ev = __shfl(incl, 63, 64);
+        const unsigned long long evmask = __ballot(my_ev > 0);
+        const int first_ev = evmask ? __shfl(my_first, __builtin_ctzll(evmask), 64) : -1;
+        if (lane == 0) {
+            TileRec r;
+            r.first_event = first_ev >= 0 ? a.abs0 + t0 + first_ev : -1;
+            r.n_events = total_ev;
+            r.post_count = total_cnt;
+            r.last_s = -1; r.hi = r.mid = r.lo = 0.f;
+            if (last_ev >= 0) {
+                const int s = last_ev - W;                          // tile-local
+                float hi, mid, lo;
+                sync_thresholds(BT, s + HIST_BB, hi, mid, lo);
+                r.last_s = a.abs0 + t0 + s; r.hi = hi; r.mid = mid; r.lo = lo;
+            }
+            a.recs[(size_t)ch * a.n_tiles + tile] = r;
+            a.tsum[(size_t)ch * a.n_tiles + tile] =
+                first_ev >= 0 ? pack_tsum(first_ev, last_ev, total_ev, total_cnt) : 0ull;
+        }
+        phase_sync();                                               // BT / CT / CAND are rewritten by the next tile
     }
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the kernels on random IQ (within-process A/B across env settings is done by the caller).
-usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|run] [channels=1] [fmt=cf32|u8]"""
+usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|run|split] [channels=1] [fmt=cf32|u8]
+mode split = run, plus the per-kernel split from the library's own HIP events."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,6 +30,8 @@ def step():
         fe.run_dev(iq)
 for _ in range(5):
     step()
+if mode == "split":
+    fe.profile_enable(True)
 torch.cuda.synchronize()
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
 for e0, e1 in ev:          # back-to-back launches, no host sync in between (steady-state clocks)
@@ -40,3 +43,6 @@ bps = 8.8 if fmt == "cf32" else 2.8
 tag = " ".join("%s=%s" % (k[6:], os.path.basename(v)) for k, v in sorted(os.environ.items()) if k.startswith("P25FE_"))
 print("%-6s C=%d n=%d %s [%s]: med %.4f min %.4f p90 %.4f ms -> %.1f Gsamples/s, %.0f GB/s"
       % (mode, C, n, fmt, tag, med, mn, p90, C * n / med / 1e6, C * n * bps / med / 1e6))
+if mode == "split":
+    ms, calls = fe.profile_read()
+    print("       per-kernel ms (K1 K2 K3 K4): " + " ".join("%.4f" % (m / max(1, calls)) for m in ms))
