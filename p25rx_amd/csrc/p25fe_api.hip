@@ -352,7 +352,8 @@ static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, si
     l.n_groups = (int)n_groups; l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
-    hipLaunchKernelGGL(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(NT), 0, st, l);
+    l.tsum = h->tsum.as<unsigned long long>();
+    hipLaunchKernelGGL(k_slice, dim3((unsigned)((n_tiles + K4_SUBS - 1) / K4_SUBS), (unsigned)h->C), dim3(WV), 0, st, l);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 4, st);
     return P25FE_OK;

@@ -606,8 +606,6 @@ constexpr int W = P25FE_PEAK_W;
 constexpr int SPS = P25FE_SPS;
 constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
 constexpr int TB = 1024;                                     // baseband samples per tile
-constexpr int NT = 128;                                      // threads per workgroup in K2 / K4 (256 x 2048 and 512 x 4096 measured slower)
-constexpr int VPT = TB / NT;                                 // 8 consecutive samples per thread
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
 
 struct TileRec {            // per (channel, tile) summary written by K2
@@ -687,40 +685,6 @@ __device__ __forceinline__ int wave_incl_sum(int v, int lane)
         if (lane >= d) v += o;
     }
     return v;
-}
-
-// Block-wide exclusive scans over per-thread (last event index inside the tile, count).  scratch: >= 8 ints.
-__device__ __forceinline__ int block_excl_max(int v, int* sh, int tid)
-{
-    const int lane = tid & 63, wv = tid >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc = o > inc ? o : inc;
-    }
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    int prev = __shfl_up(inc, 1, 64);
-    if (lane == 0) prev = -1;
-    int carry = -1;
-    for (int k = 0; k < wv; ++k) carry = sh[k] > carry ? sh[k] : carry;
-    __syncthreads();
-    return prev > carry ? prev : carry;
-}
-__device__ __forceinline__ int block_excl_sum(int v, int* sh, int tid, int& total)
-{
-    const int lane = tid & 63, wv = tid >> 6;
-    const int inc = wave_incl_sum(v, lane);
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    int carry = 0;
-    for (int k = 0; k < wv; ++k) carry += sh[k];
-    total = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) total += sh[k];
-    __syncthreads();
-    return carry + inc - v;
 }
 
 struct SyncArgs {
@@ -1236,6 +1200,7 @@ struct SliceArgs {
     const ScanOut* outs;
     const TileRec* recs;
     const GroupCarry* carries;          // [ch][n_groups]
+    const unsigned long long* tsum;     // [ch][n_tiles] K2's packed summaries (0: no event in the tile)
     int n_groups;
     uint8_t* dibits;            // [ch][dibit_stride]
     long dibit_stride;
@@ -1244,135 +1209,221 @@ struct SliceArgs {
     long sync_stride;
 };
 
-// K4: slice the anchored symbol instants of one tile.  No LDS tile: a thread reads its own 8 samples and
-// 8 event flags straight from global memory (both were just written and are L2 / MALL resident).
-__global__ __launch_bounds__(NT) void k_slice(SliceArgs a)
+// K4: slice the anchored symbol instants.  One wave per workgroup walks K4_SUBS consecutive tiles; a lane owns 16
+// consecutive samples of a tile (read straight from global memory: the baseband and the flags were just written
+// and are L2 / MALL resident), the next tile's samples are requested before the current ones are used.
+//   * The carry-in of the workgroup's tiles (K3's ScanOut / GroupCarry, the anchor's TileRec) is fetched once, one
+//     lane per tile, and broadcast per tile with v_readlane: two dependent loads per workgroup, not per tile.
+//   * A tile WITHOUT events (7 of 8 in a P25 stream; K2's packed summary says so) needs no flags and no scan: the
+//     instants and their ranks are closed forms of the carry-in anchor.  Without an anchor it is skipped unread.
+#ifndef P25FE_K4_SUBS
+#define P25FE_K4_SUBS 4
+#endif
+#ifndef P25FE_K4_WPS
+#define P25FE_K4_WPS 3
+#endif
+constexpr int K4_SUBS = P25FE_K4_SUBS;
+constexpr int K4_VPL = TB / WV;                                  // 16 samples per lane
+static_assert(K4_VPL > SPS && K4_VPL <= 2 * SPS, "closed forms assume 1..2 instants per lane");
+
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ long rl_l(long v, int l)
 {
-    __shared__ int shl[8];
-    __shared__ int shi[8];
-    const int tid = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
-    const long t0 = (long)tile * TB;
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffL), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((long)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned char slice_dibit(float v, float hi, float mid, float lo)
+{
+    return v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
+}
+
+__global__ __launch_bounds__(WV, P25FE_K4_WPS) void k_slice(SliceArgs a)
+{
+    const int lane = threadIdx.x, ch = blockIdx.y;
+    const int tile_first = blockIdx.x * K4_SUBS;
     const float* bbp = a.bb + (size_t)ch * a.bb_stride;
-    const long tn = (a.n - t0 < TB) ? a.n - t0 : TB;
-    const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
-    const GroupCarry gc = a.carries[(size_t)ch * a.n_groups + tile / K3_GROUP];
-    struct { long anchor_s; float hi, mid, lo; int valid; unsigned long long dibit_off; unsigned event_off; } co;
-    co.event_off = (unsigned)(gc.event_base + so.event_off);
-    if (so.src >= 0) {                                   // an event of this group governs the tile's start
-        const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
-        co.anchor_s = t.last_s; co.hi = t.hi; co.mid = t.mid; co.lo = t.lo; co.valid = 1;
-        co.dibit_off = gc.base_after_first + so.dibit_off;
-    } else {                                             // the group's carry-in governs it: closed-form count so far
-        co.anchor_s = gc.anchor_s; co.hi = gc.hi; co.mid = gc.mid; co.lo = gc.lo; co.valid = gc.valid;
-        const long glo = a.abs0 + (long)(tile / K3_GROUP) * K3_GROUP * TB;
-        co.dibit_off = gc.dibit_base + (gc.valid ? (unsigned long long)count_instants(gc.anchor_s, glo, a.abs0 + t0) : 0ull);
-    }
+    const bool aligned = ((reinterpret_cast<uintptr_t>(bbp) & 15u) == 0) && ((a.ev_stride & 15) == 0);
 
-    uint8_t evl[VPT];
-    float bv[VPT];
+    // carry-in of tile tile_first + l, computed by lane l (lanes >= K4_SUBS repeat the last one)
+    long c_anchor; float c_hi, c_mid, c_lo; int c_valid, c_has_ev; unsigned long long c_dibit_off; unsigned c_event_off, c_ph;
     {
-        const uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0 + tid * VPT;
-        const float* bp = bbp + t0 + tid * VPT;
-        const bool full = tid * VPT + VPT <= tn;
-        if (full && ((a.ev_stride & 7) == 0)) {
-            const uint2 pk = *reinterpret_cast<const uint2*>(evp);
-#pragma unroll
-            for (int u = 0; u < VPT; ++u) evl[u] = (uint8_t)(((u < 4 ? pk.x : pk.y) >> (8 * (u & 3))) & 0xffu);
-        } else {
-#pragma unroll
-            for (int u = 0; u < VPT; ++u) evl[u] = (tid * VPT + u < tn) ? evp[u] : 0;
+        int tl = tile_first + (lane < K4_SUBS ? lane : K4_SUBS - 1);
+        tl = tl < a.n_tiles ? tl : a.n_tiles - 1;
+        const long t0 = (long)tl * TB;
+        const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tl];
+        const GroupCarry gc = a.carries[(size_t)ch * a.n_groups + tl / K3_GROUP];
+        c_has_ev = a.tsum[(size_t)ch * a.n_tiles + tl] != 0ull;
+        c_event_off = (unsigned)(gc.event_base + so.event_off);
+        if (so.src >= 0) {                                   // an event of this group governs the tile's start
+            const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
+            c_anchor = t.last_s; c_hi = t.hi; c_mid = t.mid; c_lo = t.lo; c_valid = 1;
+            c_dibit_off = gc.base_after_first + so.dibit_off;
+        } else {                                             // the group's carry-in governs it: closed-form count so far
+            c_anchor = gc.anchor_s; c_hi = gc.hi; c_mid = gc.mid; c_lo = gc.lo; c_valid = gc.valid;
+            const long glo = a.abs0 + (long)(tl / K3_GROUP) * K3_GROUP * TB;
+            c_dibit_off = gc.dibit_base + (gc.valid ? (unsigned long long)count_instants(gc.anchor_s, glo, a.abs0 + t0) : 0ull);
         }
-        if (full && ((reinterpret_cast<uintptr_t>(bp) & 15u) == 0)) {
-            const float4 b0 = reinterpret_cast<const float4*>(bp)[0], b1 = reinterpret_cast<const float4*>(bp)[1];
-            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < VPT; ++u) bv[u] = (tid * VPT + u < tn) ? bp[u] : 0.f;
-        }
+        // distance of the tile's first sample to the carry-in anchor, mod 10 (the one 64-bit modulo)
+        c_ph = c_valid ? (unsigned)((a.abs0 + t0 - c_anchor) % SPS) : 0u;
     }
 
-    int my_last = -1;
-    int my_ev = 0;
+    float4 nb[4];
+    uint4 nev = make_uint4(0u, 0u, 0u, 0u);
+    // request tile t's samples (and flags if it has events); whole, aligned tiles only -- others are read element-wise
+    auto request = [&](int t, int has_ev, int valid) {
+        const long t0 = (long)t * TB;
+        const bool fast = aligned && t < a.n_tiles && a.n - t0 >= TB;
+        if (fast && (has_ev || valid)) {
+            // with events: a lane's 16 consecutive samples; without: lane-interleaved vectors (contiguous 1 KB per load)
+            const float4* bp = reinterpret_cast<const float4*>(bbp + t0) + (has_ev ? lane * 4 : lane);
+            const int qs = has_ev ? 1 : WV;
 #pragma unroll
-    for (int u = 0; u < VPT; ++u)
-        if (evl[u]) { my_last = tid * VPT + u; ++my_ev; }
-    const int incoming = block_excl_max(my_last, shl, tid);
-    // walk my 8 samples: count, then rank, then emit
-    int cur = incoming;
-    int cnt = 0;
-    unsigned inst = 0;
-    // distance of my first sample to the carry-in anchor, mod 10 (one 64-bit modulo per thread, then 32-bit)
-    // (wave-uniform 64-bit modulo once, then 32-bit per thread)
-    const unsigned base_ph = co.valid ? (unsigned)((a.abs0 + t0 - co.anchor_s) % SPS) : 0u;
-    const unsigned cph = (base_ph + (unsigned)(tid * VPT)) % (unsigned)SPS;
-    if (my_ev == 0) {
-        // common case: no event inside my 8 samples -> one governing anchor, and since 8 < 10 at most ONE instant
-        const int i0 = tid * VPT;
-        const int navail = (int)tn - i0 < VPT ? (int)tn - i0 : VPT;
-        unsigned ph = 0u;
-        bool gov = false;
-        if (cur >= 0) { ph = (unsigned)(i0 - (cur - W)) % (unsigned)SPS; gov = true; }
-        else if (co.valid) { ph = cph; gov = true; }
-        const int f = (int)((SPS - ph) % (unsigned)SPS);        // offset of the first instant at or after i0
-        if (gov && f < navail) { cnt = 1; inst = 1u << f; }
-    } else {
+            for (int q = 0; q < 4; ++q) nb[q] = bp[q * qs];
+            if (has_ev) nev = *reinterpret_cast<const uint4*>(a.events + (size_t)ch * a.ev_stride + t0 + lane * K4_VPL);
+        }
+    };
+    request(tile_first, rl_i(c_has_ev, 0), rl_i(c_valid, 0));
+
+#pragma unroll 1
+    for (int it = 0; it < K4_SUBS; ++it) {
+        const int tile = tile_first + it;
+        if (tile >= a.n_tiles) break;                               // uniform
+        const long t0 = (long)tile * TB;
+        const int tn = (a.n - t0 < TB) ? (int)(a.n - t0) : TB;
+        const int has_ev = rl_i(c_has_ev, it), valid = rl_i(c_valid, it);
+        const bool fast = aligned && tn == TB;
+        if (fast && !has_ev) {
+            // no event in the tile: instants at i = f0 + 10 m under the carry-in anchor, ranks in closed form.  The lane
+            // holds four groups of 4 consecutive samples (interleaved vectors), each with at most one instant (4 < 10).
+            float4 cb[4];
 #pragma unroll
-        for (int u = 0; u < VPT; ++u) {
-            const int i = tid * VPT + u;
-            if (i < (int)tn) {
+            for (int q = 0; q < 4; ++q) cb[q] = nb[q];
+            if (it + 1 < K4_SUBS) request(tile + 1, rl_i(c_has_ev, it + 1), rl_i(c_valid, it + 1));
+            if (!valid) continue;                                   // nothing decided yet: no instants
+            const float hi0 = rl_f(c_hi, it), mid0 = rl_f(c_mid, it), lo0 = rl_f(c_lo, it);
+            const unsigned base_ph = (unsigned)rl_i((int)c_ph, it);
+            uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + (unsigned long long)rl_l((long)c_dibit_off, it);
+            const int f0 = (int)((SPS - base_ph) % (unsigned)SPS);  // first instant of the tile
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = 4 * (lane + q * WV);
+                const unsigned ph = (base_ph + (unsigned)g) % (unsigned)SPS;
+                const int f = (int)((SPS - ph) % (unsigned)SPS);
+#if defined(P25FE_ABLATE4) && P25FE_ABLATE4 == 2     // measurement build: fast-path stores suppressed
+                if (f < 4 && cb[q].x == 123.f) {
+#else
+                if (f < 4) {
+#endif
+                    const float v = f == 0 ? cb[q].x : f == 1 ? cb[q].y : f == 2 ? cb[q].z : cb[q].w;
+                    out[(unsigned)(g + f - f0) / (unsigned)SPS] = slice_dibit(v, hi0, mid0, lo0);
+                }
+            }
+            continue;
+        }
+        float bv[K4_VPL];
+        unsigned evw[4] = {0u, 0u, 0u, 0u};
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { bv[4 * q] = nb[q].x; bv[4 * q + 1] = nb[q].y; bv[4 * q + 2] = nb[q].z; bv[4 * q + 3] = nb[q].w; }
+            evw[0] = nev.x; evw[1] = nev.y; evw[2] = nev.z; evw[3] = nev.w;
+        } else {
+            const float* bp = bbp + t0 + lane * K4_VPL;
+            const uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0 + lane * K4_VPL;
+#pragma unroll
+            for (int u = 0; u < K4_VPL; ++u) {
+                const bool in = lane * K4_VPL + u < tn;
+                bv[u] = in ? bp[u] : 0.f;
+                if (has_ev && in && evp[u]) evw[u >> 2] |= 1u << (8 * (u & 3));
+            }
+        }
+        if (it + 1 < K4_SUBS) request(tile + 1, rl_i(c_has_ev, it + 1), rl_i(c_valid, it + 1));
+        if (!has_ev && !valid) continue;                            // nothing decided yet: no instants
+
+        const float hi0 = rl_f(c_hi, it), mid0 = rl_f(c_mid, it), lo0 = rl_f(c_lo, it);
+        const unsigned base_ph = (unsigned)rl_i((int)c_ph, it);
+        const unsigned long long dibit_off = (unsigned long long)rl_l((long)c_dibit_off, it);
+        uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + dibit_off;
+        const int i0 = lane * K4_VPL;
+
+#if defined(P25FE_ABLATE4) && P25FE_ABLATE4 == 1     // measurement build: tiles with events skipped
+        if (bv[0] != 123.f) continue;
+#endif
+        // general tile: events inside.  Latest own event before each lane's first sample, count, rank, emit.
+        int my_last = -1, my_ev = 0;
+#pragma unroll
+        for (int u = 0; u < K4_VPL; ++u)
+            if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) { my_last = i0 + u; ++my_ev; }
+        const int incl = wave_incl_max_i(my_last, lane);
+        int incoming = __shfl_up(incl, 1, 64);
+        if (lane == 0) incoming = -1;
+        int cur = incoming;
+        int cnt = 0;
+        unsigned inst = 0;
+        const unsigned cph = (base_ph + (unsigned)i0) % (unsigned)SPS;
+#pragma unroll
+        for (int u = 0; u < K4_VPL; ++u) {
+            const int i = i0 + u;
+            if (i < tn) {
                 bool is = false;
                 if (cur >= 0) is = ((unsigned)(i - (cur - W)) % (unsigned)SPS) == 0u;
-                else if (co.valid) is = ((cph + (unsigned)u) % (unsigned)SPS) == 0u;
+                else if (valid) is = ((cph + (unsigned)u) % (unsigned)SPS) == 0u;
                 if (is) { ++cnt; inst |= 1u << u; }
-                if (evl[u]) cur = i;
+                if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) cur = i;
             }
         }
-    }
-    // one block scan for both ranks: instants in the low half, events in the high half (each <= 2048 per tile)
-    int total;
-    const int packed = block_excl_sum(cnt | (my_ev << 16), shi, tid, total);
-    int rank = packed & 0xffff;
-    int evrank = packed >> 16;
-    uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + co.dibit_off;
-    cur = incoming;
-    int thr_for = -2;                      // tile-local anchor whose thresholds are cached in hi / mid / lo
-    float hi = co.hi, mid = co.mid, lo = co.lo;
+        // one wave scan for both ranks: instants in the low half, events in the high half (each <= 1024 per tile)
+        const int mine = cnt | (my_ev << 16);
+        const int packed = wave_incl_sum(mine, lane) - mine;
+        int rank = packed & 0xffff;
+        int evrank = packed >> 16;
+        const unsigned event_off = (unsigned)rl_i((int)c_event_off, it);
+        cur = incoming;
+        int thr_for = -2;                      // tile-local anchor whose thresholds are cached in hi / mid / lo
+        float hi = hi0, mid = mid0, lo = lo0;
+        // K2 left the thresholds of the tile's LAST event in its TileRec: with one event per tile (the normal case)
+        // no lane recomputes anything; only earlier events of a multi-event tile take the 24-load path below.
+        const TileRec own = a.recs[(size_t)ch * a.n_tiles + tile];
+        const int own_last = (int)(own.last_s - a.abs0 - t0) + W;
 #pragma unroll
-    for (int u = 0; u < VPT; ++u) {
-        const int i = tid * VPT + u;
-        if (i < (int)tn) {
-            // the instant at index i (if any) is governed by events decided before i
-            if ((inst >> u) & 1u) {
-                if (cur >= 0 && cur != thr_for) {
-                    // thresholds of an in-tile anchor: same arithmetic as K2 (same bits), from global memory;
-                    // in-tile events are rare, so this beats staging the tile and its 240-sample halo in LDS
-                    const long s = t0 + cur - W;               // local index of the sync word's last symbol
-                    float Pp = 0.f, Nn = 0.f;
-#pragma unroll
-                    for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-                        const float v = bb_at(bbp, a.n_hist, a.n, s - SPS * (P25FE_SYNC_DIBITS - 1 - j));
-                        if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
+        for (int u = 0; u < K4_VPL; ++u) {
+            const int i = i0 + u;
+            if (i < tn) {
+                // the instant at index i (if any) is governed by events decided before i
+                if ((inst >> u) & 1u) {
+                    if (cur >= 0 && cur != thr_for && cur == own_last) {
+                        hi = own.hi; mid = own.mid; lo = own.lo;
+                        thr_for = cur;
                     }
-                    Pp = Pp * P25FE_SYNC_INV_NPOS;
-                    Nn = Nn * P25FE_SYNC_INV_NNEG;
-                    mid = (Pp + Nn) * 0.5f;
-                    const float span = (Pp - Nn) * 0.5f;
-                    const float d = span * P25FE_SLICE_FRAC;
-                    hi = mid + d;
-                    lo = mid - d;
-                    thr_for = cur;
+                    if (cur >= 0 && cur != thr_for) {
+                        // thresholds of an in-tile anchor: same arithmetic as K2 (same bits), from global memory
+                        const long s = t0 + cur - W;               // local index of the sync word's last symbol
+                        float Pp = 0.f, Nn = 0.f;
+#pragma unroll
+                        for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
+                            const float v = bb_at(bbp, a.n_hist, a.n, s - SPS * (P25FE_SYNC_DIBITS - 1 - j));
+                            if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
+                        }
+                        Pp = Pp * P25FE_SYNC_INV_NPOS;
+                        Nn = Nn * P25FE_SYNC_INV_NNEG;
+                        mid = (Pp + Nn) * 0.5f;
+                        const float span = (Pp - Nn) * 0.5f;
+                        const float d = span * P25FE_SLICE_FRAC;
+                        hi = mid + d;
+                        lo = mid - d;
+                        thr_for = cur;
+                    }
+                    out[rank++] = slice_dibit(bv[u], hi, mid, lo);
                 }
-                const float v = bv[u];
-                out[rank++] = v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
-            }
-            if (evl[u]) {
-                if (a.sync_pos && (long)(co.event_off + evrank) < a.sync_stride) {
-                    a.sync_pos[(size_t)ch * a.sync_stride + co.event_off + evrank] = a.abs0 + t0 + i - W;
-                    // index of the first dibit this detection governs = dibits for instants <= i
-                    a.sync_dibit[(size_t)ch * a.sync_stride + co.event_off + evrank] = co.dibit_off + rank;
+                if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) {
+                    if (a.sync_pos && (long)(event_off + evrank) < a.sync_stride) {
+                        a.sync_pos[(size_t)ch * a.sync_stride + event_off + evrank] = a.abs0 + t0 + i - W;
+                        // index of the first dibit this detection governs = dibits for instants <= i
+                        a.sync_dibit[(size_t)ch * a.sync_stride + event_off + evrank] = dibit_off + rank;
+                    }
+                    ++evrank;
+                    cur = i;
                 }
-                ++evrank;
-                cur = i;
             }
         }
     }

@@ -14,7 +14,12 @@ C = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 fmt = sys.argv[5] if len(sys.argv) > 5 else "cf32"
 n = int(secs * 240000) // 8 * 8
 dev = torch.device("cuda", 0)
-if fmt == "cf32":
+if fmt == "cf32" and mode in ("run", "split"):      # the symbol receiver's cost depends on the signal: real C4FM
+    from p25rx_amd import c4fm
+    iq = torch.empty((C, n, 2), dtype=torch.float32, device=dev)
+    for c in range(C):
+        c4fm.synth_torch(n, seed=1 + c, device=dev, out=iq[c])
+elif fmt == "cf32":
     iq = torch.randn((C, n, 2), dtype=torch.float32, device=dev) * 0.3
 else:
     iq = torch.randint(0, 256, (C, n, 2), dtype=torch.uint8, device=dev)
