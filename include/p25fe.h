@@ -207,6 +207,42 @@ typedef struct p25fe_nid {
 int p25fe_nid_dev(p25fe_t *h, const uint8_t *d_dibits, size_t n_dibits, const uint64_t *d_sync_dibit,
                   const int64_t *d_sync_pos, size_t n_sync, p25fe_nid_t *d_out, void *stream);
 
+/* The same for a whole channel batch without a host round trip: channel c's stream is d_dibits + c * dibit_stride
+ * with d_result[c].n_dibits dibits, its events d_sync_dibit / d_sync_pos + c * sync_stride (the outputs of
+ * p25fe_slice_dev), min(d_result[c].n_sync, sync_stride) of them; records go to d_out + c * sync_stride. */
+int p25fe_nid_batch_dev(p25fe_t *h, const uint8_t *d_dibits, size_t dibit_stride, const p25fe_result_t *d_result,
+                        const uint64_t *d_sync_dibit, const int64_t *d_sync_pos, size_t sync_stride,
+                        p25fe_nid_t *d_out, void *stream);
+
+/* Per-channel observability record: what the reference pushes to its hub as
+ * HubEvent::UpdateSignalPower (src/demod.rs:95-101, "sigPower" src/hub.rs:344) and HubEvent::UpdateStats
+ * (src/recv.rs:162-165, 212-215; "updateStats" src/hub.rs:401-402), restricted to what exists on this path: the
+ * "bch" row of serialize_stats (src/hub.rs:559) -- p25::stats::CodeStats as serialised by serialize_code_stats
+ * (src/hub.rs:574-581: totalWords = words, errWords = errs, totalSymbols = words * size, fixedSymbols = fixed) --
+ * plus the receiver's lock state.  The other code rows (Golay, Hamming, RS, Viterbi) belong to the out-of-scope
+ * frame decoder. */
+typedef struct p25fe_code_stats {
+    uint64_t words;                      /* code words seen (NIDs complete in the dibit stream) */
+    uint64_t errs;                       /* of those, undecodable (more than 11 bit errors) */
+    uint64_t fixed;                      /* corrected bits over the decodable words */
+    uint32_t size;                       /* symbols per word: 63 */
+    uint32_t reserved;
+} p25fe_code_stats_t;
+
+typedef struct p25fe_chan_stats {
+    float sig_power_dbm;                 /* copied from d_power_dbm[c]; NaN when not supplied */
+    int32_t locked;                      /* an anchor is in force at the end of the range */
+    uint64_t n_dibits;
+    uint64_t n_sync;                     /* detections decided in the range */
+    int64_t last_sync_pos;               /* s of the last detection, -1 if none */
+    p25fe_code_stats_t bch;
+} p25fe_chan_stats_t;
+
+/* d_result[C] from p25fe_slice_dev / p25fe_run_dev; d_nid[C][sync_stride] from p25fe_nid_batch_dev (nullable: bch
+ * stays zero); d_power_dbm[C] from p25fe_demod_dev (nullable).  Writes d_stats[C]. */
+int p25fe_chan_stats_dev(p25fe_t *h, const p25fe_result_t *d_result, const p25fe_nid_t *d_nid, size_t sync_stride,
+                         const float *d_power_dbm, p25fe_chan_stats_t *d_stats, void *stream);
+
 /* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1/2 record HIP
  * events on the caller's stream around each kernel (K1 front end, K2 sync, K3 scan, K4 slice).
  * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel

@@ -38,6 +38,10 @@ RESULT_DTYPE = np.dtype([("n_baseband", "<u8"), ("n_dibits", "<u8"), ("n_sync", 
 NID_DTYPE = np.dtype([("raw", "<u8"), ("sync_pos", "<i8"), ("nac", "<u2"), ("duid", "u1"), ("n_errors", "u1"),
                       ("valid", "<i4")])
 assert NID_DTYPE.itemsize == 24
+CODE_STATS_DTYPE = np.dtype([("words", "<u8"), ("errs", "<u8"), ("fixed", "<u8"), ("size", "<u4"), ("reserved", "<u4")])
+CHAN_STATS_DTYPE = np.dtype([("sig_power_dbm", "<f4"), ("locked", "<i4"), ("n_dibits", "<u8"), ("n_sync", "<u8"),
+                             ("last_sync_pos", "<i8"), ("bch", CODE_STATS_DTYPE)])
+assert CHAN_STATS_DTYPE.itemsize == 64
 assert ANCHOR_DTYPE.itemsize == C.sizeof(Anchor) and RESULT_DTYPE.itemsize == C.sizeof(Result)
 
 # every symbol include/p25fe.h declares (tests check the library exports exactly these)
@@ -48,6 +52,7 @@ SYMBOLS = [
     "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
+    "p25fe_nid_batch_dev", "p25fe_chan_stats_dev",
 ]
 
 
@@ -107,6 +112,8 @@ def load():
     L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, vp, vp]
     L.p25fe_shard_resolve_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_nid_dev.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
+    L.p25fe_nid_batch_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp]
+    L.p25fe_chan_stats_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_profile_enable.argtypes = [vp, C.c_int]
     L.p25fe_profile_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
     L.p25fe_predecim_dev.argtypes = [vp, vp, sz, sz, sz, u64, vp, sz, vp]

@@ -686,7 +686,33 @@ int p25fe_nid_dev(p25fe_t* h, const uint8_t* d_dibits, size_t n_dibits, const ui
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_nid, dim3((unsigned)n_sync), dim3(256), 0, (hipStream_t)stream, d_dibits,
                        (unsigned long long)n_dibits, reinterpret_cast<const unsigned long long*>(d_sync_dibit),
-                       reinterpret_cast<const long*>(d_sync_pos), d_out);
+                       reinterpret_cast<const long*>(d_sync_pos), d_out, (const p25fe_result_t*)nullptr, 0ull, 0ull);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+int p25fe_nid_batch_dev(p25fe_t* h, const uint8_t* d_dibits, size_t dibit_stride, const p25fe_result_t* d_result,
+                        const uint64_t* d_sync_dibit, const int64_t* d_sync_pos, size_t sync_stride,
+                        p25fe_nid_t* d_out, void* stream)
+{
+    if (!h || !d_dibits || !d_result || !d_sync_dibit || !d_out) return P25FE_ERR_ARG;
+    if (sync_stride == 0) return P25FE_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_nid, dim3((unsigned)sync_stride, (unsigned)h->C), dim3(256), 0, (hipStream_t)stream, d_dibits,
+                       0ull, reinterpret_cast<const unsigned long long*>(d_sync_dibit),
+                       reinterpret_cast<const long*>(d_sync_pos), d_out, d_result, (unsigned long long)dibit_stride,
+                       (unsigned long long)sync_stride);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+int p25fe_chan_stats_dev(p25fe_t* h, const p25fe_result_t* d_result, const p25fe_nid_t* d_nid, size_t sync_stride,
+                         const float* d_power_dbm, p25fe_chan_stats_t* d_stats, void* stream)
+{
+    if (!h || !d_result || !d_stats) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_chan_stats, dim3((unsigned)h->C), dim3(256), 0, (hipStream_t)stream, d_result, d_nid,
+                       (unsigned long long)sync_stride, d_power_dbm, d_stats);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }

@@ -1435,13 +1435,24 @@ __global__ __launch_bounds__(WV, P25FE_K4_WPS) void k_slice(SliceArgs a)
 // 65536 BCH(63,16,23) code words by exhaustive Hamming search (256 per thread, two 256-entry XOR tables in LDS) --
 // equivalent to a bounded-distance decoder when at most t = 11 bits are wrong, and embarrassingly parallel.
 // ------------------------------------------------------------------------------------------
+// Batch form: blockIdx.y = channel, per-channel strides, event / dibit counts read from the channel's p25fe_result_t.
 __global__ __launch_bounds__(256) void k_nid(const uint8_t* dibits, unsigned long long n_dibits, const unsigned long long* sync_dibit,
-                                             const long* sync_pos, p25fe_nid_t* out)
+                                             const long* sync_pos, p25fe_nid_t* out, const p25fe_result_t* results,
+                                             unsigned long long dibit_stride, unsigned long long sync_stride)
 {
     __shared__ unsigned long long LO[256], HI[256];
     __shared__ unsigned long long raw_sh;
     __shared__ unsigned best_sh[4];
     const int tid = threadIdx.x, k = blockIdx.x;
+    if (results) {                                              // uniform
+        const p25fe_result_t r = results[blockIdx.y];
+        if ((unsigned long long)k >= r.n_sync) return;
+        n_dibits = r.n_dibits;
+        dibits += blockIdx.y * dibit_stride;
+        sync_dibit += blockIdx.y * sync_stride;
+        if (sync_pos) sync_pos += blockIdx.y * sync_stride;
+        out += blockIdx.y * sync_stride;
+    }
     {
         unsigned long long a = 0, b = 0;
 #pragma unroll
@@ -1485,6 +1496,46 @@ __global__ __launch_bounds__(256) void k_nid(const uint8_t* dibits, unsigned lon
         r.n_errors = have ? (uint8_t)dist : 0;
         r.valid = have ? (dist <= P25FE_NID_T ? 1 : 0) : -1;
         out[k] = r;
+    }
+}
+
+// Per-channel observability record (src/hub.rs:344, 401-402, 557-581): one workgroup per
+// channel folds the channel's NID records into the "bch" CodeStats row and copies the lock state.
+__global__ __launch_bounds__(256) void k_chan_stats(const p25fe_result_t* results, const p25fe_nid_t* nid,
+                                                    unsigned long long sync_stride, const float* power_dbm,
+                                                    p25fe_chan_stats_t* stats)
+{
+    __shared__ unsigned long long sh[3][4];
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    const p25fe_result_t r = results[ch];
+    unsigned long long words = 0, errs = 0, fixed = 0;
+    if (nid) {
+        const unsigned long long n = r.n_sync < sync_stride ? r.n_sync : sync_stride;
+        for (unsigned long long k = tid; k < n; k += 256) {
+            const p25fe_nid_t v = nid[ch * sync_stride + k];
+            if (v.valid >= 0) { ++words; if (v.valid == 0) ++errs; else fixed += v.n_errors; }
+        }
+    }
+    unsigned long long acc[3] = {words, errs, fixed};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+        if ((tid & 63) == 0) sh[q][tid >> 6] = acc[q];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        p25fe_chan_stats_t o;
+        o.sig_power_dbm = power_dbm ? power_dbm[ch] : __int_as_float(0x7fc00000);
+        o.locked = r.anchor_out.valid;
+        o.n_dibits = r.n_dibits;
+        o.n_sync = r.n_sync;
+        o.last_sync_pos = (r.n_sync > 0 && r.anchor_out.valid) ? r.anchor_out.s : -1;
+        o.bch.words = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        o.bch.errs = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        o.bch.fixed = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+        o.bch.size = 63; o.bch.reserved = 0;
+        stats[ch] = o;
     }
 }
 

@@ -218,6 +218,31 @@ class FrontEnd:
                                        C.c_void_p(out.data_ptr()), self._stream()))
         return out[:n_sync]
 
+    def nid_batch_dev(self, dibits, results, sync_dibit, sync_pos=None):
+        """Channel batch: dibits [C, dibit_stride] uint8, results uint8 [C, sizeof(p25fe_result_t)], sync_dibit /
+        sync_pos [C, sync_stride] (all device tensors, as written by slice_dev) -> uint8 tensor [C, sync_stride, 24]
+        (rows k >= results[c].n_sync are left untouched: zero)."""
+        import torch
+        sync_stride = sync_dibit.shape[1]
+        out = torch.zeros((self.C, max(sync_stride, 1), 24), dtype=torch.uint8, device=dibits.device)
+        self._chk(self.L.p25fe_nid_batch_dev(self.h, C.c_void_p(dibits.data_ptr()), dibits.stride(0),
+                                             C.c_void_p(results.data_ptr()), C.c_void_p(sync_dibit.data_ptr()),
+                                             C.c_void_p(sync_pos.data_ptr()) if sync_pos is not None else None,
+                                             sync_stride, C.c_void_p(out.data_ptr()), self._stream()))
+        return out[:, :sync_stride]
+
+    def chan_stats_dev(self, results, nid=None, power_dbm=None):
+        """results [C, sizeof(p25fe_result_t)], nid [C, sync_stride, 24] (optional), power_dbm [C] float32
+        (optional) -> uint8 tensor [C, 64] (view with _lib.CHAN_STATS_DTYPE after .cpu())."""
+        import torch
+        out = torch.empty((self.C, 64), dtype=torch.uint8, device=results.device)
+        self._chk(self.L.p25fe_chan_stats_dev(self.h, C.c_void_p(results.data_ptr()),
+                                              C.c_void_p(nid.data_ptr()) if nid is not None else None,
+                                              nid.shape[1] if nid is not None else 0,
+                                              C.c_void_p(power_dbm.data_ptr()) if power_dbm is not None else None,
+                                              C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def profile_enable(self, on=True):
         self._chk(self.L.p25fe_profile_enable(self.h, 1 if on else 0))
 

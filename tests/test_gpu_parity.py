@@ -446,3 +446,58 @@ def test_nid_after_sync_matches_oracle(O, FE):
     cut = int(sdh[-1]) + 10
     g2 = np.frombuffer(fe.nid_dev(d2, cut, sd[0, :ns], sp[0, :ns]).cpu().numpy().tobytes(), dtype=NID_DTYPE)
     assert g2["valid"][-1] == -1 and g2[:-1].tobytes() == got[:-1].tobytes()
+
+
+def test_channel_batch_nid_and_stats(O, FE):
+    """Next row: per-channel observability for a channel batch -- sigPower (src/demod.rs:95-101)
+    and the "bch" CodeStats row (src/hub.rs:559, 574-581) -- with no host round trip between the kernels.  Channels
+    at different SNRs (one noise only, one so noisy that NIDs fail) against the oracle run channel by channel."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd._lib import NID_DTYPE, CHAN_STATS_DTYPE
+    from p25rx_amd.frontend import parse_results
+    snrs = [30.0, 12.0, -4.0, None, -9.0]         # dB in 240 kHz: below ~0 dB the discriminator clicks corrupt NID bits
+    C, secs, cap = len(snrs), 3.0, 64
+    nidf = lambda f: ((0x293 + f) & 0xFFF, (3 * f) & 15)
+    n = int(secs * 240000)
+    iq = np.zeros((C, n), dtype=np.complex64)
+    rng = np.random.default_rng(9)
+    for c, snr in enumerate(snrs):
+        if snr is None:
+            iq[c] = (0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        else:
+            iq[c] = c4fm.synth(secs, seed=70 + c, snr_db=snr, frame_dibits=600, nid=nidf, amplitude=0.2 + 0.1 * c)[0]
+    t = torch.from_numpy(iq.view(np.float32).reshape(C, n, 2)).cuda()
+    fe = FE(n_channels=C)
+    bb, nb, pw = fe.demod_dev(t, want_power=True)
+    dib, res, sp, sd = fe.slice_dev(bb, nb, sync_cap=cap)
+    nid = fe.nid_batch_dev(dib, res, sd, sp)
+    st = np.frombuffer(fe.chan_stats_dev(res, nid, pw).cpu().numpy().tobytes(), dtype=CHAN_STATS_DTYPE)
+    rs = parse_results(res)
+    nid_h = nid.cpu().numpy()
+    seen_err = seen_fixed = False
+    for c in range(C):
+        d = O.Demod()
+        bbo, p_ref = d.feed_cf32(iq[c], want_power=True)
+        r = O.Recv()
+        dd, spo, sdo = r.feed(bbo)
+        ns = len(spo)
+        assert int(rs[c]["n_sync"]) == ns and int(rs[c]["n_dibits"]) == len(dd) and ns <= cap
+        got = np.frombuffer(nid_h[c, :ns].tobytes(), dtype=NID_DTYPE)
+        ref = O.nid_decode(dd, np.asarray(sdo, dtype=np.uint64), np.asarray(spo, dtype=np.int64))
+        assert got.tobytes() == ref.tobytes(), c
+        assert not nid_h[c, ns:].any()                              # rows past n_sync untouched
+        words = int((ref["valid"] >= 0).sum()); errs = int((ref["valid"] == 0).sum())
+        fixed = int(ref["n_errors"][ref["valid"] == 1].sum())
+        s = st[c]
+        assert (int(s["bch"]["words"]), int(s["bch"]["errs"]), int(s["bch"]["fixed"]), int(s["bch"]["size"])) == (words, errs, fixed, 63)
+        assert int(s["n_sync"]) == ns and int(s["n_dibits"]) == len(dd)
+        assert int(s["locked"]) == (1 if ns else 0)
+        assert int(s["last_sync_pos"]) == (int(spo[-1]) if ns else -1)
+        assert abs(float(s["sig_power_dbm"]) - p_ref) <= 1e-3       # dB; tree vs sequential reduction (SURVEY 8d)
+        seen_err |= errs > 0
+        seen_fixed |= fixed > 0
+    assert int(st[3]["n_sync"]) == 0 and int(st[0]["bch"]["errs"]) == 0 and int(st[0]["bch"]["words"]) >= 11
+    assert seen_fixed and seen_err
+    st2 = np.frombuffer(fe.chan_stats_dev(res).cpu().numpy().tobytes(), dtype=CHAN_STATS_DTYPE)
+    assert np.isnan(st2["sig_power_dbm"]).all() and not st2["bch"]["words"].any()
