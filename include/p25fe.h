@@ -214,6 +214,20 @@ int p25fe_nid_batch_dev(p25fe_t *h, const uint8_t *d_dibits, size_t dibit_stride
                         const uint64_t *d_sync_dibit, const int64_t *d_sync_pos, size_t sync_stride,
                         p25fe_nid_t *d_out, void *stream);
 
+/* Polyphase channeliser (no reference counterpart -- the reference tunes ONE channel,
+ * src/sdr.rs:64-65): one cf32 capture at 2.4 Msps -> P25FE_CHZ_CHANNELS = 192 channels on the 12.5 kHz raster
+ * (channel c centred c * 12.5 kHz above the capture's centre, c >= 96 below it), each at 240 ksps -- the stream
+ * stage 1 (src/demod.rs:74-84) would deliver for a tuner on that channel, ready for p25fe_demod_dev / p25fe_run_dev
+ * of a 192-channel handle (ch_stride = out_stride).  docs/SPEC.md 3.11; channel 0 equals p25fe_predecim_dev.
+ * d_iq: owned sample 0 (16-byte aligned), n_hist valid samples before it (>= 79 for exact continuation), abs0 its
+ * absolute index (fixes the decimation grid and the mixer phase, so any chunking gives the same stream);
+ * d_out: [192][out_stride] cf32, n_out = p25fe_n_predecim(abs0, n) samples per channel; rows are written in whole
+ * 64-sample tiles, so out_stride >= n_out rounded up to 64 (P25FE_ERR_ARG otherwise) and row samples >= n_out are
+ * unspecified.  The handle only supplies the device. */
+#define P25FE_CHZ_CHANNELS_ABI 192
+int p25fe_channelise_dev(p25fe_t *h, const float *d_iq, size_t n_hist, size_t n, uint64_t abs0, float *d_out,
+                         size_t out_stride, void *stream);
+
 /* Per-channel observability record: what the reference pushes to its hub as
  * HubEvent::UpdateSignalPower (src/demod.rs:95-101, "sigPower" src/hub.rs:344) and HubEvent::UpdateStats
  * (src/recv.rs:162-165, 212-215; "updateStats" src/hub.rs:401-402), restricted to what exists on this path: the

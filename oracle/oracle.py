@@ -94,6 +94,8 @@ def _bind(lib):
     lib.p25o_predecim_destroy.argtypes = [vp]
     lib.p25o_predecim_feed.restype = sz
     lib.p25o_predecim_feed.argtypes = [vp, vp, sz, vp]
+    lib.p25o_channelise.restype = sz
+    lib.p25o_channelise.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, sz, sz, C.c_uint64, vp, sz]
     lib.p25o_nid_decode.restype = sz
     lib.p25o_nid_decode.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp]
     lib.p25o_run_cf32.restype = C.c_int64
@@ -179,6 +181,23 @@ class PreDecim:
         out = np.empty(iq.size // self.decim + 2, dtype=np.complex64)
         n = self.L.p25o_predecim_feed(self.h, _ptr(iq), iq.size, _ptr(out))
         return out[:n].copy()
+
+
+def channelise(iq, n_hist=0, abs0=0, spec=None, libpath=None):
+    """SPEC 3.11: wideband cf32 @ 2.4 Msps -> [192, n_out] complex64 @ 240 ksps (plain mix / filter / decimate in
+    double precision).  iq holds n_hist samples of history followed by the owned range."""
+    L = lib(libpath)
+    s = spec or load_spec()
+    taps = np.array(s["pre_taps"], dtype=np.float32)
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    n = iq.size - n_hist
+    M, D = s["chz_channels"], s["pre_decim"]
+    cap = n // D + 2
+    out = np.zeros((M, cap), dtype=np.complex64)
+    base = iq[n_hist:] if n_hist else iq
+    k = L.p25o_channelise(_ptr(taps), len(taps), D, M, C.c_void_p(iq.ctypes.data + 8 * n_hist), n_hist, n, abs0,
+                          _ptr(out), cap)
+    return out[:, :k].copy()
 
 
 class Recv:

@@ -245,6 +245,46 @@ size_t p25o_predecim_feed(p25o_predecim *p, const float *iq, size_t n, float *ou
     return len;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Polyphase channeliser (SPEC 3.11; next row, SURVEY.md section 8f rank 4 -- no reference counterpart: the
+ * reference tunes one channel, src/sdr.rs:64-65).  Stated the plain way -- mix channel c to DC, low-pass with SPEC
+ * 3.0's taps, keep every 10th sample -- and evaluated in double precision:
+ *   y_c[m] = sum_p h[p] x[n - p] e^{-j 2 pi c (n - p) / M},   n = absolute index of decimation instant m
+ * (n = 9 mod 10, as in 3.0), x = 0 before the stream.  The GPU uses a factored DFT in fp32; parity is by tolerance.
+ * x: owned sample 0 (n_hist valid samples before it), abs0: its absolute index.  out: [M][out_stride] cf32.
+ * Returns the number of output instants. */
+size_t p25o_channelise(const float *taps, int ntaps, int decim, int M, const float *iq, size_t n_hist, size_t n,
+                       uint64_t abs0, float *out, size_t out_stride)
+{
+    const cf32 *x = (const cf32 *)iq;
+    double *cs = malloc(sizeof(double) * 2 * (size_t)M);
+    for (int k = 0; k < M; k++) {
+        cs[2 * k] = cos(2.0 * 3.14159265358979323846 * k / M);
+        cs[2 * k + 1] = sin(2.0 * 3.14159265358979323846 * k / M);
+    }
+    const size_t o0 = (size_t)((decim - 1 + decim - abs0 % (uint64_t)decim) % decim);
+    size_t len = 0;
+    for (size_t i = o0; i < n; i += (size_t)decim, len++) {
+        for (int c = 0; c < M; c++) {
+            double re = 0.0, im = 0.0;
+            for (int p = 0; p < ntaps; p++) {
+                const long j = (long)i - p;                       /* owned-relative index */
+                if (j < -(long)n_hist) break;
+                const uint64_t na = (uint64_t)((long)abs0 + j);    /* absolute index (j >= -n_hist >= -abs0) */
+                const int k = (int)(((uint64_t)c * (na % (uint64_t)M)) % (uint64_t)M);
+                const double wr = cs[2 * k], wi = -cs[2 * k + 1];  /* e^{-j 2 pi c n / M} */
+                const double xr = x[j].re, xi = x[j].im, h = taps[p];
+                re += h * (xr * wr - xi * wi);
+                im += h * (xr * wi + xi * wr);
+            }
+            cf32 *y = (cf32 *)out + (size_t)c * out_stride + len;
+            y->re = (float)re; y->im = (float)im;
+        }
+    }
+    free(cs);
+    return len;
+}
+
 /* demod::power_dbm (src/demod.rs:123-134), transcribed operation for operation. */
 float p25o_power_dbm(const cf32 *samples, size_t n, float resistance)
 {

@@ -52,7 +52,7 @@ SYMBOLS = [
     "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
-    "p25fe_nid_batch_dev", "p25fe_chan_stats_dev",
+    "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev",
 ]
 
 
@@ -114,6 +114,7 @@ def load():
     L.p25fe_nid_dev.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
     L.p25fe_nid_batch_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp]
     L.p25fe_chan_stats_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    L.p25fe_channelise_dev.argtypes = [vp, vp, sz, sz, u64, vp, sz, vp]
     L.p25fe_profile_enable.argtypes = [vp, C.c_int]
     L.p25fe_profile_read.argtypes = [vp, C.POINTER(C.c_double * 4), C.POINTER(u64)]
     L.p25fe_predecim_dev.argtypes = [vp, vp, sz, sz, sz, u64, vp, sz, vp]

@@ -210,3 +210,32 @@ def synth_torch(n_iq, seed, device, snr_db=30.0, frame_dibits=864, amplitude=0.5
     if pos < n_iq:
         out[pos:].zero_()
     return out, d.numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# wideband scene for the channeliser (SPEC 3.11): several C4FM carriers on the 12.5 kHz raster of a 2.4 Msps capture
+# ---------------------------------------------------------------------------------------------
+FS_WIDE = 2400000
+CHZ_CHANNELS = 192
+
+
+def synth_wideband(seconds, carriers, snr_db=25.0, seed=0, frame_dibits=864, nid=None):
+    """carriers: {raster index c (0..191): (seed, relative amplitude)}.  Each carrier is c4fm.synth at 240 ksps,
+    interpolated x10 and shifted to c * 12.5 kHz (c >= 96: negative frequencies).  Returns (wide complex64 @ 2.4 Msps,
+    {c: truth dibits})."""
+    from scipy import signal as sps
+    n = int(round(seconds * FS_WIDE))
+    wide = np.zeros(n, dtype=np.complex128)
+    truth = {}
+    k = np.arange(n)
+    for c, (sd, amp) in carriers.items():
+        iq, d, _ = synth(seconds, seed=sd, snr_db=None, frame_dibits=frame_dibits, nid=nid)
+        up = sps.resample_poly(iq.astype(np.complex128), FS_WIDE // FS_IQ, 1)[:n]
+        wide[:len(up)] += amp * up * np.exp(2j * np.pi * ((c * k[:len(up)]) % CHZ_CHANNELS) / CHZ_CHANNELS)
+        truth[c] = d
+    if snr_db is not None:
+        rng = np.random.Generator(np.random.PCG64(seed + 0xC42))
+        # noise density such that a 0.5-amplitude carrier has `snr_db` in ITS 240 kHz channel stream
+        sigma = 0.5 * 10.0 ** (-snr_db / 20.0) / np.sqrt(2.0) * np.sqrt(FS_WIDE / FS_IQ)
+        wide += sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return wide.astype(np.complex64), truth

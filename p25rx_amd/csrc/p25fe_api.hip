@@ -415,6 +415,25 @@ int p25fe_predecim_dev(p25fe_t* h, const float* d_iq, size_t ch_stride, size_t n
     return P25FE_OK;
 }
 
+int p25fe_channelise_dev(p25fe_t* h, const float* d_iq, size_t n_hist, size_t n, uint64_t abs0, float* d_out,
+                         size_t out_stride, void* stream)
+{
+    static_assert(P25FE_CHZ_CHANNELS_ABI == CZ_M, "header and spec disagree");
+    if (!h || !d_iq || !d_out) return P25FE_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_iq) & 15u) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 7u) != 0) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t n_out = p25fe_n_predecim(abs0, n);
+    if (n_out == 0) return P25FE_OK;
+    if (out_stride < round_up(n_out, (size_t)WV)) return P25FE_ERR_ARG;      // rows are written in whole 64-instant tiles
+    ChzArgs a;
+    a.x = d_iq; a.n_hist = (long)n_hist; a.n_new = (long)n; a.abs0 = (long)abs0;
+    a.o0 = (int)((PD - 1 + PD - abs0 % PD) % PD);
+    a.y = d_out; a.y_stride = (long)out_stride; a.n_out = (long)n_out;
+    hipLaunchKernelGGL(k_channelise, dim3((unsigned)((n_out + WV - 1) / WV)), dim3(WV), 0, (hipStream_t)stream, a);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
 int p25fe_slice_dev(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb, uint64_t abs_bb0,
                     const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos,
                     uint64_t* d_sync_dibit, size_t sync_stride, p25fe_result_t* d_result, void* stream)

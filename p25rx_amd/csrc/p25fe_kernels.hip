@@ -575,6 +575,207 @@ __global__ __launch_bounds__(WV, P25FE_K0_WPS) void k_predecim(K0Args a)
     flush();
 }
 
+// ------------------------------------------------------------------------------------------
+// K6: polyphase channeliser (SPEC 3.11; SURVEY.md section 8f rank 4, no reference counterpart -- the reference tunes
+// one channel, src/sdr.rs:64-65).  One 2.4 Msps capture -> 192 channels on the 12.5 kHz raster, each at 240 ksps, i.e.
+// the stream stage 1 would deliver for a tuner on that channel:
+//     y_c[m] = sum_{p<80} h[p] x[n-p] e^{-j 2 pi c (n-p)/192}
+//            = e^{-j 2 pi c n/192} * sum_p (h[p] x[n-p]) e^{+j 2 pi c p/192},        n = absolute instant, h = SPEC 3.0's taps.
+// The inner sum is a 192-point DFT of 80 non-zero inputs.  With p = 16 p1 + p2 and c = c1 + 12 c2 the kernel
+// e^{+j 2 pi c p/192} splits into V12^{c1 p1} * V192^{c1 p2} * V16^{c2 p2} (the cross term is a whole turn):
+//   for each c1 (12, uniform loop):  B[p2] = (sum_{p1<5} a[16 p1 + p2] V12^{c1 p1}) * V192^{c1 p2}      (pruned radix-12)
+//                                    Y[c2] = sum_{p2<16} B[p2] V16^{c2 p2}                               (radix-4 x 4 FFT)
+//                                    y[c1 + 12 c2] = Y[c2] * conj(V192^{(c n) mod 192})                  (rotation, LDS table)
+// ~6.5 kFLOP per output instant instead of 61 k for the direct contraction: this is why the stage is NOT cast as a
+// GEMM for the matrix cores -- in fp32 they run at the vector rate and the dense form costs 9x the arithmetic, while
+// the kernel is bound by writing 192 x 8 B per 10 input samples (161.6 B per input sample, 154 of them output).
+// A lane owns one output instant (all twiddles are compile-time immediates, every store is 512 contiguous bytes of
+// one channel row); the 80 products a[p] stay in registers, the window is staged polyphase as in K0.
+// ------------------------------------------------------------------------------------------
+constexpr int CZ_M = P25FE_CHZ_CHANNELS;                        // 192
+constexpr int CZ_C1 = 12, CZ_C2 = 16, CZ_P1 = T0 / CZ_C2;       // c = c1 + 12 c2; p = 16 p1 + p2, p1 < 5
+static_assert(T0 == CZ_C2 * CZ_P1 && CZ_M == CZ_C1 * CZ_C2 && CZ_P1 == 5, "factorisation of the 192-point DFT");
+#ifndef P25FE_CZ_G
+#define P25FE_CZ_G 4
+#endif
+#ifndef P25FE_CZ_WPS
+#define P25FE_CZ_WPS 3
+#endif
+constexpr int CZ_G = P25FE_CZ_G;                                         // c1 values whose partial sums are held at once
+constexpr int CZ_NIN = PD * WV + (T0 - PD);                     // 710 window positions for 64 instants
+constexpr int CZ_JP = CZ_NIN / PD + 2;                          // 73 entries per phase row (odd)
+constexpr int CZ_NV = (CZ_NIN + 2 + 2 * WV - 1) / (2 * WV);     // 16-B vectors per lane: 6
+
+struct ChzArgs {
+    const float* x;         // owned sample 0 (cf32 @ 2.4 Msps), 16-B aligned
+    long n_hist, n_new;
+    long abs0;              // absolute index of owned sample 0
+    int o0;                 // first decimation instant inside the owned range, 0..9
+    float* y;               // [192][y_stride] cf32 @ 240 ksps
+    long y_stride;          // samples
+    long n_out;
+};
+
+__device__ __forceinline__ float2 cz_mul_const(float2 v, float wr, float wi)      // v * (wr + j wi), constants folded
+{
+    if (wi == 0.0f) return wr == 1.0f ? v : make_float2(v.x * wr, v.y * wr);
+    if (wr == 0.0f) return make_float2(-(v.y * wi), v.x * wi);
+    return make_float2(__builtin_fmaf(-v.y, wi, v.x * wr), __builtin_fmaf(v.y, wr, v.x * wi));
+}
+// c1-dependent twiddles, read with scalar loads inside the (rolled) c1 loop: [c1][p1 - 1] = V12^{c1 p1} for p1 = 1..4,
+// [c1][4 + p2] = V192^{c1 p2}
+struct CzC { float x, y; };
+struct CzTw { CzC v[CZ_C1][4 + CZ_C2]; };
+constexpr CzTw cz_make_tw()
+{
+    CzTw t{};
+    for (int c1 = 0; c1 < CZ_C1; ++c1) {
+        for (int p1 = 1; p1 < CZ_P1; ++p1) {
+            const int k = 16 * ((c1 * p1) % CZ_C1);
+            t.v[c1][p1 - 1].x = P25FE_CHZ_W[2 * k]; t.v[c1][p1 - 1].y = P25FE_CHZ_W[2 * k + 1];
+        }
+        for (int p2 = 0; p2 < CZ_C2; ++p2) {
+            const int k = c1 * p2;
+            t.v[c1][4 + p2].x = P25FE_CHZ_W[2 * k]; t.v[c1][4 + p2].y = P25FE_CHZ_W[2 * k + 1];
+        }
+    }
+    return t;
+}
+__constant__ CzTw CZ_TW = cz_make_tw();
+__device__ __forceinline__ float2 cz_mac(float2 acc, float2 v, CzC w)              // acc + v * w
+{
+    acc.x = __builtin_fmaf(v.x, w.x, acc.x); acc.y = __builtin_fmaf(v.y, w.x, acc.y);
+    acc.x = __builtin_fmaf(-v.y, w.y, acc.x); acc.y = __builtin_fmaf(v.x, w.y, acc.y);
+    return acc;
+}
+__device__ __forceinline__ float2 cz_mul(float2 v, CzC w)
+{
+    return make_float2(__builtin_fmaf(-v.y, w.y, v.x * w.x), __builtin_fmaf(v.y, w.x, v.x * w.y));
+}
+// radix-4 butterfly for the +j kernel: y_f = sum_a x_a (+j)^{f a}
+__device__ __forceinline__ void cz_bf4(float2& x0, float2& x1, float2& x2, float2& x3)
+{
+    const float2 t0 = make_float2(x0.x + x2.x, x0.y + x2.y), t1 = make_float2(x0.x - x2.x, x0.y - x2.y);
+    const float2 t2 = make_float2(x1.x + x3.x, x1.y + x3.y), t3 = make_float2(x1.x - x3.x, x1.y - x3.y);
+    x0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+    x2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+    x1 = make_float2(t1.x - t3.y, t1.y + t3.x);                 // t1 + j t3
+    x3 = make_float2(t1.x + t3.y, t1.y - t3.x);                 // t1 - j t3
+}
+
+__global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
+{
+    __shared__ float2 X[PD * CZ_JP];
+    __shared__ float2 ROT[CZ_M];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < CZ_M; k += WV) ROT[k] = make_float2(P25FE_CHZ_W[2 * k], -P25FE_CHZ_W[2 * k + 1]);
+    const long m0 = (long)blockIdx.x * WV;
+    {   // stage the window: positions k = 0 .. CZ_NIN-1 are inputs base + k
+        const uint4* xb = reinterpret_cast<const uint4*>(a.x);
+        const long base = (long)a.o0 + PD * m0 - (T0 - 1);
+        const long v0 = base >> 1;
+        const int sh = (int)(base - (v0 << 1));
+        long lo = ((-a.n_hist) >> 1) - v0, hi = ((a.n_new - 1) >> 1) - v0;
+        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
+        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
+        const int lo32 = (int)lo, hi32 = (int)hi;
+        const uint4* q = xb + v0;
+        uint4 v[CZ_NV];
+#pragma unroll
+        for (int j = 0; j < CZ_NV; ++j) {
+            int r = lane + j * WV;
+            r = r < lo32 ? lo32 : r;
+            r = r > hi32 ? hi32 : r;
+            v[j] = q[r];
+        }
+        const bool interior = (v0 << 1) >= -a.n_hist && (v0 << 1) + 2L * CZ_NV * WV <= a.n_new;   // uniform
+#pragma unroll
+        for (int j = 0; j < CZ_NV; ++j) {
+            const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 2 * (lane + j * WV) + e - sh;
+                float2 s2 = make_float2(__uint_as_float(w[2 * e]), __uint_as_float(w[2 * e + 1]));
+                if (!interior) {
+                    const long i = ((v0 + lane + (long)j * WV) << 1) + e;
+                    if (i < -a.n_hist || i >= a.n_new) s2 = make_float2(0.f, 0.f);
+                }
+                if (k >= 0 && k < CZ_NIN) X[((unsigned)k % PD) * CZ_JP + (unsigned)k / PD] = s2;
+            }
+        }
+    }
+    phase_sync();
+
+    const long m = m0 + lane;
+    const unsigned nm = (unsigned)((unsigned long long)(a.abs0 + a.o0 + PD * m) % (unsigned long long)CZ_M);
+    const unsigned step2 = (CZ_C1 * nm) % (unsigned)CZ_M;       // index step of the rotation from c to c + 12
+    unsigned idx1 = 0;                                          // (c1 * nm) mod 192
+    float2* yb = reinterpret_cast<float2*>(a.y) + m;
+
+    // c1 in groups of CZ_G (a rolled loop: the c1-dependent twiddles come from CZ_TW by scalar loads): the 80 products
+    // a[p] = h[p] x[n - p] are re-formed from LDS once per group (window position 79 + 10 lane - p -> phase
+    // 9 - p % 10, column lane + 7 - p / 10) instead of living in 160 registers
+#pragma unroll 1
+    for (int c1g = 0; c1g < CZ_C1; c1g += CZ_G) {
+        float2 BB[CZ_G][CZ_C2];
+#pragma unroll
+        for (int p2 = 0; p2 < CZ_C2; ++p2) {
+            float2 a5[CZ_P1];
+#pragma unroll
+            for (int p1 = 0; p1 < CZ_P1; ++p1) {
+                const int p = CZ_C2 * p1 + p2;
+                const float2 xv = lds_read_c(X + (PD - 1 - p % PD) * CZ_JP + lane + (T0 / PD - 1) - p / PD);
+                a5[p1] = make_float2(P25FE_DEFAULT_PRE_TAPS[p] * xv.x, P25FE_DEFAULT_PRE_TAPS[p] * xv.y);
+            }
+#pragma unroll
+            for (int q = 0; q < CZ_G; ++q) {
+                const CzC* tw = CZ_TW.v[c1g + q];
+                float2 acc = a5[0];                             // p1 = 0: V12^0 = 1
+#pragma unroll
+                for (int p1 = 1; p1 < CZ_P1; ++p1) acc = cz_mac(acc, a5[p1], tw[p1 - 1]);
+                float2 bv = p2 ? cz_mul(acc, tw[4 + p2]) : acc;
+                // pin the value here: otherwise the arithmetic is sunk below ALL the (ordered, volatile) window reads of the
+                // group and their 160 result registers stay live -- spills at any useful occupancy
+                asm volatile("" : "+v"(bv.x), "+v"(bv.y));
+                BB[q][p2] = bv;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CZ_G; ++q) {
+        const int c1 = c1g + q;
+        // 16-point DFT, kernel V16^{c2 p2} = e^{+j 2 pi c2 p2 / 16}: p2 = 4 a + b, c2 = e + 4 f
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cz_bf4(BB[q][b], BB[q][4 + b], BB[q][8 + b], BB[q][12 + b]);        // slot 4 e + b <- Z[b][e]
+#pragma unroll
+        for (int e = 1; e < 4; ++e)
+#pragma unroll
+            for (int b = 1; b < 4; ++b) {
+                const int k = 12 * (e * b);                     // V16^{e b} = W[12 e b]
+                BB[q][4 * e + b] = cz_mul_const(BB[q][4 * e + b], P25FE_CHZ_W[2 * k], P25FE_CHZ_W[2 * k + 1]);
+            }
+        unsigned idx[4];                                        // rotation index of c = c1 + 12 (e + 4 f), by e
+        idx[0] = idx1;
+#pragma unroll
+        for (int e = 1; e < 4; ++e) { idx[e] = idx[e - 1] + step2; idx[e] = idx[e] >= (unsigned)CZ_M ? idx[e] - CZ_M : idx[e]; }
+        const unsigned step8 = (4u * step2) % (unsigned)CZ_M;   // from f to f + 1: c grows by 48
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cz_bf4(BB[q][4 * e], BB[q][4 * e + 1], BB[q][4 * e + 2], BB[q][4 * e + 3]);                 // slot 4 e + f <- Y[e + 4 f]
+            unsigned ix = idx[e];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float2 rot = ROT[ix];
+                const float2 yv = BB[q][4 * e + f];
+                const float2 o = make_float2(__builtin_fmaf(-yv.y, rot.y, yv.x * rot.x), __builtin_fmaf(yv.y, rot.x, yv.x * rot.y));
+                yb[(size_t)(c1 + CZ_C1 * (e + 4 * f)) * a.y_stride] = o;   // rows are padded to whole tiles: no predicate
+                ix += step8; ix = ix >= (unsigned)CZ_M ? ix - CZ_M : ix;
+            }
+        }
+        idx1 += nm; idx1 = idx1 >= (unsigned)CZ_M ? idx1 - CZ_M : idx1;
+        }
+    }
+}
+
 // finish power_dbm (src/demod.rs:123-134): 30 + 10 log10( (sum / N) / R ), R = 1
 __global__ void k_power_finish(const float* partial, int n_partial, long n, float* out_dbm)
 {

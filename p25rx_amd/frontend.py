@@ -11,6 +11,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import FMT_CF32, FMT_U8, RESULT_DTYPE, ANCHOR_DTYPE
+CHZ_CHANNELS = 192                  # P25FE_CHZ_CHANNELS (include/p25fe_spec.h)
 
 
 def _p(a):
@@ -184,6 +185,18 @@ class FrontEnd:
             out = torch.empty((self.C, (no + 3) // 2 * 2, 2), dtype=torch.float32, device=iq.device)
         self._chk(self.L.p25fe_predecim_dev(self.h, C.c_void_p(iq.data_ptr() + 8 * offset), stride, n_hist, n, abs0,
                                             C.c_void_p(out.data_ptr()), out.stride(0) // 2, self._stream()))
+        return out, no
+
+    def channelise_dev(self, iq, n_hist=0, abs0=0, offset=0, out=None):
+        """SPEC 3.11: wideband cf32 @ 2.4 Msps [n, 2] (device) -> [192, n_out (padded), 2] cf32 @ 240 ksps."""
+        import torch
+        assert iq.dtype == torch.float32 and iq.dim() == 2 and iq.shape[1] == 2
+        n = iq.shape[0] - offset
+        no = self.L.p25fe_n_predecim(abs0, n)
+        if out is None:
+            out = torch.empty((CHZ_CHANNELS, max(64, (no + 63) // 64 * 64), 2), dtype=torch.float32, device=iq.device)
+        self._chk(self.L.p25fe_channelise_dev(self.h, C.c_void_p(iq.data_ptr() + 8 * offset), n_hist, n, abs0,
+                                              C.c_void_p(out.data_ptr()), out.stride(0) // 2, self._stream()))
         return out, no
 
     def slice_dev(self, bb, n_bb, n_hist_bb=0, abs_bb0=0, anchor_in=None, offset=0, sync_cap=0):

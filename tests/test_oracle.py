@@ -227,3 +227,35 @@ def test_nid_code_and_decode(spec):
     bad2[D + 11] ^= 3                                                # the status symbol is not part of the NID
     assert O.nid_decode(bad2, sdib[2:3])[0]["n_errors"] == 0
     assert O.nid_decode(dib[:D + 20], sdib[2:3])[0]["valid"] == -1   # stream ends inside the NID
+
+
+def test_channeliser_oracle(spec):
+    """SPEC 3.11 (next row): the plain mix / filter / decimate restatement against numpy in fp64,
+    its channel 0 against the pre-decimator of 3.0, chunk invariance through (n_hist, abs0), and a tone KAT: a tone
+    d Hz above raster slot c comes out of channel c at d Hz with the prototype's gain, and is absent 40 slots away."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    n = 12000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * 0.3
+    y = O.channelise(x)
+    assert y.shape == (192, n // 10)
+    h = np.array(spec["pre_taps"], dtype=np.float64)
+    k = np.arange(n)
+    for c in (0, 1, 37, 95, 96, 191):
+        z = np.convolve(x.astype(np.complex128) * np.exp(-2j * np.pi * ((c * k) % 192) / 192), h)[:n][9::10]
+        assert np.abs(z - y[c]).max() < 5e-7
+    assert np.abs(y[0] - O.PreDecim().feed(x)).max() < 1e-6          # 3.0 is channel 0 (fp32 vs fp64 accumulation)
+    for off in (1000, 1234, 5557):
+        y2 = O.channelise(x[off - 79:], n_hist=79, abs0=off)
+        first = len([m for m in range(n // 10) if 10 * m + 9 < off])
+        assert np.array_equal(y2, y[:, first:])
+    c, d = 53, 2000.0
+    t = np.arange(48000) / 2.4e6
+    tone = (0.5 * np.exp(2j * np.pi * (c * 12500.0 + d) * t)).astype(np.complex64)
+    yt = O.channelise(tone)
+    g = abs(np.sum(h * np.exp(-2j * np.pi * d / 2.4e6 * np.arange(len(h)))))
+    seg = yt[c, 100:]
+    assert abs(np.abs(seg).mean() - 0.5 * g) < 1e-4
+    f_est = np.angle(np.sum(seg[1:] * np.conj(seg[:-1]))) * 240000 / (2 * np.pi)
+    assert abs(f_est - d) < 1.0
+    assert np.abs(yt[(c + 40) % 192, 100:]).max() < 1e-3             # 500 kHz away: stop band of the prototype

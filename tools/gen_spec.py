@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 T1, T2 = 31, 41
 T0, PRE_DECIM, FS_WIDE = 80, 10, 2400000.0
+CHZ_M = 192                          # channeliser: 2.4 Msps / 12.5 kHz raster (SPEC 3.11)
 FS_IN, FS_BB = 240000.0, 48000.0
 DECIM = 5
 SPS = 10                      # baseband samples per symbol (48000 / 4800)
@@ -146,6 +147,9 @@ def main():
         "sync_peak_w": 5,
         "slice_frac": float(np.float32(2.0 / 3.0)),
         "pi": float(np.float32(np.pi)), "half_pi": float(np.float32(np.pi / 2.0)),
+        "chz_channels": CHZ_M, "chz_spacing_hz": FS_WIDE / CHZ_M,
+        "chz_w": [[float(np.float32(np.round(np.cos(2 * np.pi * k / CHZ_M), 15))),     # quarter turns exactly 0 / +-1
+                   float(np.float32(np.round(np.sin(2 * np.pi * k / CHZ_M), 15)))] for k in range(CHZ_M)],
         "nid_gen_poly": NID_GEN_POLY, "nid_rows": nid_rows, "nid_t": 11, "nid_status_pos": 35,
     }
 
@@ -156,13 +160,15 @@ def main():
 
     def arr(name, vals):
         body = ",\n    ".join(", ".join(hexf(v) for v in vals[i:i + 4]) for i in range(0, len(vals), 4))
-        return "static const float %s[%d] = {\n    %s\n};\n" % (name, len(vals), body)
+        return "static P25FE_SPEC_CONST float %s[%d] = {\n    %s\n};\n" % (name, len(vals), body)
 
     h = []
     h.append("/* GENERATED by tools/gen_spec.py -- do not edit.  Build-defined numeric spec of the\n"
              " * p25fe hot path (the reference keeps these numbers in un-vendored crates: p25_filts,\n"
              " * demod_fm, rtlsdr_iq, p25 -- SURVEY.md section 0).  fp64-derived, rounded once to fp32. */\n")
     h.append("#ifndef P25FE_SPEC_H\n#define P25FE_SPEC_H\n\n")
+    h.append("#ifdef __cplusplus\n#define P25FE_SPEC_CONST constexpr   /* usable in constant expressions (twiddle tables) */\n"
+             "#else\n#define P25FE_SPEC_CONST const\n#endif\n\n")
     h.append("#define P25FE_DECIM %d            /* src/demod.rs:50 */\n" % DECIM)
     h.append("#define P25FE_SPS %d               /* 48000 / 4800 baud; src/demod.rs:52 */\n" % SPS)
     h.append("#define P25FE_T1 %d               /* decimator taps */\n" % T1)
@@ -198,6 +204,9 @@ def main():
     h.append(arr("P25FE_DEFAULT_PRE_TAPS", list(pre)))
     h.append("\n")
     h.append(arr("P25FE_ATAN_COEFFS", list(atc)))
+    h.append("\n/* channeliser (SPEC 3.11): e^{+j 2 pi k / 192} as (cos, sin) pairs, k = 0..191 */\n")
+    h.append("#define P25FE_CHZ_CHANNELS %d       /* 2.4 Msps / 12.5 kHz raster */\n" % CHZ_M)
+    h.append(arr("P25FE_CHZ_W", [v for pair in spec["chz_w"] for v in pair]))
     h.append("\n#endif /* P25FE_SPEC_H */\n")
     os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
     with open(os.path.join(ROOT, "include", "p25fe_spec.h"), "w") as f:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the kernels on random IQ (within-process A/B across env settings is done by the caller).
-usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|run|split] [channels=1] [fmt=cf32|u8]
+usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|chz|run|split] [channels=1] [fmt=cf32|u8]
 mode split = run, plus the per-kernel split from the library's own HIP events."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,6 +31,8 @@ def step():
         bb, nb = fe.demod_dev(iq, bb=bb)
     elif mode == "k0":                      # config 3 stage 0: the buffer is read as a 2.4 Msps capture
         bb, nb = fe.predecim_dev(iq, out=bb)
+    elif mode == "chz":                     # channeliser: the buffer is one 2.4 Msps capture -> 192 channels
+        bb, nb = fe.channelise_dev(iq[0], out=bb)
     else:
         fe.run_dev(iq)
 for _ in range(5):
@@ -45,6 +47,8 @@ torch.cuda.synchronize()
 ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
 med, mn, p90 = ts[len(ts) // 2], ts[0], ts[int(len(ts) * 0.9)]
 bps = 8.8 if fmt == "cf32" else 2.8
+if mode == "chz":
+    bps = 8.0 + 192 * 8 / 10.0              # 8 B read + 192 channels x 8 B per 10 input samples
 tag = " ".join("%s=%s" % (k[6:], os.path.basename(v)) for k, v in sorted(os.environ.items()) if k.startswith("P25FE_"))
 print("%-6s C=%d n=%d %s [%s]: med %.4f min %.4f p90 %.4f ms -> %.1f Gsamples/s, %.0f GB/s"
       % (mode, C, n, fmt, tag, med, mn, p90, C * n / med / 1e6, C * n * bps / med / 1e6))
