@@ -715,6 +715,14 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
     // c1 in groups of CZ_G (a rolled loop: the c1-dependent twiddles come from CZ_TW by scalar loads): the 80 products
     // a[p] = h[p] x[n - p] are re-formed from LDS once per group (window position 79 + 10 lane - p -> phase
     // 9 - p % 10, column lane + 7 - p / 10) instead of living in 160 registers
+#if defined(P25FE_ABLATE6)                          // measurement build (tools/k6_variants.sh): the store stream alone
+    {
+        const float2 xv = lds_read_c(X + lane);
+#pragma unroll 1
+        for (int c = 0; c < CZ_M; ++c) yb[(size_t)c * a.y_stride] = make_float2(xv.x + (float)c, xv.y);
+        return;
+    }
+#endif
 #pragma unroll 1
     for (int c1g = 0; c1g < CZ_C1; c1g += CZ_G) {
         float2 BB[CZ_G][CZ_C2];
