@@ -7,7 +7,7 @@ d = sys.argv[1]
 def short(k):
     if "p25k::" not in k:
         return None
-    for s in ("k_frontend", "k_sync", "k_scan", "k_slice", "k_power"):
+    for s in ("k_frontend", "k_sync", "k_scan_groups", "k_scan", "k_slice", "k_power", "k_predecim", "k_channelise", "k_nid", "k_chan_stats"):
         if "p25k::" + s in k:
             return s
     return None
