@@ -910,14 +910,14 @@ struct SyncArgs {
 };
 
 // K2: correlate, peak-pick, flag events, summarise the tile.  Built like K1: one wave per workgroup (no s_barrier,
-// wave-level scans only), K2_SUBS consecutive tiles per workgroup with the next tile's window prefetched into
-// registers (16-B loads) while the current one is correlated.
+// wave-level scans only), 16-B window loads.  K2_SUBS > 1 walks consecutive tiles with the next window prefetched into
+// registers; measured on config 2: 1 tile per workgroup 0.070 ms, 2: 0.077, 4: 0.081, 8: 0.089 -- short-lived waves win.
 //   correlation: lanes 0..59 = 10 sample phases x 6 slot blocks; a lane produces K2_CQ = 18 symbol-spaced outputs
 //   from a sliding window of 41 LDS reads (2.3 reads per output instead of 24), each output with its own
 //   accumulators in tap order j = 0..23 (SPEC 3.7);
 //   peak pick / instant count: a lane owns 16 consecutive samples (<= 2 symbol instants without an event inside).
 #ifndef P25FE_K2_SUBS
-#define P25FE_K2_SUBS 2
+#define P25FE_K2_SUBS 1
 #endif
 constexpr int K2_SUBS = P25FE_K2_SUBS;
 constexpr int K2_CQ = 18;
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(WV, 3) void k_sync(SyncArgs a)
         const int tn = (a.n - t0 < TB) ? (int)(a.n - t0) : TB;      // samples in this tile
         stage(tile);
         phase_sync();
-        {
+        if (K2_SUBS > 1) {                                          // compile-time
             const int nxt = tile + 1 < a.n_tiles ? tile + 1 : tile; // unconditional prefetch (clamped: re-reads this tile)
             load(it + 1 < K2_SUBS ? nxt : tile);
         }
@@ -1426,10 +1426,10 @@ struct SliceArgs {
 //   * A tile WITHOUT events (7 of 8 in a P25 stream; K2's packed summary says so) needs no flags and no scan: the
 //     instants and their ranks are closed forms of the carry-in anchor.  Without an anchor it is skipped unread.
 #ifndef P25FE_K4_SUBS
-#define P25FE_K4_SUBS 4
+#define P25FE_K4_SUBS 1
 #endif
 #ifndef P25FE_K4_WPS
-#define P25FE_K4_WPS 3
+#define P25FE_K4_WPS 4
 #endif
 constexpr int K4_SUBS = P25FE_K4_SUBS;
 constexpr int K4_VPL = TB / WV;                                  // 16 samples per lane
