@@ -865,6 +865,24 @@ __device__ __forceinline__ void sync_thresholds(const float* BT, int is, float& 
     lo = mid - d;
 }
 
+// the same from global memory (s = range-local index of the sync word's last symbol): same operations, same bits
+__device__ __forceinline__ void sync_thresholds_global(const float* bbp, long n_hist, long n, long s, float& hi, float& mid, float& lo)
+{
+    float Pp = 0.f, Nn = 0.f;
+#pragma unroll
+    for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
+        const float v = bb_at(bbp, n_hist, n, s - SPS * (P25FE_SYNC_DIBITS - 1 - j));
+        if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
+    }
+    Pp = Pp * P25FE_SYNC_INV_NPOS;
+    Nn = Nn * P25FE_SYNC_INV_NNEG;
+    mid = (Pp + Nn) * 0.5f;
+    const float span = (Pp - Nn) * 0.5f;
+    const float d = span * P25FE_SLICE_FRAC;
+    hi = mid + d;
+    lo = mid - d;
+}
+
 // number of n in [lo, hi) with n > s and (n - s) % SPS == 0   (closed form)
 __host__ __device__ inline long count_instants(long s, long lo, long hi)
 {
@@ -949,7 +967,9 @@ __device__ __forceinline__ int wave_sum_i(int v)
 __global__ __launch_bounds__(WV, 3) void k_sync(SyncArgs a)
 {
     __shared__ __attribute__((aligned(16))) float BT[K2_BT];      // BT[k] = b[t0 - HIST_BB + k]
-    __shared__ float CT[K2_NC + 2];                               // CT[k] = c[t0 - 2W + k]
+    float* const CT = BT;                                         // CT[k] = c[t0 - 2W + k] OVERWRITES the window once every lane
+                                                                  // has its taps in registers (one wave: program order) --
+                                                                  // 7.2 KB of LDS per wave instead of 11.3: 22 waves per CU
     __shared__ __attribute__((aligned(8))) uint8_t CAND[K2_NC + 16];   // flag of position k at CAND[k - W + 8]: sample i's flag at the 8-aligned CAND[i + 8]
 
     const int lane = threadIdx.x, ch = blockIdx.y;
@@ -1135,7 +1155,7 @@ __global__ __launch_bounds__(WV, 3) void k_sync(SyncArgs a)
             if (last_ev >= 0) {
                 const int s = last_ev - W;                          // tile-local
                 float hi, mid, lo;
-                sync_thresholds(BT, s + HIST_BB, hi, mid, lo);
+                sync_thresholds_global(bbp, a.n_hist, a.n, t0 + s, hi, mid, lo);   // rare; the LDS window is gone
                 r.last_s = a.abs0 + t0 + s; r.hi = hi; r.mid = mid; r.lo = lo;
             }
             a.recs[(size_t)ch * a.n_tiles + tile] = r;
@@ -1606,20 +1626,7 @@ __global__ __launch_bounds__(WV, P25FE_K4_WPS) void k_slice(SliceArgs a)
                     }
                     if (cur >= 0 && cur != thr_for) {
                         // thresholds of an in-tile anchor: same arithmetic as K2 (same bits), from global memory
-                        const long s = t0 + cur - W;               // local index of the sync word's last symbol
-                        float Pp = 0.f, Nn = 0.f;
-#pragma unroll
-                        for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-                            const float v = bb_at(bbp, a.n_hist, a.n, s - SPS * (P25FE_SYNC_DIBITS - 1 - j));
-                            if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
-                        }
-                        Pp = Pp * P25FE_SYNC_INV_NPOS;
-                        Nn = Nn * P25FE_SYNC_INV_NNEG;
-                        mid = (Pp + Nn) * 0.5f;
-                        const float span = (Pp - Nn) * 0.5f;
-                        const float d = span * P25FE_SLICE_FRAC;
-                        hi = mid + d;
-                        lo = mid - d;
+                        sync_thresholds_global(bbp, a.n_hist, a.n, t0 + cur - W, hi, mid, lo);
                         thr_for = cur;
                     }
                     out[rank++] = slice_dibit(bv[u], hi, mid, lo);
