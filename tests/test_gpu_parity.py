@@ -554,3 +554,47 @@ def test_channeliser_parity_and_end_to_end(O, FE):
             assert np.array_equal(got, O.run_cf32(chan)), c             # downstream of the channeliser: bit-exact as ever
         elif min(abs(c - k) if abs(c - k) <= 96 else 192 - abs(c - k) for k in carriers) > 1:
             assert int(r["n_sync"][c]) == 0, c                          # idle slot (adjacent slots see the skirt)
+
+
+def test_dense_sync_events_and_noise(O, FE):
+    """Symbol receiver stress: sync words so dense that a 1024-sample tile holds several detections (K2's in-tile
+    counts, K4's event path incl. the thresholds of non-last events), timing jumps between frames, loud noise that
+    produces candidates but no lock, and an amplitude step -- dibits, sync positions and sync dibit indices equal the
+    oracle's, through the one-shot device path and through ragged streaming chunks."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    rng = np.random.default_rng(77)
+    pieces = []
+    for fd, snr, amp, toff in ((26, 25.0, 0.5, 0), (40, 14.0, 0.25, 3), (100, 10.0, 0.7, 17), (31, 30.0, 0.1, 41)):
+        iq = c4fm.synth(0.6, seed=200 + fd, snr_db=snr, frame_dibits=fd, amplitude=amp, timing_offset=toff)[0]
+        pieces.append(iq)
+        pieces.append((0.3 * (rng.standard_normal(5003) + 1j * rng.standard_normal(5003))).astype(np.complex64))
+    iq = np.concatenate(pieces)
+    iq = iq[:len(iq) // 8 * 8]
+    bb_ref = O.Demod().feed_cf32(iq)
+    rcv = O.Recv()
+    d_ref, sp_ref, sd_ref = rcv.feed(bb_ref)
+    assert len(sp_ref) > 250                                         # several events per tile on the dense stretches
+    gaps = np.diff(sp_ref)
+    assert (gaps < 512).sum() > 100
+    fe = FE()
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    bb, nb = fe.demod_dev(t)
+    assert np.array_equal(bb[0, :nb].cpu().numpy().view(np.uint32), bb_ref.view(np.uint32))
+    dib, res, sp, sd = fe.slice_dev(bb[0], nb, sync_cap=4096)
+    r = parse_results(res)[0]
+    nd, ns = int(r["n_dibits"]), int(r["n_sync"])
+    assert nd == len(d_ref) and ns == len(sp_ref)
+    assert np.array_equal(dib[0, :nd].cpu().numpy(), d_ref)
+    assert np.array_equal(sp[0, :ns].cpu().numpy(), sp_ref)
+    assert np.array_equal(sd[0, :ns].cpu().numpy().astype(np.uint64), sd_ref.astype(np.uint64))
+    # streaming, ragged chunks (host entry points)
+    fe2 = FE()
+    cuts = sorted(set(int(x) for x in rng.integers(1, nb - 1, size=40))) + [nb]
+    got_d, got_s, o = [], [], 0
+    for c in cuts:
+        dd, ss, _ = fe2.slice(bb_ref[o:c])
+        got_d.append(dd); got_s.append(ss); o = c
+    assert np.array_equal(np.concatenate(got_d), d_ref)
+    assert np.array_equal(np.concatenate(got_s), sp_ref)
