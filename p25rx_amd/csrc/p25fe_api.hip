@@ -242,14 +242,15 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0, sizeof(float) * (size_t)h->C, st));
         return P25FE_OK;
     }
-    // Segments are SHORT: two sub-tiles per one-wave workgroup.  Measured on config 2 (profiles/): one long
-    // segment per resident wave (44 sub-tiles, no tail round) ran K1 in 0.305 ms, 2 sub-tiles per workgroup in
-    // 0.232 ms -- neighbouring workgroups then stream neighbouring DRAM pages and the dispatcher balances the CUs,
-    // which outweighs recomputing the 50-sample filter halo once per 590 outputs (8 %).  P25FE_SUBS overrides.
+    // Segments are SHORT: three sub-tiles per one-wave workgroup.  Measured on config 2 (profiles/): one long
+    // segment per resident wave (44 sub-tiles, no tail round) ran K1 in 0.305 ms, 2-4 sub-tiles per workgroup in
+    // 0.23-0.27 ms depending on the box -- neighbouring workgroups then stream neighbouring DRAM pages and the
+    // dispatcher balances the CUs, which outweighs recomputing the 50-sample filter halo once per segment (5.5 % at
+    // 3 sub-tiles; A/B on one box, three rounds: 2 -> 0.275, 3 -> 0.264, 4 -> 0.269 ms).  P25FE_SUBS overrides.
     const int pk = h->k1_p;
     const long sub = (long)WV * pk;
     static const long subs_env = [] { const char* e = getenv("P25FE_SUBS"); return e ? atol(e) : 0L; }();
-    long subs = subs_env > 0 ? subs_env : 2;
+    long subs = subs_env > 0 ? subs_env : 3;
     if (subs > 32768) subs = 32768;
     const long seg_len = (sub - HALO_D) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;

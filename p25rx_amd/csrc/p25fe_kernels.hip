@@ -44,7 +44,11 @@ template <int PK> struct Geo {
     static constexpr int XWIN = DEC * SUB + (T1 - DEC);   // input samples feeding one sub-tile of d
     static constexpr int XIN_N = 8 + (XWIN + 8 + 7) / 8 * 8;   // 8 spare entries in front + window + loader slack
     static constexpr int D_N = D_CARRY + SUB;
-    static constexpr size_t LDS_BYTES = sizeof(float2) * (XIN_N + D_N) + sizeof(float) * (SUB + T1 + T2 + 3);
+    // LDS: [d carry 40][window region XIN_N][taps].  The sub-tile's new d samples and the output transpose OVERWRITE the
+    // front of the window region once the decimator has consumed it (one wave: program order), so that 11 one-wave
+    // workgroups fit a CU's 160 KB instead of 9 (occupancy is what bounds the overlap of HBM, LDS and VALU work).
+    static constexpr size_t LDS_BYTES = sizeof(float2) * (D_CARRY + XIN_N) + sizeof(float) * (T1 + T2 + 3);
+    static_assert(sizeof(float2) * XIN_N >= sizeof(float2) * SUB + sizeof(float) * SUB, "d and the transpose fit the window region");
     static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
     static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
@@ -231,10 +235,10 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     constexpr int P = PK;
     constexpr int NBACK = G::NBACK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* XIN = reinterpret_cast<float2*>(smem) + 8;              // 8 spare entries in front (loader shift)
-    float2* D = reinterpret_cast<float2*>(smem) + G::XIN_N;        // [D_CARRY | SUB]
-    float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose
-    float* TAPS = OUT + SUB;                                        // [T1 | T2], only when !CT
+    float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region
+    float2* XIN = D + D_CARRY + 8;                                  // 8 spare entries in front (loader shift)
+    float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose, also inside the window region
+    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
     if (!CT) {
         for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
@@ -318,6 +322,9 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
                     }
                 }
             }
+            // d overwrites the front of the window: every lane's window reads must be complete first.  (The compiler
+            // reasons per thread and could prove a lane's own store and loads disjoint -- the fence orders the wave.)
+            phase_sync();
 #pragma unroll
             for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = acc[p];
         }
