@@ -15,6 +15,7 @@
 // Stencil / element-wise work: no MFMA.  HBM-bound by design: 8 B in + 0.8 B out per IQ sample.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "p25fe.h"
 #include "p25fe_spec.h"
@@ -133,17 +134,21 @@ __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((
 // ------------------------------------------------------------------------------------------
 template <int FMT, int PK> struct Loader {
     using G = Geo<PK>;
-    static constexpr int LOG_SPV = FMT == P25FE_FMT_CF32 ? 1 : 3;   // samples per 16-B vector: 2 (cf32) or 8 (u8 pairs)
+    // A lane's vector always holds TWO samples -- 16 B of cf32 or 4 B of u8 pairs -- which become one 16-B LDS store,
+    // lane-consecutive and therefore conflict-free.  (u8 used to load 16 B = 8 samples per lane: the 64-B lane stride of
+    // the resulting ds_write_b128 is a 4-way bank conflict in every 8-lane group and cost 20 % of the kernel.)
+    static constexpr int LOG_SPV = 1;
     static constexpr int SPV = 1 << LOG_SPV;
-    static constexpr int NV = (G::XWIN + SPV + SPV * WV - 1) / (SPV * WV);   // vectors per lane: 13 / 4 for PK = 5
-    uint4 v[NV];
+    static constexpr int NV = (G::XWIN + SPV + SPV * WV - 1) / (SPV * WV);   // vectors per lane: 13 for PK = 5
+    using V = typename std::conditional<FMT == P25FE_FMT_CF32, uint4, unsigned>::type;
+    V v[NV];
 
     // base: pointer to owned sample 0 of this channel; first: index of the first window sample;
     // i_last: last sample index this workgroup will ever need (loads past it collapse onto one cached vector)
     __device__ __forceinline__ void load(const void* base, long first, long n_hist, long n_new, long i_last, int tid)
     {
         const long v0 = first >> LOG_SPV;                           // floor division (arithmetic shift), uniform
-        const uint4* q = reinterpret_cast<const uint4*>(base) + v0; // uniform base of the window
+        const V* q = reinterpret_cast<const V*>(base) + v0;         // uniform base of the window
         const long last = i_last < n_new - 1 ? i_last : n_new - 1;
         // clamp range relative to the window, saturated to 32 bits: one v_med3_i32 per vector
         long lo = ((-n_hist) >> LOG_SPV) - v0;                      // vector holding sample -n_hist
@@ -158,7 +163,7 @@ template <int FMT, int PK> struct Loader {
             r = r > hi32 ? hi32 : r;
 #if defined(P25FE_ABLATE) && P25FE_ABLATE == 6     // measurement build: every window load hits one cached vector row
             r = tid;
-            v[j] = reinterpret_cast<const uint4*>(base)[r];
+            v[j] = reinterpret_cast<const V*>(base)[r];
             continue;
 #endif
             v[j] = q[r];
@@ -174,15 +179,15 @@ template <int FMT, int PK> struct Loader {
         const bool interior = first_al >= -n_hist && first_al + (long)NV * SPV * WV <= n_new;   // uniform
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
             for (int e = 0; e < SPV; ++e) {
                 const int k = SPV * (tid + j * WV) + e;
                 float2 s;
-                if (FMT == P25FE_FMT_CF32) {
-                    s = make_float2(__uint_as_float(w[2 * (e & 1)]), __uint_as_float(w[2 * (e & 1) + 1]));
+                if constexpr (FMT == P25FE_FMT_CF32) {
+                    const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                    s = make_float2(__uint_as_float(w[2 * e]), __uint_as_float(w[2 * e + 1]));
                 } else {
-                    const unsigned pair = (w[(e >> 1) & 3] >> (16 * (e & 1))) & 0xffffu;
+                    const unsigned pair = (v[j] >> (16 * e)) & 0xffffu;
                     s = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
                 }
                 if (!interior) {
