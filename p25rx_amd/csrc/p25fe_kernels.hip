@@ -43,7 +43,7 @@ template <int PK> struct Geo {
     static constexpr int P = PK;
     static constexpr int SUB = WV * PK;                   // decimated samples per sub-tile (320 for PK = 5)
     static constexpr int XWIN = DEC * SUB + (T1 - DEC);   // input samples feeding one sub-tile of d
-    static constexpr int XIN_N = 8 + (XWIN + 8 + 7) / 8 * 8;   // 8 spare entries in front + window + loader slack
+    static constexpr int XIN_N = (XWIN + 1 + 7) / 8 * 8;       // window + the 0 / 1 sample alignment shift, rounded up
     static constexpr int D_N = D_CARRY + SUB;
     // LDS: [d carry 40][window region XIN_N][taps].  The sub-tile's new d samples and the output transpose OVERWRITE the
     // front of the window region once the decimator has consumed it (one wave: program order), so that 11 one-wave
@@ -170,33 +170,34 @@ template <int FMT, int PK> struct Loader {
         }
     }
 
-    // XIN[k] must hold sample first + k; vector j of lane tid holds samples SPV * (vfirst + j * WV) + e
+    // XIN[k] receives sample first_al + k, first_al = first rounded down to a vector boundary: vector j of lane tid is
+    // ONE aligned 16-B LDS store (ds_write_b128, lane-consecutive: conflict-free).  The consumers add the 0 / 1 sample
+    // shift to their read base.  (Storing at XIN - shift made the alignment unknown at compile time: every staging
+    // store became a ds_write2_b64 whose 16-B lane stride is a 2-way bank conflict -- 23 % of K1's LDS cycles.)
     __device__ __forceinline__ void store(float2* XIN, long first, long n_hist, long n_new, int tid) const
     {
         const long first_al = (first >> LOG_SPV) << LOG_SPV;
-        const int sh = (int)(first - first_al);                     // 0 .. SPV-1
-        float2* XS = XIN - sh;                                      // XIN is preceded by 8 spare entries
         const bool interior = first_al >= -n_hist && first_al + (long)NV * SPV * WV <= n_new;   // uniform
+        float4* XV = reinterpret_cast<float4*>(__builtin_assume_aligned(XIN, 16));
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
+            float2 s[SPV];
 #pragma unroll
             for (int e = 0; e < SPV; ++e) {
-                const int k = SPV * (tid + j * WV) + e;
-                float2 s;
                 if constexpr (FMT == P25FE_FMT_CF32) {
                     const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-                    s = make_float2(__uint_as_float(w[2 * e]), __uint_as_float(w[2 * e + 1]));
+                    s[e] = make_float2(__uint_as_float(w[2 * e]), __uint_as_float(w[2 * e + 1]));
                 } else {
                     const unsigned pair = (v[j] >> (16 * e)) & 0xffffu;
-                    s = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
+                    s[e] = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
                 }
                 if (!interior) {
                     const long i = first_al + SPV * (long)(tid + j * WV) + e;
-                    if (i < -n_hist || i >= n_new) s = make_float2(0.f, 0.f);
+                    if (i < -n_hist || i >= n_new) s[e] = make_float2(0.f, 0.f);
                 }
-                // only the last round of vectors can run past the window: everything else is stored unconditionally
-                if (j < NV - 1 || k < G::XIN_N - 8) XS[k] = s;
             }
+            // only the last round of vectors can run past the window: everything else is stored unconditionally
+            if (j < NV - 1 || SPV * (tid + j * WV) + SPV <= G::XIN_N) XV[tid + j * WV] = make_float4(s[0].x, s[0].y, s[1].x, s[1].y);
         }
     }
 };
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     constexpr int NBACK = G::NBACK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region
-    float2* XIN = D + D_CARRY + 8;                                  // 8 spare entries in front (loader shift)
+    float2* XIN = D + D_CARRY;                                      // 16-B aligned: staged with ds_write_b128
     float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose, also inside the window region
     float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
 
     for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB) {
         if (dlo >= m_seg1) break;                                  // uniform
-        const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[k] = x[first + k]
+        const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[xsh + k] = x[first + k]
+        const int xsh = (int)(first & 1);                           // window start relative to the aligned staging origin
         ld.store(XIN, first, a.n_hist, a.n_new, tid);
         phase_sync();
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Lane: d[dlo + P tid + p], p = 0..P-1.
         // Output p needs x[first + 5(P tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[5 P tid + 5p + 30 - k].
         {
-            const float2* w = XIN + (DEC * P) * tid;
+            const float2* w = XIN + xsh + (DEC * P) * tid;
             float2 acc[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p] = make_float2(0.f, 0.f);
