@@ -468,7 +468,9 @@ constexpr int K0_SUB = WV * K0_P;            // 192 outputs per sub-tile
 constexpr int K0_SUBS = P25FE_K0_SUBS;       // sub-tiles per workgroup (prefetch pipeline depth)
 constexpr int K0_HALO = T0 - PD;             // 70 input samples of left context
 constexpr int K0_NIN = PD * K0_SUB + K0_HALO;       // 1990 window positions
-constexpr int K0_JP = K0_NIN / PD + 2;       // 201 entries per phase row (odd: spreads the staging writes)
+constexpr int K0_JP = 205;                   // entries per phase row (>= K0_NIN / PD + 2); = 13 mod 16: staging position t lands on
+                                             // bank pair 13 t + c (mod 16) whether or not the phase wraps -> conflict-free ds_write_b64
+static_assert(K0_JP >= K0_NIN / PD + 2 && K0_JP % 16 == 13, "polyphase row pitch");
 constexpr int K0_NV = (K0_NIN + 2 + 2 * WV - 1) / (2 * WV);   // 16-B vectors per lane: 16
 constexpr int HIST_PRE = K0_HALO + PD - 1;   // 79: history needed for exact results
 
@@ -617,7 +619,8 @@ static_assert(T0 == CZ_C2 * CZ_P1 && CZ_M == CZ_C1 * CZ_C2 && CZ_P1 == 5, "facto
 #endif
 constexpr int CZ_G = P25FE_CZ_G;                                         // c1 values whose partial sums are held at once
 constexpr int CZ_NIN = PD * WV + (T0 - PD);                     // 710 window positions for 64 instants
-constexpr int CZ_JP = CZ_NIN / PD + 2;                          // 73 entries per phase row (odd)
+constexpr int CZ_JP = 77;                                       // entries per phase row (>= 73), = 13 mod 16 as in K0
+static_assert(CZ_JP >= CZ_NIN / PD + 2 && CZ_JP % 16 == 13, "polyphase row pitch");
 constexpr int CZ_NV = (CZ_NIN + 2 + 2 * WV - 1) / (2 * WV);     // 16-B vectors per lane: 6
 
 struct ChzArgs {
