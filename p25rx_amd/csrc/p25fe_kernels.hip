@@ -792,7 +792,12 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
                 const float2 rot = ROT[ix];
                 const float2 yv = BB[q][4 * e + f];
                 const float2 o = make_float2(__builtin_fmaf(-yv.y, rot.y, yv.x * rot.x), __builtin_fmaf(yv.y, rot.x, yv.x * rot.y));
-                yb[(size_t)(c1 + CZ_C1 * (e + 4 * f)) * a.y_stride] = o;   // rows are padded to whole tiles: no predicate
+                {   // streaming store (nt): 22 GB of output per minute of capture never fit a cache; measured +4.5 %.
+                    // Rows are padded to whole tiles: no predicate.
+                    typedef float __attribute__((ext_vector_type(2))) f32x2;
+                    f32x2 ov; ov.x = o.x; ov.y = o.y;
+                    __builtin_nontemporal_store(ov, reinterpret_cast<f32x2*>(yb + (size_t)(c1 + CZ_C1 * (e + 4 * f)) * a.y_stride));
+                }
                 ix += step8; ix = ix >= (unsigned)CZ_M ? ix - CZ_M : ix;
             }
         }
