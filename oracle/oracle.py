@@ -100,6 +100,8 @@ def _bind(lib):
     lib.p25o_nid_decode.argtypes = [vp, C.c_int, vp, sz, vp, vp, sz, vp]
     lib.p25o_run_cf32.restype = C.c_int64
     lib.p25o_run_cf32.argtypes = [C.POINTER(Config), vp, sz, vp, sz]
+    lib.p25o_run_cf32_mt.restype = C.c_int64
+    lib.p25o_run_cf32_mt.argtypes = [C.POINTER(Config), vp, sz, C.c_int]
     lib.p25o_has_fma.restype = C.c_int
     return lib
 
@@ -262,6 +264,14 @@ def power_dbm(samples, resistance=1.0):
 def atan2f(y, x, cfg=None):
     cfg = cfg or make_config()
     return lib().p25o_atan2f(C.byref(cfg), y, x)
+
+
+def run_cf32_mt(iq, nthreads, cfg=None, libpath=None):
+    """Throughput helper for bench.py: `nthreads` independent time shards on as many threads; returns the dibit count."""
+    L = lib(libpath)
+    cfg = cfg or make_config()
+    iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    return int(L.p25o_run_cf32_mt(C.byref(cfg), _ptr(iq), iq.size, int(nthreads)))
 
 
 def run_cf32(iq, cfg=None, libpath=None):

@@ -512,6 +512,39 @@ int64_t p25o_run_cf32(const p25o_config *cfg, const float *iq, size_t n, uint8_t
     return rc ? rc : (int64_t)total;
 }
 
+/* The same port on several host cores (bench.py's second CPU figure, SURVEY.md section 8d ii): the capture is cut into
+ * `nthreads` contiguous time shards, each run through p25o_run_cf32 from a fresh state on its own thread.  Symbols at
+ * the shard boundaries are NOT stitched -- this is a throughput figure, not a parity path.  Returns the dibit total. */
+#include <pthread.h>
+typedef struct { const p25o_config *cfg; const float *iq; size_t n; int64_t out; } mt_job;
+static void *mt_worker(void *p)
+{
+    mt_job *j = p;
+    size_t cap = j->n / 50 + 64;
+    uint8_t *dib = malloc(cap);
+    j->out = dib ? p25o_run_cf32(j->cfg, j->iq, j->n, dib, cap) : -1;
+    free(dib);
+    return NULL;
+}
+int64_t p25o_run_cf32_mt(const p25o_config *cfg, const float *iq, size_t n, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    mt_job jobs[256];
+    pthread_t th[256];
+    for (int k = 0; k < nthreads; k++) {
+        size_t lo = n * (size_t)k / (size_t)nthreads, hi = n * (size_t)(k + 1) / (size_t)nthreads;
+        jobs[k].cfg = cfg; jobs[k].iq = iq + 2 * lo; jobs[k].n = hi - lo; jobs[k].out = 0;
+        if (pthread_create(&th[k], NULL, mt_worker, &jobs[k])) return -1;
+    }
+    int64_t total = 0;
+    for (int k = 0; k < nthreads; k++) {
+        pthread_join(th[k], NULL);
+        total = (total < 0 || jobs[k].out < 0) ? -1 : total + jobs[k].out;
+    }
+    return total;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Network identifier after the frame sync (what MessageReceiver reports as
  * MessageEvent::PacketNID, src/recv.rs:216-222, and policy.handle_nid consumes, src/policy.rs:92).
