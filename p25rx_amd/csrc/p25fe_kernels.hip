@@ -9,6 +9,12 @@
 //   K3 k_scan     : per-channel scan of the tile summaries (symbol-timing anchor carry and
 //                   dibit offsets) -- the serial state of the receiver turned into a scan.
 //   K4 k_slice    : 4-level slicer at the anchored symbol instants -> dibits.
+// Either side of the path (SURVEY.md section 8f / BASELINE.json config 3):
+//   K0 k_predecim   : 2.4 Msps -> 240 ksps, 80-tap 10:1 decimating FIR (config 3's extra stage).
+//   K5 k_nid        : network identifier after each frame sync, exhaustive BCH(63,16,23) search; k_chan_stats folds the
+//                     records into the reference's per-channel statistics shape (src/hub.rs:557-581).
+//   K6 k_channelise : one 2.4 Msps capture -> 192 channel streams at 240 ksps (factored 192-point DFT in registers).
+// All of them: one wave per workgroup, no s_barrier, short-lived workgroups (measured fastest for every kernel here).
 //
 // Arithmetic contract (docs/SPEC.md section 3): fp32, fma only where the spec says fma, single
 // accumulator per output in tap order 0..T-1.  Compiled with -ffp-contract=off.
