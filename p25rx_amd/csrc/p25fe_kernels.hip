@@ -14,7 +14,8 @@
 //   K5 k_nid        : network identifier after each frame sync, exhaustive BCH(63,16,23) search; k_chan_stats folds the
 //                     records into the reference's per-channel statistics shape (src/hub.rs:557-581).
 //   K6 k_channelise : one 2.4 Msps capture -> 192 channel streams at 240 ksps (factored 192-point DFT in registers).
-// All of them: one wave per workgroup, no s_barrier, short-lived workgroups (measured fastest for every kernel here).
+// K0, K1, K2, K4, K6 (everything that touches sample data): one wave per workgroup, no s_barrier, short-lived workgroups --
+// measured fastest for each of them.  K3 and K5 are small block-wide scans / searches.
 //
 // Arithmetic contract (docs/SPEC.md section 3): fp32, fma only where the spec says fma, single
 // accumulator per output in tap order 0..T-1.  Compiled with -ffp-contract=off.
