@@ -342,7 +342,7 @@ static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, si
         hipLaunchKernelGGL(k_scan, dim3((unsigned)n_groups, (unsigned)h->C), dim3(NT3), 0, st, c);
         HIPCHK(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_scan_groups, dim3((unsigned)((h->C + 63) / 64)), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(k_scan_groups, dim3((unsigned)h->C), dim3(WV), 0, st, c);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 3, st);
     if (!do_slice) { prof_mark(h, 4, st); return P25FE_OK; }
