@@ -66,6 +66,7 @@ struct p25fe {
     std::vector<uint64_t> total_dibits;    // [C]
     // profiling ring: PROF_RING calls x 5 events (before K1, after K1, K2, K3, K4)
     bool prof_on = false;
+    int prof_level = 1;             // 1: events around every kernel, 2: around K1 only (two records per call, not five)
     std::vector<hipEvent_t> prof_ev;
     uint64_t prof_calls = 0;
     int prof_slot = -1;                    // slot being recorded by the current call
@@ -223,7 +224,8 @@ void p25fe_destroy(p25fe_t* h)
 static void prof_begin(p25fe_t* h) { h->prof_slot = h->prof_on ? (int)(h->prof_calls++ % PROF_RING) : -1; }
 static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 {
-    if (h->prof_slot >= 0) (void)hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st);
+    if (h->prof_slot >= 0 && (idx <= 1 || h->prof_level == 1))      // level 2: only the two events around K1
+        (void)hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -746,6 +748,7 @@ int p25fe_profile_enable(p25fe_t* h, int on)
         for (auto& e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
     }
     h->prof_on = on != 0;
+    h->prof_level = on == 2 ? 2 : 1;
     h->prof_calls = 0;
     return P25FE_OK;
 }
@@ -756,9 +759,10 @@ int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
     for (int k = 0; k < 4; ++k) ms[k] = 0.0;
     const uint64_t calls = h->prof_calls;
     const uint64_t kept = calls < (uint64_t)PROF_RING ? calls : (uint64_t)PROF_RING;
+    const int nk = h->prof_level == 2 ? 1 : 4;
     for (uint64_t s = 0; s < kept; ++s) {
-        HIPCHK(h, hipEventSynchronize(h->prof_ev[s * 5 + 4]));
-        for (int k = 0; k < 4; ++k) {
+        HIPCHK(h, hipEventSynchronize(h->prof_ev[s * 5 + nk]));
+        for (int k = 0; k < nk; ++k) {
             float t = 0.f;
             HIPCHK(h, hipEventElapsedTime(&t, h->prof_ev[s * 5 + k], h->prof_ev[s * 5 + k + 1]));
             ms[k] += t;

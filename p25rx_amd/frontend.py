@@ -257,7 +257,8 @@ class FrontEnd:
         return out
 
     def profile_enable(self, on=True):
-        self._chk(self.L.p25fe_profile_enable(self.h, 1 if on else 0))
+        """True / 1: events around every kernel; 2: around K1 only; False / 0: off."""
+        self._chk(self.L.p25fe_profile_enable(self.h, int(on)))
 
     def profile_read(self):
         """-> (ms per kernel [K1 front end, K2 sync, K3 scan, K4 slice] summed over calls, n_calls)."""
