@@ -1057,10 +1057,7 @@ __global__ __launch_bounds__(WV, 3) void k_sync(SyncArgs a)
         const int tn = (a.n - t0 < TB) ? (int)(a.n - t0) : TB;      // samples in this tile
         stage(tile);
         phase_sync();
-        if (K2_SUBS > 1) {                                          // compile-time
-            const int nxt = tile + 1 < a.n_tiles ? tile + 1 : tile; // unconditional prefetch (clamped: re-reads this tile)
-            load(it + 1 < K2_SUBS ? nxt : tile);
-        }
+        if (K2_SUBS > 1 && it + 1 < K2_SUBS && tile + 1 < a.n_tiles) load(tile + 1);   // uniform; prefetch the next window
 #if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 1   // measurement builds only: stop after the LDS staging
         if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = BT[tile % K2_BT] == 123.f ? 1ull : 0ull;
         phase_sync();
