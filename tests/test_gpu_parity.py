@@ -598,3 +598,44 @@ def test_dense_sync_events_and_noise(O, FE):
         got_d.append(dd); got_s.append(ss); o = c
     assert np.array_equal(np.concatenate(got_d), d_ref)
     assert np.array_equal(np.concatenate(got_s), sp_ref)
+
+
+def test_config2_full_size_properties(FE):
+    """BASELINE.json configs[1] at its FULL size (1 channel x 600 s = 1.44e8 samples, generated in HBM), checked through
+    size-independent properties: demod(mod(d)) == d for the cf32 capture and for the same capture quantised to RTL-SDR
+    u8 pairs; sync count = frames; and range invariance -- the capture processed as two device ranges with history and
+    an anchor hand-over gives the same baseband bits and the same dibits as the single pass."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    n = 600 * 240000
+    iq, truth = c4fm.synth_torch(n, seed=1000, device="cuda", snr_db=30.0)
+    fe = FE()
+    dib, res = fe.run_dev(iq)
+    r = parse_results(res)[0]
+    nd = int(r["n_dibits"])
+    got = dib[0, :nd].cpu().numpy()
+    k = min(nd, len(truth) - 24)
+    assert k > 2879000 and np.array_equal(got[:k], truth[24:24 + k])
+    assert int(r["n_sync"]) == len(truth) // 864 + (1 if len(truth) % 864 >= 24 else 0)
+    # u8 quantisation of the same capture (inverse of SPEC 3.1): still every symbol
+    u8 = torch.clamp(torch.round((iq + 1.0) * 127.5), 0, 255).to(torch.uint8)
+    d8, r8 = fe.run_dev(u8)
+    g8 = d8[0, :int(parse_results(r8)[0]["n_dibits"])].cpu().numpy()
+    k8 = min(len(g8), len(truth) - 24)
+    assert k8 > 2879000 and np.array_equal(g8[:k8], truth[24:24 + k8])
+    del u8, d8
+    # two ranges: [0, cut) and [cut, n) with 2000 samples of history; baseband bit-identical, dibits identical
+    cut = 71_000_008
+    bb_all, nb_all = fe.demod_dev(iq)
+    bb1, nb1 = fe.demod_dev(iq[:cut])
+    bb2, nb2 = fe.demod_dev(iq[cut - 2000:], n_hist=2000, abs0=cut, offset=2000)
+    assert nb1 + nb2 == nb_all
+    assert torch.equal(bb1[0, :nb1].view(torch.int32), bb_all[0, :nb1].view(torch.int32))
+    assert torch.equal(bb2[0, :nb2].view(torch.int32), bb_all[0, nb1:nb_all].view(torch.int32))
+    d1, r1, _, _ = fe.slice_dev(bb_all[0], nb1)
+    a1 = parse_results(r1)[0]
+    d2, r2, _, _ = fe.slice_dev(bb_all[0], nb2, n_hist_bb=nb1, abs_bb0=nb1, anchor_in=a1["anchor_out"], offset=nb1)
+    n1, n2 = int(a1["n_dibits"]), int(parse_results(r2)[0]["n_dibits"])
+    assert n1 + n2 == nd
+    assert torch.equal(d1[0, :n1], dib[0, :n1]) and torch.equal(d2[0, :n2], dib[0, n1:nd])
