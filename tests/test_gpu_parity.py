@@ -639,3 +639,31 @@ def test_config2_full_size_properties(FE):
     n1, n2 = int(a1["n_dibits"]), int(parse_results(r2)[0]["n_dibits"])
     assert n1 + n2 == nd
     assert torch.equal(d1[0, :n1], dib[0, :n1]) and torch.equal(d2[0, :n2], dib[0, n1:nd])
+
+
+def test_config4_full_size_properties(FE):
+    """BASELINE.json configs[3] at its FULL size: 256 channels x 60 s x 240 ksps, channel-major (29.5 GB, 3.7e9 samples --
+    beyond 32-bit indices).  Channel c is the same generated capture delayed by c symbols, so every channel's dibits
+    must equal the modulator's symbols at its own offset, and all channels must agree with each other."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    C, n = 256, 60 * 240000
+    base, truth = c4fm.synth_torch(n + 50 * C, seed=4242, device="cuda", snr_db=30.0)
+    iq = torch.empty((C, n, 2), dtype=torch.float32, device="cuda")
+    for c in range(C):
+        iq[c] = base[50 * c: 50 * c + n]
+    del base
+    fe = FE(n_channels=C)
+    dib, res = fe.run_dev(iq)
+    r = parse_results(res)
+    dib_h = dib.cpu().numpy()
+    for c in range(C):
+        nd = int(r["n_dibits"][c])
+        # the first sync word that lies fully inside channel c's capture is frame 0's (4 lead symbols precede it) or frame 1's
+        ok = False
+        for j in (24, 864 + 24):
+            k = min(nd, len(truth) - j) - 8
+            ok = ok or (k > 286000 and np.array_equal(dib_h[c, :k], truth[j:j + k]))
+        assert ok, (c, nd)
+        assert int(r["n_sync"][c]) >= 332, (c, int(r["n_sync"][c]))
