@@ -667,3 +667,21 @@ def test_config4_full_size_properties(FE):
             ok = ok or (k > 286000 and np.array_equal(dib_h[c, :k], truth[j:j + k]))
         assert ok, (c, nd)
         assert int(r["n_sync"][c]) >= 332, (c, int(r["n_sync"][c]))
+
+
+def test_config5_full_size_single_gpu(FE):
+    """BASELINE.json configs[4]'s capture at its FULL size on one GPU: 3 600 s x 240 ksps = 8.64e8 samples (6.9 GB: byte
+    offsets beyond 32 bits inside one channel, 843 750 tiles, 412 scan groups): every one of the 17.28 M dibits equals
+    the modulator's symbol, one sync per frame."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    n = 3600 * 240000
+    iq, truth = c4fm.synth_torch(n, seed=77, device="cuda", snr_db=30.0)
+    dib, res = FE().run_dev(iq)
+    r = parse_results(res)[0]
+    nd = int(r["n_dibits"])
+    got = dib[0, :nd].cpu().numpy()
+    k = min(nd, len(truth) - 24)
+    assert k > 17_279_000 and np.array_equal(got[:k], truth[24:24 + k])
+    assert int(r["n_sync"]) == len(truth) // 864 + (1 if len(truth) % 864 >= 24 else 0)
