@@ -3,7 +3,8 @@
 The GPU kernels cannot run here, so the per-shard compute is a TEST DOUBLE built on the CPU oracle
 (OracleShardFE below); what is under test is the product's N > 1 logic: the halo exchange, the
 all-gather of shard summaries, p25fe_shard_resolve (real C-ABI host function) and the resulting
-carry-in / dibit offsets.  The concatenated shard outputs must equal one oracle pass over the capture.
+carry-in / dibit offsets -- through TimeShard.step and through TimeShard.step_device (the bench's N > 1 step).
+The concatenated shard outputs must equal one oracle pass over the capture.
 """
 import os
 import socket
@@ -71,7 +72,17 @@ class OracleShardFE:
         assert L.p25fe_shard_resolve(p(summaries), p(bb0), p(bbn), n, p(anc), p(off)) == 0
         return anc, off
 
+    def shard_resolve_dev(self, summ_all, d_bb0, d_bbn, anchors=None, offsets=None):
+        """Stand-in for the one-thread device kernel: the same C-ABI host function on CPU tensors."""
+        import torch
+        summ = np.frombuffer(summ_all.numpy().tobytes(), dtype=self._lib.RESULT_DTYPE)
+        anc, off = self.shard_resolve(summ, d_bb0.numpy().astype(np.uint64), d_bbn.numpy().astype(np.uint64))
+        a_t = torch.from_numpy(np.frombuffer(anc.tobytes(), dtype=np.uint8).copy()).view(len(anc), -1)
+        return a_t, torch.from_numpy(off.astype(np.int64))
+
     def shard_pass2(self, anchor_in, n_bb, device, result=None, dibits=None):
+        if not isinstance(anchor_in, np.ndarray):                # uint8 tensor holding one p25fe_anchor_t
+            anchor_in = np.frombuffer(anchor_in.numpy().tobytes(), dtype=self._lib.ANCHOR_DTYPE)
         a = anchor_in[0]
         dib, spos = self.own
         pre = np.zeros(0, np.uint8)
@@ -106,6 +117,13 @@ def _worker(rank, world, port, q):
         if rank > 0:                                            # halo really is the left neighbour's tail
             left = iq[rank * N_PER_RANK - ts.halo:rank * N_PER_RANK]
             assert np.array_equal(buf[:ts.halo].numpy().view(np.complex64).reshape(-1), left)
+        out_host = fe.out
+        # the bench's variant of the step: no host synchronisation, carry resolved from the all-gathered tensor
+        ts.setup_device(torch, "cpu")
+        buf[:ts.halo].zero_()
+        d_off = ts.step_device(buf, result, summ_all, None)
+        assert np.array_equal(fe.out, out_host)
+        assert int(d_off[rank]) == off
         q.put((rank, off, fe.out, O.run_cf32(iq) if rank == 0 else None))
     finally:
         dist.destroy_process_group()
