@@ -55,7 +55,7 @@ struct p25fe {
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
     // scratch
-    DevBuf iq_stage, bb_buf, events, recs, tsum, outs, aggs, carries, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    DevBuf iq_stage, bb_buf, pl_f, pl_bits, evl, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
@@ -70,10 +70,24 @@ struct p25fe {
     std::vector<hipEvent_t> prof_ev;
     uint64_t prof_calls = 0;
     int prof_slot = -1;                    // slot being recorded by the current call
-    // shard context between pass1 and pass2
-    size_t sh_nbb = 0, sh_bb_stride = 0;
+    // shard context between pass1 and pass2 (the planar baseband and the tile summaries stay in the scratch buffers;
+    // every other entry point that touches them clears sh_nbb, so a stale pass 2 fails instead of slicing garbage)
+    bool sh_valid = false;
+    size_t sh_nbb = 0;
     uint64_t sh_abs_bb0 = 0;
-    size_t sh_hist_bb = 0;
+};
+
+// geometry of the planar scratch for n_bb owned baseband samples (p25fe_recv.hip: Planar)
+struct PlanarGeo {
+    size_t n_tiles, ps, bw;
+    explicit PlanarGeo(size_t n_bb)
+    {
+        n_tiles = (n_bb + TS - 1) / TS;
+        if (n_tiles == 0) n_tiles = 1;
+        ps = (size_t)TSYM * n_tiles + 96;          // K1 writes symbols < 768 n_tiles + 32; K2 reads words < 24 n_tiles + 3
+        ps = (ps + 63) / 64 * 64;
+        bw = ps / 32;
+    }
 };
 
 constexpr int PROF_RING = 64;
@@ -194,6 +208,10 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     P25FE_FOR_K1(5)
     P25FE_FOR_K1(3)
 #undef P25FE_FOR_K1
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); h->d_taps.release(); delete h; return P25FE_ERR_HIP; }
@@ -209,7 +227,7 @@ void p25fe_destroy(p25fe_t* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->events, &h->recs, &h->tsum, &h->outs, &h->aggs, &h->carries, &h->power_partial, &h->power_out,
+    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->pl_f, &h->pl_bits, &h->evl, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
                       &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
@@ -233,7 +251,7 @@ static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 // --------------------------------------------------------------------------------------------
 static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
-                           hipStream_t st)
+                           hipStream_t st, const PlanarGeo* planar = nullptr)
 {
     if (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) return P25FE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_x) & 15u) != 0) return P25FE_ERR_ARG;     // 16-B vector loads
@@ -249,13 +267,14 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     // 0.23-0.27 ms depending on the box -- neighbouring workgroups then stream neighbouring DRAM pages and the
     // dispatcher balances the CUs, which outweighs recomputing the 50-sample filter halo once per segment (5.5 % at
     // 3 sub-tiles; A/B on one box, three rounds: 2 -> 0.275, 3 -> 0.264, 4 -> 0.269 ms).  P25FE_SUBS overrides.
-    const int pk = h->k1_p;
+    const int pk = planar ? 5 : h->k1_p;
     const long sub = (long)WV * pk;
     static const long subs_env = [] { const char* e = getenv("P25FE_SUBS"); return e ? atol(e) : 0L; }();
     long subs = subs_env > 0 ? subs_env : 3;
     if (subs > 32768) subs = 32768;
-    const long seg_len = (sub - HALO_D) + (subs - 1) * sub;
+    const long seg_len = (sub - SEG_HALO) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;
+    if (planar && (m_begin + PLPAD < SEG_HALO || (m_begin + PLPAD) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
 
     K1Args a;
     a.x = d_x;
@@ -269,25 +288,31 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.subs_per_seg = (int)subs;
     a.m_begin = m_begin;
     a.power_partial = nullptr;
+    a.bbp = nullptr; a.plane_stride = a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_stride = a.bits_ch_stride = 0;
+    if (planar) {
+        a.bbp = h->pl_f.as<float>(); a.plane_stride = (long)planar->ps; a.bbp_ch_stride = (long)(SPS * planar->ps);
+        a.bits = h->pl_bits.as<uint8_t>(); a.bits_stride = (long)(4 * planar->bw); a.bits_ch_stride = (long)(4 * SPS * planar->bw);
+    }
     if (d_power_dbm) {
         HIPCHK(h, h->power_partial.ensure(sizeof(float) * (size_t)h->C * (size_t)n_seg));
         a.power_partial = h->power_partial.as<float>();
     }
     dim3 grid((unsigned)n_seg, (unsigned)h->C);
     const Taps* dt = h->d_taps.as<Taps>();
-#define P25FE_LAUNCH_K1(PK)                                                                                               \
+#define P25FE_LAUNCH_K1(PK, OM)                                                                                           \
     do {                                                                                                                  \
         const size_t lds = Geo<PK>::LDS_BYTES;                                                                            \
         if (fmt == P25FE_FMT_CF32) {                                                                                      \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK>), grid, dim3(WV), lds, st, a, dt);  \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK>), grid, dim3(WV), lds, st, a, dt);                 \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK, OM>), grid, dim3(WV), lds, st, a, dt);  \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK, OM>), grid, dim3(WV), lds, st, a, dt);                 \
         } else {                                                                                                          \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, PK>), grid, dim3(WV), lds, st, a, dt);    \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK>), grid, dim3(WV), lds, st, a, dt);                   \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, PK, OM>), grid, dim3(WV), lds, st, a, dt);    \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK, OM>), grid, dim3(WV), lds, st, a, dt);                   \
         }                                                                                                                 \
     } while (0)
-    if (pk == 3) P25FE_LAUNCH_K1(3);
-    else P25FE_LAUNCH_K1(5);
+    if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
+    else if (pk == 3) P25FE_LAUNCH_K1(3, OUT_LINEAR);
+    else P25FE_LAUNCH_K1(5, OUT_LINEAR);
 #undef P25FE_LAUNCH_K1
     HIPCHK(h, hipGetLastError());
     if (d_power_dbm) {
@@ -301,82 +326,96 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
 static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
 {
     const size_t C = (size_t)h->C;
-    const size_t n_tiles = (n_bb + TB - 1) / TB;
-    HIPCHK(h, h->events.ensure(C * round_up(n_bb + 8, 16)));
-    HIPCHK(h, h->recs.ensure(C * (n_tiles + 1) * sizeof(TileRec)));
-    HIPCHK(h, h->tsum.ensure(C * (n_tiles + 1) * sizeof(unsigned long long)));
-    const size_t n_groups = (n_tiles + K3_GROUP - 1) / K3_GROUP + 1;
-    HIPCHK(h, h->aggs.ensure(C * n_groups * sizeof(GroupAgg)));
-    HIPCHK(h, h->carries.ensure(C * n_groups * sizeof(GroupCarry)));
-    HIPCHK(h, h->outs.ensure(C * (n_tiles + 1) * sizeof(ScanOut)));
+    const PlanarGeo g(n_bb);
+    HIPCHK(h, h->pl_f.ensure(C * SPS * g.ps * sizeof(float)));
+    HIPCHK(h, h->pl_bits.ensure(C * SPS * g.bw * sizeof(uint32_t)));
+    HIPCHK(h, h->evl.ensure(C * g.n_tiles * EVCAP * sizeof(uint16_t)));
+    HIPCHK(h, h->recs.ensure(C * g.n_tiles * sizeof(TileRec)));
+    HIPCHK(h, h->tsum.ensure(C * g.n_tiles * sizeof(unsigned long long)));
+    HIPCHK(h, h->outs.ensure(C * g.n_tiles * sizeof(ScanOut)));
     return P25FE_OK;
 }
 
-static int launch_sync(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
-                       uint64_t abs_bb0, hipStream_t st)
+static Planar planar_view(const p25fe_t* h, const PlanarGeo& g)
 {
-    const size_t n_tiles = (n_bb + TB - 1) / TB;
-    SyncArgs s;
-    s.bb = d_bb; s.bb_stride = (long)bb_stride; s.n_hist = (long)n_hist_bb; s.n = (long)n_bb; s.abs0 = (long)abs_bb0;
-    s.n_tiles = (int)n_tiles;
-    s.events = h->events.as<uint8_t>();
-    s.ev_stride = (long)round_up(n_bb + 8, 16);
-    s.recs = h->recs.as<TileRec>();
-    s.tsum = h->tsum.as<unsigned long long>();
-    hipLaunchKernelGGL(k_sync, dim3((unsigned)((n_tiles + K2_SUBS - 1) / K2_SUBS), (unsigned)h->C), dim3(WV), 0, st, s);
+    Planar p;
+    p.f = h->pl_f.as<float>(); p.ps = (long)g.ps; p.f_ch = (long)(SPS * g.ps);
+    p.bits = h->pl_bits.as<uint32_t>(); p.bw = (long)g.bw; p.bits_ch = (long)(SPS * g.bw);
+    return p;
+}
+
+// linear baseband (n_hist_bb valid samples before d_bb) -> the planar scratch
+static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb, hipStream_t st)
+{
+    const PlanarGeo g(n_bb);
+    PlanarizeArgs a;
+    a.bb = d_bb; a.bb_stride = (long)bb_stride; a.n_hist = (long)n_hist_bb; a.n = (long)n_bb;
+    a.f = h->pl_f.as<float>(); a.ps = (long)g.ps; a.f_ch = (long)(SPS * g.ps);
+    a.bits = h->pl_bits.as<uint32_t>(); a.bw = (long)g.bw; a.bits_ch = (long)(SPS * g.bw);
+    hipLaunchKernelGGL(k_planarize, dim3((unsigned)(g.ps / WV), (unsigned)h->C), dim3(WV * SPS), 0, st, a);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
 
-static int launch_scan_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
-                             uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits,
-                             size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
-                             p25fe_result_t* d_result, bool do_slice, hipStream_t st)
+// K2 on the planar scratch
+static int launch_detect(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, hipStream_t st)
 {
-    const size_t n_tiles = (n_bb + TB - 1) / TB;
+    const PlanarGeo g(n_bb);
+    DetArgs d;
+    d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = (long)abs_bb0; d.n_tiles = (int)g.n_tiles;
+    d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>();
+    hipLaunchKernelGGL(k_detect, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+// K3 (+ K4 when do_slice) on the summaries of launch_detect
+static int launch_scan_slice(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in,
+                             uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit,
+                             size_t sync_stride, p25fe_result_t* d_result, bool do_slice, hipStream_t st)
+{
+    const PlanarGeo g(n_bb);
+    const int n_tiles = n_bb ? (int)g.n_tiles : 0;
     ScanArgs c;
-    c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>(); c.n_tiles = (int)n_tiles; c.n = (long)n_bb;
-    c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result; c.n_baseband = n_bb;
-    const size_t n_groups = (n_tiles + K3_GROUP - 1) / K3_GROUP;
-    c.aggs = h->aggs.as<GroupAgg>(); c.carries = h->carries.as<GroupCarry>(); c.n_groups = (int)n_groups;
-    c.n_channels = h->C;
-    if (n_groups) {
-        hipLaunchKernelGGL(k_scan, dim3((unsigned)n_groups, (unsigned)h->C), dim3(NT3), 0, st, c);
-        HIPCHK(h, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_scan_groups, dim3((unsigned)h->C), dim3(WV), 0, st, c);
+    c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>();
+    c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
+    c.n_baseband = n_bb;
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, c);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 3, st);
-    if (!do_slice) { prof_mark(h, 4, st); return P25FE_OK; }
+    if (!do_slice || n_tiles == 0) { prof_mark(h, 4, st); return P25FE_OK; }
     SliceArgs l;
-    l.bb = d_bb; l.bb_stride = (long)bb_stride; l.n_hist = (long)n_hist_bb; l.n = (long)n_bb; l.abs0 = (long)abs_bb0;
-    l.n_tiles = (int)n_tiles; l.events = h->events.as<uint8_t>(); l.ev_stride = (long)round_up(n_bb + 8, 16);
-    l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.carries = h->carries.as<GroupCarry>();
-    l.n_groups = (int)n_groups; l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
+    l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = (long)abs_bb0; l.n_tiles = n_tiles;
+    l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.tsum = h->tsum.as<unsigned long long>();
+    l.evl = h->evl.as<uint16_t>(); l.anchor_in = d_anchor_in;
+    l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
-    l.tsum = h->tsum.as<unsigned long long>();
-    hipLaunchKernelGGL(k_slice, dim3((unsigned)((n_tiles + K4_SUBS - 1) / K4_SUBS), (unsigned)h->C), dim3(WV), 0, st, l);
+    hipLaunchKernelGGL(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, l);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 4, st);
     return P25FE_OK;
 }
 
+// stages 6-7 on a LINEAR device baseband: planarize, detect, scan, slice
 static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
                      uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits,
                      size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
                      p25fe_result_t* d_result, hipStream_t st)
 {
+    h->sh_valid = false;
     if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
-        return launch_scan_slice(h, d_bb, bb_stride, n_hist_bb, 0, abs_bb0, d_anchor_in, d_dibits, dibit_stride,
-                                 nullptr, nullptr, 0, d_result, false, st);
+        return launch_scan_slice(h, 0, abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
+                                 false, st);
     int rc = ensure_slice_scratch(h, n_bb);
     if (rc) return rc;
-    rc = launch_sync(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, st);
+    rc = launch_planarize(h, d_bb, bb_stride, n_hist_bb, n_bb, st);
+    if (rc) return rc;
+    rc = launch_detect(h, n_bb, abs_bb0, st);
     if (rc) return rc;
     prof_mark(h, 2, st);
-    return launch_scan_slice(h, d_bb, bb_stride, n_hist_bb, n_bb, abs_bb0, d_anchor_in, d_dibits, dibit_stride,
-                             d_sync_pos, d_sync_dibit, sync_stride, d_result, true, st);
+    return launch_scan_slice(h, n_bb, abs_bb0, d_anchor_in, d_dibits, dibit_stride, d_sync_pos, d_sync_dibit,
+                             sync_stride, d_result, true, st);
 }
 
 extern "C" {
@@ -453,18 +492,24 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
+    h->sh_valid = false;
     const size_t n_bb = p25fe_n_baseband(0, n);
-    const size_t bb_stride = round_up(n_bb + 4, 4);
-    HIPCHK(h, h->bb_buf.ensure((size_t)h->C * bb_stride * sizeof(float)));
+    if (n_bb == 0)
+        return launch_scan_slice(h, 0, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st);
     int rc = ensure_slice_scratch(h, n_bb);
     if (rc) return rc;
+    const PlanarGeo g(n_bb);
     prof_begin(h);
     prof_mark(h, 0, st);
-    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, 0, h->bb_buf.as<float>(), bb_stride, nullptr, st);
+    // K1 writes the baseband straight into the polyphase layout (+ sign planes); the 240 history positions in front
+    // of the stream come out as the zeros of a fresh DemodTask (outputs of an all-zero input)
+    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g);
     if (rc) return rc;
     prof_mark(h, 1, st);
-    rc = dev_slice(h, h->bb_buf.as<float>(), bb_stride, 0, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr,
-                   nullptr, 0, d_result, st);
+    rc = launch_detect(h, n_bb, 0, st);
+    if (rc) return rc;
+    prof_mark(h, 2, st);
+    rc = launch_scan_slice(h, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st);
     h->prof_slot = -1;
     return rc;
 }
@@ -476,40 +521,44 @@ int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, s
                       p25fe_result_t* d_result, void* stream)
 {
     if (!h || !d_iq || !d_result) return P25FE_ERR_ARG;
+    h->sh_valid = false;
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     const size_t n_bb = p25fe_n_baseband(abs0, n);
     const uint64_t abs_bb0 = p25fe_n_baseband(0, (size_t)abs0);      // baseband samples before this shard
-    const size_t bb_stride = round_up(BBPAD + n_bb + 4, 4);
-    HIPCHK(h, h->bb_buf.ensure((size_t)h->C * bb_stride * sizeof(float)));
     int rc = ensure_slice_scratch(h, n_bb);
     if (rc) return rc;
-    float* bb0 = h->bb_buf.as<float>() + BBPAD;
-    const size_t hist_bb = abs_bb0 < BBPAD ? (size_t)abs_bb0 : BBPAD;
+    const PlanarGeo g(n_bb);
     prof_begin(h);
     prof_mark(h, 0, st);
-    rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)hist_bb, bb0, bb_stride, nullptr, st);
-    if (rc) return rc;
-    prof_mark(h, 1, st);
-    rc = launch_sync(h, bb0, bb_stride, hist_bb, n_bb, abs_bb0, st);
-    if (rc) return rc;
+    if (n_bb) {
+        // the receiver's 240 history samples are recomputed from the IQ halo (zeros before the start of the stream)
+        rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g);
+        if (rc) return rc;
+        prof_mark(h, 1, st);
+        rc = launch_detect(h, n_bb, abs_bb0, st);
+        if (rc) return rc;
+    }
     prof_mark(h, 2, st);
-    h->sh_nbb = n_bb; h->sh_bb_stride = bb_stride; h->sh_abs_bb0 = abs_bb0; h->sh_hist_bb = hist_bb;
-    rc = launch_scan_slice(h, bb0, bb_stride, hist_bb, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                           d_result, false, st);
+    rc = launch_scan_slice(h, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0, d_result, false, st);
     h->prof_slot = -1;
-    return rc;
+    if (rc) return rc;
+    h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0;
+    return P25FE_OK;
 }
 
 int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride,
                       p25fe_result_t* d_result, void* stream)
 {
-    if (!h || !d_dibits || !d_result || h->sh_nbb == 0) return P25FE_ERR_ARG;
+    if (!h || !d_dibits || !d_result || !h->sh_valid) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    float* bb0 = h->bb_buf.as<float>() + BBPAD;
-    return launch_scan_slice(h, bb0, h->sh_bb_stride, h->sh_hist_bb, h->sh_nbb, h->sh_abs_bb0, d_anchor_in, d_dibits,
-                             dibit_stride, nullptr, nullptr, 0, d_result, true, (hipStream_t)stream);
+    prof_begin(h);
+    prof_mark(h, 2, (hipStream_t)stream);
+    const int rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr,
+                                     0, d_result, true, (hipStream_t)stream);
+    h->prof_slot = -1;
+    return rc;
 }
 
 int p25fe_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,

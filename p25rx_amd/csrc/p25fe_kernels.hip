@@ -42,6 +42,22 @@ constexpr int BOX = P25FE_BOXCAR;
 constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9])
 constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50
 constexpr int D_CARRY = T2 - 1;              // d carried between sub-tiles
+// Outputs recomputed (and dropped) at the start of every segment.  HALO_D = 50 would do for the arithmetic; 80 = one
+// byte of every sign-bit plane (8 symbols x 10 samples), so that with segment lengths that are multiples of 80 every
+// sub-tile starts on a byte boundary of the polyphase layout below and no two workgroups ever share a byte.
+constexpr int SEG_HALO = 80;
+static_assert(SEG_HALO >= HALO_D && SEG_HALO % 80 == 0, "segment halo covers the filter memory and is byte-aligned per plane");
+
+// Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
+// 240 history samples of the receiver at m = -240..-1), sample p lives in plane r = p % 10 at symbol index i = p / 10:
+//   bbp[r * plane_stride + i]                       fp32, and its sign bit in
+//   bits[r * bits_stride + i / 32] bit (i % 32)     (1 = negative or -0)
+// One plane is what a locked 4800 Bd slicer reads (every 10th sample, contiguous), a 24-symbol sync window is 96
+// contiguous bytes, and the sign planes (1/32 of the baseband) are all the frame-sync prefilter has to touch.
+constexpr int SPS_ = P25FE_SPS;
+constexpr int PLPAD = 320;                   // >= 240 + SEG_HALO, multiple of 320 (owned sample 0 = bit 0 of word 1)
+static_assert(PLPAD % 320 == 0 && PLPAD >= 240 + SEG_HALO, "planar pad");
+constexpr int OUT_LINEAR = 0, OUT_PLANAR = 1;
 // history (input samples before the first owned one) needed for exact results
 constexpr int HIST_IQ = DEC * HALO_D + (T1 - 1) + (DEC - 1);   // 284
 
@@ -114,6 +130,21 @@ __device__ __forceinline__ float wave_shr1(float v, float lane0)
 template <int L> __device__ __forceinline__ float lane_bcast(float v)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L));
+}
+
+// v with lane L replaced by the wave-uniform value x (v_writelane_b32)
+template <int L> __device__ __forceinline__ unsigned lane_set(unsigned v, unsigned x)
+{
+    // This hipcc has no writelane builtin.  gfx950 needs 2 wait states between a VALU write of an SGPR (the v_cmp of
+    // a ballot) and a VALU read of it; the compiler cannot see into the asm, so the padding is part of it (without it
+    // the word of plane 0 -- v_cmp vcc immediately followed by this read of vcc_lo -- came out stale).
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(L));
+    return v;
+}
+// value of v held by lane `src` (ds_bpermute_b32: the LDS crossbar, no memory)
+__device__ __forceinline__ unsigned lane_gather(unsigned v, int src)
+{
+    return (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
 }
 
 // Phase boundary inside the one-wave workgroup: LDS operations of one wave execute in order, so only
@@ -236,13 +267,22 @@ struct K1Args {
     int subs_per_seg;
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
     float* power_partial;   // nullable: [n_channels][gridDim.x] partial sums of |y|^2
+    // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + PLPAD >= SEG_HALO,
+    // (m_begin + PLPAD) % 80 == 0 and a segment length that is a multiple of 80.
+    float* bbp;             // channel 0
+    long plane_stride;      // floats per plane
+    long bbp_ch_stride;     // floats per channel (10 planes)
+    uint8_t* bits;          // channel 0, addressed by byte
+    long bits_stride;       // bytes per plane
+    long bits_ch_stride;    // bytes per channel
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
 // registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
-template <int FMT, bool CT, int PK>
+template <int FMT, bool CT, int PK, int OM = OUT_LINEAR>
 __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
+    static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
     using G = Geo<PK>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
@@ -260,7 +300,7 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     auto tap_dec = [&](int k) -> float { return CT ? P25FE_DEFAULT_DECIM_TAPS[k] : TAPS[k]; };
     auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
-    const long seg_len = (long)(SUB - HALO_D) + (long)(a.subs_per_seg - 1) * SUB;
+    const long seg_len = (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
     const long m_seg0 = a.m_begin + (long)blockIdx.x * seg_len;
     if (m_seg0 >= a.n_out) return;
     const long m_seg1 = (m_seg0 + seg_len < a.n_out) ? m_seg0 + seg_len : a.n_out;
@@ -272,7 +312,7 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
 
     Loader<FMT, PK> ld;
-    long dlo = m_seg0 - HALO_D;                                    // first d index of this sub-tile
+    long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
     ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid);
     float pw = 0.f;
@@ -295,12 +335,30 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     for (int q = 0; q < P; ++q) outv[q] = 0.f;
     int out_rel = -2 * SUB;                                         // out_lo - m_seg0; nothing in range yet
     const int seg_n = (int)(m_seg1 - m_seg0);
-    float* const bb_seg = bb + m_seg0;
+    float* const bb_seg = OM == OUT_LINEAR ? bb + m_seg0 : nullptr;
+    // planar: lane = (half h = tid >> 5, symbol tid & 31) holds, in outv[q], plane 5 h + q of the sub-tile's 32 symbols
+    const int pl_sym = tid & 31, pl_h5 = (tid >> 5) * 5;
+    float* const bbp_seg = OM == OUT_PLANAR ? a.bbp + (size_t)ch * a.bbp_ch_stride + (m_seg0 + PLPAD) / SPS_ : nullptr;
+    uint8_t* const bits_seg = OM == OUT_PLANAR ? a.bits + (size_t)ch * a.bits_ch_stride + (m_seg0 + PLPAD) / (8 * SPS_) : nullptr;
+    unsigned bitsv = 0u;                                            // lanes 0..39: byte (tid & 3) of plane (tid >> 2)
     auto flush_outputs = [&]() {
+        if constexpr (OM == OUT_LINEAR) {
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const int r = out_rel + tid + q * WV;                   // output index relative to the segment start
-            if (r >= 0 && r < seg_n) bb_seg[r] = outv[q];
+            for (int q = 0; q < P; ++q) {
+                const int r = out_rel + tid + q * WV;               // output index relative to the segment start
+                if (r >= 0 && r < seg_n) bb_seg[r] = outv[q];
+            }
+        } else {
+            const int i_rel = out_rel / SPS_;                       // symbol index of the sub-tile relative to the segment (multiple of 8)
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
+                if (r >= 0 && r < seg_n) bbp_seg[(size_t)(pl_h5 + q) * a.plane_stride + i_rel + pl_sym] = outv[q];
+            }
+            // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
+            // either wholly inside the segment or wholly halo (the range's last byte may carry bits past n_out: unread)
+            const int r0 = out_rel + 8 * SPS_ * (tid & 3) + (tid >> 2);
+            if (tid < 4 * SPS_ && r0 >= 0 && r0 < seg_n) bits_seg[(size_t)(tid >> 2) * a.bits_stride + (i_rel >> 3) + (tid & 3)] = (uint8_t)bitsv;
         }
     };
 
@@ -436,8 +494,28 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         }
         phase_sync();
         // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
+        if constexpr (OM == OUT_LINEAR) {
 #pragma unroll
-        for (int q = 0; q < P; ++q) outv[q] = OUT[tid + q * WV];
+            for (int q = 0; q < P; ++q) outv[q] = OUT[tid + q * WV];
+        } else {
+            // polyphase: lanes 0..31 take planes 0..4, lanes 32..63 planes 5..9 of the sub-tile's 32 symbols (lane stride 10
+            // dwords: a 2-way conflict on 5 reads); a ballot of the sign bits is one 32-symbol word of two planes at once.
+            unsigned w = 0u;
+            unsigned long long sg[5];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                outv[q] = OUT[SPS_ * pl_sym + pl_h5 + q];
+                sg[q] = __builtin_amdgcn_ballot_w64(__float_as_int(outv[q]) < 0);
+            }
+            // lane q: word of plane q, lane q + 5: plane q + 5
+            w = lane_set<0>(w, (unsigned)sg[0]); w = lane_set<5>(w, (unsigned)(sg[0] >> 32));
+            w = lane_set<1>(w, (unsigned)sg[1]); w = lane_set<6>(w, (unsigned)(sg[1] >> 32));
+            w = lane_set<2>(w, (unsigned)sg[2]); w = lane_set<7>(w, (unsigned)(sg[2] >> 32));
+            w = lane_set<3>(w, (unsigned)sg[3]); w = lane_set<8>(w, (unsigned)(sg[3] >> 32));
+            w = lane_set<4>(w, (unsigned)sg[4]); w = lane_set<9>(w, (unsigned)(sg[4] >> 32));
+            const unsigned pw_ = lane_gather(w, tid >> 2);          // lane j <- word of plane j >> 2
+            bitsv = (pw_ >> (8 * (tid & 3))) & 0xffu;
+        }
         out_rel = (int)(dlo - m_seg0);
         phase_sync();
     }
@@ -832,864 +910,11 @@ __global__ void k_power_finish(const float* partial, int n_partial, long n, floa
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K2..K4: symbol receiver as a scan (SPEC 3.7-3.8)
-//
-// A detection at s (sync word's last symbol) is DECIDED at e = s + W (the peak window is complete)
-// and governs instants n > e: instant n is
-// governed by the detection with the latest e <= n.  Tiles own the EVENTS whose e falls in
-// them, so every dependency points left.
-// ------------------------------------------------------------------------------------------
-constexpr int W = P25FE_PEAK_W;
-constexpr int SPS = P25FE_SPS;
-constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
-constexpr int TB = 1024;                                     // baseband samples per tile
-constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: left context of a tile
+}  // namespace p25k
 
-struct TileRec {            // per (channel, tile) summary written by K2
-    long first_event;       // absolute decision index e = s + W of the tile's first event, -1 if none
-    long last_s;            // s of the tile's last event (absolute), valid if first_event >= 0
-    float hi, mid, lo;      // thresholds of the last event
-    int n_events;
-    long post_count;        // instants in (first_event, tile_end) under the tile's own events
-};
+#include "p25fe_recv.hip"   // K2..K4: the symbol receiver (sync detect, scan, slicer) on the polyphase layout
 
-// Packed per-tile summary for the scan (one coalesced 8-byte word per tile):
-//   bits  0..12  first_off + 1   (0: the tile has no event)      bits 13..25  last_off + 1
-//   bits 26..38  n_events                                          bits 39..51  post_count
-constexpr int TS_BITS = 13;                                  // TB + 1 <= 2^13
-constexpr unsigned long long TS_MASK = (1ull << TS_BITS) - 1;
-__host__ __device__ inline unsigned long long pack_tsum(int first_off, int last_off, int n_events, int post_count)
-{
-    return (unsigned long long)(first_off + 1) | ((unsigned long long)(last_off + 1) << TS_BITS) |
-           ((unsigned long long)n_events << (2 * TS_BITS)) | ((unsigned long long)post_count << (3 * TS_BITS));
-}
-
-struct ScanOut {            // per (channel, tile) carry-in written by K3
-    int src;                        // tile whose last event is this tile's carry-in anchor; -1: the range's anchor_in
-    unsigned event_off;             // events of the range before this tile
-    unsigned long long dibit_off;   // dibits of the range before this tile
-};
-
-__device__ __forceinline__ float bb_at(const float* bbp, long n_hist, long n, long i)
-{
-    return (i >= -n_hist && i < n) ? bbp[i] : 0.0f;
-}
-
-// thresholds from the sync word ending at local LDS index `is` (SPEC 3.8)
-__device__ __forceinline__ void sync_thresholds(const float* BT, int is, float& hi, float& mid, float& lo)
-{
-    float Pp = 0.f, Nn = 0.f;
-#pragma unroll
-    for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-        const float v = BT[is - SPS * (P25FE_SYNC_DIBITS - 1 - j)];
-        if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
-    }
-    Pp = Pp * P25FE_SYNC_INV_NPOS;
-    Nn = Nn * P25FE_SYNC_INV_NNEG;
-    mid = (Pp + Nn) * 0.5f;
-    const float span = (Pp - Nn) * 0.5f;
-    const float d = span * P25FE_SLICE_FRAC;
-    hi = mid + d;
-    lo = mid - d;
-}
-
-// the same from global memory (s = range-local index of the sync word's last symbol): same operations, same bits
-__device__ __forceinline__ void sync_thresholds_global(const float* bbp, long n_hist, long n, long s, float& hi, float& mid, float& lo)
-{
-    float Pp = 0.f, Nn = 0.f;
-#pragma unroll
-    for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-        const float v = bb_at(bbp, n_hist, n, s - SPS * (P25FE_SYNC_DIBITS - 1 - j));
-        if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
-    }
-    Pp = Pp * P25FE_SYNC_INV_NPOS;
-    Nn = Nn * P25FE_SYNC_INV_NNEG;
-    mid = (Pp + Nn) * 0.5f;
-    const float span = (Pp - Nn) * 0.5f;
-    const float d = span * P25FE_SLICE_FRAC;
-    hi = mid + d;
-    lo = mid - d;
-}
-
-// number of n in [lo, hi) with n > s and (n - s) % SPS == 0   (closed form)
-__host__ __device__ inline long count_instants(long s, long lo, long hi)
-{
-    if (lo <= s) lo = s + 1;
-    if (hi <= lo) return 0;
-    // first k with s + SPS*k >= lo
-    const long k0 = (lo - s + SPS - 1) / SPS;
-    const long k1 = (hi - 1 - s) / SPS;           // last k with s + SPS*k <= hi-1
-    return k1 >= k0 ? k1 - k0 + 1 : 0;
-}
-
-// wave-level inclusive max scan (64 lanes)
-__device__ __forceinline__ long wave_incl_max(long v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const long o = __shfl_up(v, d, 64);
-        if (lane >= d) v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_incl_sum(int v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
-
-struct SyncArgs {
-    const float* bb;        // owned baseband sample 0 of channel 0
-    long bb_stride;
-    long n_hist;            // valid samples before it
-    long n;                 // owned samples per channel
-    long abs0;              // absolute index of owned sample 0
-    int n_tiles;
-    uint8_t* events;        // [ch][n] event flags (e-indexed)
-    long ev_stride;
-    TileRec* recs;          // [ch][n_tiles]
-    unsigned long long* tsum;   // [ch][n_tiles] packed summaries for K3
-};
-
-// K2: correlate, peak-pick, flag events, summarise the tile.  Built like K1: one wave per workgroup (no s_barrier,
-// wave-level scans only), 16-B window loads.  K2_SUBS > 1 walks consecutive tiles with the next window prefetched into
-// registers; measured on config 2: 1 tile per workgroup 0.070 ms, 2: 0.077, 4: 0.081, 8: 0.089 -- short-lived waves win.
-//   correlation: lanes 0..59 = 10 sample phases x 6 slot blocks; a lane produces K2_CQ = 18 symbol-spaced outputs
-//   from a sliding window of 41 LDS reads (2.3 reads per output instead of 24), each output with its own
-//   accumulators in tap order j = 0..23 (SPEC 3.7);
-//   peak pick / instant count: a lane owns 16 consecutive samples (<= 2 symbol instants without an event inside).
-#ifndef P25FE_K2_SUBS
-#define P25FE_K2_SUBS 1
-#endif
-constexpr int K2_SUBS = P25FE_K2_SUBS;
-constexpr int K2_CQ = 18;
-constexpr int K2_LANES = SPS * 6;                                // 60 lanes busy in the correlation
-constexpr int K2_NC = TB + 2 * W;                                // c[] positions a tile needs: 1034
-constexpr int K2_VPL = TB / WV;                                  // 16 samples per lane
-constexpr int K2_NV = 6;                                         // 16-B vectors per lane: window of 1310 (+3 shift) floats
-constexpr int K2_BT = 4 * WV * K2_NV;                            // 1536 floats of LDS (every vector has a slot)
-static_assert(SPS * K2_CQ * (K2_LANES / SPS) >= K2_NC, "correlation lanes must cover the tile");
-static_assert(SPS * K2_CQ * (K2_LANES / SPS - 1) + SPS - 1 + SPS * (K2_CQ + P25FE_SYNC_DIBITS - 2) + 3 < K2_BT, "window fits");
-static_assert(K2_VPL > SPS && K2_VPL <= 2 * SPS, "instant count closed form assumes 1..2 instants per lane");
-
-__device__ __forceinline__ int wave_incl_max_i(int v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-__global__ __launch_bounds__(WV, 3) void k_sync(SyncArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float BT[K2_BT];      // BT[k] = b[t0 - HIST_BB + k]
-    float* const CT = BT;                                         // CT[k] = c[t0 - 2W + k] OVERWRITES the window once every lane
-                                                                  // has its taps in registers (one wave: program order) --
-                                                                  // 7.2 KB of LDS per wave instead of 11.3: 22 waves per CU
-    __shared__ __attribute__((aligned(8))) uint8_t CAND[K2_NC + 16];   // flag of position k at CAND[k - W + 8]: sample i's flag at the 8-aligned CAND[i + 8]
-
-    const int lane = threadIdx.x, ch = blockIdx.y;
-    const float* bbp = a.bb + (size_t)ch * a.bb_stride;
-    const long A = (long)(reinterpret_cast<uintptr_t>(bbp) >> 2);          // float address of owned sample 0
-    const float4* vec0 = reinterpret_cast<const float4*>(reinterpret_cast<uintptr_t>(bbp) & ~(uintptr_t)15);
-    const long Av = A >> 2;                                                // vector address of vec0 (the vector holding sample 0)
-    const long vlo = ((A - a.n_hist) >> 2) - Av, vhi = ((A + a.n - 1) >> 2) - Av;   // loadable vectors (relative)
-
-    float4 v[K2_NV];
-    auto load = [&](int tile) {
-        const long P = A + (long)tile * TB - HIST_BB;                      // float address of BT[0]
-        const long V0 = (P >> 2) - Av;
-        long lo = vlo - V0, hi = vhi - V0;
-        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
-        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
-        const int lo32 = (int)lo, hi32 = (int)hi;
-        const float4* q = vec0 + V0;
-#pragma unroll
-        for (int j = 0; j < K2_NV; ++j) {
-            int r = lane + j * WV;
-            r = r < lo32 ? lo32 : r;
-            r = r > hi32 ? hi32 : r;
-            v[j] = q[r];
-        }
-    };
-    auto stage = [&](int tile) {
-        const long t0 = (long)tile * TB;
-        const long P = A + t0 - HIST_BB;
-        const int sh = (int)(P & 3);
-        const bool fast = sh == 0 && t0 - HIST_BB >= -a.n_hist && t0 - HIST_BB + K2_BT <= a.n;   // uniform
-        if (fast) {
-#pragma unroll
-            for (int j = 0; j < K2_NV; ++j) *reinterpret_cast<float4*>(&BT[4 * (lane + j * WV)]) = v[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < K2_NV; ++j) {
-                const float w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 4 * (lane + j * WV) + e - sh;
-                    const long i = t0 - HIST_BB + k;
-                    if (k >= 0 && k < K2_BT) BT[k] = (i >= -a.n_hist && i < a.n) ? w4[e] : 0.0f;
-                }
-            }
-        }
-    };
-
-    const int tile_first = blockIdx.x * K2_SUBS;
-    load(tile_first);
-#pragma unroll 1
-    for (int it = 0; it < K2_SUBS; ++it) {
-        const int tile = tile_first + it;
-        if (tile >= a.n_tiles) break;                               // uniform
-        const long t0 = (long)tile * TB;                            // local index of the tile's first sample
-        const int tn = (a.n - t0 < TB) ? (int)(a.n - t0) : TB;      // samples in this tile
-        stage(tile);
-        phase_sync();
-        if (K2_SUBS > 1 && it + 1 < K2_SUBS && tile + 1 < a.n_tiles) load(tile + 1);   // uniform; prefetch the next window
-#if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 1   // measurement builds only: stop after the LDS staging
-        if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = BT[tile % K2_BT] == 123.f ? 1ull : 0ull;
-        phase_sync();
-        continue;
-#endif
-
-        // c[s], cand[s] for s = t0 - 2W + k, k in [0, TB + 2W): needs b[s - 230 .. s] = BT[k + 10 j], j = 0..23.
-        if (lane < K2_LANES) {
-            const int r = lane % SPS, qb = lane / SPS;
-            const int base = SPS * K2_CQ * qb + r;                  // k of the lane's first output
-            float w[K2_CQ + P25FE_SYNC_DIBITS - 1];
-#pragma unroll
-            for (int m = 0; m < K2_CQ + P25FE_SYNC_DIBITS - 1; ++m) w[m] = BT[base + SPS * m];
-#pragma unroll
-            for (int i = 0; i < K2_CQ; ++i) {
-                const int k = base + SPS * i;
-                float c = 0.f, e = 0.f;
-#pragma unroll
-                for (int j = 0; j < P25FE_SYNC_DIBITS; ++j) {
-                    const float x = w[i + j];
-                    c = ((P25FE_SYNC_SIGN_MASK >> j) & 1u) ? c + x : c - x;
-                    e = __builtin_fmaf(x, x, e);
-                }
-                if (k < K2_NC) {
-                    CT[k] = c;
-                    CAND[k - W + 8] = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
-                }
-            }
-        }
-        phase_sync();
-#if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 2   // stop after the correlation
-        if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = (CT[tile % K2_NC] == 123.f || CAND[tile % K2_NC]) ? 1ull : 0ull;
-        phase_sync();
-        continue;
-#endif
-
-        // event at local index i (decided when sample t0 + i arrives) <=> detection at s = t0 + i - W -> CT index
-        // k = i + W.  The peak window s + W = t0 + i - 1 < n is guaranteed by i < tn.  CAND is stored shifted so that
-        // a lane's 16 flags are two aligned 8-byte LDS reads; no candidate among them (the common case) skips the test.
-        int my_last = -1, my_first = -1, my_ev = 0;
-        unsigned evw[4] = {0u, 0u, 0u, 0u};                         // 16 event flags, one byte each
-        {
-            const uint2 c0 = *reinterpret_cast<const uint2*>(&CAND[lane * K2_VPL + 8]);
-            const uint2 c1 = *reinterpret_cast<const uint2*>(&CAND[lane * K2_VPL + 16]);
-            const unsigned cw[4] = {c0.x, c0.y, c1.x, c1.y};
-            if ((c0.x | c0.y | c1.x | c1.y) != 0u) {
-#pragma unroll
-                for (int u = 0; u < K2_VPL; ++u) {
-                    const int i = lane * K2_VPL + u;
-                    const int k = i + W;
-                    const bool cand = ((cw[u >> 2] >> (8 * (u & 3))) & 0xffu) != 0u;
-                    if (i < tn && cand) {
-                        const float cm = CT[k];
-                        bool det = true;
-#pragma unroll
-                        for (int d = 1; d <= W; ++d) det = det && (cm > CT[k - d]) && (cm >= CT[k + d]);
-                        if (det) {
-                            evw[u >> 2] |= 1u << (8 * (u & 3));
-                            if (my_first < 0) my_first = i;
-                            my_last = i; ++my_ev;
-                        }
-                    }
-                }
-            }
-        }
-        if (a.events) {
-            uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0;
-            if (lane * K2_VPL + K2_VPL <= tn && ((a.ev_stride & 15) == 0)) {
-                *reinterpret_cast<uint4*>(evp + lane * K2_VPL) = make_uint4(evw[0], evw[1], evw[2], evw[3]);
-            } else {
-#pragma unroll
-                for (int u = 0; u < K2_VPL; ++u)
-                    if (lane * K2_VPL + u < tn) evp[lane * K2_VPL + u] = (uint8_t)((evw[u >> 2] >> (8 * (u & 3))) & 1u);
-            }
-        }
-#if defined(P25FE_ABLATE2) && P25FE_ABLATE2 <= 3   // stop after peak pick + event flags
-        if (my_last == 12345) a.tsum[(size_t)ch * a.n_tiles + tile] = 1ull;
-        phase_sync();
-        continue;
-#endif
-
-        // latest own event before each lane's first sample, then count instants under own events
-        const int incl = wave_incl_max_i(my_last, lane);
-        int incoming = __shfl_up(incl, 1, 64);
-        if (lane == 0) incoming = -1;
-        int cur = incoming;                                         // tile-local index of the governing event, -1: carry-in (unknown here)
-        int cnt = 0;
-        const int i0 = lane * K2_VPL;
-        if (my_ev == 0) {
-            // common case: no event inside my 16 samples -> one or two instants, closed form
-            if (cur >= 0) {
-                const int navail = tn - i0 < K2_VPL ? tn - i0 : K2_VPL;
-                const unsigned ph = (unsigned)(i0 - (cur - W)) % (unsigned)SPS;
-                const int f = (int)((SPS - ph) % (unsigned)SPS);
-                cnt = (f < navail ? 1 : 0) + (f + SPS < navail ? 1 : 0);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < K2_VPL; ++u) {
-                const int i = i0 + u;
-                if (i < tn) {
-                    if (cur >= 0) {                                 // events decided BEFORE this sample govern it
-                        const unsigned dist = (unsigned)(i - (cur - W));   // > 0: distance to the anchor
-                        if (dist % (unsigned)SPS == 0u) ++cnt;
-                    }
-                    if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) cur = i;
-                }
-            }
-        }
-        const int total_packed = wave_sum_i(cnt | (my_ev << 16));   // instants low half, events high half
-        const int total_cnt = total_packed & 0xffff, total_ev = total_packed >> 16;
-        const int last_ev = __shfl(incl, 63, 64);
-        const unsigned long long evmask = __ballot(my_ev > 0);
-        const int first_ev = evmask ? __shfl(my_first, __builtin_ctzll(evmask), 64) : -1;
-        if (lane == 0) {
-            TileRec r;
-            r.first_event = first_ev >= 0 ? a.abs0 + t0 + first_ev : -1;
-            r.n_events = total_ev;
-            r.post_count = total_cnt;
-            r.last_s = -1; r.hi = r.mid = r.lo = 0.f;
-            if (last_ev >= 0) {
-                const int s = last_ev - W;                          // tile-local
-                float hi, mid, lo;
-                sync_thresholds_global(bbp, a.n_hist, a.n, t0 + s, hi, mid, lo);   // rare; the LDS window is gone
-                r.last_s = a.abs0 + t0 + s; r.hi = hi; r.mid = mid; r.lo = lo;
-            }
-            a.recs[(size_t)ch * a.n_tiles + tile] = r;
-            a.tsum[(size_t)ch * a.n_tiles + tile] =
-                first_ev >= 0 ? pack_tsum(first_ev, last_ev, total_ev, total_cnt) : 0ull;
-        }
-        phase_sync();                                               // BT / CT / CAND are rewritten by the next tile
-    }
-}
-
-// The scan over tiles is two-level so that it does not run on a single CU: K3a scans groups of K3_GROUP tiles in
-// parallel (one workgroup each, no carry-in), K3b walks the (few) group aggregates and hands every group its carry,
-// K4 adds the group carry to the group-local values.
-struct GroupAgg {           // per (channel, group), written by K3a
-    int first_tile;         // absolute index of the group's first tile with an event, -1 if none
-    int last_tile;          // ... last tile with an event
-    long first_event;       // absolute decision index of the group's first event
-    unsigned long long cnt_after_first;   // dibits governed by the group's own events
-    unsigned long long n_events;
-};
-struct GroupCarry {         // per (channel, group), written by K3b
-    long anchor_s;          // anchor in force at the group's first sample
-    float hi, mid, lo;
-    int valid;
-    unsigned long long dibit_base;         // dibits of the range before the group
-    unsigned long long base_after_first;   // dibit_base + dibits before the group's first own event
-    unsigned long long event_base;         // events of the range before the group
-};
-
-struct ScanArgs {
-    const TileRec* recs;
-    const unsigned long long* tsum;
-    ScanOut* outs;          // group-local: src absolute or -1, offsets relative to the group's first own event / start
-    GroupAgg* aggs;         // [ch][n_groups]
-    GroupCarry* carries;    // [ch][n_groups]
-    int n_tiles;
-    int n_groups;
-    int n_channels;
-    long n;                 // owned samples per channel
-    long abs0;
-    const p25fe_anchor_t* anchor_in;    // nullable, [ch]
-    p25fe_result_t* result;             // [ch]
-    unsigned long long n_baseband;      // to report
-};
-
-constexpr int NT3 = 1024;
-
-// 1024-thread inclusive scans: wave shuffles, then the 16 wave totals through LDS.
-__device__ __forceinline__ long block_incl_max1024(long v, long* sh, int tid, long& total)
-{
-    const int lane = tid & 63, wv = tid >> 6;
-    long inc = wave_incl_max(v, lane);
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    long carry = -1, tot = -1;
-#pragma unroll
-    for (int k = 0; k < NT3 / 64; ++k) {
-        const long t = sh[k];
-        if (k < wv) carry = t > carry ? t : carry;
-        tot = t > tot ? t : tot;
-    }
-    __syncthreads();
-    total = tot;
-    return inc > carry ? inc : carry;
-}
-__device__ __forceinline__ unsigned long long wave_incl_sum64(unsigned long long v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned long long block_incl_sum1024(unsigned long long v, unsigned long long* sh, int tid,
-                                                                  unsigned long long& total)
-{
-    const int lane = tid & 63, wv = tid >> 6;
-    const unsigned long long inc = wave_incl_sum64(v, lane);
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    unsigned long long carry = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < NT3 / 64; ++k) {
-        const unsigned long long t = sh[k];
-        if (k < wv) carry += t;
-        tot += t;
-    }
-    __syncthreads();
-    total = tot;
-    return inc + carry;
-}
-
-constexpr int K3_GROUP = 2048;                                   // tiles per K3a workgroup (2 per thread, 16 KB of LDS)
-
-// K3a: one workgroup per (group of K3_GROUP tiles, channel), no carry-in.  The packed tile summaries are staged in
-// LDS; every thread walks a contiguous run of tiles; two block scans (latest event tile; dibit / event counts).
-__global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
-{
-    __shared__ unsigned long long TS[K3_GROUP];
-    __shared__ long shl[NT3 / 64];
-    __shared__ unsigned long long shu[NT3 / 64];
-    __shared__ long excl_tmp[NT3 / 64];
-    const int tid = threadIdx.x, grp = blockIdx.x, ch = blockIdx.y;
-    const unsigned long long* tsum = a.tsum + (size_t)ch * a.n_tiles;
-    ScanOut* outs = a.outs + (size_t)ch * a.n_tiles;
-    const int c0 = grp * K3_GROUP;
-    const int cn = (a.n_tiles - c0 < K3_GROUP) ? a.n_tiles - c0 : K3_GROUP;
-
-    for (int k = tid; k < cn; k += NT3) TS[k] = tsum[c0 + k];
-    __syncthreads();
-    const int per = (cn + NT3 - 1) / NT3;
-    const int k0 = tid * per, k1 = (k0 + per < cn) ? k0 + per : cn;
-
-    // pass 1: latest event tile inside my run -> block exclusive max
-    long last = -1;
-    for (int k = k0; k < k1; ++k) if (TS[k] & TS_MASK) last = k;
-    long tot_max;
-    const long incl = block_incl_max1024(last, shl, tid, tot_max);
-    long excl = __shfl_up(incl, 1, 64);
-    if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
-    __syncthreads();
-    if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
-    __syncthreads();
-
-    // passes 2 and 3 walk the run with the anchor expressed as a PHASE: ph = (tile_start - s) mod 10, so the
-    // closed-form instant counts are 32-bit.  Tiles before the group's first event (src < 0) are governed by the
-    // group's carry-in, which is not known here: they contribute nothing and K4 adds their part from GroupCarry.
-    auto phase_at = [&](int k, long src, bool& v) -> unsigned {   // phase of tile k's start under anchor `src`
-        v = src >= 0;
-        if (!v) return 0u;
-        const int last_off = (int)((TS[src] >> TS_BITS) & TS_MASK) - 1;
-        const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TB - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
-        return dist % (unsigned)SPS;
-    };
-    auto count32 = [&](unsigned ph, int len) -> unsigned {        // n in [0, len): (ph + n) % 10 == 0
-        const int f = (int)((SPS - ph) % (unsigned)SPS);          // first instant offset
-        return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
-    };
-    auto tile_len = [&](int k) -> int {
-        const long rem = a.n - (long)(c0 + k) * TB;
-        return rem < TB ? (int)rem : TB;
-    };
-    unsigned long long my_cnt = 0, my_ev = 0;
-    {
-        long src = excl;
-        bool v = false;
-        unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
-        for (int k = k0; k < k1; ++k) {
-            const unsigned long long u = TS[k];
-            const int first1 = (int)(u & TS_MASK);
-            const int len = first1 ? first1 : tile_len(k);        // instant AT the event index is still the old anchor's
-            my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
-            my_ev += (u >> (2 * TS_BITS)) & TS_MASK;
-            if (first1) {
-                src = k; v = true;
-                const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
-                ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;     // next tile's start under the new anchor
-            } else {
-                ph = (ph + (unsigned)TB) % (unsigned)SPS;
-            }
-        }
-    }
-    unsigned long long tot_cnt, tot_ev;
-    const unsigned long long icnt = block_incl_sum1024(my_cnt, shu, tid, tot_cnt);
-    const unsigned long long iev = block_incl_sum1024(my_ev, shu, tid, tot_ev);
-
-    // pass 3: write the per-tile group-local carry-ins
-    {
-        long src = excl;
-        bool v = false;
-        unsigned ph = k0 < k1 ? phase_at(k0, src, v) : 0u;
-        unsigned long long dc = icnt - my_cnt, ec = iev - my_ev;
-        for (int k = k0; k < k1; ++k) {
-            const unsigned long long u = TS[k];
-            const int first1 = (int)(u & TS_MASK);
-            const int len = first1 ? first1 : tile_len(k);
-            const unsigned pre = v ? count32(ph, len) : 0u;
-            ScanOut o;
-            o.src = src >= 0 ? (int)(c0 + src) : -1;
-            o.event_off = (unsigned)ec;
-            o.dibit_off = dc;
-            outs[c0 + k] = o;
-            dc += pre + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
-            ec += (u >> (2 * TS_BITS)) & TS_MASK;
-            if (first1) {
-                src = k; v = true;
-                const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
-                ph = (unsigned)(TB - last_off + W) % (unsigned)SPS;
-            } else {
-                ph = (ph + (unsigned)TB) % (unsigned)SPS;
-            }
-        }
-    }
-    // group aggregate: first / last event tile (min over first-event holders = the thread with excl < 0 and an event)
-    __shared__ int first_tile_sh;
-    if (tid == 0) first_tile_sh = -1;
-    __syncthreads();
-    if (last >= 0 && excl < 0) {
-        int f = -1;
-        for (int k = k1 - 1; k >= k0; --k) if (TS[k] & TS_MASK) f = k;
-        first_tile_sh = f;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        GroupAgg g;
-        g.first_tile = first_tile_sh >= 0 ? c0 + first_tile_sh : -1;
-        g.last_tile = tot_max >= 0 ? c0 + (int)tot_max : -1;
-        g.first_event = -1;
-        if (first_tile_sh >= 0)
-            g.first_event = a.abs0 + (long)(c0 + first_tile_sh) * TB + (long)(TS[first_tile_sh] & TS_MASK) - 1;
-        g.cnt_after_first = tot_cnt;
-        g.n_events = tot_ev;
-        a.aggs[(size_t)ch * a.n_groups + grp] = g;
-    }
-}
-
-// K3b: one thread per channel walks the group aggregates (a 1-hour capture has ~80 groups) and hands every group its
-// carry-in anchor and bases; also writes the range summary.
-// K3b: one WAVE per channel.  The walk over the group aggregates is serial (each group's carry-in is the previous one's
-// carry-out), but its inputs are not: lane g fetches group g's aggregate and the TileRec of its last event tile (two
-// dependent loads, all lanes at once) into LDS, then lane 0 walks LDS.  A one-thread walk with the loads inside took 9 us
-// for the 14 groups of config 2.
-__global__ __launch_bounds__(WV) void k_scan_groups(ScanArgs a)
-{
-    __shared__ GroupAgg AG[WV];
-    __shared__ TileRec TR[WV];
-    const int ch = blockIdx.x, lane = threadIdx.x;
-    const TileRec* recs = a.recs + (size_t)ch * a.n_tiles;
-    p25fe_anchor_t A;
-    A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
-    if (a.anchor_in) A = a.anchor_in[ch];
-    unsigned long long B = 0, E = 0, base_first = 0;
-    long first_event = -1;
-    for (int g0 = 0; g0 < a.n_groups; g0 += WV) {
-        const int ng = a.n_groups - g0 < WV ? a.n_groups - g0 : WV;
-        if (lane < ng) {
-            const GroupAgg ag = a.aggs[(size_t)ch * a.n_groups + g0 + lane];
-            AG[lane] = ag;
-            if (ag.first_tile >= 0) TR[lane] = recs[ag.last_tile];
-        }
-        phase_sync();
-        if (lane == 0) {
-            for (int k = 0; k < ng; ++k) {
-                const int g = g0 + k;
-                const GroupAgg ag = AG[k];
-                const long lo = a.abs0 + (long)g * K3_GROUP * TB;
-                long hi = lo + (long)K3_GROUP * TB;
-                if (hi > a.abs0 + a.n) hi = a.abs0 + a.n;
-                GroupCarry c;
-                c.anchor_s = A.s; c.hi = A.hi; c.mid = A.mid; c.lo = A.lo; c.valid = A.valid;
-                c.dibit_base = B;
-                c.event_base = E;
-                const long pre_hi = ag.first_tile >= 0 ? ag.first_event + 1 : hi;
-                const unsigned long long lead = A.valid ? (unsigned long long)count_instants(A.s, lo, pre_hi) : 0ull;
-                c.base_after_first = B + lead;
-                a.carries[(size_t)ch * a.n_groups + g] = c;
-                B += lead;
-                if (ag.first_tile >= 0) {
-                    if (first_event < 0) { first_event = ag.first_event; base_first = B; }
-                    B += ag.cnt_after_first;
-                    const TileRec t = TR[k];
-                    A.valid = 1; A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo;
-                }
-                E += ag.n_events;
-            }
-        }
-        phase_sync();
-    }
-    if (lane == 0) {
-        p25fe_result_t r;
-        r.n_baseband = a.n_baseband;
-        r.n_dibits = B;
-        r.n_sync = E;
-        r.anchor_out = A;
-        r.first_event = first_event;
-        r.n_dibits_after_first = first_event >= 0 ? B - base_first : 0;
-        a.result[ch] = r;
-    }
-}
-
-struct SliceArgs {
-    const float* bb;
-    long bb_stride;
-    long n_hist;
-    long n;
-    long abs0;
-    int n_tiles;
-    const uint8_t* events;
-    long ev_stride;
-    const ScanOut* outs;
-    const TileRec* recs;
-    const GroupCarry* carries;          // [ch][n_groups]
-    const unsigned long long* tsum;     // [ch][n_tiles] K2's packed summaries (0: no event in the tile)
-    int n_groups;
-    uint8_t* dibits;            // [ch][dibit_stride]
-    long dibit_stride;
-    int64_t* sync_pos;          // nullable
-    uint64_t* sync_dibit;       // nullable
-    long sync_stride;
-};
-
-// K4: slice the anchored symbol instants.  One wave per workgroup walks K4_SUBS consecutive tiles; a lane owns 16
-// consecutive samples of a tile (read straight from global memory: the baseband and the flags were just written
-// and are L2 / MALL resident), the next tile's samples are requested before the current ones are used.
-//   * The carry-in of the workgroup's tiles (K3's ScanOut / GroupCarry, the anchor's TileRec) is fetched once, one
-//     lane per tile, and broadcast per tile with v_readlane: two dependent loads per workgroup, not per tile.
-//   * A tile WITHOUT events (7 of 8 in a P25 stream; K2's packed summary says so) needs no flags and no scan: the
-//     instants and their ranks are closed forms of the carry-in anchor.  Without an anchor it is skipped unread.
-#ifndef P25FE_K4_SUBS
-#define P25FE_K4_SUBS 1
-#endif
-#ifndef P25FE_K4_WPS
-#define P25FE_K4_WPS 4
-#endif
-constexpr int K4_SUBS = P25FE_K4_SUBS;
-constexpr int K4_VPL = TB / WV;                                  // 16 samples per lane
-static_assert(K4_VPL > SPS && K4_VPL <= 2 * SPS, "closed forms assume 1..2 instants per lane");
-
-__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-__device__ __forceinline__ long rl_l(long v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffL), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
-    return ((long)hi << 32) | (unsigned)lo;
-}
-__device__ __forceinline__ unsigned char slice_dibit(float v, float hi, float mid, float lo)
-{
-    return v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
-}
-
-__global__ __launch_bounds__(WV, P25FE_K4_WPS) void k_slice(SliceArgs a)
-{
-    const int lane = threadIdx.x, ch = blockIdx.y;
-    const int tile_first = blockIdx.x * K4_SUBS;
-    const float* bbp = a.bb + (size_t)ch * a.bb_stride;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(bbp) & 15u) == 0) && ((a.ev_stride & 15) == 0);
-
-    // carry-in of tile tile_first + l, computed by lane l (lanes >= K4_SUBS repeat the last one)
-    long c_anchor; float c_hi, c_mid, c_lo; int c_valid, c_has_ev; unsigned long long c_dibit_off; unsigned c_event_off, c_ph;
-    {
-        int tl = tile_first + (lane < K4_SUBS ? lane : K4_SUBS - 1);
-        tl = tl < a.n_tiles ? tl : a.n_tiles - 1;
-        const long t0 = (long)tl * TB;
-        const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tl];
-        const GroupCarry gc = a.carries[(size_t)ch * a.n_groups + tl / K3_GROUP];
-        c_has_ev = a.tsum[(size_t)ch * a.n_tiles + tl] != 0ull;
-        c_event_off = (unsigned)(gc.event_base + so.event_off);
-        if (so.src >= 0) {                                   // an event of this group governs the tile's start
-            const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
-            c_anchor = t.last_s; c_hi = t.hi; c_mid = t.mid; c_lo = t.lo; c_valid = 1;
-            c_dibit_off = gc.base_after_first + so.dibit_off;
-        } else {                                             // the group's carry-in governs it: closed-form count so far
-            c_anchor = gc.anchor_s; c_hi = gc.hi; c_mid = gc.mid; c_lo = gc.lo; c_valid = gc.valid;
-            const long glo = a.abs0 + (long)(tl / K3_GROUP) * K3_GROUP * TB;
-            c_dibit_off = gc.dibit_base + (gc.valid ? (unsigned long long)count_instants(gc.anchor_s, glo, a.abs0 + t0) : 0ull);
-        }
-        // distance of the tile's first sample to the carry-in anchor, mod 10 (the one 64-bit modulo)
-        c_ph = c_valid ? (unsigned)((a.abs0 + t0 - c_anchor) % SPS) : 0u;
-    }
-
-    float4 nb[4];
-    uint4 nev = make_uint4(0u, 0u, 0u, 0u);
-    // request tile t's samples (and flags if it has events); whole, aligned tiles only -- others are read element-wise
-    auto request = [&](int t, int has_ev, int valid) {
-        const long t0 = (long)t * TB;
-        const bool fast = aligned && t < a.n_tiles && a.n - t0 >= TB;
-        if (fast && (has_ev || valid)) {
-            // with events: a lane's 16 consecutive samples; without: lane-interleaved vectors (contiguous 1 KB per load)
-            const float4* bp = reinterpret_cast<const float4*>(bbp + t0) + (has_ev ? lane * 4 : lane);
-            const int qs = has_ev ? 1 : WV;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nb[q] = bp[q * qs];
-            if (has_ev) nev = *reinterpret_cast<const uint4*>(a.events + (size_t)ch * a.ev_stride + t0 + lane * K4_VPL);
-        }
-    };
-    request(tile_first, rl_i(c_has_ev, 0), rl_i(c_valid, 0));
-
-#pragma unroll 1
-    for (int it = 0; it < K4_SUBS; ++it) {
-        const int tile = tile_first + it;
-        if (tile >= a.n_tiles) break;                               // uniform
-        const long t0 = (long)tile * TB;
-        const int tn = (a.n - t0 < TB) ? (int)(a.n - t0) : TB;
-        const int has_ev = rl_i(c_has_ev, it), valid = rl_i(c_valid, it);
-        const bool fast = aligned && tn == TB;
-        if (fast && !has_ev) {
-            // no event in the tile: instants at i = f0 + 10 m under the carry-in anchor, ranks in closed form.  The lane
-            // holds four groups of 4 consecutive samples (interleaved vectors), each with at most one instant (4 < 10).
-            float4 cb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cb[q] = nb[q];
-            if (it + 1 < K4_SUBS) request(tile + 1, rl_i(c_has_ev, it + 1), rl_i(c_valid, it + 1));
-            if (!valid) continue;                                   // nothing decided yet: no instants
-            const float hi0 = rl_f(c_hi, it), mid0 = rl_f(c_mid, it), lo0 = rl_f(c_lo, it);
-            const unsigned base_ph = (unsigned)rl_i((int)c_ph, it);
-            uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + (unsigned long long)rl_l((long)c_dibit_off, it);
-            const int f0 = (int)((SPS - base_ph) % (unsigned)SPS);  // first instant of the tile
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = 4 * (lane + q * WV);
-                const unsigned ph = (base_ph + (unsigned)g) % (unsigned)SPS;
-                const int f = (int)((SPS - ph) % (unsigned)SPS);
-#if defined(P25FE_ABLATE4) && P25FE_ABLATE4 == 2     // measurement build: fast-path stores suppressed
-                if (f < 4 && cb[q].x == 123.f) {
-#else
-                if (f < 4) {
-#endif
-                    const float v = f == 0 ? cb[q].x : f == 1 ? cb[q].y : f == 2 ? cb[q].z : cb[q].w;
-                    out[(unsigned)(g + f - f0) / (unsigned)SPS] = slice_dibit(v, hi0, mid0, lo0);
-                }
-            }
-            continue;
-        }
-        float bv[K4_VPL];
-        unsigned evw[4] = {0u, 0u, 0u, 0u};
-        if (fast) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { bv[4 * q] = nb[q].x; bv[4 * q + 1] = nb[q].y; bv[4 * q + 2] = nb[q].z; bv[4 * q + 3] = nb[q].w; }
-            evw[0] = nev.x; evw[1] = nev.y; evw[2] = nev.z; evw[3] = nev.w;
-        } else {
-            const float* bp = bbp + t0 + lane * K4_VPL;
-            const uint8_t* evp = a.events + (size_t)ch * a.ev_stride + t0 + lane * K4_VPL;
-#pragma unroll
-            for (int u = 0; u < K4_VPL; ++u) {
-                const bool in = lane * K4_VPL + u < tn;
-                bv[u] = in ? bp[u] : 0.f;
-                if (has_ev && in && evp[u]) evw[u >> 2] |= 1u << (8 * (u & 3));
-            }
-        }
-        if (it + 1 < K4_SUBS) request(tile + 1, rl_i(c_has_ev, it + 1), rl_i(c_valid, it + 1));
-        if (!has_ev && !valid) continue;                            // nothing decided yet: no instants
-
-        const float hi0 = rl_f(c_hi, it), mid0 = rl_f(c_mid, it), lo0 = rl_f(c_lo, it);
-        const unsigned base_ph = (unsigned)rl_i((int)c_ph, it);
-        const unsigned long long dibit_off = (unsigned long long)rl_l((long)c_dibit_off, it);
-        uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + dibit_off;
-        const int i0 = lane * K4_VPL;
-
-#if defined(P25FE_ABLATE4) && P25FE_ABLATE4 == 1     // measurement build: tiles with events skipped
-        if (bv[0] != 123.f) continue;
-#endif
-        // general tile: events inside.  Latest own event before each lane's first sample, count, rank, emit.
-        int my_last = -1, my_ev = 0;
-#pragma unroll
-        for (int u = 0; u < K4_VPL; ++u)
-            if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) { my_last = i0 + u; ++my_ev; }
-        const int incl = wave_incl_max_i(my_last, lane);
-        int incoming = __shfl_up(incl, 1, 64);
-        if (lane == 0) incoming = -1;
-        int cur = incoming;
-        int cnt = 0;
-        unsigned inst = 0;
-        const unsigned cph = (base_ph + (unsigned)i0) % (unsigned)SPS;
-#pragma unroll
-        for (int u = 0; u < K4_VPL; ++u) {
-            const int i = i0 + u;
-            if (i < tn) {
-                bool is = false;
-                if (cur >= 0) is = ((unsigned)(i - (cur - W)) % (unsigned)SPS) == 0u;
-                else if (valid) is = ((cph + (unsigned)u) % (unsigned)SPS) == 0u;
-                if (is) { ++cnt; inst |= 1u << u; }
-                if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) cur = i;
-            }
-        }
-        // one wave scan for both ranks: instants in the low half, events in the high half (each <= 1024 per tile)
-        const int mine = cnt | (my_ev << 16);
-        const int packed = wave_incl_sum(mine, lane) - mine;
-        int rank = packed & 0xffff;
-        int evrank = packed >> 16;
-        const unsigned event_off = (unsigned)rl_i((int)c_event_off, it);
-        cur = incoming;
-        int thr_for = -2;                      // tile-local anchor whose thresholds are cached in hi / mid / lo
-        float hi = hi0, mid = mid0, lo = lo0;
-        // K2 left the thresholds of the tile's LAST event in its TileRec: with one event per tile (the normal case)
-        // no lane recomputes anything; only earlier events of a multi-event tile take the 24-load path below.
-        const TileRec own = a.recs[(size_t)ch * a.n_tiles + tile];
-        const int own_last = (int)(own.last_s - a.abs0 - t0) + W;
-#pragma unroll
-        for (int u = 0; u < K4_VPL; ++u) {
-            const int i = i0 + u;
-            if (i < tn) {
-                // the instant at index i (if any) is governed by events decided before i
-                if ((inst >> u) & 1u) {
-                    if (cur >= 0 && cur != thr_for && cur == own_last) {
-                        hi = own.hi; mid = own.mid; lo = own.lo;
-                        thr_for = cur;
-                    }
-                    if (cur >= 0 && cur != thr_for) {
-                        // thresholds of an in-tile anchor: same arithmetic as K2 (same bits), from global memory
-                        sync_thresholds_global(bbp, a.n_hist, a.n, t0 + cur - W, hi, mid, lo);
-                        thr_for = cur;
-                    }
-                    out[rank++] = slice_dibit(bv[u], hi, mid, lo);
-                }
-                if ((evw[u >> 2] >> (8 * (u & 3))) & 1u) {
-                    if (a.sync_pos && (long)(event_off + evrank) < a.sync_stride) {
-                        a.sync_pos[(size_t)ch * a.sync_stride + event_off + evrank] = a.abs0 + t0 + i - W;
-                        // index of the first dibit this detection governs = dibits for instants <= i
-                        a.sync_dibit[(size_t)ch * a.sync_stride + event_off + evrank] = dibit_off + rank;
-                    }
-                    ++evrank;
-                    cur = i;
-                }
-            }
-        }
-    }
-}
+namespace p25k {
 
 // ------------------------------------------------------------------------------------------
 // K5: network identifier after each frame sync (MessageEvent::PacketNID, src/recv.rs:216-222).

@@ -1,0 +1,699 @@
+// p25fe_recv.hip -- K2..K4: the symbol receiver (front half of MessageReceiver::feed, src/recv.rs:148-150, 204-210)
+// on the polyphase baseband layout that K1 writes (PLPAD in p25fe_kernels.hip; included from there).
+//
+//   K2 k_detect : frame-sync detection (SPEC 3.7).  The 48-flop correlation is NOT evaluated at every sample: a sync
+//                 candidate needs a normalised correlation >= sqrt(0.85) = 0.922 with the 24-symbol sign pattern,
+//                 which forces at most 4 of the 24 symbol-spaced samples to have the wrong sign (proof below).  K1
+//                 leaves the sign of every baseband sample in ten bit planes (1/32 of the baseband), so the screen is
+//                 5 integer ops per sample on 3.6 MB instead of 48 flops per sample on 115 MB; the few positions that
+//                 pass (0.08 % of random data) get the exact SPEC 3.7 arithmetic from the float planes, where a
+//                 24-symbol window is 96 contiguous bytes.  Same detections as evaluating c / e everywhere, bit for bit.
+//   K3 k_scan   : the receiver's serial state (anchor in force, dibits / events so far) as a scan over tile summaries.
+//   K4 k_slice  : 4-level slicer (SPEC 3.8): a locked receiver reads ONE plane, contiguously.
+//   k_planarize : linear baseband -> planes + sign bits, for the entry points that are handed a 48 kHz float stream
+//                 (p25fe_slice / p25fe_slice_dev: the RecvEvent::Baseband hand-off of src/demod.rs:116).
+//
+// Why <= 4 sign mismatches.  Let v_j be the 24 window samples, g_j = +-1 the sync signs, c = sum g_j v_j,
+// e = sum v_j^2.  Write v = a g + w with w orthogonal to g: c = 24 a, e = 24 a^2 + |w|^2.  A candidate has c > 0 and
+// c^2 >= 20.4 e, i.e. |w|^2 <= 24 a^2 (24 / 20.4 - 1) = 4.24 a^2.  A sample whose sign disagrees with g_j (g_j v_j <= 0)
+// has g_j w_j <= -a, so w_j^2 >= a^2: at most 4 of them fit.  The fp32 evaluation of c and e moves the ratio by
+// < 1e-5 relative, nowhere near the 18 % that separates 4.24 from 5.  The screen counts a mismatch only where the
+// SIGN BIT disagrees (a +0 under a '+' symbol is not counted), which can only under-count: still a superset.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace p25k {
+
+constexpr int W = P25FE_PEAK_W;
+constexpr int SPS = P25FE_SPS;
+constexpr int NSYN = P25FE_SYNC_DIBITS;
+constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
+constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: baseband history the receiver needs
+static_assert(SPS == SPS_ && PLPAD >= HIST_BB + SEG_HALO, "planar layout matches the receiver");
+
+constexpr int TSYM = 768;                                    // symbols of every plane per tile (24 words of sign bits)
+constexpr int TS = TSYM * SPS;                               // 7680 baseband samples (decision indices) per tile
+constexpr int TWORDS = TSYM / 32;                            // 24
+constexpr int EVCAP = TS / (W + 1) + 8;                      // 1288: detections are at least W + 1 samples apart
+constexpr unsigned SYNC_NEG_MASK = ~P25FE_SYNC_SIGN_MASK & 0xffffffu;   // bit j: sync symbol j (oldest first) is -3
+constexpr int SCREEN_MAX_MISMATCH = 4;
+
+struct Planar {             // polyphase baseband of one call (PLPAD in p25fe_kernels.hip)
+    const float* f;         // channel 0: f[r * ps + i] = b[10 i + r - PLPAD]
+    long ps;                // floats per plane
+    long f_ch;              // floats per channel
+    const uint32_t* bits;   // channel 0: sign planes, bits[r * bw + i / 32] bit i % 32
+    long bw;                // words per plane
+    long bits_ch;           // words per channel
+};
+
+struct TileRec {            // per (channel, tile) summary written by K2
+    long first_event;       // absolute decision index e = s + W of the tile's first event, -1 if none
+    long last_s;            // s of the tile's last event (absolute), valid if first_event >= 0
+    float hi, mid, lo;      // thresholds of the last event
+    int n_events;
+    long post_count;        // instants in (first_event, tile_end) under the tile's own events
+};
+
+// Packed per-tile summary for the scan (one coalesced 8-byte word per tile):
+//   bits  0..12  first_off + 1   (0: the tile has no event)      bits 13..25  last_off + 1
+//   bits 26..38  n_events                                          bits 39..51  post_count
+constexpr int TS_BITS = 13;
+static_assert(TS + 1 <= (1 << TS_BITS), "tile offsets fit the packed summary");
+constexpr unsigned long long TS_MASK = (1ull << TS_BITS) - 1;
+__host__ __device__ inline unsigned long long pack_tsum(int first_off, int last_off, int n_events, int post_count)
+{
+    return (unsigned long long)(first_off + 1) | ((unsigned long long)(last_off + 1) << TS_BITS) |
+           ((unsigned long long)n_events << (2 * TS_BITS)) | ((unsigned long long)post_count << (3 * TS_BITS));
+}
+
+struct ScanOut {            // per (channel, tile) carry-in written by K3
+    int src;                        // tile whose last event is in force at this tile's first sample; -1: the range's anchor_in
+    unsigned event_off;             // events of the range before this tile
+    unsigned long long dibit_off;   // dibits of the range before this tile
+};
+
+// number of n in [lo, hi) with n > s and (n - s) % SPS == 0   (closed form)
+__host__ __device__ inline long count_instants(long s, long lo, long hi)
+{
+    if (lo <= s) lo = s + 1;
+    if (hi <= lo) return 0;
+    const long k0 = (lo - s + SPS - 1) / SPS;     // first k with s + SPS*k >= lo
+    const long k1 = (hi - 1 - s) / SPS;           // last k with s + SPS*k <= hi-1
+    return k1 >= k0 ? k1 - k0 + 1 : 0;
+}
+
+__device__ __forceinline__ unsigned char slice_dibit(float v, float hi, float mid, float lo)
+{
+    return v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
+}
+
+// SPEC 3.7 on one window: w[j] = v_j, j = 0 (oldest) .. 23, symbol spaced = contiguous in a plane
+__device__ __forceinline__ void sync_corr(const float* __restrict__ w, float& c, float& e)
+{
+    float cc = 0.f, ee = 0.f;
+#pragma unroll
+    for (int j = 0; j < NSYN; ++j) {
+        const float x = w[j];
+        cc = ((P25FE_SYNC_SIGN_MASK >> j) & 1u) ? cc + x : cc - x;
+        ee = __builtin_fmaf(x, x, ee);
+    }
+    c = cc; e = ee;
+}
+
+// SPEC 3.8: thresholds from the sync word's own levels
+__device__ __forceinline__ void sync_thresholds(const float* __restrict__ w, float& hi, float& mid, float& lo)
+{
+    float Pp = 0.f, Nn = 0.f;
+#pragma unroll
+    for (int j = 0; j < NSYN; ++j) {
+        const float v = w[j];
+        if ((P25FE_SYNC_SIGN_MASK >> j) & 1u) Pp = Pp + v; else Nn = Nn + v;
+    }
+    Pp = Pp * P25FE_SYNC_INV_NPOS;
+    Nn = Nn * P25FE_SYNC_INV_NNEG;
+    mid = (Pp + Nn) * 0.5f;
+    const float span = (Pp - Nn) * 0.5f;
+    const float d = span * P25FE_SLICE_FRAC;
+    hi = mid + d;
+    lo = mid - d;
+}
+
+// window of the sync word whose last symbol is planar sample p (p = m + PLPAD): 24 contiguous floats of plane p % 10
+__device__ __forceinline__ const float* sync_window(const float* f, long ps, long p)
+{
+    const long i = p / SPS;
+    return f + (p - i * SPS) * ps + (i - (NSYN - 1));
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_sum(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ long wave_incl_max(long v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long o = __shfl_up(v, d, 64);
+        if (lane >= d) v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_incl_sum64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ int lane_rank(unsigned long long mask)      // set bits of mask below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: frame-sync detection.  One wave per tile of TS decision indices e = s + W (tile t owns the detections DECIDED in
+// [TS t, TS t + tn): every dependency points left).  Lane (plane r = lane / 6, block = lane % 6) screens 128 symbol
+// positions of its plane from five 32-bit words of sign bits.
+// ------------------------------------------------------------------------------------------
+struct DetArgs {
+    Planar pl;
+    long n;                 // owned baseband samples per channel
+    long abs0;              // absolute index of owned sample 0
+    int n_tiles;
+    TileRec* recs;          // [ch][n_tiles]
+    unsigned long long* tsum;   // [ch][n_tiles]
+    uint16_t* evl;          // [ch][n_tiles][EVCAP] decision offsets of the tile's detections, ascending
+};
+
+constexpr int K2_LANES = 60;                                     // 10 planes x 6 blocks of 4 words
+constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test
+
+__global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
+{
+    __shared__ uint16_t HITS[K2_HCAP];
+    __shared__ unsigned EVB[TS / 32];                            // detections of the tile, bit = decision offset
+    __shared__ uint16_t EVS[EVCAP];                              // the same, sorted list
+    __shared__ uint16_t CANDS[WV];
+    __shared__ float CN[5][12];
+
+    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
+    const long ps = a.pl.ps;
+    const long t0 = (long)tile * TS;
+    const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
+    const long pbase = t0 + PLPAD - W;                           // planar index of the position decided at tile offset 0
+
+    for (int k = lane; k < TS / 32; k += WV) EVB[k] = 0u;
+
+    // ---- screen: hit words, bit u of hw[j] = position (word step j, bit u) has <= 4 sign mismatches
+    unsigned hw[4] = {0u, 0u, 0u, 0u};
+    const int r = lane / 6, blk = lane % 6;
+    const int dlt = r >= SPS / 2 ? 1 : 0;                        // planes 5..9 start one symbol earlier (PLPAD - W = 315)
+    if (lane < K2_LANES) {
+        const uint32_t* bw = a.pl.bits + (size_t)ch * a.pl.bits_ch + (size_t)r * a.pl.bw + (size_t)tile * TWORDS + 4 * blk;
+        unsigned wd[6];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wd[k] = bw[k];
+        wd[5] = 0u;
+        if (dlt) {                                                // shift the 160-bit string up by one: same code for both halves
+#pragma unroll
+            for (int k = 4; k >= 1; --k) wd[k] = __builtin_amdgcn_alignbit(wd[k], wd[k - 1], 31);
+            wd[0] <<= 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned acc = 0u;
+#pragma unroll
+            for (int u = 31; u >= 0; --u) {
+                // position = local bit 32 (j + 1) + u; its window = bits [pos - 23, pos] = 24 bits from bit 9 + u of word j
+                const unsigned win = u <= 22 ? __builtin_amdgcn_alignbit(wd[j + 1], wd[j], 9 + u)
+                                             : __builtin_amdgcn_alignbit(wd[j + 2], wd[j + 1], u - 23);
+                const unsigned x = (win ^ SYNC_NEG_MASK) & 0xffffffu;
+                const int t = __builtin_popcount(x) - (SCREEN_MAX_MISMATCH + 1);     // negative <=> screened in
+                acc = __builtin_amdgcn_alignbit(acc, (unsigned)t, 31);                // acc = acc << 1 | sign(t)
+            }
+            hw[j] = acc;
+        }
+    }
+
+    // ---- exact test of the screened positions (SPEC 3.7), candidates -> peak test against their 10 neighbours
+    int nh = 0;
+    auto flush_hits = [&]() {
+        for (int b = 0; b < nh; b += WV) {
+            const int h = b + lane;
+            const bool act = h < nh;
+            const int eo = act ? (int)HITS[h] : 0;
+            bool cand = false;
+            if (act) {
+                float c, e;
+                sync_corr(sync_window(f, ps, pbase + eo), c, e);
+                cand = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
+            }
+            const unsigned long long cm = __ballot(cand);
+            const int nc = __popcll(cm);
+            if (cand) CANDS[lane_rank(cm)] = (uint16_t)eo;
+            phase_sync();
+            for (int cb = 0; cb < nc; cb += 5) {
+                const int q = lane / 11, d = lane - 11 * q;
+                const bool act2 = lane < 55 && cb + q < nc;
+                const int ec = act2 ? (int)CANDS[cb + q] : 0;
+                if (act2) {
+                    float c, e;
+                    sync_corr(sync_window(f, ps, pbase + ec + d - W), c, e);
+                    CN[q][d] = c;
+                }
+                phase_sync();
+                if (act2 && d == W) {
+                    const float c0 = CN[q][W];
+                    bool det = true;
+#pragma unroll
+                    for (int i = 1; i <= W; ++i) det = det && (c0 > CN[q][W - i]) && (c0 >= CN[q][W + i]);
+                    if (det) atomicOr(&EVB[ec >> 5], 1u << (ec & 31));
+                }
+                phase_sync();
+            }
+        }
+        nh = 0;
+    };
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        unsigned hwj = hw[j];
+        while (true) {
+            const bool any = hwj != 0u;
+            if (__ballot(any) == 0ull) break;
+            int eo = TS;
+            if (any) {
+                const int u = __builtin_ctz(hwj);
+                hwj &= hwj - 1u;
+                eo = SPS * (128 * blk + 32 * (j + 1) + u - dlt) + r - (PLPAD - W);
+            }
+            const bool keep = eo < tn;                              // positions past the end of the range are not decided here
+            const unsigned long long km = __ballot(keep);
+            if (keep) HITS[nh + lane_rank(km)] = (uint16_t)eo;
+            nh += __popcll(km);
+            phase_sync();
+            if (nh > K2_HCAP - WV) flush_hits();
+        }
+    }
+    flush_hits();
+    phase_sync();
+
+    // ---- sorted event list + tile summary
+    int cnt = 0;
+    unsigned ew[4] = {0u, 0u, 0u, 0u};
+    if (lane < TS / 128) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ew[k] = EVB[4 * lane + k]; cnt += __builtin_popcount(ew[k]); }
+    }
+    const int incl = wave_incl_sum(cnt, lane);
+    const int n_ev = __shfl(incl, WV - 1, 64);
+    if (n_ev == 0) {
+        if (lane == 0) {
+            TileRec rc;
+            rc.first_event = -1; rc.last_s = -1; rc.hi = rc.mid = rc.lo = 0.f; rc.n_events = 0; rc.post_count = 0;
+            a.recs[(size_t)ch * a.n_tiles + tile] = rc;
+            a.tsum[(size_t)ch * a.n_tiles + tile] = 0ull;
+        }
+        return;
+    }
+    {
+        int pos = incl - cnt;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned w_ = ew[k];
+            while (w_) {
+                const int u = __builtin_ctz(w_);
+                w_ &= w_ - 1u;
+                EVS[pos++] = (uint16_t)(128 * lane + 32 * k + u);
+            }
+        }
+    }
+    phase_sync();
+    uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+    int post = 0;
+    for (int k = lane; k < n_ev; k += WV) {
+        const int ek = EVS[k];
+        evl[k] = (uint16_t)ek;
+        const int nxt = k + 1 < n_ev ? (int)EVS[k + 1] + 1 : tn;
+        post += (int)count_instants(ek - W, ek + 1, nxt);          // instants in (e_k, e_{k+1}] under anchor s_k
+    }
+    post = wave_sum_i(post);
+    const int first_off = EVS[0], last_off = EVS[n_ev - 1];
+    float hi, mid, lo;
+    sync_thresholds(sync_window(f, ps, pbase + last_off), hi, mid, lo);    // uniform: every lane, same window
+    if (lane == 0) {
+        TileRec rc;
+        rc.first_event = a.abs0 + t0 + first_off;
+        rc.last_s = a.abs0 + t0 + last_off - W;
+        rc.hi = hi; rc.mid = mid; rc.lo = lo;
+        rc.n_events = n_ev;
+        rc.post_count = post;
+        a.recs[(size_t)ch * a.n_tiles + tile] = rc;
+        a.tsum[(size_t)ch * a.n_tiles + tile] = pack_tsum(first_off, last_off, n_ev, post);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: scan of the tile summaries.  One workgroup per channel walks the tiles in chunks of K3_CHUNK; inside a chunk
+// every thread owns a short run of tiles and two block scans (latest event tile; dibit / event counts, the counts of
+// event-free stretches in closed form through the phase (tile_start - s) mod 10) give every tile its carry-in.  The
+// state carried from chunk to chunk is the receiver's: anchor in force, dibits and events so far.
+// ------------------------------------------------------------------------------------------
+struct ScanArgs {
+    const TileRec* recs;
+    const unsigned long long* tsum;
+    ScanOut* outs;
+    int n_tiles;
+    long n;                 // owned samples per channel
+    long abs0;
+    const p25fe_anchor_t* anchor_in;    // nullable, [ch]
+    p25fe_result_t* result;             // [ch]
+    unsigned long long n_baseband;      // to report
+};
+
+constexpr int NT3 = 512;                                     // 8 waves: 256 VGPRs each (1024 threads spilled 25 of their 128)
+constexpr int K3_CHUNK = 4096;
+
+__device__ __forceinline__ long block_incl_max(long v, long* sh, int tid, long& total)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    long inc = wave_incl_max(v, lane);
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    long carry = -1, tot = -1;
+#pragma unroll
+    for (int k = 0; k < NT3 / 64; ++k) {
+        const long t = sh[k];
+        if (k < wv) carry = t > carry ? t : carry;
+        tot = t > tot ? t : tot;
+    }
+    __syncthreads();
+    total = tot;
+    return inc > carry ? inc : carry;
+}
+__device__ __forceinline__ unsigned long long block_incl_sum(unsigned long long v, unsigned long long* sh, int tid,
+                                                                  unsigned long long& total)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long inc = wave_incl_sum64(v, lane);
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    unsigned long long carry = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT3 / 64; ++k) {
+        const unsigned long long t = sh[k];
+        if (k < wv) carry += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return inc + carry;
+}
+
+__global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
+{
+    __shared__ unsigned long long TSL[K3_CHUNK];
+    __shared__ long shl[NT3 / 64];
+    __shared__ unsigned long long shu[NT3 / 64];
+    __shared__ long excl_tmp[NT3 / 64];
+    // carried state
+    __shared__ int c_valid, c_src;
+    __shared__ long c_s, c_first_event;
+    __shared__ unsigned long long c_cnt, c_ev, c_base_first;
+    __shared__ long n_first_event;                                // found in the current chunk
+    __shared__ unsigned long long n_base_first;
+
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    const unsigned long long* tsum = a.tsum + (size_t)ch * a.n_tiles;
+    ScanOut* outs = a.outs + (size_t)ch * a.n_tiles;
+    if (tid == 0) {
+        p25fe_anchor_t A;
+        A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
+        if (a.anchor_in) A = a.anchor_in[ch];
+        c_valid = A.valid; c_s = A.s; c_src = -1;
+        c_cnt = 0; c_ev = 0; c_first_event = -1; c_base_first = 0;
+    }
+    __syncthreads();
+
+    auto count32 = [&](unsigned ph, int len) -> unsigned {        // n in [0, len): (ph + n) % 10 == 0
+        const int f = (int)((SPS - ph) % (unsigned)SPS);          // first instant offset
+        return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
+    };
+
+    for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
+        const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
+        for (int k = tid; k < cn; k += NT3) TSL[k] = tsum[c0 + k];
+        if (tid == 0) n_first_event = -1;
+        __syncthreads();
+        const int per = (cn + NT3 - 1) / NT3;
+        const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
+
+        // pass 1: latest event tile inside my run -> block exclusive max
+        long last = -1;
+        for (int k = k0; k < k1; ++k) if (TSL[k] & TS_MASK) last = k;
+        long tot_max;
+        const long incl = block_incl_max(last, shl, tid, tot_max);
+        long excl = __shfl_up(incl, 1, 64);
+        if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
+        __syncthreads();
+        if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
+        __syncthreads();
+
+        const int cv = c_valid, csrc = c_src;
+        const long cs = c_s;
+        const unsigned long long ccnt = c_cnt, cev = c_ev;
+        const long cfirst = c_first_event;
+
+        // phase of tile k's first sample under the anchor in force there: ph = (tile_start - s) mod 10
+        auto phase_at = [&](int k, long src, bool& v) -> unsigned {
+            if (src >= 0) {
+                v = true;
+                const int last_off = (int)((TSL[src] >> TS_BITS) & TS_MASK) - 1;
+                const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TS - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
+                return dist % (unsigned)SPS;
+            }
+            v = cv != 0;
+            if (!v) return 0u;
+            return (unsigned)((a.abs0 + (long)(c0 + k) * TS - cs) % SPS);          // the one 64-bit modulo per thread
+        };
+        auto tile_len = [&](int k) -> int {
+            const long rem = a.n - (long)(c0 + k) * TS;
+            return rem < TS ? (int)rem : TS;
+        };
+        bool v0 = false;
+        const unsigned ph0 = k0 < k1 ? phase_at(k0, excl, v0) : 0u;
+        // pass 2: dibits / events of my run
+        unsigned long long my_cnt = 0, my_ev = 0;
+        if (k0 < k1) {
+            bool v = v0;
+            unsigned ph = ph0;
+            for (int k = k0; k < k1; ++k) {
+                const unsigned long long u = TSL[k];
+                const int first1 = (int)(u & TS_MASK);
+                const int len = first1 ? first1 : tile_len(k);    // the instant AT the decision index is still the old anchor's
+                my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
+                my_ev += (u >> (2 * TS_BITS)) & TS_MASK;
+                if (first1) {
+                    v = true;
+                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
+                    ph = (unsigned)(TS - last_off + W) % (unsigned)SPS;      // next tile's start under the new anchor
+                } else {
+                    ph = (ph + (unsigned)TS) % (unsigned)SPS;
+                }
+            }
+        }
+        unsigned long long tot_cnt, tot_ev;
+        const unsigned long long icnt = block_incl_sum(my_cnt, shu, tid, tot_cnt);
+        const unsigned long long iev = block_incl_sum(my_ev, shu, tid, tot_ev);
+
+        // pass 3: per-tile carry-ins
+        if (k0 < k1) {
+            long src = excl;
+            bool v = v0;
+            unsigned ph = ph0;
+            unsigned long long dc = ccnt + icnt - my_cnt, ec = cev + iev - my_ev;
+            for (int k = k0; k < k1; ++k) {
+                const unsigned long long u = TSL[k];
+                const int first1 = (int)(u & TS_MASK);
+                const int len = first1 ? first1 : tile_len(k);
+                const unsigned pre = v ? count32(ph, len) : 0u;
+                ScanOut o;
+                o.src = src >= 0 ? (int)(c0 + src) : csrc;
+                o.event_off = (unsigned)ec;
+                o.dibit_off = dc;
+                outs[c0 + k] = o;
+                if (first1 && src < 0 && cfirst < 0) {            // the range's first own detection
+                    n_first_event = a.abs0 + (long)(c0 + k) * TS + first1 - 1;
+                    n_base_first = dc + pre;
+                }
+                dc += pre + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
+                ec += (u >> (2 * TS_BITS)) & TS_MASK;
+                if (first1) {
+                    src = k; v = true;
+                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
+                    ph = (unsigned)(TS - last_off + W) % (unsigned)SPS;
+                } else {
+                    ph = (ph + (unsigned)TS) % (unsigned)SPS;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (tot_max >= 0) {
+                const int last_off = (int)((TSL[tot_max] >> TS_BITS) & TS_MASK) - 1;
+                c_valid = 1;
+                c_s = a.abs0 + (long)(c0 + tot_max) * TS + last_off - W;
+                c_src = c0 + (int)tot_max;
+            }
+            c_cnt = ccnt + tot_cnt;
+            c_ev = cev + tot_ev;
+            if (cfirst < 0 && n_first_event >= 0) { c_first_event = n_first_event; c_base_first = n_base_first; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p25fe_result_t r;
+        r.n_baseband = a.n_baseband;
+        r.n_dibits = c_cnt;
+        r.n_sync = c_ev;
+        p25fe_anchor_t A;
+        A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
+        if (a.anchor_in) A = a.anchor_in[ch];
+        if (c_src >= 0) {
+            const TileRec t = a.recs[(size_t)ch * a.n_tiles + c_src];
+            A.valid = 1; A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo;
+        }
+        r.anchor_out = A;
+        r.first_event = c_first_event;
+        r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
+        a.result[ch] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: slicer.  One wave per tile.  A tile is a short list of segments -- [tile start, first own detection] under the
+// carry-in anchor, then one per own detection -- and inside a segment the symbol instants are CONSECUTIVE floats of one
+// plane: lane-consecutive loads, lane-consecutive byte stores.
+// ------------------------------------------------------------------------------------------
+struct SliceArgs {
+    Planar pl;
+    long n;
+    long abs0;
+    int n_tiles;
+    const ScanOut* outs;
+    const TileRec* recs;
+    const unsigned long long* tsum;
+    const uint16_t* evl;
+    const p25fe_anchor_t* anchor_in;    // nullable, [ch]
+    uint8_t* dibits;            // [ch][dibit_stride]
+    long dibit_stride;
+    int64_t* sync_pos;          // nullable
+    uint64_t* sync_dibit;       // nullable
+    long sync_stride;
+};
+
+__global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
+{
+    __shared__ uint16_t EV[EVCAP];
+    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
+    const long ps = a.pl.ps;
+    const long t0 = (long)tile * TS;
+    const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
+    const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
+    const unsigned long long u = a.tsum[(size_t)ch * a.n_tiles + tile];
+    const int n_ev = (int)((u >> (2 * TS_BITS)) & TS_MASK);
+
+    // carry-in anchor
+    int valid = 0;
+    long s_abs = 0;
+    float hi = 0.f, mid = 0.f, lo = 0.f;
+    if (so.src >= 0) {
+        const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
+        valid = 1; s_abs = t.last_s; hi = t.hi; mid = t.mid; lo = t.lo;
+    } else if (a.anchor_in) {
+        const p25fe_anchor_t A = a.anchor_in[ch];
+        valid = A.valid; s_abs = A.s; hi = A.hi; mid = A.mid; lo = A.lo;
+    }
+    if (!valid && n_ev == 0) return;                                // nothing decided yet: no instants
+    if (n_ev) {
+        const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+        for (int k = lane; k < n_ev; k += WV) EV[k] = evl[k];
+        phase_sync();
+    }
+    uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
+
+    // instants m in [m_lo, m_hi) (tile-local) that are congruent to the anchor: first one at m_lo + off
+    auto emit = [&](int off, int m_lo, int m_hi, float h, float m, float l, int rank) -> int {
+        const int m_first = m_lo + off;
+        if (m_first >= m_hi) return 0;
+        const int count = (m_hi - 1 - m_first) / SPS + 1;
+        const long p = t0 + m_first + PLPAD;
+        const long i0 = p / SPS;
+        const float* src = f + (p - i0 * SPS) * ps + i0;
+        uint8_t* dst = out + rank;
+        for (int j0 = 0; j0 < count; j0 += 4 * WV) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * WV + lane;
+                v[q] = j < count ? src[j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * WV + lane;
+                if (j < count) dst[j] = slice_dibit(v[q], h, m, l);
+            }
+        }
+        return count;
+    };
+
+    int rank = 0;
+    {
+        const int m_hi = n_ev ? (int)(u & TS_MASK) : tn;            // first_off + 1: the instant AT the decision index is the old anchor's
+        if (valid) {
+            const unsigned ph = (unsigned)((a.abs0 + t0 - s_abs) % SPS);     // tile start is past the anchor: positive
+            rank += emit((int)((SPS - ph) % (unsigned)SPS), 0, m_hi, hi, mid, lo, 0);
+        }
+    }
+    for (int k = 0; k < n_ev; ++k) {
+        const int ek = EV[k];
+        const int m_hi = k + 1 < n_ev ? (int)EV[k + 1] + 1 : tn;
+        float h, m, l;
+        sync_thresholds(sync_window(f, ps, t0 + ek - W + PLPAD), h, m, l);     // uniform window; same arithmetic as K2
+        if (lane == 0 && a.sync_pos && (long)(so.event_off + k) < a.sync_stride) {
+            a.sync_pos[(size_t)ch * a.sync_stride + so.event_off + k] = a.abs0 + t0 + ek - W;
+            // index of the first dibit this detection governs = dibits for instants <= e_k
+            a.sync_dibit[(size_t)ch * a.sync_stride + so.event_off + k] = so.dibit_off + (unsigned long long)rank;
+        }
+        // instants n > e_k with n = s_k + 10 j: the first is s_k + 10 = e_k + 5
+        rank += emit(SPS - W - 1, ek + 1, m_hi, h, m, l, rank);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// linear baseband -> planes + sign bits (entry points that receive a 48 kHz float stream).  Workgroup = 10 waves,
+// wave r fills 64 symbols of plane r: the ten waves read the same 2.5 KB of the linear stream (L1), every plane row
+// is written as one contiguous 256-byte store, and the ballot of the sign bits is the plane's 64-bit word.
+// ------------------------------------------------------------------------------------------
+struct PlanarizeArgs {
+    const float* bb;        // owned baseband sample 0 of channel 0
+    long bb_stride;
+    long n_hist;            // valid samples before it
+    long n;                 // owned samples
+    float* f;               // planar out, channel 0
+    long ps, f_ch;
+    uint32_t* bits;
+    long bw, bits_ch;
+};
+
+__global__ __launch_bounds__(WV * SPS) void k_planarize(PlanarizeArgs a)
+{
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6, ch = blockIdx.y;
+    const long i = (long)blockIdx.x * WV + lane;
+    const long m = SPS * i + r - PLPAD;
+    const long hist = a.n_hist < HIST_BB ? a.n_hist : HIST_BB;
+    const float v = (m >= -hist && m < a.n) ? a.bb[(size_t)ch * a.bb_stride + m] : 0.0f;
+    if (i < a.ps) a.f[(size_t)ch * a.f_ch + (size_t)r * a.ps + i] = v;
+    const unsigned long long sg = __ballot(__float_as_int(v) < 0);
+    if (lane < 2) {
+        const long w = (long)blockIdx.x * 2 + lane;
+        if (w < a.bw) a.bits[(size_t)ch * a.bits_ch + (size_t)r * a.bw + w] = (unsigned)(sg >> (32 * lane));
+    }
+}
+
+}  // namespace p25k

@@ -685,3 +685,27 @@ def test_config5_full_size_single_gpu(FE):
     k = min(nd, len(truth) - 24)
     assert k > 17_279_000 and np.array_equal(got[:k], truth[24:24 + k])
     assert int(r["n_sync"]) == len(truth) // 864 + (1 if len(truth) % 864 >= 24 else 0)
+
+
+@pytest.mark.gpu
+def test_run_dev_every_symbol_phase(O, FE):
+    """The fused path keeps the baseband in ten polyphase planes and a locked receiver reads only the plane of its
+    symbol phase: sweep the timing offset so that every plane (and its sign-bit plane) carries the sync words and the
+    symbol instants at least once.  (A stale sign-bit word of plane 0 was invisible to every single-phase test.)"""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    fe = FE()
+    phases = set()
+    for off in range(0, 50, 3):
+        iq, _, _ = c4fm.synth(0.4, seed=900 + off, snr_db=25.0, timing_offset=off, frame_dibits=200 + off)
+        rx = O.Recv()
+        ref, spos, _ = rx.feed(O.Demod().feed_cf32(iq))
+        assert len(spos) >= 3
+        phases.add(int(spos[0]) % 10)
+        t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+        dib, res = fe.run_dev(t)
+        r = parse_results(res)[0]
+        assert int(r["n_dibits"]) == len(ref) and int(r["n_sync"]) == len(spos), off
+        assert np.array_equal(dib[0, :len(ref)].cpu().numpy(), ref), off
+    assert len(phases) == 10, phases
