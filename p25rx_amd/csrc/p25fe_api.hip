@@ -50,6 +50,7 @@ struct p25fe {
     int n_cu = 256;
     Taps taps;
     int k1_p = 5;                          // FIR outputs per thread
+    bool k1_dma = false;                   // P25FE_K1_DMA=1: cf32 windows by LDS-DMA instead of register staging (measured slower)
     bool default_taps = true;              // taps == p25fe_spec.h tables bit for bit -> immediate-coefficient kernels
     DevBuf d_taps;                         // device copy for the generic kernels
     hipStream_t stream = nullptr;          // for the host-pointer calls
@@ -79,15 +80,15 @@ struct p25fe {
 
 // geometry of the planar scratch for n_bb owned baseband samples (p25fe_recv.hip: Planar)
 struct PlanarGeo {
-    size_t n_tiles, ps, bw;
+    size_t n_tiles, n_blocks;
     explicit PlanarGeo(size_t n_bb)
     {
         n_tiles = (n_bb + TS - 1) / TS;
         if (n_tiles == 0) n_tiles = 1;
-        ps = (size_t)TSYM * n_tiles + 96;          // K1 writes symbols < 768 n_tiles + 32; K2 reads words < 24 n_tiles + 3
-        ps = (ps + 63) / 64 * 64;
-        bw = ps / 32;
+        n_blocks = (size_t)TWORDS * n_tiles + 6;   // K1 writes symbols < 768 n_tiles + 32; K2 reads words < 24 n_tiles + 5
     }
+    size_t floats() const { return n_blocks * PL_BLK; }
+    size_t words() const { return n_blocks * SPS; }
 };
 
 constexpr int PROF_RING = 64;
@@ -196,6 +197,8 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     {
         const char* pv = getenv("P25FE_K1_P");            // tuning knob: FIR outputs per lane (5 default, 3)
         h->k1_p = (pv && atoi(pv) == 3) ? 3 : 5;
+        const char* dv = getenv("P25FE_K1_DMA");
+        h->k1_dma = dv && atoi(dv) == 1;
     }
     auto set_lds = [&](const void* f, size_t bytes) {
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -208,6 +211,10 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     P25FE_FOR_K1(5)
     P25FE_FOR_K1(3)
 #undef P25FE_FOR_K1
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_LINEAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
@@ -286,12 +293,14 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.bb_stride = (long)bb_stride;
     a.n_out = (long)n_out;
     a.subs_per_seg = (int)subs;
+    static const int xg_env = [] { const char* e = getenv("P25FE_XCD_GROUP"); return e ? atoi(e) : 0; }();
+    a.xcd_group = xg_env;
     a.m_begin = m_begin;
     a.power_partial = nullptr;
-    a.bbp = nullptr; a.plane_stride = a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_stride = a.bits_ch_stride = 0;
+    a.bbp = nullptr; a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_ch_stride = 0;
     if (planar) {
-        a.bbp = h->pl_f.as<float>(); a.plane_stride = (long)planar->ps; a.bbp_ch_stride = (long)(SPS * planar->ps);
-        a.bits = h->pl_bits.as<uint8_t>(); a.bits_stride = (long)(4 * planar->bw); a.bits_ch_stride = (long)(4 * SPS * planar->bw);
+        a.bbp = h->pl_f.as<float>(); a.bbp_ch_stride = (long)planar->floats();
+        a.bits = h->pl_bits.as<uint8_t>(); a.bits_ch_stride = (long)(4 * planar->words());
     }
     if (d_power_dbm) {
         HIPCHK(h, h->power_partial.ensure(sizeof(float) * (size_t)h->C * (size_t)n_seg));
@@ -310,9 +319,19 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
             else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK, OM>), grid, dim3(WV), lds, st, a, dt);                   \
         }                                                                                                                 \
     } while (0)
-    if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
+#define P25FE_LAUNCH_K1_DMA(OM)                                                                                           \
+    do {                                                                                                                  \
+        const size_t lds = Geo<5>::LDS_BYTES_DMA;                                                                         \
+        if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);  \
+        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);                 \
+    } while (0)
+    const bool dma = h->k1_dma && fmt == P25FE_FMT_CF32 && pk == 5;
+    if (dma && planar) P25FE_LAUNCH_K1_DMA(OUT_PLANAR);
+    else if (dma) P25FE_LAUNCH_K1_DMA(OUT_LINEAR);
+    else if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
     else if (pk == 3) P25FE_LAUNCH_K1(3, OUT_LINEAR);
     else P25FE_LAUNCH_K1(5, OUT_LINEAR);
+#undef P25FE_LAUNCH_K1_DMA
 #undef P25FE_LAUNCH_K1
     HIPCHK(h, hipGetLastError());
     if (d_power_dbm) {
@@ -327,8 +346,8 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
 {
     const size_t C = (size_t)h->C;
     const PlanarGeo g(n_bb);
-    HIPCHK(h, h->pl_f.ensure(C * SPS * g.ps * sizeof(float)));
-    HIPCHK(h, h->pl_bits.ensure(C * SPS * g.bw * sizeof(uint32_t)));
+    HIPCHK(h, h->pl_f.ensure(C * g.floats() * sizeof(float)));
+    HIPCHK(h, h->pl_bits.ensure(C * g.words() * sizeof(uint32_t)));
     HIPCHK(h, h->evl.ensure(C * g.n_tiles * EVCAP * sizeof(uint16_t)));
     HIPCHK(h, h->recs.ensure(C * g.n_tiles * sizeof(TileRec)));
     HIPCHK(h, h->tsum.ensure(C * g.n_tiles * sizeof(unsigned long long)));
@@ -339,8 +358,8 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
 static Planar planar_view(const p25fe_t* h, const PlanarGeo& g)
 {
     Planar p;
-    p.f = h->pl_f.as<float>(); p.ps = (long)g.ps; p.f_ch = (long)(SPS * g.ps);
-    p.bits = h->pl_bits.as<uint32_t>(); p.bw = (long)g.bw; p.bits_ch = (long)(SPS * g.bw);
+    p.f = h->pl_f.as<float>(); p.f_ch = (long)g.floats();
+    p.bits = h->pl_bits.as<uint32_t>(); p.bits_ch = (long)g.words();
     return p;
 }
 
@@ -350,9 +369,9 @@ static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, siz
     const PlanarGeo g(n_bb);
     PlanarizeArgs a;
     a.bb = d_bb; a.bb_stride = (long)bb_stride; a.n_hist = (long)n_hist_bb; a.n = (long)n_bb;
-    a.f = h->pl_f.as<float>(); a.ps = (long)g.ps; a.f_ch = (long)(SPS * g.ps);
-    a.bits = h->pl_bits.as<uint32_t>(); a.bw = (long)g.bw; a.bits_ch = (long)(SPS * g.bw);
-    hipLaunchKernelGGL(k_planarize, dim3((unsigned)(g.ps / WV), (unsigned)h->C), dim3(WV * SPS), 0, st, a);
+    a.f = h->pl_f.as<float>(); a.f_ch = (long)g.floats();
+    a.bits = h->pl_bits.as<uint32_t>(); a.bits_ch = (long)g.words(); a.n_blocks = (long)g.n_blocks;
+    hipLaunchKernelGGL(k_planarize, dim3((unsigned)((g.n_blocks + 1) / 2), (unsigned)h->C), dim3(WV * SPS), 0, st, a);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }

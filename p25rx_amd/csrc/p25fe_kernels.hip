@@ -49,15 +49,18 @@ constexpr int SEG_HALO = 80;
 static_assert(SEG_HALO >= HALO_D && SEG_HALO % 80 == 0, "segment halo covers the filter memory and is byte-aligned per plane");
 
 // Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
-// 240 history samples of the receiver at m = -240..-1), sample p lives in plane r = p % 10 at symbol index i = p / 10:
-//   bbp[r * plane_stride + i]                       fp32, and its sign bit in
-//   bits[r * bits_stride + i / 32] bit (i % 32)     (1 = negative or -0)
-// One plane is what a locked 4800 Bd slicer reads (every 10th sample, contiguous), a 24-symbol sync window is 96
-// contiguous bytes, and the sign planes (1/32 of the baseband) are all the frame-sync prefilter has to touch.
+// 240 history samples of the receiver at m = -240..-1), sample p belongs to plane r = p % 10 at symbol index i = p / 10.
+// Storage is BLOCKED: a block holds 32 consecutive symbols of all ten planes,
+//   bbp[(i / 32) * 320 + r * 32 + i % 32]          fp32  (one block = 1280 contiguous bytes = one K1 sub-tile)
+//   bits[(i / 32) * 10 + r]  bit (i % 32)           sign of that sample (1 = negative or -0)
+// A locked 4800 Bd slicer reads one plane: 128 contiguous bytes per 32 symbols; a 24-symbol sync window is 96 bytes
+// in at most two pieces; the sign words (1/32 of the baseband) are all the frame-sync screen has to touch.
 constexpr int SPS_ = P25FE_SPS;
 constexpr int PLPAD = 320;                   // >= 240 + SEG_HALO, multiple of 320 (owned sample 0 = bit 0 of word 1)
 static_assert(PLPAD % 320 == 0 && PLPAD >= 240 + SEG_HALO, "planar pad");
 constexpr int OUT_LINEAR = 0, OUT_PLANAR = 1;
+constexpr int PL_BLK = 32 * P25FE_SPS;       // floats per block
+__host__ __device__ inline long planar_index(long i, int r) { return (i >> 5) * PL_BLK + r * 32 + (i & 31); }
 // history (input samples before the first owned one) needed for exact results
 constexpr int HIST_IQ = DEC * HALO_D + (T1 - 1) + (DEC - 1);   // 284
 
@@ -73,6 +76,10 @@ template <int PK> struct Geo {
     // workgroups fit a CU's 160 KB instead of 9 (occupancy is what bounds the overlap of HBM, LDS and VALU work).
     static constexpr size_t LDS_BYTES = sizeof(float2) * (D_CARRY + XIN_N) + sizeof(float) * (T1 + T2 + 3);
     static_assert(sizeof(float2) * XIN_N >= sizeof(float2) * SUB + sizeof(float) * SUB, "d and the transpose fit the window region");
+    // LDS-DMA variant (LD_DMA below): [d carry 40 | d SUB (the output transpose overlays its front)][window: NVD KB][taps].
+    // The window cannot be overlaid: the next one is in flight into it while d, y and the outputs are produced.
+    static constexpr int NVD = (XWIN + 2 + 2 * WV - 1) / (2 * WV);            // 1-KB DMA pieces per window: 13 for PK = 5
+    static constexpr size_t LDS_BYTES_DMA = sizeof(float2) * (D_N + 2 * WV * NVD) + sizeof(float) * (T1 + T2 + 3);
     static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
     static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
@@ -88,7 +95,10 @@ __device__ __forceinline__ float spec_atan2f(float y, float x)
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
     const float mx = ax > ay ? ax : ay;
     const float mn = ax > ay ? ay : ax;
-    if (mx == 0.0f) return 0.0f;
+    // Branch-free: the spec's "if mx == 0 return +0" is a select at the END (0 / 0 = NaN flows through the polynomial and
+    // is discarded).  With the early return every call sat in its own exec-masked block, and a lane's five calls -- a
+    // correctly rounded division and a 7-deep Horner chain each -- ran one after the other with no instruction-level
+    // parallelism; as straight-line code the scheduler interleaves the five chains.
     const float t = mn / mx;
     const float s = t * t;
     float p = P25FE_ATAN_COEFFS[P25FE_ATAN_NCOEF - 1];
@@ -98,7 +108,7 @@ __device__ __forceinline__ float spec_atan2f(float y, float x)
     if (ay > ax) r = P25FE_HALF_PI - r;
     if (x < 0.0f) r = P25FE_PI - r;
     if (y < 0.0f) r = -r;
-    return r;
+    return mx == 0.0f ? 0.0f : r;
 }
 
 // SPEC 3.4: FM discriminator, angle of s * conj(prev) times fs / (2 pi dev)   (src/demod.rs:54, 110)
@@ -111,14 +121,29 @@ __device__ __forceinline__ float fm_discriminate(float2 s, float2 prev)
     return spec_atan2f(im, re) * P25FE_FM_GAIN;
 }
 
+// Complex sample as a native 2-vector: fma on it is ONE v_pk_fma_f32 (re and im lanes, each a fused multiply-add, SPEC
+// section 2).  Written explicitly so that the packing does not depend on the SLP vectoriser: one build of this kernel
+// paired the imaginary parts of two different outputs instead and paid 175 v_mov_b32 per sub-tile to assemble the pairs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cfma(float tap, v2f s, v2f acc)
+{
+    const v2f t = {tap, tap};
+    return __builtin_elementwise_fma(t, s, acc);
+}
+
 // One complex sample from LDS as a single ds_read_b64.  The volatile 64-bit access keeps the compiler from
 // pairing neighbouring reads into ds_read2_b64, which moves 16 B per lane at HALF the LDS rate of two
 // ds_read_b64 (MI355X_MICROARCH.md LDS table: 8 vs 2+2 cycles per wave-instruction).
-__device__ __forceinline__ float2 lds_read_c(const float2* p)
+__device__ __forceinline__ v2f lds_read_v2(const float2* p)
 {
     typedef const volatile unsigned long long __attribute__((address_space(3))) * lds_u64_ptr;
     const unsigned long long u = *((lds_u64_ptr)p);                 // generic -> LDS address space: stays a DS op
-    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+    return __builtin_bit_cast(v2f, u);
+}
+__device__ __forceinline__ float2 lds_read_c(const float2* p)
+{
+    const v2f v = lds_read_v2(p);
+    return make_float2(v.x, v.y);
 }
 
 // Value held by lane-1 of the wave; lane 0 receives `lane0` (DPP wave_shr:1 -- one VALU op, no LDS).
@@ -132,13 +157,24 @@ template <int L> __device__ __forceinline__ float lane_bcast(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L));
 }
 
-// v with lane L replaced by the wave-uniform value x (v_writelane_b32)
-template <int L> __device__ __forceinline__ unsigned lane_set(unsigned v, unsigned x)
+// Lanes 0..9 of the result hold the ten wave-uniform words: lane q = low half of m[q], lane q + 5 = high half
+// (v_writelane_b32; this hipcc has no builtin for it).  gfx950 needs 2 wait states between a VALU write of an SGPR
+// (the v_cmp of a ballot) and a VALU read of it, and the compiler cannot see into the asm: all ten words are inputs of
+// ONE block that starts with the padding.  (Without it the word of plane 0 -- v_cmp vcc immediately followed by the
+// read of vcc_lo -- came out stale.)
+__device__ __forceinline__ unsigned lanes_from_ballots(const unsigned long long (&m)[5])
 {
-    // This hipcc has no writelane builtin.  gfx950 needs 2 wait states between a VALU write of an SGPR (the v_cmp of
-    // a ballot) and a VALU read of it; the compiler cannot see into the asm, so the padding is part of it (without it
-    // the word of plane 0 -- v_cmp vcc immediately followed by this read of vcc_lo -- came out stale).
-    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(L));
+    unsigned v = 0u;
+    asm("s_nop 1\n\t"
+        "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 5\n\t"
+        "v_writelane_b32 %0, %3, 1\n\tv_writelane_b32 %0, %4, 6\n\t"
+        "v_writelane_b32 %0, %5, 2\n\tv_writelane_b32 %0, %6, 7\n\t"
+        "v_writelane_b32 %0, %7, 3\n\tv_writelane_b32 %0, %8, 8\n\t"
+        "v_writelane_b32 %0, %9, 4\n\tv_writelane_b32 %0, %10, 9"
+        : "+v"(v)
+        : "s"((unsigned)m[0]), "s"((unsigned)(m[0] >> 32)), "s"((unsigned)m[1]), "s"((unsigned)(m[1] >> 32)),
+          "s"((unsigned)m[2]), "s"((unsigned)(m[2] >> 32)), "s"((unsigned)m[3]), "s"((unsigned)(m[3] >> 32)),
+          "s"((unsigned)m[4]), "s"((unsigned)(m[4] >> 32)));
     return v;
 }
 // value of v held by lane `src` (ds_bpermute_b32: the LDS crossbar, no memory)
@@ -199,7 +235,7 @@ template <int FMT, int PK> struct Loader {
             int r = tid + j * WV;
             r = r < lo32 ? lo32 : r;
             r = r > hi32 ? hi32 : r;
-#if defined(P25FE_ABLATE) && P25FE_ABLATE == 6     // measurement build: every window load hits one cached vector row
+#if (defined(P25FE_ABLATE) && P25FE_ABLATE == 6) || defined(P25FE_ABLATE_CACHED)     // measurement build: every window load hits one cached vector row
             r = tid;
             v[j] = reinterpret_cast<const V*>(base)[r];
             continue;
@@ -241,6 +277,57 @@ template <int FMT, int PK> struct Loader {
 };
 
 // ------------------------------------------------------------------------------------------
+// window loader, LDS-DMA form (cf32 only): global -> LDS directly (global_load_lds_dwordx4: each lane supplies a global
+// address, the 64 x 16 B land lane-consecutively at a wave-uniform LDS address -- exactly the staging layout of
+// Loader::store).  No staging registers (52 VGPRs) and no ds_write_b128 pass (13 per sub-tile at ~13 cycles each of the
+// CU's VGPR -> LDS path: 45 us of the kernel's 207 us of arithmetic-side time, measured with tools/ablate.sh).  The same
+// clamped, branch-free addresses as above; samples outside [-n_hist, n_new) are zeroed in LDS after the data has landed
+// (boundary sub-tiles only).
+// ------------------------------------------------------------------------------------------
+constexpr int LD_REGS = 0, LD_DMA = 1;
+template <int PK> struct DmaLoader {
+    using G = Geo<PK>;
+    static constexpr int NV = G::NVD;
+    __device__ __forceinline__ void issue(const void* base, long first, long n_hist, long n_new, long i_last, int tid, float2* XIN) const
+    {
+        const long v0 = first >> 1;
+        const uint4* q = reinterpret_cast<const uint4*>(base) + v0;
+        const long last = i_last < n_new - 1 ? i_last : n_new - 1;
+        long lo = ((-n_hist) >> 1) - v0;
+        long hi = (last >> 1) - v0;
+        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
+        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
+        const int lo32 = (int)lo, hi32 = (int)hi;
+        typedef __attribute__((address_space(3))) char* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        lds_ptr dst = (lds_ptr)XIN;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            int r = tid + j * WV;
+            r = r < lo32 ? lo32 : r;
+            r = r > hi32 ? hi32 : r;
+#if (defined(P25FE_ABLATE) && P25FE_ABLATE == 6) || defined(P25FE_ABLATE_CACHED)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const uint4*>(base) + tid), dst + 1024 * j, 16, 0, 0);
+            continue;
+#endif
+            __builtin_amdgcn_global_load_lds((glb_ptr)(q + r), dst + 1024 * j, 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void fixup(float2* XIN, long first, long n_hist, long n_new, int tid) const
+    {
+        const long first_al = (first >> 1) << 1;
+        if (first_al >= -n_hist && first_al + (long)NV * 2 * WV <= n_new) return;      // uniform: interior window
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const long i = first_al + 2 * (long)(tid + j * WV) + e;
+                if (i < -n_hist || i >= n_new) XIN[2 * (tid + j * WV) + e] = make_float2(0.f, 0.f);
+            }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // K1: fused front end.  One wave walks `subs_per_seg` consecutive sub-tiles of one channel.
 //   * the next sub-tile's input window is prefetched into registers while the current one is
 //     processed; it reaches LDS (time-linear cf32) at the top of the next iteration;
@@ -265,33 +352,40 @@ struct K1Args {
     long bb_stride;
     long n_out;             // outputs per channel
     int subs_per_seg;
+    int xcd_group;          // > 0: workgroups b, b + 8, b + 16, ... (same XCD) take xcd_group consecutive segments (see k_frontend)
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
     float* power_partial;   // nullable: [n_channels][gridDim.x] partial sums of |y|^2
     // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + PLPAD >= SEG_HALO,
     // (m_begin + PLPAD) % 80 == 0 and a segment length that is a multiple of 80.
     float* bbp;             // channel 0
-    long plane_stride;      // floats per plane
-    long bbp_ch_stride;     // floats per channel (10 planes)
+    long bbp_ch_stride;     // floats per channel (a whole number of blocks)
     uint8_t* bits;          // channel 0, addressed by byte
-    long bits_stride;       // bytes per plane
     long bits_ch_stride;    // bytes per channel
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
 // registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
-template <int FMT, bool CT, int PK, int OM = OUT_LINEAR>
-__global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+// Register budget of the planar / DMA variants: minimum waves per SIMD the kernel is compiled for.  Same-box A/B
+// (tools/ab.sh, 3 processes x 30 launches): with 3 the planar kernel is allocated the SAME 146 VGPRs as with 2 but is
+// scheduled differently and ran 300 us instead of 272 us.
+#ifndef P25FE_K1_PLANAR_WPS
+#define P25FE_K1_PLANAR_WPS 2
+#endif
+template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int LD = LD_REGS>
+__global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
+    static_assert(LD == LD_REGS || FMT == P25FE_FMT_CF32, "LDS-DMA moves raw samples: cf32 only (u8 is converted on the way)");
+    constexpr bool DMA = LD == LD_DMA;
     static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
     using G = Geo<PK>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
     constexpr int NBACK = G::NBACK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region
-    float2* XIN = D + D_CARRY;                                      // 16-B aligned: staged with ds_write_b128
-    float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose, also inside the window region
-    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2], only when !CT
+    float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region (register loader)
+    float2* XIN = DMA ? D + G::D_N : D + D_CARRY;                   // 16-B aligned: staged with ds_write_b128 / written by the DMA
+    float* OUT = reinterpret_cast<float*>(DMA ? D + D_CARRY : D + G::D_N);      // [SUB] output transpose: inside the window region / over d's front
+    float* TAPS = reinterpret_cast<float*>(DMA ? XIN + 2 * WV * G::NVD : D + D_CARRY + G::XIN_N);   // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
     if (!CT) {
         for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
@@ -301,7 +395,20 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
     const long seg_len = (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
-    const long m_seg0 = a.m_begin + (long)blockIdx.x * seg_len;
+    // Workgroup -> segment.  Workgroup b runs on XCD b % 8 (observed, for speed only): inside every run of 8 G segments
+    // XCD x takes the G consecutive ones [x G, x G + G), one after the other, so that a segment's 9 % halo re-read was
+    // fetched into the SAME XCD's L2 by its left neighbour a moment ago -- while all eight XCDs still stream the same
+    // ~1 MB of the capture (whole eighths per XCD measured 4 % slower: eight far-apart DRAM streams).
+    long seg = blockIdx.x;
+    if (a.xcd_group > 0) {
+        const long run = 8L * a.xcd_group;
+        const long full = (long)gridDim.x / run * run;              // the tail keeps the identity map
+        if (seg < full) {
+            const long x = seg & 7, k = seg >> 3;
+            seg = (k / a.xcd_group) * run + x * a.xcd_group + k % a.xcd_group;
+        }
+    }
+    const long m_seg0 = a.m_begin + seg * seg_len;
     if (m_seg0 >= a.n_out) return;
     const long m_seg1 = (m_seg0 + seg_len < a.n_out) ? m_seg0 + seg_len : a.n_out;
     const int ch = blockIdx.y;
@@ -311,10 +418,11 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
     for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
 
-    Loader<FMT, PK> ld;
+    typename std::conditional<DMA, DmaLoader<PK>, Loader<FMT, PK>>::type ld;
     long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
-    ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid);
+    if constexpr (DMA) ld.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
+    else ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid);
     float pw = 0.f;
 
     // context carried across sub-tiles in wave-uniform registers: the last channel output and the
@@ -338,8 +446,9 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
     float* const bb_seg = OM == OUT_LINEAR ? bb + m_seg0 : nullptr;
     // planar: lane = (half h = tid >> 5, symbol tid & 31) holds, in outv[q], plane 5 h + q of the sub-tile's 32 symbols
     const int pl_sym = tid & 31, pl_h5 = (tid >> 5) * 5;
-    float* const bbp_seg = OM == OUT_PLANAR ? a.bbp + (size_t)ch * a.bbp_ch_stride + (m_seg0 + PLPAD) / SPS_ : nullptr;
-    uint8_t* const bits_seg = OM == OUT_PLANAR ? a.bits + (size_t)ch * a.bits_ch_stride + (m_seg0 + PLPAD) / (8 * SPS_) : nullptr;
+    const int i_seg = OM == OUT_PLANAR ? (int)((m_seg0 + PLPAD) / SPS_) : 0;     // symbol index of the segment's first output (multiple of 8)
+    float* const bbp_ch = OM == OUT_PLANAR ? a.bbp + (size_t)ch * a.bbp_ch_stride : nullptr;
+    uint8_t* const bits_ch = OM == OUT_PLANAR ? a.bits + (size_t)ch * a.bits_ch_stride : nullptr;
     unsigned bitsv = 0u;                                            // lanes 0..39: byte (tid & 3) of plane (tid >> 2)
     auto flush_outputs = [&]() {
         if constexpr (OM == OUT_LINEAR) {
@@ -349,16 +458,28 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
                 if (r >= 0 && r < seg_n) bb_seg[r] = outv[q];
             }
         } else {
-            const int i_rel = out_rel / SPS_;                       // symbol index of the sub-tile relative to the segment (multiple of 8)
+            const int i_sub = i_seg + out_rel / SPS_;               // symbol index of the sub-tile (multiple of 8, >= 0)
+            const int i = i_sub + pl_sym;
+            float* const row = bbp_ch + (size_t)(i >> 5) * PL_BLK + (i & 31) + 32 * pl_h5;
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
-                if (r >= 0 && r < seg_n) bbp_seg[(size_t)(pl_h5 + q) * a.plane_stride + i_rel + pl_sym] = outv[q];
+#if defined(P25FE_EXP) && (P25FE_EXP & 2)      // measurement build: lane-consecutive (wrong) addresses
+                if (r >= 0 && r < seg_n) bbp_ch[(long)i_seg * SPS_ + out_rel + tid + q * WV] = outv[q];
+#else
+                if (r >= 0 && r < seg_n) row[32 * q] = outv[q];
+#endif
             }
             // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
             // either wholly inside the segment or wholly halo (the range's last byte may carry bits past n_out: unread)
             const int r0 = out_rel + 8 * SPS_ * (tid & 3) + (tid >> 2);
-            if (tid < 4 * SPS_ && r0 >= 0 && r0 < seg_n) bits_seg[(size_t)(tid >> 2) * a.bits_stride + (i_rel >> 3) + (tid & 3)] = (uint8_t)bitsv;
+            const int ib = i_sub + 8 * (tid & 3);
+#if defined(P25FE_EXP) && (P25FE_EXP & 1)      // measurement build: no sign planes
+            if (false)
+#else
+            if (tid < 4 * SPS_ && r0 >= 0 && r0 < seg_n)
+#endif
+                bits_ch[((size_t)(ib >> 5) * SPS_ + (tid >> 2)) * 4 + ((ib >> 3) & 3)] = (uint8_t)bitsv;
         }
     };
 
@@ -366,11 +487,18 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         if (dlo >= m_seg1) break;                                  // uniform
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[xsh + k] = x[first + k]
         const int xsh = (int)(first & 1);                           // window start relative to the aligned staging origin
-        ld.store(XIN, first, a.n_hist, a.n_new, tid);
+        if constexpr (DMA) {
+            // the window was requested right after the previous sub-tile's decimator; everything older in the memory
+            // queue (the previous outputs' stores) is older than it, so a full drain waits for nothing else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
+        } else {
+            ld.store(XIN, first, a.n_hist, a.n_new, tid);
+        }
         phase_sync();
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
-        ld.load(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid);
+        if constexpr (!DMA) ld.load(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
         continue;
@@ -379,28 +507,28 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         // Output p needs x[first + 5(P tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[5 P tid + 5p + 30 - k].
         {
             const float2* w = XIN + xsh + (DEC * P) * tid;
-            float2 acc[P];
+            v2f acc[P];
 #pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = make_float2(0.f, 0.f);
+            for (int p = 0; p < P; ++p) acc[p] = v2f{0.f, 0.f};
 #pragma unroll
             for (int j = DEC * (P - 1) + T1 - 1; j >= 0; --j) {    // newest to oldest => tap order 0..T1-1
-                const float2 s = lds_read_c(w + j);
+                const v2f s = lds_read_v2(w + j);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = DEC * p + (T1 - 1) - j;
-                    if (k >= 0 && k < T1) {
-                        acc[p].x = __builtin_fmaf(tap_dec(k), s.x, acc[p].x);
-                        acc[p].y = __builtin_fmaf(tap_dec(k), s.y, acc[p].y);
-                    }
+                    if (k >= 0 && k < T1) acc[p] = cfma(tap_dec(k), s, acc[p]);
                 }
             }
             // d overwrites the front of the window: every lane's window reads must be complete first.  (The compiler
             // reasons per thread and could prove a lane's own store and loads disjoint -- the fence orders the wave.)
             phase_sync();
 #pragma unroll
-            for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = acc[p];
+            for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = make_float2(acc[p].x, acc[p].y);
         }
         phase_sync();
+        // the decimator has consumed the window (its reads fed the accumulators just stored): let the next one stream
+        // into the same LDS while the channel filter, the discriminator and the boxcar run
+        if constexpr (DMA) ld.issue(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid, XIN);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
         continue;
@@ -409,20 +537,20 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         float2 y[P];
         {
             const float2* w = D + P * tid;
+            v2f yv[P];
 #pragma unroll
-            for (int p = 0; p < P; ++p) y[p] = make_float2(0.f, 0.f);
+            for (int p = 0; p < P; ++p) yv[p] = v2f{0.f, 0.f};
 #pragma unroll
             for (int j = (P - 1) + T2 - 1; j >= 0; --j) {
-                const float2 s = lds_read_c(w + j);
+                const v2f s = lds_read_v2(w + j);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
-                    if (k >= 0 && k < T2) {
-                        y[p].x = __builtin_fmaf(tap_ch(k), s.x, y[p].x);
-                        y[p].y = __builtin_fmaf(tap_ch(k), s.y, y[p].y);
-                    }
+                    if (k >= 0 && k < T2) yv[p] = cfma(tap_ch(k), s, yv[p]);
                 }
             }
+#pragma unroll
+            for (int p = 0; p < P; ++p) y[p] = make_float2(yv[p].x, yv[p].y);
             if (a.power_partial) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
@@ -439,6 +567,8 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         for (int k = tid; k < D_CARRY; k += WV) D[k] = D[SUB + k];
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 3
+#pragma unroll
+        for (int p = 0; p < P; ++p) asm volatile("" ::"v"(y[p].x), "v"(y[p].y));     // keep the filter alive
         continue;
 #endif
         // ---- stage 4: FM discriminator (src/demod.rs:109-111) on the lane's own P outputs; the sample before
@@ -456,7 +586,8 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         }
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
-        asm volatile("" ::"v"(f[0]), "v"(f[P - 1]));
+#pragma unroll
+        for (int p = 0; p < P; ++p) asm volatile("" ::"v"(f[p]));
         continue;
 #endif
         // ---- stage 5: boxcar (src/demod.rs:114): b[m] = (fm[m] + fm[m-1] + ... + fm[m-9]) / 10, newest first.
@@ -482,7 +613,11 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
                         acc = acc + prevf[b - 1][q + b * P];
                     }
                 }
+#if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
+                asm volatile("" ::"v"(acc));
+#else
                 OUT[P * tid + p] = acc * P25FE_BOXCAR_SCALE;        // lane stride P dwords (odd): conflict-free
+#endif
             }
             // next sub-tile's lane 0 / 1 / ... read these: lane 63 is one lane back, lane 62 two, ...
 #pragma unroll
@@ -492,6 +627,9 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
                 f_carry[0][p] = lane_bcast<WV - 1>(f[p]);
             }
         }
+#if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
+        continue;
+#endif
         phase_sync();
         // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
         if constexpr (OM == OUT_LINEAR) {
@@ -507,12 +645,9 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
                 outv[q] = OUT[SPS_ * pl_sym + pl_h5 + q];
                 sg[q] = __builtin_amdgcn_ballot_w64(__float_as_int(outv[q]) < 0);
             }
-            // lane q: word of plane q, lane q + 5: plane q + 5
-            w = lane_set<0>(w, (unsigned)sg[0]); w = lane_set<5>(w, (unsigned)(sg[0] >> 32));
-            w = lane_set<1>(w, (unsigned)sg[1]); w = lane_set<6>(w, (unsigned)(sg[1] >> 32));
-            w = lane_set<2>(w, (unsigned)sg[2]); w = lane_set<7>(w, (unsigned)(sg[2] >> 32));
-            w = lane_set<3>(w, (unsigned)sg[3]); w = lane_set<8>(w, (unsigned)(sg[3] >> 32));
-            w = lane_set<4>(w, (unsigned)sg[4]); w = lane_set<9>(w, (unsigned)(sg[4] >> 32));
+#if !(defined(P25FE_EXP) && (P25FE_EXP & 1))
+            w = lanes_from_ballots(sg);                              // lane q: word of plane q, lane q + 5: plane q + 5
+#endif
             const unsigned pw_ = lane_gather(w, tid >> 2);          // lane j <- word of plane j >> 2
             bitsv = (pw_ >> (8 * (tid & 3))) & 0xffu;
         }
@@ -525,7 +660,7 @@ __global__ __launch_bounds__(WV, (Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Ar
         // wave reduction of the |y|^2 partials (tree; tolerance vs the sequential fold is in the tests)
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) pw = pw + __shfl_down(pw, d, 64);
-        if (tid == 0) a.power_partial[(size_t)ch * gridDim.x + blockIdx.x] = pw;
+        if (tid == 0) a.power_partial[(size_t)ch * gridDim.x + blockIdx.x] = pw;     // any order: summed by k_power_finish
     }
 }
 

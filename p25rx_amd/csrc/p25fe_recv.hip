@@ -38,12 +38,10 @@ constexpr int EVCAP = TS / (W + 1) + 8;                      // 1288: detections
 constexpr unsigned SYNC_NEG_MASK = ~P25FE_SYNC_SIGN_MASK & 0xffffffu;   // bit j: sync symbol j (oldest first) is -3
 constexpr int SCREEN_MAX_MISMATCH = 4;
 
-struct Planar {             // polyphase baseband of one call (PLPAD in p25fe_kernels.hip)
-    const float* f;         // channel 0: f[r * ps + i] = b[10 i + r - PLPAD]
-    long ps;                // floats per plane
+struct Planar {             // blocked polyphase baseband of one call (PLPAD / planar_index in p25fe_kernels.hip)
+    const float* f;         // channel 0: f[planar_index(i, r)] = b[10 i + r - PLPAD]
     long f_ch;              // floats per channel
-    const uint32_t* bits;   // channel 0: sign planes, bits[r * bw + i / 32] bit i % 32
-    long bw;                // words per plane
+    const uint32_t* bits;   // channel 0: bits[(i / 32) * 10 + r] bit i % 32 = sign of that sample
     long bits_ch;           // words per channel
 };
 
@@ -88,8 +86,21 @@ __device__ __forceinline__ unsigned char slice_dibit(float v, float hi, float mi
     return v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
 }
 
-// SPEC 3.7 on one window: w[j] = v_j, j = 0 (oldest) .. 23, symbol spaced = contiguous in a plane
-__device__ __forceinline__ void sync_corr(const float* __restrict__ w, float& c, float& e)
+// The 24 symbol-spaced samples v_j, j = 0 (oldest) .. 23, of the sync word whose last symbol is planar sample p
+// (p = m + PLPAD): consecutive symbols of plane p % 10 -- contiguous inside a block, 288 floats further in the next.
+__device__ __forceinline__ void sync_gather(const float* __restrict__ f, long p, float (&v)[NSYN])
+{
+    const long i = p / SPS;
+    const int r = (int)(p - i * SPS);
+    const long first = i - (NSYN - 1);
+    const float* base = f + planar_index(first, r);
+    const int n0 = 32 - (int)(first & 31);                      // samples left in the first block
+#pragma unroll
+    for (int j = 0; j < NSYN; ++j) v[j] = base[j + (j >= n0 ? PL_BLK - 32 : 0)];
+}
+
+// SPEC 3.7 on one window
+__device__ __forceinline__ void sync_corr(const float (&w)[NSYN], float& c, float& e)
 {
     float cc = 0.f, ee = 0.f;
 #pragma unroll
@@ -102,7 +113,7 @@ __device__ __forceinline__ void sync_corr(const float* __restrict__ w, float& c,
 }
 
 // SPEC 3.8: thresholds from the sync word's own levels
-__device__ __forceinline__ void sync_thresholds(const float* __restrict__ w, float& hi, float& mid, float& lo)
+__device__ __forceinline__ void sync_thresholds(const float (&w)[NSYN], float& hi, float& mid, float& lo)
 {
     float Pp = 0.f, Nn = 0.f;
 #pragma unroll
@@ -117,13 +128,6 @@ __device__ __forceinline__ void sync_thresholds(const float* __restrict__ w, flo
     const float d = span * P25FE_SLICE_FRAC;
     hi = mid + d;
     lo = mid - d;
-}
-
-// window of the sync word whose last symbol is planar sample p (p = m + PLPAD): 24 contiguous floats of plane p % 10
-__device__ __forceinline__ const float* sync_window(const float* f, long ps, long p)
-{
-    const long i = p / SPS;
-    return f + (p - i * SPS) * ps + (i - (NSYN - 1));
 }
 
 __device__ __forceinline__ int wave_sum_i(int v)
@@ -192,7 +196,6 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
 
     const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
-    const long ps = a.pl.ps;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
     const long pbase = t0 + PLPAD - W;                           // planar index of the position decided at tile offset 0
@@ -204,10 +207,10 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     const int r = lane / 6, blk = lane % 6;
     const int dlt = r >= SPS / 2 ? 1 : 0;                        // planes 5..9 start one symbol earlier (PLPAD - W = 315)
     if (lane < K2_LANES) {
-        const uint32_t* bw = a.pl.bits + (size_t)ch * a.pl.bits_ch + (size_t)r * a.pl.bw + (size_t)tile * TWORDS + 4 * blk;
+        const uint32_t* bw = a.pl.bits + (size_t)ch * a.pl.bits_ch + ((size_t)tile * TWORDS + 4 * blk) * SPS + r;
         unsigned wd[6];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) wd[k] = bw[k];
+        for (int k = 0; k < 5; ++k) wd[k] = bw[SPS * k];
         wd[5] = 0u;
         if (dlt) {                                                // shift the 160-bit string up by one: same code for both halves
 #pragma unroll
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
             const int eo = act ? (int)HITS[h] : 0;
             bool cand = false;
             if (act) {
-                float c, e;
-                sync_corr(sync_window(f, ps, pbase + eo), c, e);
+                float c, e, v[NSYN];
+                sync_gather(f, pbase + eo, v);
+                sync_corr(v, c, e);
                 cand = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
             }
             const unsigned long long cm = __ballot(cand);
@@ -252,8 +256,9 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
                 const bool act2 = lane < 55 && cb + q < nc;
                 const int ec = act2 ? (int)CANDS[cb + q] : 0;
                 if (act2) {
-                    float c, e;
-                    sync_corr(sync_window(f, ps, pbase + ec + d - W), c, e);
+                    float c, e, v[NSYN];
+                    sync_gather(f, pbase + ec + d - W, v);
+                    sync_corr(v, c, e);
                     CN[q][d] = c;
                 }
                 phase_sync();
@@ -334,7 +339,11 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     post = wave_sum_i(post);
     const int first_off = EVS[0], last_off = EVS[n_ev - 1];
     float hi, mid, lo;
-    sync_thresholds(sync_window(f, ps, pbase + last_off), hi, mid, lo);    // uniform: every lane, same window
+    {
+        float v[NSYN];
+        sync_gather(f, pbase + last_off, v);                        // uniform: every lane, same window
+        sync_thresholds(v, hi, mid, lo);
+    }
     if (lane == 0) {
         TileRec rc;
         rc.first_event = a.abs0 + t0 + first_off;
@@ -591,7 +600,6 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
     __shared__ uint16_t EV[EVCAP];
     const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
-    const long ps = a.pl.ps;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
     const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
@@ -624,14 +632,16 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
         const int count = (m_hi - 1 - m_first) / SPS + 1;
         const long p = t0 + m_first + PLPAD;
         const long i0 = p / SPS;
-        const float* src = f + (p - i0 * SPS) * ps + i0;
+        const float* src = f + (i0 >> 5) * PL_BLK + (int)(p - i0 * SPS) * 32;     // block of symbol i0, row of the plane
+        const int o0 = (int)(i0 & 31);
         uint8_t* dst = out + rank;
         for (int j0 = 0; j0 < count; j0 += 4 * WV) {
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = j0 + q * WV + lane;
-                v[q] = j < count ? src[j] : 0.f;
+                const int jj = o0 + j;                              // symbol index relative to the first block
+                v[q] = j < count ? src[(jj >> 5) * PL_BLK + (jj & 31)] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -654,7 +664,11 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
         const int ek = EV[k];
         const int m_hi = k + 1 < n_ev ? (int)EV[k + 1] + 1 : tn;
         float h, m, l;
-        sync_thresholds(sync_window(f, ps, t0 + ek - W + PLPAD), h, m, l);     // uniform window; same arithmetic as K2
+        {
+            float v[NSYN];
+            sync_gather(f, t0 + ek - W + PLPAD, v);                 // uniform window; same arithmetic as K2
+            sync_thresholds(v, h, m, l);
+        }
         if (lane == 0 && a.sync_pos && (long)(so.event_off + k) < a.sync_stride) {
             a.sync_pos[(size_t)ch * a.sync_stride + so.event_off + k] = a.abs0 + t0 + ek - W;
             // index of the first dibit this detection governs = dibits for instants <= e_k
@@ -676,24 +690,23 @@ struct PlanarizeArgs {
     long n_hist;            // valid samples before it
     long n;                 // owned samples
     float* f;               // planar out, channel 0
-    long ps, f_ch;
+    long f_ch;
     uint32_t* bits;
-    long bw, bits_ch;
+    long bits_ch;
+    long n_blocks;          // blocks per channel
 };
 
 __global__ __launch_bounds__(WV * SPS) void k_planarize(PlanarizeArgs a)
 {
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6, ch = blockIdx.y;
-    const long i = (long)blockIdx.x * WV + lane;
+    const long i = (long)blockIdx.x * WV + lane;                    // two blocks per workgroup
     const long m = SPS * i + r - PLPAD;
     const long hist = a.n_hist < HIST_BB ? a.n_hist : HIST_BB;
     const float v = (m >= -hist && m < a.n) ? a.bb[(size_t)ch * a.bb_stride + m] : 0.0f;
-    if (i < a.ps) a.f[(size_t)ch * a.f_ch + (size_t)r * a.ps + i] = v;
+    const bool in = (i >> 5) < a.n_blocks;
+    if (in) a.f[(size_t)ch * a.f_ch + planar_index(i, r)] = v;
     const unsigned long long sg = __ballot(__float_as_int(v) < 0);
-    if (lane < 2) {
-        const long w = (long)blockIdx.x * 2 + lane;
-        if (w < a.bw) a.bits[(size_t)ch * a.bits_ch + (size_t)r * a.bw + w] = (unsigned)(sg >> (32 * lane));
-    }
+    if ((lane & 31) == 0 && in) a.bits[(size_t)ch * a.bits_ch + (i >> 5) * SPS + r] = (unsigned)(sg >> (lane & 32));
 }
 
 }  // namespace p25k

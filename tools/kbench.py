@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Interleaved kernel A/B on one box: every round runs each requested mode once, so that rocprofv3's per-kernel
+averages (tools/ab.sh) compare like with like (same box, same clocks, same thermal state).
+usage: kbench.py [seconds=600] [rounds=30] [channels=1] mode...   modes: lin (K1, linear baseband), run (K1 planar ->
+K2 -> K3 -> K4), lin_u8, run_u8, k0, chz"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from p25rx_amd.frontend import FrontEnd
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+modes = sys.argv[4:] or ["lin", "run"]
+n = int(secs * 240000) // 8 * 8
+dev = torch.device("cuda", 0)
+from p25rx_amd import c4fm
+iq = torch.empty((C, n, 2), dtype=torch.float32, device=dev)
+for c in range(C):
+    c4fm.synth_torch(n, seed=1 + c, device=dev, out=iq[c])
+iq8 = None
+if any(m.endswith("u8") for m in modes):
+    iq8 = torch.clamp(torch.round((iq + 1.0) * 127.5), 0, 255).to(torch.uint8)
+fe = FrontEnd(n_channels=C)
+os.environ["P25FE_K1_DMA"] = "1"          # second handle: LDS-DMA K1 loader (modes with suffix _d)
+fe_r = FrontEnd(n_channels=C)
+os.environ.pop("P25FE_K1_DMA")
+bb = None
+def step(m):
+    global bb
+    if m == "lin":
+        bb, _ = fe.demod_dev(iq, bb=bb)
+    elif m == "lin_d":
+        bb, _ = fe_r.demod_dev(iq, bb=bb)
+    elif m == "run_d":
+        fe_r.run_dev(iq)
+    elif m == "lin_u8":
+        bb, _ = fe.demod_dev(iq8, bb=bb)
+    elif m == "run":
+        fe.run_dev(iq)
+    elif m == "run_u8":
+        fe.run_dev(iq8)
+    elif m == "k0":
+        fe.predecim_dev(iq)
+    elif m == "chz":
+        fe.channelise_dev(iq[0])
+for _ in range(3):
+    for m in modes:
+        step(m)
+torch.cuda.synchronize()
+for _ in range(rounds):
+    for m in modes:
+        step(m)
+torch.cuda.synchronize()
+print("kbench done: %s x %d rounds, C=%d n=%d" % (modes, rounds, C, n))
