@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 #define P25FE_MAX_TAPS 64
-#define P25FE_ABI_VERSION 1
+#define P25FE_ABI_VERSION 2        /* 2: p25fe_shard_resolve* write n_shards + 1 offsets */
 
 typedef enum p25fe_status {
     P25FE_OK = 0,
@@ -171,22 +171,47 @@ int p25fe_run_dev(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_
  * first shard).  Pass 1 demodulates, detects frame syncs and fills d_result[c] with the
  * shard summary (first_event, n_dibits_after_first, anchor_out) assuming no carry-in.  The
  * caller exchanges summaries (all_gather of a few bytes), resolves each shard's carry-in
- * anchor with p25fe_shard_resolve on the host, then pass 2 slices. */
+ * anchor with p25fe_shard_resolve on the host, then pass 2 slices.
+ * ORDERING: pass 2 works on the baseband and the detections that pass 1 left in the handle's
+ * scratch.  No other call that demodulates or slices (p25fe_run_*, p25fe_demod_*, p25fe_slice*,
+ * another shard's pass 1) may come between a shard's pass 1 and its pass 2 on the same handle:
+ * any of them invalidates the shard context and pass 2 then returns P25FE_ERR_ARG (as it does
+ * after a failed pass 1) instead of slicing stale data. */
 size_t p25fe_shard_halo(void);
 int p25fe_shard_pass1(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                       uint64_t abs0, p25fe_result_t *d_result, void *stream);
 int p25fe_shard_pass2(p25fe_t *h, const p25fe_anchor_t *d_anchor_in, uint8_t *d_dibits, size_t dibit_stride,
                       p25fe_result_t *d_result, void *stream);
+/* The same pass 1 in two launches, so that the exchange of the filter-state overlap hides behind K1: _main enqueues
+ * the front end for every part of the shard whose input lies inside the OWNED samples (all but the first ~900
+ * baseband samples) and may run while the left neighbour's halo is still on the wire; _finish (same arguments, after
+ * the halo has arrived in front of d_iq) enqueues the remaining head, the sync detection and the scan, and fills
+ * d_result.  p25fe_shard_pass1 == _main + _finish. */
+int p25fe_shard_pass1_main(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
+                           uint64_t abs0, void *stream);
+int p25fe_shard_pass1_finish(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
+                             uint64_t abs0, p25fe_result_t *d_result, void *stream);
+
 /* Host-side combine: summaries[r] for r = 0..n_shards-1 in time order (one channel) ->
- * anchor_in[r] and dibit_offset[r]. Pure integer/struct logic, no device work. */
+ * anchor_in[r] (n_shards entries) and dibit_offset[r] (n_shards + 1 entries: shard r's dibits occupy
+ * [dibit_offset[r], dibit_offset[r + 1]) of the whole stream, the last entry is the total).
+ * Pure integer/struct logic, no device work. */
 int p25fe_shard_resolve(const p25fe_result_t *summaries, const uint64_t *shard_bb0, const uint64_t *shard_bb_n,
                         size_t n_shards, p25fe_anchor_t *anchor_in, uint64_t *dibit_offset);
 
 /* Same combine on the device (one tiny kernel, no host synchronisation): all arrays are device pointers, e.g. the
- * all-gathered summaries; writes n_shards anchors / offsets; pass d_anchor_in + rank to p25fe_shard_pass2. */
+ * all-gathered summaries; writes n_shards anchors and n_shards + 1 offsets; pass d_anchor_in + rank to p25fe_shard_pass2. */
 int p25fe_shard_resolve_dev(p25fe_t *h, const p25fe_result_t *d_summaries, const uint64_t *d_shard_bb0,
                             const uint64_t *d_shard_bb_n, size_t n_shards, p25fe_anchor_t *d_anchor_in,
                             uint64_t *d_dibit_offset, void *stream);
+
+/* Dibit gather, receiving side (BASELINE.json config 5: "RCCL ... carrying ... the reduced dibit stream"): after an
+ * all-gather of the shards' dibit buffers (each `cap` bytes, shard r at d_gathered + r * cap, its first
+ * dibit_offset[r + 1] - dibit_offset[r] bytes valid) write the contiguous stream to d_out[0 .. dibit_offset[n_shards]).
+ * d_dibit_offset: the n_shards + 1 entries of p25fe_shard_resolve_dev.  The consumer is the ordered stream that
+ * RecvTask feeds into MessageReceiver (src/recv.rs:148-150). */
+int p25fe_shard_compact_dev(p25fe_t *h, const uint8_t *d_gathered, size_t cap, const uint64_t *d_dibit_offset,
+                            size_t n_shards, uint8_t *d_out, size_t out_cap, void *stream);
 
 /* Network identifier that follows each frame sync (next row after the dibits, SURVEY.md section 8f: what
  * p25::MessageReceiver reports as MessageEvent::PacketNID, src/recv.rs:216-222, consumed by
@@ -206,6 +231,11 @@ typedef struct p25fe_nid {
  * Writes n_sync records.  All device pointers; enqueued on `stream`. */
 int p25fe_nid_dev(p25fe_t *h, const uint8_t *d_dibits, size_t n_dibits, const uint64_t *d_sync_dibit,
                   const int64_t *d_sync_pos, size_t n_sync, p25fe_nid_t *d_out, void *stream);
+
+/* Host-buffer form (the file-driven harness: p25fe_replay -j): copies the stream and the events to the device, runs the
+ * same kernel, copies the n_sync records back; synchronous. */
+int p25fe_nid(p25fe_t *h, const uint8_t *dibits, size_t n_dibits, const uint64_t *sync_dibit, const int64_t *sync_pos,
+              size_t n_sync, p25fe_nid_t *out);
 
 /* The same for a whole channel batch without a host round trip: channel c's stream is d_dibits + c * dibit_stride
  * with d_result[c].n_dibits dibits, its events d_sync_dibit / d_sync_pos + c * sync_stride (the outputs of
@@ -257,8 +287,9 @@ typedef struct p25fe_chan_stats {
 int p25fe_chan_stats_dev(p25fe_t *h, const p25fe_result_t *d_result, const p25fe_nid_t *d_nid, size_t sync_stride,
                          const float *d_power_dbm, p25fe_chan_stats_t *d_stats, void *stream);
 
-/* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1/2 record HIP
- * events on the caller's stream around each kernel (K1 front end, K2 sync, K3 scan, K4 slice).
+/* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1 record HIP
+ * events on the caller's stream around each kernel (K1 front end, K2 sync detect, K3 scan, K4 slice);
+ * p25fe_shard_pass2 records its own slot with K3 and K4 only (ms[0], ms[1] of that slot read as 0).
  * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel
  * and the number of calls since the last read (at most the last 64 calls are kept).
  * on = 1: events around every kernel (five records per call); on = 2: around K1 only (two records; ms[1..3] read

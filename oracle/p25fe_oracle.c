@@ -532,13 +532,15 @@ int64_t p25o_run_cf32_mt(const p25o_config *cfg, const float *iq, size_t n, int 
     if (nthreads > 256) nthreads = 256;
     mt_job jobs[256];
     pthread_t th[256];
+    int started = 0, failed = 0;
     for (int k = 0; k < nthreads; k++) {
         size_t lo = n * (size_t)k / (size_t)nthreads, hi = n * (size_t)(k + 1) / (size_t)nthreads;
         jobs[k].cfg = cfg; jobs[k].iq = iq + 2 * lo; jobs[k].n = hi - lo; jobs[k].out = 0;
-        if (pthread_create(&th[k], NULL, mt_worker, &jobs[k])) return -1;
+        if (pthread_create(&th[k], NULL, mt_worker, &jobs[k])) { failed = 1; break; }
+        started++;
     }
-    int64_t total = 0;
-    for (int k = 0; k < nthreads; k++) {
+    int64_t total = failed ? -1 : 0;
+    for (int k = 0; k < started; k++) {      /* the workers use jobs[] on this stack: always join what was started */
         pthread_join(th[k], NULL);
         total = (total < 0 || jobs[k].out < 0) ? -1 : total + jobs[k].out;
     }

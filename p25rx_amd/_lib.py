@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libp25fe.so")
 MAX_TAPS = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 FMT_CF32, FMT_U8 = 0, 1
 
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -52,7 +52,8 @@ SYMBOLS = [
     "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
-    "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev",
+    "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
+    "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev",
 ]
 
 
@@ -108,10 +109,14 @@ def load():
     L.p25fe_shard_halo.argtypes = []
     L.p25fe_shard_halo.restype = sz
     L.p25fe_shard_pass1.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, vp]
+    L.p25fe_shard_pass1_main.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp]
+    L.p25fe_shard_pass1_finish.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, vp]
+    L.p25fe_shard_compact_dev.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
     L.p25fe_shard_pass2.argtypes = [vp, vp, vp, sz, vp, vp]
     L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, vp, vp]
     L.p25fe_shard_resolve_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_nid_dev.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
+    L.p25fe_nid.argtypes = [vp, vp, sz, vp, vp, sz, vp]
     L.p25fe_nid_batch_dev.argtypes = [vp, vp, sz, vp, vp, vp, sz, vp, vp]
     L.p25fe_chan_stats_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_channelise_dev.argtypes = [vp, vp, sz, sz, u64, vp, sz, vp]

@@ -69,11 +69,14 @@ struct p25fe {
     bool prof_on = false;
     int prof_level = 1;             // 1: events around every kernel, 2: around K1 only (two records per call, not five)
     std::vector<hipEvent_t> prof_ev;
+    std::vector<uint8_t> prof_mask;        // per slot: which of its five events were recorded
     uint64_t prof_calls = 0;
     int prof_slot = -1;                    // slot being recorded by the current call
     // shard context between pass1 and pass2 (the planar baseband and the tile summaries stay in the scratch buffers;
     // every other entry point that touches them clears sh_nbb, so a stale pass 2 fails instead of slicing garbage)
     bool sh_valid = false;
+    size_t sh_main_nbb = (size_t)-1;       // shard whose main K1 launch is out, waiting for p25fe_shard_pass1_finish
+    uint64_t sh_main_abs0 = 0;
     size_t sh_nbb = 0;
     uint64_t sh_abs_bb0 = 0;
 };
@@ -168,7 +171,7 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
 {
     if (!cfg || !out) return P25FE_ERR_ARG;
     *out = nullptr;
-    if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_decim_taps < 1 ||
+    if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_channels > 65535 /* grid.y */ || cfg->n_decim_taps < 1 ||
         cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_T2)
         return P25FE_ERR_ARG;
     int ndev = 0;
@@ -246,11 +249,17 @@ void p25fe_destroy(p25fe_t* h)
 // --------------------------------------------------------------------------------------------
 // profiling hook
 // --------------------------------------------------------------------------------------------
-static void prof_begin(p25fe_t* h) { h->prof_slot = h->prof_on ? (int)(h->prof_calls++ % PROF_RING) : -1; }
+static void prof_begin(p25fe_t* h)
+{
+    h->prof_slot = h->prof_on ? (int)(h->prof_calls++ % PROF_RING) : -1;
+    if (h->prof_slot >= 0) h->prof_mask[(size_t)h->prof_slot] = 0;
+}
 static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 {
-    if (h->prof_slot >= 0 && (idx <= 1 || h->prof_level == 1))      // level 2: only the two events around K1
-        (void)hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st);
+    if (h->prof_slot >= 0 && (idx <= 1 || h->prof_level == 1)) {    // level 2: only the two events around K1
+        if (hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st) == hipSuccess)
+            h->prof_mask[(size_t)h->prof_slot] |= (uint8_t)(1u << idx);
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -258,15 +267,18 @@ static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 // --------------------------------------------------------------------------------------------
 static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
-                           hipStream_t st, const PlanarGeo* planar = nullptr)
+                           hipStream_t st, const PlanarGeo* planar = nullptr, int part = 0)
 {
+    // part: 0 = every segment; 1 = only the segments whose input window lies inside the owned samples (a shard's main
+    // launch, runs while the halo is still on the wire); 2 = the others (the shard's head, after the halo has arrived)
     if (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) return P25FE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_x) & 15u) != 0) return P25FE_ERR_ARG;     // 16-B vector loads
     if (h->C > 1 && (ch_stride % (fmt == P25FE_FMT_CF32 ? 2 : 8)) != 0) return P25FE_ERR_ARG;
     const size_t n_out = p25fe_n_baseband(abs0, n);
     const long total = (long)n_out - m_begin;
     if (total <= 0) {
-        if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0, sizeof(float) * (size_t)h->C, st));
+        // power_dbm of an empty chunk: the reference divides 0 by 0 (src/demod.rs:123-134) -> NaN (0xffffffff is a quiet NaN)
+        if (d_power_dbm) HIPCHK(h, hipMemsetAsync(d_power_dbm, 0xff, sizeof(float) * (size_t)h->C, st));
         return P25FE_OK;
     }
     // Segments are SHORT: three sub-tiles per one-wave workgroup.  Measured on config 2 (profiles/): one long
@@ -293,6 +305,18 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.bb_stride = (long)bb_stride;
     a.n_out = (long)n_out;
     a.subs_per_seg = (int)subs;
+    a.seg_first = 0;
+    long seg_count = n_seg;
+    if (part) {
+        if (d_power_dbm) return P25FE_ERR_ARG;
+        // segment k reads input from o0 + 5 (m_begin + k seg_len - SEG_HALO) - (T1 - 1) on
+        const long o0 = (long)((4 + 5 - abs0 % 5) % 5);
+        long k_min = 0;
+        while (k_min < n_seg && o0 + DEC * (m_begin + k_min * seg_len - SEG_HALO) - (T1 - 1) < 0) ++k_min;
+        if (part == 1) { a.seg_first = (int)k_min; seg_count = n_seg - k_min; }
+        else seg_count = k_min;
+        if (seg_count <= 0) return P25FE_OK;
+    }
     static const int xg_env = [] { const char* e = getenv("P25FE_XCD_GROUP"); return e ? atoi(e) : 0; }();
     a.xcd_group = xg_env;
     a.m_begin = m_begin;
@@ -306,7 +330,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         HIPCHK(h, h->power_partial.ensure(sizeof(float) * (size_t)h->C * (size_t)n_seg));
         a.power_partial = h->power_partial.as<float>();
     }
-    dim3 grid((unsigned)n_seg, (unsigned)h->C);
+    dim3 grid((unsigned)seg_count, (unsigned)h->C);
     const Taps* dt = h->d_taps.as<Taps>();
 #define P25FE_LAUNCH_K1(PK, OM)                                                                                           \
     do {                                                                                                                  \
@@ -536,26 +560,39 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
 // --------------------------------------------------------------------------------------------
 // time shards
 // --------------------------------------------------------------------------------------------
-int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
-                      p25fe_result_t* d_result, void* stream)
+static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                            p25fe_result_t* d_result, hipStream_t st, bool do_main, bool do_finish)
 {
-    if (!h || !d_iq || !d_result) return P25FE_ERR_ARG;
-    h->sh_valid = false;
+    if (!h || !d_iq || (do_finish && !d_result)) return P25FE_ERR_ARG;
+    if (do_main) h->sh_valid = false;
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = (hipStream_t)stream;
     const size_t n_bb = p25fe_n_baseband(abs0, n);
     const uint64_t abs_bb0 = p25fe_n_baseband(0, (size_t)abs0);      // baseband samples before this shard
     int rc = ensure_slice_scratch(h, n_bb);
     if (rc) return rc;
     const PlanarGeo g(n_bb);
-    prof_begin(h);
-    prof_mark(h, 0, st);
+    // the receiver's 240 history samples are recomputed from the IQ halo (zeros before the start of the stream)
+    if (do_main) {
+        prof_begin(h);
+        prof_mark(h, 0, st);
+        if (n_bb) {
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g,
+                                 do_finish ? 0 : 1);
+            if (rc) return rc;
+        }
+        h->sh_main_nbb = n_bb; h->sh_main_abs0 = abs0;
+    }
+    if (!do_finish) return P25FE_OK;
+    if (!do_main) {
+        if (h->sh_main_nbb != n_bb || h->sh_main_abs0 != abs0) return P25FE_ERR_ARG;     // finish without its main launch
+        if (n_bb) {
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g, 2);
+            if (rc) return rc;
+        }
+    }
+    prof_mark(h, 1, st);
     if (n_bb) {
-        // the receiver's 240 history samples are recomputed from the IQ halo (zeros before the start of the stream)
-        rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g);
-        if (rc) return rc;
-        prof_mark(h, 1, st);
         rc = launch_detect(h, n_bb, abs_bb0, st);
         if (rc) return rc;
     }
@@ -564,7 +601,26 @@ int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, s
     h->prof_slot = -1;
     if (rc) return rc;
     h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0;
+    h->sh_main_nbb = (size_t)-1;
     return P25FE_OK;
+}
+
+int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                      p25fe_result_t* d_result, void* stream)
+{
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, true, true);
+}
+
+int p25fe_shard_pass1_main(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                           void* stream)
+{
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, nullptr, (hipStream_t)stream, true, false);
+}
+
+int p25fe_shard_pass1_finish(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                             p25fe_result_t* d_result, void* stream)
+{
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, false, true);
 }
 
 int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride,
@@ -596,6 +652,18 @@ int p25fe_shard_resolve_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_summaries, d_shard_bb0, d_shard_bb_n,
                        (int)n_shards, d_anchor_in, d_dibit_offset);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+int p25fe_shard_compact_dev(p25fe_t* h, const uint8_t* d_gathered, size_t cap, const uint64_t* d_dibit_offset,
+                            size_t n_shards, uint8_t* d_out, size_t out_cap, void* stream)
+{
+    if (!h || !d_gathered || !d_dibit_offset || !d_out || n_shards == 0 || n_shards > 65535) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const unsigned bx = (unsigned)((cap + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(k_shard_compact, dim3(bx ? bx : 1, (unsigned)n_shards), dim3(256), 0, (hipStream_t)stream, d_gathered,
+                       (unsigned long long)cap, d_dibit_offset, (int)n_shards, d_out, (unsigned long long)out_cap);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
@@ -781,6 +849,33 @@ int p25fe_nid_dev(p25fe_t* h, const uint8_t* d_dibits, size_t n_dibits, const ui
     return P25FE_OK;
 }
 
+// host-buffer form for the file-driven harness: one channel's whole dibit stream and its sync events
+int p25fe_nid(p25fe_t* h, const uint8_t* dibits, size_t n_dibits, const uint64_t* sync_dibit, const int64_t* sync_pos,
+              size_t n_sync, p25fe_nid_t* out)
+{
+    if (!h || (!dibits && n_dibits) || !sync_dibit || !out) return P25FE_ERR_ARG;
+    if (n_sync == 0) return P25FE_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf d_dib, d_sd, d_sp, d_out;
+    int rc = P25FE_OK;
+    hipError_t e = d_dib.ensure(n_dibits + 16);
+    if (e == hipSuccess) e = d_sd.ensure(n_sync * sizeof(uint64_t));
+    if (e == hipSuccess) e = d_out.ensure(n_sync * sizeof(p25fe_nid_t));
+    if (e == hipSuccess && sync_pos) e = d_sp.ensure(n_sync * sizeof(int64_t));
+    if (e == hipSuccess && n_dibits) e = hipMemcpyAsync(d_dib.p, dibits, n_dibits, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_sd.p, sync_dibit, n_sync * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && sync_pos) e = hipMemcpyAsync(d_sp.p, sync_pos, n_sync * sizeof(int64_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        rc = p25fe_nid_dev(h, d_dib.as<uint8_t>(), n_dibits, d_sd.as<uint64_t>(), sync_pos ? d_sp.as<int64_t>() : nullptr,
+                           n_sync, d_out.as<p25fe_nid_t>(), h->stream);
+        if (rc == P25FE_OK) e = hipMemcpyAsync(out, d_out.p, n_sync * sizeof(p25fe_nid_t), hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    d_dib.release(); d_sd.release(); d_sp.release(); d_out.release();
+    if (e != hipSuccess) { h->last_hip = (int)e; return P25FE_ERR_HIP; }
+    return rc;
+}
+
 int p25fe_nid_batch_dev(p25fe_t* h, const uint8_t* d_dibits, size_t dibit_stride, const p25fe_result_t* d_result,
                         const uint64_t* d_sync_dibit, const int64_t* d_sync_pos, size_t sync_stride,
                         p25fe_nid_t* d_out, void* stream)
@@ -813,6 +908,7 @@ int p25fe_profile_enable(p25fe_t* h, int on)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (on && h->prof_ev.empty()) {
         h->prof_ev.resize((size_t)PROF_RING * 5);
+        h->prof_mask.assign((size_t)PROF_RING, 0);
         for (auto& e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
     }
     h->prof_on = on != 0;
@@ -827,10 +923,12 @@ int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
     for (int k = 0; k < 4; ++k) ms[k] = 0.0;
     const uint64_t calls = h->prof_calls;
     const uint64_t kept = calls < (uint64_t)PROF_RING ? calls : (uint64_t)PROF_RING;
-    const int nk = h->prof_level == 2 ? 1 : 4;
     for (uint64_t s = 0; s < kept; ++s) {
-        HIPCHK(h, hipEventSynchronize(h->prof_ev[s * 5 + nk]));
-        for (int k = 0; k < nk; ++k) {
+        const unsigned m = h->prof_mask[s];                          // a slot holds the events its call recorded: all five
+        for (int k = 4; k >= 0; --k)                                 // (run_dev, shard pass 1) or 2..4 (shard pass 2)
+            if (m & (1u << k)) { HIPCHK(h, hipEventSynchronize(h->prof_ev[s * 5 + k])); break; }
+        for (int k = 0; k < 4; ++k) {
+            if ((m & (3u << k)) != (3u << k)) continue;
             float t = 0.f;
             HIPCHK(h, hipEventElapsedTime(&t, h->prof_ev[s * 5 + k], h->prof_ev[s * 5 + k + 1]));
             ms[k] += t;

@@ -353,6 +353,7 @@ struct K1Args {
     long n_out;             // outputs per channel
     int subs_per_seg;
     int xcd_group;          // > 0: workgroups b, b + 8, b + 16, ... (same XCD) take xcd_group consecutive segments (see k_frontend)
+    int seg_first;          // first segment of this launch (a shard's head segment is launched after its halo has arrived)
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
     float* power_partial;   // nullable: [n_channels][gridDim.x] partial sums of |y|^2
     // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + PLPAD >= SEG_HALO,
@@ -399,8 +400,8 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     // XCD x takes the G consecutive ones [x G, x G + G), one after the other, so that a segment's 9 % halo re-read was
     // fetched into the SAME XCD's L2 by its left neighbour a moment ago -- while all eight XCDs still stream the same
     // ~1 MB of the capture (whole eighths per XCD measured 4 % slower: eight far-apart DRAM streams).
-    long seg = blockIdx.x;
-    if (a.xcd_group > 0) {
+    long seg = (long)blockIdx.x + a.seg_first;
+    if (a.xcd_group > 0 && a.seg_first == 0) {
         const long run = 8L * a.xcd_group;
         const long full = (long)gridDim.x / run * run;              // the tail keeps the identity map
         if (seg < full) {
@@ -1041,7 +1042,7 @@ __global__ void k_power_finish(const float* partial, int n_partial, long n, floa
     }
     if (threadIdx.x == 0) {
         const float avg = red[0] / (float)n;
-        out_dbm[ch] = n > 0 ? 30.0f + 10.0f * log10f(avg / 1.0f) : 0.0f;
+        out_dbm[ch] = 30.0f + 10.0f * log10f(avg / 1.0f);       // n = 0: 0 / 0 -> NaN, as the reference's fold over an empty chunk
     }
 }
 
@@ -1181,6 +1182,20 @@ __host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summari
         off += pre + (summaries[r].first_event >= 0 ? summaries[r].n_dibits_after_first : 0);
         if (summaries[r].first_event >= 0) cur = summaries[r].anchor_out;
     }
+    dibit_offset[n_shards] = off;            // total: shard r holds offset[r + 1] - offset[r] dibits
+}
+
+// Dibit gather, second half: the all-gathered, padded per-shard streams -> one contiguous stream.  Shard r's dibits
+// are gathered[r * cap .. + offset[r + 1] - offset[r]) and belong at out[offset[r] ..).
+__global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, unsigned long long cap, const uint64_t* offset,
+                                                        int n_shards, uint8_t* out, unsigned long long out_cap)
+{
+    const int r = blockIdx.y;
+    if (r >= n_shards) return;
+    const unsigned long long o0 = offset[r], n = offset[r + 1] - o0;
+    const uint8_t* src = gathered + (unsigned long long)r * cap;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n && i < cap; i += (unsigned long long)gridDim.x * 256)
+        if (o0 + i < out_cap) out[o0 + i] = src[i];
 }
 
 __global__ void k_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,

@@ -281,15 +281,41 @@ class FrontEnd:
                                            C.c_void_p(result.data_ptr()), self._stream()))
         return result
 
+    def shard_pass1_main(self, iq, offset, n_hist, abs0):
+        """K1 over everything that does not need the left halo (may run while the halo is still on the wire)."""
+        fmt, n_total, stride = self._iq_view(iq)
+        ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
+        self._chk(self.L.p25fe_shard_pass1_main(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0,
+                                                self._stream()))
+
+    def shard_pass1_finish(self, iq, offset, n_hist, abs0, result=None):
+        """The shard's head (needs the halo) + sync detection + scan; same arguments as shard_pass1_main."""
+        import torch
+        fmt, n_total, stride = self._iq_view(iq)
+        if result is None:
+            result = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=iq.device)
+        ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
+        self._chk(self.L.p25fe_shard_pass1_finish(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0,
+                                                  C.c_void_p(result.data_ptr()), self._stream()))
+        return result
+
+    def shard_compact_dev(self, gathered, offsets, out):
+        """gathered uint8 [n_shards, cap] (all-gathered shard streams), offsets int64 [n_shards + 1] -> out uint8 [total]."""
+        self._chk(self.L.p25fe_shard_compact_dev(self.h, C.c_void_p(gathered.data_ptr()), gathered.shape[1],
+                                                 C.c_void_p(offsets.data_ptr()), gathered.shape[0],
+                                                 C.c_void_p(out.data_ptr()), out.numel(), self._stream()))
+        return out
+
     def shard_resolve_dev(self, summ_all, d_bb0, d_bbn, anchors=None, offsets=None):
         """Device-side combine: summ_all uint8 [n_shards, sizeof(result)], d_bb0 / d_bbn int64 device tensors.
-        Returns (anchors uint8 [n_shards, sizeof(anchor)], offsets int64 [n_shards]) without synchronising."""
+        Returns (anchors uint8 [n_shards, sizeof(anchor)], offsets int64 [n_shards + 1], last = total) without
+        synchronising."""
         import torch
         n = summ_all.shape[0]
         if anchors is None:
             anchors = torch.empty((n, ANCHOR_DTYPE.itemsize), dtype=torch.uint8, device=summ_all.device)
         if offsets is None:
-            offsets = torch.empty(n, dtype=torch.int64, device=summ_all.device)
+            offsets = torch.empty(n + 1, dtype=torch.int64, device=summ_all.device)
         self._chk(self.L.p25fe_shard_resolve_dev(self.h, C.c_void_p(summ_all.data_ptr()), C.c_void_p(d_bb0.data_ptr()),
                                                  C.c_void_p(d_bbn.data_ptr()), n, C.c_void_p(anchors.data_ptr()),
                                                  C.c_void_p(offsets.data_ptr()), self._stream()))
@@ -317,7 +343,7 @@ class FrontEnd:
         bbn = np.ascontiguousarray(bbn, dtype=np.uint64)
         n = len(summaries)
         anc = np.zeros(n, dtype=ANCHOR_DTYPE)
-        off = np.zeros(n, dtype=np.uint64)
+        off = np.zeros(n + 1, dtype=np.uint64)                   # [n] = total dibits of the capture
         self._chk(self.L.p25fe_shard_resolve(_p(summaries), _p(bb0), _p(bbn), n, _p(anc), _p(off)))
         return anc, off
 

@@ -60,14 +60,13 @@ public:
     // DemodTask::run (src/demod.rs:62-119); returns when the reader channel closes.
     void run()
     {
-        unsigned notifier = 0;                                        // Throttler::new(4), :67
         std::vector<uint8_t> bytes;
         while (reader_.recv(bytes)) {                                 // :70
             Baseband bb;
             bb.samples.resize(bytes.size() / 2 / 5 + 2);
             size_t n_out = 0;
             float power = 0.f;
-            const bool want = (++notifier % 4) == 0;                  // :95
+            const bool want = (++notifier_ % 4) == 0;                 // :95
             expect(p25fe_demod_u8(h_.get(), bytes.data(), bytes.size(), bb.samples.data(), bb.samples.size(), &n_out,
                                   want ? &power : nullptr),
                    "unable to demodulate");                           // :74-93, 97, 109-114
@@ -82,6 +81,9 @@ private:
     Reader& reader_;
     Hub& hub_;
     Chan& chan_;
+    // Throttler::new(4) (src/demod.rs:67): the reference creates it once, before the loop that never returns.  A
+    // driver that calls run() once per chunk must see the same every-4th-chunk cadence, so the counter lives here.
+    unsigned notifier_ = 0;
 };
 
 struct Symbols {

@@ -1,11 +1,26 @@
-// p25fe_replay -- file-in / file-out driver in the role of the reference's replay.rs
-// (src/replay.rs:26-57, src/main.rs:95-98, 162-169): deterministic harness for the hot path.
+// p25fe_replay -- file-in / file-out driver in the role of the reference's command line for this path
+// (src/main.rs:95-102, 162-175, 278-283 and src/replay.rs:26-57): a deterministic harness for the hot path.
 //
-//   p25fe_replay u8   <iq.u8>    <dibits.out>   RTL-SDR style interleaved u8 I/Q, 32768-byte chunks (src/consts.rs:6)
-//   p25fe_replay cf32 <iq.cf32>  <dibits.out>   Complex32 I/Q, 16384-sample chunks
-//   p25fe_replay bb   <bb.f32le> <dibits.out>   48 kHz f32le baseband, the reference's -w / -r format (src/main.rs:101)
+//   p25fe_replay [-w BB.f32le] [-j EVENTS.jsonl] [-b CHUNKS] u8|cf32|bb <in> <dibits.out>
+//
+//     u8    RTL-SDR style interleaved u8 I/Q, the reference's live input (src/consts.rs:6: 32768-byte chunks)
+//     cf32  Complex32 I/Q at 240 ksps
+//     bb    48 kHz f32le baseband: what `p25rx -w FILE` records and `p25rx -r FILE` replays (src/main.rs:95-102)
+//
+//     -w FILE   write the baseband as f32le / 48 kHz / mono while receiving -- the reference's `-w`
+//               (src/main.rs:99-102, 174-175): RecvTask::run hands every chunk to a callback AFTER feeding it
+//               (src/recv.rs:152), and the callback appends it to the file (src/main.rs:278-283).
+//               `p25fe_replay bb FILE ...` on that file reproduces the dibits of the recording run.
+//     -j FILE   JSON lines in the vocabulary of the reference's hub: {"event":"sigPower"} per power report
+//               (HubEvent::UpdateSignalPower, src/demod.rs:95-101, src/hub.rs:344), {"event":"nid"} per frame sync
+//               (MessageEvent::PacketNID, src/recv.rs:216-222), one final {"event":"updateStats"} with the "bch"
+//               row of serialize_stats (src/hub.rs:401-402, 559, 574-581).
+//     -b N      file chunks per library call (default 64; 1 = the reference's cadence of one 32768-byte buffer per
+//               DemodTask iteration, which also fixes the every-4th-chunk power report of src/demod.rs:67, 95).
+//               The dibits do not depend on N (streaming semantics); only the PCIe transfer size does.
 //
 // Wires DemodTask -> RecvTask exactly like src/main.rs:270-287, single-threaded through in-memory channels.
+#include <cinttypes>
 #include <cstring>
 #include <deque>
 #include <fstream>
@@ -26,64 +41,131 @@ template <class T> struct Chan {
     }
 };
 
+// hub side of the harness: power reports become JSON lines as they arrive
+struct Hub {
+    FILE* js = nullptr;
+    size_t n_power = 0;
+    void send(HubEvent e)
+    {
+        ++n_power;
+        if (js) std::fprintf(js, "{\"event\":\"sigPower\",\"dbm\":%.4f}\n", (double)e.signal_power_dbm);
+    }
+};
+
 struct Sink {
     std::ofstream out;
+    std::vector<uint8_t> all_dibits;            // kept for the NID pass at the end of the file (-j)
+    std::vector<int64_t> sync_pos;
+    std::vector<uint64_t> sync_dibit;
+    bool keep = false;
     size_t n_sync = 0, n_dibits = 0;
     void send(Symbols s)
     {
         out.write(reinterpret_cast<const char*>(s.dibits.data()), (std::streamsize)s.dibits.size());
         n_dibits += s.dibits.size();
         n_sync += s.sync_pos.size();
+        if (keep) {
+            all_dibits.insert(all_dibits.end(), s.dibits.begin(), s.dibits.end());
+            sync_pos.insert(sync_pos.end(), s.sync_pos.begin(), s.sync_pos.end());
+            sync_dibit.insert(sync_dibit.end(), s.sync_dibit.begin(), s.sync_dibit.end());
+        }
     }
 };
 
+static int usage(const char* argv0)
+{
+    std::fprintf(stderr, "usage: %s [-w BB.f32le] [-j EVENTS.jsonl] [-b CHUNKS] u8|cf32|bb <in> <dibits.out>\n", argv0);
+    return 2;
+}
+
 int main(int argc, char** argv)
 {
-    if (argc != 4) {
-        std::fprintf(stderr, "usage: %s u8|cf32|bb <in> <dibits.out>\n", argv[0]);
-        return 2;
+    const char *wpath = nullptr, *jpath = nullptr;
+    size_t batch = 64;
+    int a = 1;
+    for (; a < argc && argv[a][0] == '-' && argv[a][1] != '\0'; a += 2) {
+        if (a + 1 >= argc) return usage(argv[0]);
+        if (!std::strcmp(argv[a], "-w")) wpath = argv[a + 1];
+        else if (!std::strcmp(argv[a], "-j")) jpath = argv[a + 1];
+        else if (!std::strcmp(argv[a], "-b")) batch = (size_t)std::strtoull(argv[a + 1], nullptr, 10);
+        else return usage(argv[0]);
     }
-    const std::string mode = argv[1];
-    std::ifstream in(argv[2], std::ios::binary);
-    if (!in) { std::fprintf(stderr, "unable to open %s\n", argv[2]); return 1; }
+    if (argc - a != 3 || batch == 0) return usage(argv[0]);
+    const std::string mode = argv[a];
+    std::ifstream in(argv[a + 1], std::ios::binary);
+    if (!in) { std::fprintf(stderr, "unable to open %s\n", argv[a + 1]); return 1; }
     Handle h(0, 1);
     Chan<std::vector<uint8_t>> reader;
-    Chan<HubEvent> hub;
+    Hub hub;
     Chan<Baseband> chan;
     Sink sink;
-    sink.out.open(argv[3], std::ios::binary);
+    sink.out.open(argv[a + 2], std::ios::binary);
+    sink.keep = jpath != nullptr;
+    if (jpath && !(hub.js = std::fopen(jpath, "w"))) { std::fprintf(stderr, "unable to open %s\n", jpath); return 1; }
+    std::ofstream bbfile;                                             // samples_file, src/main.rs:174-175
+    if (wpath) {
+        bbfile.open(wpath, std::ios::binary);
+        if (!bbfile) { std::fprintf(stderr, "unable to open baseband file\n"); return 1; }
+    }
+    auto dump = [&](const std::vector<float>& s) {                    // the closure of src/main.rs:278-283
+        if (wpath) bbfile.write(reinterpret_cast<const char*>(s.data()), (std::streamsize)(s.size() * sizeof(float)));
+    };
     RecvTask<Chan<Baseband>, Sink> recv(h, chan, sink);
 
     if (mode == "u8") {
-        std::vector<uint8_t> buf(BUF_BYTES);
-        DemodTask<Chan<std::vector<uint8_t>>, Chan<HubEvent>, Chan<Baseband>> demod(h, reader, hub, chan);
+        std::vector<uint8_t> buf(BUF_BYTES * batch);
+        DemodTask<Chan<std::vector<uint8_t>>, Hub, Chan<Baseband>> demod(h, reader, hub, chan);
         while (in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size()) || in.gcount() > 0) {
             std::vector<uint8_t> chunk(buf.begin(), buf.begin() + (in.gcount() & ~std::streamsize(1)));
             reader.send(std::move(chunk));
             demod.run();
-            recv.run([](const std::vector<float>&) {});
+            recv.run(dump);
         }
     } else if (mode == "cf32") {
-        std::vector<float> buf(2 * BUF_SAMPLES), bb(BUF_SAMPLES / 5 + 2);
+        std::vector<float> buf(2 * BUF_SAMPLES * batch), bb(BUF_SAMPLES * batch / 5 + 2);
+        unsigned notifier = 0;
         while (in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(buf.size() * 4)) || in.gcount() > 0) {
             const size_t n = (size_t)in.gcount() / 8;
             size_t n_out = 0;
-            expect(p25fe_demod_cf32(h.get(), buf.data(), n, bb.data(), bb.size(), &n_out, nullptr), "unable to demodulate");
+            float power = 0.f;
+            const bool want = (++notifier % 4) == 0;                  // Throttler::new(4), src/demod.rs:67, 95
+            expect(p25fe_demod_cf32(h.get(), buf.data(), n, bb.data(), bb.size(), &n_out, want ? &power : nullptr),
+                   "unable to demodulate");
+            if (want) hub.send(HubEvent{power});
             chan.send(Baseband{std::vector<float>(bb.begin(), bb.begin() + (long)n_out)});
-            recv.run([](const std::vector<float>&) {});
+            recv.run(dump);
         }
     } else if (mode == "bb") {
-        std::vector<float> buf(8192);                                 // replay.rs reads 32768-byte blocks (src/replay.rs:27)
+        std::vector<float> buf(8192 * batch);                         // replay.rs reads 32768-byte blocks (src/replay.rs:27)
         while (in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(buf.size() * 4)) || in.gcount() > 0) {
             const size_t n = (size_t)in.gcount() / 4;                 // only the bytes actually read (replay.rs:36 re-feeds stale tail)
             chan.send(Baseband{std::vector<float>(buf.begin(), buf.begin() + (long)n)});
-            recv.run([](const std::vector<float>&) {});
+            recv.run(dump);
         }
     } else {
-        std::fprintf(stderr, "unknown mode %s\n", mode.c_str());
-        return 2;
+        return usage(argv[0]);
+    }
+
+    if (hub.js) {
+        // network identifiers of all frame syncs in one pass over the finished dibit stream, then the stats row
+        std::vector<p25fe_nid_t> nid(sink.sync_pos.size());
+        expect(p25fe_nid(h.get(), sink.all_dibits.data(), sink.all_dibits.size(), sink.sync_dibit.data(), sink.sync_pos.data(),
+                         nid.size(), nid.data()),
+               "unable to decode network identifiers");
+        uint64_t words = 0, errs = 0, fixed = 0;
+        for (const p25fe_nid_t& r : nid) {
+            std::fprintf(hub.js, "{\"event\":\"nid\",\"sync_pos\":%" PRId64 ",\"nac\":%u,\"duid\":%u,\"errors\":%u,\"valid\":%d}\n",
+                         r.sync_pos, (unsigned)r.nac, (unsigned)r.duid, (unsigned)r.n_errors, (int)r.valid);
+            if (r.valid >= 0) { ++words; if (r.valid == 0) ++errs; else fixed += r.n_errors; }
+        }
+        // serialize_code_stats (src/hub.rs:574-581): totalWords, errWords, totalSymbols = words * size, fixedSymbols
+        std::fprintf(hub.js,
+                     "{\"event\":\"updateStats\",\"dibits\":%zu,\"syncs\":%zu,\"bch\":{\"totalWords\":%" PRIu64 ",\"errWords\":%" PRIu64
+                     ",\"totalSymbols\":%" PRIu64 ",\"fixedSymbols\":%" PRIu64 "}}\n",
+                     sink.n_dibits, sink.n_sync, words, errs, words * 63, fixed);
+        std::fclose(hub.js);
     }
     std::fprintf(stderr, "p25fe_replay: %zu dibits, %zu frame syncs, %zu power reports\n", sink.n_dibits, sink.n_sync,
-                 hub.q.size());
+                 hub.n_power);
     return 0;
 }

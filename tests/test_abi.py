@@ -31,7 +31,7 @@ def test_header_symbols_all_exported(lib):
 
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
-    assert cfg.abi_version == 1 and cfg.n_channels == 1
+    assert cfg.abi_version == lib.ABI_VERSION == 2 and cfg.n_channels == 1
     assert cfg.n_decim_taps == spec["t1"] and cfg.n_chan_taps == spec["t2"]
     assert np.array_equal(np.array(cfg.decim_taps[:spec["t1"]], dtype=np.float32), np.array(spec["decim_taps"], dtype=np.float32))
     assert np.array_equal(np.array(cfg.chan_taps[:spec["t2"]], dtype=np.float32), np.array(spec["chan_taps"], dtype=np.float32))
@@ -81,7 +81,7 @@ def test_shard_resolve_host_logic(lib):
     summ[2]["anchor_out"] = (2503, 0.3, 0.1, -0.1, 1)
     summ[3]["first_event"] = -1
     anc = np.zeros(4, dtype=A)
-    off = np.zeros(4, dtype=np.uint64)
+    off = np.zeros(5, dtype=np.uint64)                         # n_shards + 1: the last entry is the capture's total
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, p(anc), p(off)) == 0
     assert anc["valid"].tolist() == [0, 1, 1, 1] and anc["s"].tolist()[1:] == [302, 302, 2503]
@@ -89,7 +89,7 @@ def test_shard_resolve_host_logic(lib):
     exp1 = 69
     exp2 = exp1 + inst(302, 1000, 2000)
     exp3 = exp2 + inst(302, 2000, 2509) + 49
-    assert off.tolist() == [0, exp1, exp2, exp3]
+    assert off.tolist() == [0, exp1, exp2, exp3, exp3 + inst(2503, 3000, 4000)]
 
 
 def test_cpp_host_driver_built_and_fails_loudly_without_gpu(lib, tmp_path):

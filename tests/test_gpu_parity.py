@@ -709,3 +709,76 @@ def test_run_dev_every_symbol_phase(O, FE):
         assert int(r["n_dibits"]) == len(ref) and int(r["n_sync"]) == len(spos), off
         assert np.array_equal(dib[0, :len(ref)].cpu().numpy(), ref), off
     assert len(phases) == 10, phases
+
+
+@pytest.mark.gpu
+def test_config5_full_size_eight_shards_one_gpu(FE):
+    """BASELINE.json configs[4] at FULL size through the sharded path: the 8.64e8-sample capture as 8 contiguous
+    shards (the code path of 8 ranks, run back to back on one GPU): pass 1 in its two launches (main, then the head
+    that needs the halo), device resolve, pass 2, dibit compaction.  Shards 1..7 start at baseband indices up to
+    1.5e8 (64-bit absolute indices, negative local ones in the head); the compacted stream must equal the single
+    pass over the whole capture, byte for byte."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.frontend import parse_results, n_baseband
+    n, W = 3600 * 240000, 8
+    iq, truth = c4fm.synth_torch(n, seed=78, device="cuda", snr_db=30.0)
+    ref, rres = FE().run_dev(iq)
+    n_ref = int(parse_results(rres)[0]["n_dibits"])
+    per = n // W
+    assert per % 8 == 0
+    fes = [FE() for _ in range(W)]
+    halo = fes[0].shard_halo()
+    summ_all = torch.empty((W, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    bb0 = [n_baseband(0, r * per) for r in range(W)]
+    bbn = [n_baseband(r * per, per) for r in range(W)]
+    cap = (max(bbn) // 10 + 64 + 15) // 16 * 16
+    for r in range(W):
+        h = halo if r else 0
+        view = iq[r * per - h:(r + 1) * per]
+        fes[r].shard_pass1_main(view, offset=h, n_hist=h, abs0=r * per)
+        res = fes[r].shard_pass1_finish(view, offset=h, n_hist=h, abs0=r * per)
+        summ_all[r] = res[0]
+    d_anc, d_off = fes[0].shard_resolve_dev(summ_all, torch.tensor(bb0, dtype=torch.int64, device="cuda"),
+                                            torch.tensor(bbn, dtype=torch.int64, device="cuda"))
+    gathered = torch.zeros((W, cap), dtype=torch.uint8, device="cuda")
+    for r in range(W):
+        fes[r].shard_pass2(d_anc[r:r + 1], bbn[r], iq.device, dibits=gathered[r:r + 1])
+    off = d_off.cpu().numpy()
+    assert int(off[-1]) == n_ref and all(off[r + 1] - off[r] <= cap for r in range(W))
+    stream = torch.zeros(n_ref + 16, dtype=torch.uint8, device="cuda")
+    fes[0].shard_compact_dev(gathered, d_off, stream)
+    assert torch.equal(stream[:n_ref], ref[0, :n_ref])
+    got = stream[:n_ref].cpu().numpy()
+    k = min(n_ref, len(truth) - 24)
+    assert k > 17_279_000 and np.array_equal(got[:k], truth[24:24 + k])
+    # a pass 2 after another call touched the handle must refuse instead of slicing stale scratch (p25fe.h, ORDERING)
+    fes[1].run_dev(iq[:240000])
+    with pytest.raises(Exception):
+        fes[1].shard_pass2(d_anc[1:2], bbn[1], iq.device)
+
+
+@pytest.mark.gpu
+def test_config3_full_size_end_to_end(FE):
+    """BASELINE.json configs[2] end to end at full size: 2.4 Msps x 60 s = 1.44e8 samples -> stage 0 (80-tap 10:1
+    pre-decimator) -> K1..K4 -> dibits, with demod(mod(d)) == d for all 288 000 symbols.  The wideband capture is the
+    240 ksps C4FM signal held for ten samples each (zero-order hold: its images sit in the nulls of the hold and in
+    the stop band of the pre-decimator)."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    n240 = 60 * 240000
+    iq240, truth = c4fm.synth_torch(n240, seed=31, device="cuda", snr_db=30.0)
+    wide = iq240.repeat_interleave(10, dim=0).contiguous()                          # [1.44e8, 2] @ 2.4 Msps
+    assert wide.shape[0] == 144_000_000
+    fe = FE()
+    narrow, n_out = fe.predecim_dev(wide)
+    assert n_out == n240
+    dib, res = fe.run_dev(narrow[:, :n_out])
+    r = parse_results(res)[0]
+    nd = int(r["n_dibits"])
+    got = dib[0, :nd].cpu().numpy()
+    kk, jj, n_match, n_err = c4fm.align_dibits(got, truth)
+    assert n_err == 0 and n_match > 287_000, (kk, jj, n_match, n_err)
+    assert int(r["n_sync"]) >= len(truth) // 864

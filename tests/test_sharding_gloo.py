@@ -1,10 +1,11 @@
-"""world_size-2 CPU test (gloo) of the time-shard orchestration in p25rx_amd/sharding.py.
+"""world_size-2 CPU tests (gloo) of the multi-GPU orchestration in p25rx_amd/sharding.py.
 
 The GPU kernels cannot run here, so the per-shard compute is a TEST DOUBLE built on the CPU oracle
-(OracleShardFE below); what is under test is the product's N > 1 logic: the halo exchange, the
-all-gather of shard summaries, p25fe_shard_resolve (real C-ABI host function) and the resulting
-carry-in / dibit offsets -- through TimeShard.step and through TimeShard.step_device (the bench's N > 1 step).
-The concatenated shard outputs must equal one oracle pass over the capture.
+(OracleShardFE below); what is under test is the product's N > 1 logic: the halo exchange (blocking and
+split around pass 1), the all-gather of shard summaries, p25fe_shard_resolve (real C-ABI host function), the
+resulting carry-in / dibit offsets, the all-gather + compaction of the dibit shards into one ordered stream --
+through TimeShard.step and through TimeShard.step_device (the bench's N > 1 step) -- and ChannelShard's channel
+blocks and summary gather.  The gathered stream must equal one oracle pass over the capture.
 """
 import os
 import socket
@@ -59,6 +60,19 @@ class OracleShardFE:
             return result
         return out
 
+    def shard_pass1_main(self, view, offset, n_hist, abs0):
+        self._main = (offset, n_hist, abs0)                        # the real one launches K1 for everything but the head
+
+    def shard_pass1_finish(self, view, offset, n_hist, abs0, result=None):
+        assert self._main == (offset, n_hist, abs0)
+        return self.shard_pass1(view, offset, n_hist, abs0, result=result)
+
+    def shard_compact_dev(self, gathered, offsets, out):
+        off = offsets.numpy()
+        for r in range(gathered.shape[0]):
+            out[int(off[r]):int(off[r + 1])] = gathered[r, :int(off[r + 1] - off[r])]
+        return out
+
     def shard_resolve(self, summaries, bb0, bbn):
         import ctypes as C
         L = self._lib.load()
@@ -67,7 +81,7 @@ class OracleShardFE:
         bbn = np.ascontiguousarray(bbn, dtype=np.uint64)
         n = len(summaries)
         anc = np.zeros(n, dtype=self._lib.ANCHOR_DTYPE)
-        off = np.zeros(n, dtype=np.uint64)
+        off = np.zeros(n + 1, dtype=np.uint64)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         assert L.p25fe_shard_resolve(p(summaries), p(bb0), p(bbn), n, p(anc), p(off)) == 0
         return anc, off
@@ -93,6 +107,9 @@ class OracleShardFE:
             v = self.bb[n - self.bb0]
             pre = np.where(v >= a["hi"], 1, np.where(v >= a["mid"], 0, np.where(v >= a["lo"], 2, 3))).astype(np.uint8)
         self.out = np.concatenate([pre, dib])
+        if dibits is not None:
+            import torch
+            dibits[0, :len(self.out)] = torch.from_numpy(self.out)
         return None, None
 
 
@@ -113,7 +130,9 @@ def _worker(rank, world, port, q):
         buf[ts.halo:] = torch.from_numpy(mine.view(np.float32).reshape(-1, 2))
         result = torch.zeros((1, fe._lib.RESULT_DTYPE.itemsize), dtype=torch.uint8)
         summ_all = torch.zeros((world, fe._lib.RESULT_DTYPE.itemsize), dtype=torch.uint8)
-        off, summ = ts.step(buf, result, summ_all, None)
+        off, summ, offs = ts.step(buf, result, summ_all, None)
+        counts, total = ts.gather_counts(offs)
+        assert len(counts) == world and total == int(offs[-1]) and counts[rank] == len(fe.out)
         if rank > 0:                                            # halo really is the left neighbour's tail
             left = iq[rank * N_PER_RANK - ts.halo:rank * N_PER_RANK]
             assert np.array_equal(buf[:ts.halo].numpy().view(np.complex64).reshape(-1), left)
@@ -121,10 +140,20 @@ def _worker(rank, world, port, q):
         # the bench's variant of the step: no host synchronisation, carry resolved from the all-gathered tensor
         ts.setup_device(torch, "cpu")
         buf[:ts.halo].zero_()
-        d_off = ts.step_device(buf, result, summ_all, None)
+        dibits = torch.zeros((1, ts.dibit_cap), dtype=torch.uint8)
+        d_off = ts.step_device(buf, result, summ_all, dibits)       # halo overlapped with pass 1, dibit gather + compaction
+        if rank > 0:
+            assert np.array_equal(buf[:ts.halo].numpy().view(np.complex64).reshape(-1), left)
         assert np.array_equal(fe.out, out_host)
-        assert int(d_off[rank]) == off
-        q.put((rank, off, fe.out, O.run_cf32(iq) if rank == 0 else None))
+        assert int(d_off[rank]) == off and int(d_off[-1]) == total
+        stream = ts.d_stream[:total].numpy().copy()                 # the whole capture's ordered dibit stream, on EVERY rank
+        # channel shards (config 4 over N GPUs): blocks partition the batch; the summary gather keeps channel order
+        from p25rx_amd.sharding import ChannelShard
+        cs = ChannelShard(rank, world, 5, dist)
+        mine_res = torch.arange(cs.c0, cs.c1, dtype=torch.uint8).view(-1, 1).repeat(1, 8)
+        allres = cs.gather_results(torch, mine_res)
+        assert allres.shape == (5, 8) and allres[:, 0].tolist() == [0, 1, 2, 3, 4]
+        q.put((rank, off, fe.out, O.run_cf32(iq) if rank == 0 else None, stream))
     finally:
         dist.destroy_process_group()
 
@@ -150,3 +179,16 @@ def test_time_shards_world2_gloo():
     assert got[0][1] == 0 and got[1][1] == len(outs[0])         # dibit offsets from p25fe_shard_resolve
     assert np.array_equal(np.concatenate(outs), ref[:sum(len(o) for o in outs)])
     assert abs(len(ref) - sum(len(o) for o in outs)) <= 1
+    for g in got:                                                # the gathered stream is the same on both ranks
+        assert np.array_equal(g[4], np.concatenate(outs))
+
+
+def test_channel_blocks_partition():
+    from p25rx_amd.sharding import ChannelShard
+    for world in (1, 2, 3, 8):
+        for n in (1, 7, 8, 256, 257):
+            blocks = [ChannelShard.block(r, world, n) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
