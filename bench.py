@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s through FM-demod + C4FM slice on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (K1 front end -> K2 sync -> K3 scan -> K4 slice) over one
-resident capture: BASELINE.json configs[1], 1 channel x 600 s of synthetic C4FM IQ at 240 ksps
-(1.44e8 cf32 samples, 1.152 GB) per GPU, generated in HBM before the timed region.
+N = 1 (the headline): a "step" is one pass of the hot path (K1 front end -> K2 sync detect -> K3 scan -> K4 slice)
+over one resident capture: BASELINE.json configs[1], 1 channel x 600 s of synthetic C4FM IQ at 240 ksps
+(1.44e8 cf32 samples, 1.152 GB), generated in HBM before the timed region.  The same JSON line carries an
+`extra` array with the other single-GPU configurations (u8 input, config 3 end to end, config 4, config 5 on one GPU),
+each timed over its own >= 100 ms region after the headline one (`--no-extra` skips them).
 
-N > 1 (one rank per GPU, RCCL): BASELINE.json configs[4]'s structure -- one long capture cut
-into N contiguous 600 s time shards (weak scaling).  Each step exchanges the filter halo with
-the left neighbour (send/recv), runs pass 1, all-gathers the 56-byte shard summaries, resolves
-the symbol-timing carry on the device and runs pass 2 -- no host synchronisation inside a step.
+N > 1 (one rank per GPU, RCCL): BASELINE.json configs[4] -- ONE 3 600 s capture cut into N contiguous time shards
+(strong scaling: the total is fixed, each rank owns 3 600 / N seconds).  A step = halo send/recv to the right neighbour
+(hidden behind K1) -> pass 1 -> all_gather of the 56-byte shard summaries -> device resolve -> pass 2 -> all_gather of
+the dibit shards + compaction into one ordered stream on every rank.  No host synchronisation inside a step.
+`--scaling weak` keeps 600 s per rank instead.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-dominant kernel (K1) from HIP events recorded inside the library on the launch stream, and
-`cpu_baseline` from the CPU oracle timed on this box's host cores (rank 0, N = 1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (K1) from HIP
+events recorded inside the library on the launch stream, and `cpu_baseline` from the CPU oracle timed on this box's
+host cores (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -28,10 +31,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE_K1 = 8.0 + 0.8  # algorithmic: 8 B cf32 read + 4 B baseband written per 5 samples
+BYTES_PER_SAMPLE_K1_U8 = 2.0 + 0.8
+PMC_FILE = os.path.join("profiles", "r02_k1_pmc.json")
 
 
 def cpu_baseline(iq_host, seconds_label):
-    """Time the oracle (scalar C port of the reference structure) on one host core."""
+    """Time the oracle (scalar C port of the reference structure) on one host core, then on all of them."""
     from oracle import oracle as O
     so = "/tmp/p25fe_oracle_timing_%d.so" % os.getpid()
     kind_flags = "-O3 -march=native"
@@ -43,42 +48,180 @@ def cpu_baseline(iq_host, seconds_label):
     t0 = time.perf_counter()
     dib = O.run_cf32(iq_host, libpath=so)
     dt = time.perf_counter() - t0
+    out = {"value": round(len(iq_host) / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "%s of the same capture (%d IQ samples), oracle/p25fe_oracle.c built %s, 1 thread, %.2f s"
+                     % (seconds_label, len(iq_host), kind_flags, dt)}
     # second figure (SURVEY 8d ii): the same port on all host cores, the capture cut into one time shard per thread
     # (pthreads inside the oracle; shard-boundary symbols are not stitched -- a throughput figure only)
     ncores = os.cpu_count() or 1
-    O.run_cf32_mt(iq_host, ncores, libpath=so)                    # untimed: the first multi-threaded pass runs at one core's
-    t0 = time.perf_counter()                                      # pace on these hosts (idle cores take a while to come up)
-    O.run_cf32_mt(iq_host, ncores, libpath=so)
-    dt_all = time.perf_counter() - t0
+    if O.run_cf32_mt(iq_host, ncores, libpath=so) >= 0:           # untimed: idle cores take a while to come up
+        t0 = time.perf_counter()
+        rc = O.run_cf32_mt(iq_host, ncores, libpath=so)
+        dt_all = time.perf_counter() - t0
+        if rc >= 0:                                               # a failed or partial pass is not a baseline
+            out["all_cores"] = {"value": round(len(iq_host) / dt_all / 1e6, 3), "cores": ncores,
+                                "note": "same sample as %d independent time shards, one thread each, %.2f s" % (ncores, dt_all)}
     if so and os.path.exists(so):
         os.unlink(so)
-    return {"value": round(len(iq_host) / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%s of the same capture (%d IQ samples), oracle/p25fe_oracle.c built %s, 1 thread, %.2f s"
-                      % (seconds_label, len(iq_host), kind_flags, dt),
-            "all_cores": {"value": round(len(iq_host) / dt_all / 1e6, 3), "cores": ncores,
-                          "note": "same sample as %d independent time shards, one thread each, %.2f s" % (ncores, dt_all)}}, dib
+    return out, dib
+
+
+def timed(torch, step, steps, warmup, dist=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def steps_for(ms_guess, min_ms=120.0, lo=5, hi=2000):
+    return int(max(lo, min(hi, np.ceil(min_ms / ms_guess))))
+
+
+def k1_frac(fe, torch, step, n_samples, bytes_per_sample, reps=8):
+    """Dominant-kernel time from the library's HIP events (on the launch stream), over a few extra steps."""
+    fe.profile_enable(1)
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    kms, ncalls = fe.profile_read()
+    fe.profile_enable(False)
+    k1 = kms[0] / max(ncalls, 1)
+    ach = bytes_per_sample * n_samples / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
+    return k1, ach, [m / max(ncalls, 1) for m in kms]
+
+
+def run_extras(torch, dev, args, iq2, truth2):
+    """The other single-GPU configurations, each over its own timed region; returns a list of dicts."""
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    out = []
+
+    def entry(name, n_samples, ms, k_name, k_ms, bps, ok, **kw):
+        ach = bps * n_samples / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        d = {"config": name, "ms_per_step": round(ms, 4), "Msamples_per_s": round(n_samples / ms / 1e3, 1),
+             "dominant_kernel": k_name, "kernel_ms": round(k_ms, 4), "achieved_GBps": round(ach, 1),
+             "frac": round(ach / HBM_PEAK_GBPS, 4), "parity_gate": bool(ok)}
+        d.update(kw)
+        out.append(d)
+
+    def gate(dib, res, truth, ch=0):
+        nd = int(parse_results(res)[ch]["n_dibits"])
+        got = dib[ch, :nd].cpu().numpy()
+        k = min(nd, len(truth) - 24)
+        return k > 0 and np.array_equal(got[:k], truth[24:24 + k])
+
+    # ---- configs[1] as RTL-SDR u8 pairs: the reference's real input format (src/demod.rs:74-84)
+    n = iq2.shape[0]
+    fe = FrontEnd(device=dev.index)
+    u8 = torch.clamp(torch.round((iq2 + 1.0) * 127.5), 0, 255).to(torch.uint8)
+    dib = res = None
+    def step_u8():
+        nonlocal dib, res
+        dib, res = fe.run_dev(u8, dibits=dib, result=res)
+    k = steps_for(0.3)
+    dt = timed(torch, step_u8, k, 5)
+    k1, _, _ = k1_frac(fe, torch, step_u8, n, BYTES_PER_SAMPLE_K1_U8)
+    entry("configs[1] as u8 I/Q pairs (the reference's input format), 1 ch x 600 s", n, dt / k * 1e3, "k_frontend<u8>", k1,
+          BYTES_PER_SAMPLE_K1_U8, gate(dib, res, truth2), steps=k, note="2.8 B per sample: VALU / LDS bound, not HBM bound")
+    del u8, fe
+
+    # ---- configs[2]: 2.4 Msps front end, 60 s = 1.44e8 samples -> stage 0 (10:1, 80 taps) -> K1..K4
+    n240 = 60 * 240000
+    iq240, truth3 = c4fm.synth_torch(n240, seed=31, device=dev, snr_db=30.0)
+    wide = iq240.repeat_interleave(10, dim=0).contiguous()          # zero-order hold: images fall in K0's stop band
+    del iq240
+    fe = FrontEnd(device=dev.index)
+    nar = dib = res = None
+    def step_c3():
+        nonlocal nar, dib, res
+        nar, no = fe.predecim_dev(wide, out=nar)
+        dib, res = fe.run_dev(nar[:, :no], dibits=dib, result=res)
+    k = steps_for(0.36)
+    dt = timed(torch, step_c3, k, 5)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        nar, _ = fe.predecim_dev(wide, out=nar)                     # K0 alone, on torch's current stream = the launch stream
+    e1.record()
+    torch.cuda.synchronize()
+    k0_ms = e0.elapsed_time(e1) / 8
+    nd = int(parse_results(res)[0]["n_dibits"])
+    al = c4fm.align_dibits(dib[0, :nd].cpu().numpy(), truth3)
+    entry("configs[2]: 2.4 Msps x 60 s -> 10:1 pre-decimator -> FIR + FM + slice, end to end", wide.shape[0], dt / k * 1e3,
+          "k_predecim", k0_ms, 8.8, al is not None and al[3] == 0 and al[2] > 287000, steps=k)
+    del wide, nar, fe
+
+    # ---- configs[3]: 256 independent channels x 60 s, channel-major (29.5 GB)
+    C, n4 = 256, 60 * 240000
+    iq4 = torch.empty((C, n4, 2), dtype=torch.float32, device=dev)
+    truth4 = None
+    for c in range(C):
+        _, t = c4fm.synth_torch(n4, seed=2000 + c, device=dev, snr_db=30.0, out=iq4[c])
+        if c == C - 1:
+            truth4 = t
+    fe = FrontEnd(n_channels=C, device=dev.index)
+    dib = res = None
+    def step_c4():
+        nonlocal dib, res
+        dib, res = fe.run_dev(iq4, dibits=dib, result=res)
+    k = steps_for(7.5)
+    dt = timed(torch, step_c4, k, 2)
+    k1, _, kms = k1_frac(fe, torch, step_c4, C * n4, BYTES_PER_SAMPLE_K1, reps=3)
+    entry("configs[3]: 256 channels x 60 s, channel-major batch", C * n4, dt / k * 1e3, "k_frontend<cf32>", k1,
+          BYTES_PER_SAMPLE_K1, gate(dib, res, truth4, C - 1), steps=k,
+          receiver_share=round((kms[1] + kms[2] + kms[3]) / max(sum(kms), 1e-9), 4))
+    del iq4, fe, dib, res
+
+    # ---- configs[4] on ONE GPU: 3 600 s x 1 channel (6.9 GB)
+    n5 = 3600 * 240000
+    iq5, truth5 = c4fm.synth_torch(n5, seed=77, device=dev, snr_db=30.0)
+    fe = FrontEnd(device=dev.index)
+    dib = res = None
+    def step_c5():
+        nonlocal dib, res
+        dib, res = fe.run_dev(iq5, dibits=dib, result=res)
+    k = steps_for(1.9)
+    dt = timed(torch, step_c5, k, 2)
+    k1, _, _ = k1_frac(fe, torch, step_c5, n5, BYTES_PER_SAMPLE_K1, reps=3)
+    entry("configs[4] on one GPU: 3 600 s x 1 channel, single pass", n5, dt / k * 1e3, "k_frontend<cf32>", k1,
+          BYTES_PER_SAMPLE_K1, gate(dib, res, truth5), steps=k)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seconds", type=float, default=600.0, help="capture length per GPU (configs[1]: 600)")
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (default: a ~130 ms timed region at 0.32 ms/step)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--seconds", type=float, default=None,
+                    help="capture length: per GPU at N = 1 / --scaling weak (default 600 = configs[1]), TOTAL at N > 1 strong "
+                         "(default 3600 = configs[4])")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1 only")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the dibit stream sharded (diagnostic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--cpu-seconds", type=float, default=600.0, help="length of the capture prefix timed on the CPU")
     args = ap.parse_args()
 
     import torch
     from p25rx_amd import c4fm
-    from p25rx_amd.frontend import FrontEnd, parse_results, n_baseband
+    from p25rx_amd.frontend import FrontEnd, parse_results
     from p25rx_amd._lib import RESULT_DTYPE
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("P25FE_BENCH_ONE_GPU"):        # test hook: every rank on GPU 0 (only useful where RCCL allows it)
-        local = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -88,7 +231,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    n = int(round(args.seconds * 240000))
+    strong = world > 1 and args.scaling == "strong"
+    if strong:
+        total_s = 3600.0 if args.seconds is None else args.seconds
+        n = int(round(total_s * 240000)) // world
+    else:
+        total_s = 600.0 if args.seconds is None else args.seconds
+        n = int(round(total_s * 240000))
     n -= n % 8                                                     # shard cut points stay 16-B aligned
     fe = FrontEnd(device=local)
     halo = fe.shard_halo()
@@ -99,46 +248,36 @@ def main():
     torch.cuda.synchronize()
 
     cap = (n // 50 + 64 + 15) // 16 * 16
-    dibits = torch.empty((1, cap), dtype=torch.uint8, device=dev)
     result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    abs0 = rank * n
-    bb0 = n_baseband(0, abs0)
-    bbn = n_baseband(abs0, n)
 
     if world == 1:
+        dibits = torch.empty((1, cap), dtype=torch.uint8, device=dev)
+
         def step():
             fe.run_dev(iq, dibits=dibits, result=result)
     else:
         from p25rx_amd.sharding import TimeShard
         ts = TimeShard(fe, rank, world, n, dist)
         ts.setup_device(torch, dev)
+        dibits = torch.zeros((1, ts.dibit_cap), dtype=torch.uint8, device=dev)
         summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
 
         def step():
-            ts.step_device(buf, result, summ_all, dibits)
+            ts.step_device(buf, result, summ_all, dibits, gather=not args.no_gather)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     fe.profile_enable(2)            # HIP events around K1 only inside the timed region (each record costs ~3 us of gap)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = timed(torch, step, args.steps, 0, dist)
     kms, ncalls = fe.profile_read()
     # per-kernel split of the other kernels: a few extra steps OUTSIDE the timed region with events around every kernel
     fe.profile_enable(1)
-    for _ in range(min(args.steps, 8)):
+    n_extra_steps = min(args.steps, 8)
+    for _ in range(n_extra_steps):
         step()
     torch.cuda.synchronize()
-    kms_all, ncalls_all = fe.profile_read()
+    kms_all, _ = fe.profile_read()
     fe.profile_enable(False)
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -150,6 +289,7 @@ def main():
     nd = int(r["n_dibits"])
     got = dibits[0, :nd].cpu().numpy()
     ok = True
+    gather_ok = None
     if world == 1:
         k = min(nd, len(truth) - 24)
         ok = bool(k > 0 and np.array_equal(got[:k], truth[24:24 + k]))
@@ -165,43 +305,66 @@ def main():
                 if k > 0 and np.array_equal(got[first:first + k], truth[j:j + k]):
                     ok = True
                     break
+        if not args.no_gather:
+            # the gathered, ordered stream holds my shard's dibits at my resolved offset
+            off = ts.d_offsets.cpu().numpy()
+            mine = ts.d_stream[int(off[rank]):int(off[rank + 1])].cpu().numpy()
+            gather_ok = bool(len(mine) == nd and np.array_equal(mine, got))
     if dist:
-        okt = torch.tensor([1 if ok else 0], device=dev)
+        okt = torch.tensor([1 if ok else 0, 1 if gather_ok in (None, True) else 0], device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
+        ok, gather_ok = bool(okt[0].item()), (None if args.no_gather else bool(okt[1].item()))
 
     if rank == 0:
         total_samples = float(n) * world * args.steps
         value = total_samples / dt / 1e6
         k1_ms = kms[0] / max(ncalls, 1)
         achieved = BYTES_PER_SAMPLE_K1 * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
-        if os.path.exists(pmc):
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, PMC_FILE)
+        if world == 1 and abs(total_s - 600.0) < 1e-9 and os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic_source = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, collected in "
+                                  "a SEPARATE run (tools/prof.sh), not by this process" % PMC_FILE)
             except Exception:
                 traffic = None
+        if world == 1:
+            workload = ("configs[1]: 1 channel x %.0f s synthetic C4FM cf32 IQ @ 240 ksps (%d samples, %.3f GB), decimating "
+                        "FIR + FM + boxcar + sync + 4-level slice" % (total_s, n, n * 8 / 1e9))
+            sharding = "none"
+        elif strong:
+            workload = ("configs[4]: ONE %.0f s capture (%d samples, %.3f GB) cut into %d contiguous time shards of %.1f s, "
+                        "decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather"
+                        % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0))
+            sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (RCCL)" % halo
+        else:
+            workload = ("configs[4] weak-scaled: %.0f s per GPU (%d samples per rank)" % (total_s, n))
+            sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (RCCL)" % halo
         out = {
             "metric": "IQ Msamples/s through FM-demod+C4FM slice",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1 channel x %.0f s synthetic C4FM cf32 IQ @ 240 ksps per GPU "
-                                   "(%d samples, %.3f GB), decimating FIR + FM + boxcar + sync + 4-level slice"
-                                   % (args.seconds, n, n * 8 / 1e9),
-                       "sharding": "none" if world == 1 else "time shards, halo %d samples, RCCL send/recv + all_gather" % halo,
+            "config": {"workload": workload, "sharding": sharding,
                        "parity_gate": "dibits == modulator symbols: %s" % ok},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_frontend<cf32>", "kernel_ms": round(k1_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_K1 * n,
-                         "other_kernels_ms": {"k_sync": round(kms_all[1] / max(ncalls_all, 1), 4),
-                                              "k_scan": round(kms_all[2] / max(ncalls_all, 1), 4),
-                                              "k_slice": round(kms_all[3] / max(ncalls_all, 1), 4),
-                                              "note": "from extra steps after the timed region"}},
+                         "whole_step": {"algorithmic_bytes_per_sample": 8.02,
+                                        "achieved": round(8.02 * n * world * args.steps / dt / 1e9, 1),
+                                        "frac_of_peak_x_gpus": round(8.02 * n * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)},
+                         "other_kernels_ms": {"k_detect": round(kms_all[1] / n_extra_steps, 4),
+                                              "k_scan": round(kms_all[2] / n_extra_steps, 4),
+                                              "k_slice": round(kms_all[3] / n_extra_steps, 4),
+                                              "note": "from extra steps after the timed region, HIP events around every kernel"
+                                                      + ("; N > 1: k_scan = pass 1 + pass 2 scans, RCCL time is in neither" if world > 1 else "")}},
         }
+        if gather_ok is not None:
+            out["config"]["gather_gate"] = "gathered stream holds every shard at its resolved offset: %s" % gather_ok
         if world == 1 and not args.no_cpu:
             ncpu = min(n, int(args.cpu_seconds * 240000))
             host = iq[:ncpu].cpu().numpy().view(np.complex64).reshape(-1)
@@ -211,6 +374,11 @@ def main():
             # the oracle on the same samples must agree with the GPU bit for bit (full prefix)
             out["config"]["oracle_gate"] = "GPU dibits == oracle dibits on the CPU sample: %s" % bool(
                 np.array_equal(cpu_dib[:kk - 1], got[:kk - 1]))
+        if world == 1 and not args.no_extra:
+            try:
+                out["extra"] = run_extras(torch, dev, args, iq, truth)
+            except Exception as e:                         # the headline line must not be lost to an extra
+                out["extra_error"] = "%s: %s" % (type(e).__name__, e)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

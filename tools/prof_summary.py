@@ -7,12 +7,13 @@ d = sys.argv[1]
 def short(k):
     if "p25k::" not in k:
         return None
-    for s in ("k_frontend", "k_sync", "k_scan_groups", "k_scan", "k_slice", "k_power", "k_predecim", "k_channelise", "k_nid", "k_chan_stats"):
+    for s in ("k_frontend", "k_detect", "k_scan", "k_slice", "k_planarize", "k_power", "k_predecim", "k_channelise", "k_nid",
+              "k_chan_stats", "k_shard"):
         if "p25k::" + s in k:
             return s
     return None
 for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
-    print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu :", os.path.relpath(f, d))
+    print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extra :", os.path.relpath(f, d))
     for r in csv.DictReader(open(f)):
         if short(r.get("Name", "")):
             print("  %-12s calls %4s  avg %10.1f ns  min %9s  max %9s  pct %s" % (
@@ -24,7 +25,7 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.cs
         k = short(r.get("Kernel_Name", ""))
         if k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print("== PMC (separate --pmc run of bench.py --steps 4):", os.path.relpath(f, d))
+    print("== PMC (separate --pmc run of bench.py --steps 4 --no-extra):", os.path.relpath(f, d))
     for k in sorted(acc):
         for c, v in sorted(acc[k].items()):
             vals[k][c] = sum(v) / len(v)
