@@ -223,10 +223,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    staged = bool(os.environ.get("P25FE_BENCH_HOST_STAGED"))     # TEST HOOK: all ranks on GPU 0, collectives through gloo + CPU
+    if staged:                                                   # copies (RCCL refuses two ranks on one GPU); never the product path
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if staged:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -256,8 +262,8 @@ def main():
         def step():
             fe.run_dev(iq, dibits=dibits, result=result)
     else:
-        from p25rx_amd.sharding import TimeShard
-        ts = TimeShard(fe, rank, world, n, dist)
+        from p25rx_amd.sharding import HostStagedComm, TimeShard
+        ts = TimeShard(fe, rank, world, n, dist, comm=HostStagedComm(dist, rank, world) if staged else None)
         ts.setup_device(torch, dev)
         dibits = torch.zeros((1, ts.dibit_cap), dtype=torch.uint8, device=dev)
         summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
@@ -279,8 +285,9 @@ def main():
     torch.cuda.synchronize()
     kms_all, _ = fe.profile_read()
     fe.profile_enable(False)
+    cdev = torch.device("cpu") if staged else dev
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -311,7 +318,7 @@ def main():
             mine = ts.d_stream[int(off[rank]):int(off[rank + 1])].cpu().numpy()
             gather_ok = bool(len(mine) == nd and np.array_equal(mine, got))
     if dist:
-        okt = torch.tensor([1 if ok else 0, 1 if gather_ok in (None, True) else 0], device=dev)
+        okt = torch.tensor([1 if ok else 0, 1 if gather_ok in (None, True) else 0], device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok, gather_ok = bool(okt[0].item()), (None if args.no_gather else bool(okt[1].item()))
 
@@ -338,7 +345,8 @@ def main():
             workload = ("configs[4]: ONE %.0f s capture (%d samples, %.3f GB) cut into %d contiguous time shards of %.1f s, "
                         "decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather"
                         % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0))
-            sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (RCCL)" % halo
+            sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (%s)" % (
+                halo, "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
         else:
             workload = ("configs[4] weak-scaled: %.0f s per GPU (%d samples per rank)" % (total_s, n))
             sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (RCCL)" % halo

@@ -206,3 +206,29 @@ def test_timeshard_step_device_two_ranks_one_gpu():
     for rank, off, stream, nd in got:
         assert off[-1] == len(ref) and off[rank + 1] - off[rank] == nd
         assert np.array_equal(stream, ref)
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_strong_split_host_staged():
+    """bench.py's N > 1 step (strong split of one capture, halo behind K1, device resolve, dibit gather) launched exactly
+    as the driver launches it, with the collectives staged through gloo (P25FE_BENCH_HOST_STAGED: two ranks cannot share
+    one GPU under RCCL).  Both gates must hold and the line must say what it measured."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, P25FE_BENCH_HOST_STAGED="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "60"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["config"]["parity_gate"].endswith("True") and d["config"]["gather_gate"].endswith("True")
+    assert "ONE 60 s capture" in d["config"]["workload"] and d["value"] > 0
