@@ -61,8 +61,10 @@ typedef enum p25fe_format {
 } p25fe_format;
 
 /* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54) and the
- * type-level tap tables of p25_filts.  Tap COUNTS are limited to P25FE_T1 / P25FE_T2 of
- * p25fe_spec.h (shorter filters are zero-padded at the old end, which is bit-neutral). */
+ * type-level tap tables of p25_filts (DecimFir / BandpassFir, src/demod.rs:27-29).  Up to
+ * P25FE_MAX_TAPS = 64 taps per filter; tables are zero-padded at the old end, which is bit-neutral
+ * (docs/SPEC.md 3.3).  The build's own tables (p25fe_default_config) run as immediate-coefficient
+ * kernels; anything else up to 31 / 41 taps, and anything longer, as generic-tap kernels. */
 typedef struct p25fe_config {
     int32_t abi_version;                 /* P25FE_ABI_VERSION */
     int32_t device;                      /* HIP device ordinal */

@@ -16,7 +16,8 @@ using namespace p25k;
 
 namespace {
 
-constexpr size_t HISTPAD = 288;      // >= HIST_IQ (284), multiple of 8: keeps 16-B alignment for u8 and cf32
+constexpr size_t HISTPAD = 448;      // >= HIST_IQ_MAX (432 with 64 + 64 taps), multiple of 8: keeps 16-B alignment for u8 and cf32
+static_assert(HISTPAD >= (size_t)HIST_IQ_MAX && HISTPAD % 8 == 0, "stream history covers the longest filters");
 constexpr size_t BBPAD = 256;        // >= HIST_BB (240), multiple of 4
 constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 1568
 constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
@@ -52,6 +53,7 @@ struct p25fe {
     int k1_p = 5;                          // FIR outputs per thread
     bool k1_dma = false;                   // P25FE_K1_DMA=1: cf32 windows by LDS-DMA instead of register staging (measured slower)
     bool default_taps = true;              // taps == p25fe_spec.h tables bit for bit -> immediate-coefficient kernels
+    bool long_taps = false;                // more than P25FE_T1 / P25FE_T2 taps -> the 64 / 64 geometry (Geo<5, 1>)
     DevBuf d_taps;                         // device copy for the generic kernels
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
@@ -172,7 +174,7 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     if (!cfg || !out) return P25FE_ERR_ARG;
     *out = nullptr;
     if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_channels > 65535 /* grid.y */ || cfg->n_decim_taps < 1 ||
-        cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_T2)
+        cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_MAX_TAPS)
         return P25FE_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
@@ -196,6 +198,7 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     memcpy(def.dec, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
     memcpy(def.ch, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
     h->default_taps = memcmp(&def, &h->taps, sizeof def) == 0;
+    h->long_taps = cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps > P25FE_T2;
     hipError_t e = hipSuccess;
     {
         const char* pv = getenv("P25FE_K1_P");            // tuning knob: FIR outputs per lane (5 default, 3)
@@ -214,6 +217,10 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     P25FE_FOR_K1(5)
     P25FE_FOR_K1(3)
 #undef P25FE_FOR_K1
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_LINEAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_LINEAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
@@ -286,7 +293,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     // 0.23-0.27 ms depending on the box -- neighbouring workgroups then stream neighbouring DRAM pages and the
     // dispatcher balances the CUs, which outweighs recomputing the 50-sample filter halo once per segment (5.5 % at
     // 3 sub-tiles; A/B on one box, three rounds: 2 -> 0.275, 3 -> 0.264, 4 -> 0.269 ms).  P25FE_SUBS overrides.
-    const int pk = planar ? 5 : h->k1_p;
+    const int pk = (planar || h->long_taps) ? 5 : h->k1_p;
+    const int t1 = h->long_taps ? TMAX : T1;
     const long sub = (long)WV * pk;
     static const long subs_env = [] { const char* e = getenv("P25FE_SUBS"); return e ? atol(e) : 0L; }();
     long subs = subs_env > 0 ? subs_env : 3;
@@ -312,7 +320,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         // segment k reads input from o0 + 5 (m_begin + k seg_len - SEG_HALO) - (T1 - 1) on
         const long o0 = (long)((4 + 5 - abs0 % 5) % 5);
         long k_min = 0;
-        while (k_min < n_seg && o0 + DEC * (m_begin + k_min * seg_len - SEG_HALO) - (T1 - 1) < 0) ++k_min;
+        while (k_min < n_seg && o0 + DEC * (m_begin + k_min * seg_len - SEG_HALO) - (t1 - 1) < 0) ++k_min;
         if (part == 1) { a.seg_first = (int)k_min; seg_count = n_seg - k_min; }
         else seg_count = k_min;
         if (seg_count <= 0) return P25FE_OK;
@@ -349,13 +357,22 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);  \
         else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);                 \
     } while (0)
-    const bool dma = h->k1_dma && fmt == P25FE_FMT_CF32 && pk == 5;
-    if (dma && planar) P25FE_LAUNCH_K1_DMA(OUT_PLANAR);
+    const bool dma = h->k1_dma && fmt == P25FE_FMT_CF32 && pk == 5 && !h->long_taps;
+#define P25FE_LAUNCH_K1_LONG(OM)                                                                                          \
+    do {                                                                                                                  \
+        const size_t lds = Geo<5, 1>::LDS_BYTES;                                                                          \
+        if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_REGS, 1>), grid, dim3(WV), lds, st, a, dt); \
+        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, 5, OM, LD_REGS, 1>), grid, dim3(WV), lds, st, a, dt);    \
+    } while (0)
+    if (h->long_taps && planar) P25FE_LAUNCH_K1_LONG(OUT_PLANAR);
+    else if (h->long_taps) P25FE_LAUNCH_K1_LONG(OUT_LINEAR);
+    else if (dma && planar) P25FE_LAUNCH_K1_DMA(OUT_PLANAR);
     else if (dma) P25FE_LAUNCH_K1_DMA(OUT_LINEAR);
     else if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
     else if (pk == 3) P25FE_LAUNCH_K1(3, OUT_LINEAR);
     else P25FE_LAUNCH_K1(5, OUT_LINEAR);
 #undef P25FE_LAUNCH_K1_DMA
+#undef P25FE_LAUNCH_K1_LONG
 #undef P25FE_LAUNCH_K1
     HIPCHK(h, hipGetLastError());
     if (d_power_dbm) {

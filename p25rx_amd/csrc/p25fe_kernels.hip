@@ -40,13 +40,13 @@ constexpr int T1 = P25FE_T1;
 constexpr int T2 = P25FE_T2;
 constexpr int BOX = P25FE_BOXCAR;
 constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9])
-constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50
-constexpr int D_CARRY = T2 - 1;              // d carried between sub-tiles
+constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50 (the build's own tap counts; Geo<PK, 1> has its own)
+constexpr int TMAX = P25FE_MAX_TAPS;         // 64: tap-count ceiling of the ABI (p25fe_config_t), the generic kernels' geometry
 // Outputs recomputed (and dropped) at the start of every segment.  HALO_D = 50 would do for the arithmetic; 80 = one
 // byte of every sign-bit plane (8 symbols x 10 samples), so that with segment lengths that are multiples of 80 every
 // sub-tile starts on a byte boundary of the polyphase layout below and no two workgroups ever share a byte.
 constexpr int SEG_HALO = 80;
-static_assert(SEG_HALO >= HALO_D && SEG_HALO % 80 == 0, "segment halo covers the filter memory and is byte-aligned per plane");
+static_assert(SEG_HALO >= HALO_Y + (TMAX - 1) && SEG_HALO % 80 == 0, "segment halo covers the filter memory (64 taps too) and is byte-aligned per plane");
 
 // Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
 // 240 history samples of the receiver at m = -240..-1), sample p belongs to plane r = p % 10 at symbol index i = p / 10.
@@ -63,9 +63,15 @@ constexpr int PL_BLK = 32 * P25FE_SPS;       // floats per block
 __host__ __device__ inline long planar_index(long i, int r) { return (i >> 5) * PL_BLK + r * 32 + (i & 31); }
 // history (input samples before the first owned one) needed for exact results
 constexpr int HIST_IQ = DEC * HALO_D + (T1 - 1) + (DEC - 1);   // 284
+constexpr int HIST_IQ_MAX = DEC * (HALO_Y + TMAX - 1) + (TMAX - 1) + (DEC - 1);   // 432 with 64 + 64 taps
 
 // PK = consecutive FIR outputs per lane (odd: lane stride 2*5*PK / 2*PK dwords -> conflict-free ds_read_b64)
-template <int PK> struct Geo {
+// TX = 0: the tap counts of docs/SPEC.md (31 / 41); TX = 1: the ABI's ceiling, 64 / 64, for caller-supplied tables such as
+// the reference's own p25_filts::DecimFir / BandpassFir (src/demod.rs:27-29, sizes not in the reference tree).
+template <int PK, int TX = 0> struct Geo {
+    static constexpr int T1 = TX ? TMAX : P25FE_T1;
+    static constexpr int T2 = TX ? TMAX : P25FE_T2;
+    static constexpr int D_CARRY = (T2 - 1 + 1) & ~1;     // d carried between sub-tiles (T2 - 1, rounded up to keep the window 16-B aligned)
     static constexpr int P = PK;
     static constexpr int SUB = WV * PK;                   // decimated samples per sub-tile (320 for PK = 5)
     static constexpr int XWIN = DEC * SUB + (T1 - DEC);   // input samples feeding one sub-tile of d
@@ -85,8 +91,8 @@ template <int PK> struct Geo {
 };
 
 struct Taps {
-    float dec[T1];
-    float ch[T2];
+    float dec[TMAX];
+    float ch[TMAX];
 };
 
 // SPEC 3.4: polynomial atan2, identical operation sequence to the oracle's restatement.
@@ -206,8 +212,8 @@ __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((
 // for straddling vectors; two paths writing the same VGPRs made the compiler put
 // s_waitcnt vmcnt(0) in front of every load, serialising 13 HBM round trips per sub-tile.)
 // ------------------------------------------------------------------------------------------
-template <int FMT, int PK> struct Loader {
-    using G = Geo<PK>;
+template <int FMT, int PK, int TX = 0> struct Loader {
+    using G = Geo<PK, TX>;
     // A lane's vector always holds TWO samples -- 16 B of cf32 or 4 B of u8 pairs -- which become one 16-B LDS store,
     // lane-consecutive and therefore conflict-free.  (u8 used to load 16 B = 8 samples per lane: the 64-B lane stride of
     // the resulting ds_write_b128 is a 4-way bank conflict in every 8-lane group and cost 20 % of the kernel.)
@@ -285,8 +291,8 @@ template <int FMT, int PK> struct Loader {
 // (boundary sub-tiles only).
 // ------------------------------------------------------------------------------------------
 constexpr int LD_REGS = 0, LD_DMA = 1;
-template <int PK> struct DmaLoader {
-    using G = Geo<PK>;
+template <int PK, int TX = 0> struct DmaLoader {
+    using G = Geo<PK, TX>;
     static constexpr int NV = G::NVD;
     __device__ __forceinline__ void issue(const void* base, long first, long n_hist, long n_new, long i_last, int tid, float2* XIN) const
     {
@@ -372,16 +378,18 @@ struct K1Args {
 #ifndef P25FE_K1_PLANAR_WPS
 #define P25FE_K1_PLANAR_WPS 2
 #endif
-template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int LD = LD_REGS>
+template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int LD = LD_REGS, int TX = 0>
 __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
+    static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
     static_assert(LD == LD_REGS || FMT == P25FE_FMT_CF32, "LDS-DMA moves raw samples: cf32 only (u8 is converted on the way)");
     constexpr bool DMA = LD == LD_DMA;
     static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
-    using G = Geo<PK>;
+    using G = Geo<PK, TX>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
     constexpr int NBACK = G::NBACK;
+    constexpr int T1 = G::T1, T2 = G::T2, D_CARRY = G::D_CARRY;      // this instantiation's tap counts (shadow the build's)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region (register loader)
     float2* XIN = DMA ? D + G::D_N : D + D_CARRY;                   // 16-B aligned: staged with ds_write_b128 / written by the DMA
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
     for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
 
-    typename std::conditional<DMA, DmaLoader<PK>, Loader<FMT, PK>>::type ld;
+    typename std::conditional<DMA, DmaLoader<PK, TX>, Loader<FMT, PK, TX>>::type ld;
     long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
     if constexpr (DMA) ld.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         // ---- stage 3: channel FIR (src/demod.rs:93). Lane: y[dlo + P tid + p] from D[P tid + p + 40 - k].
         float2 y[P];
         {
-            const float2* w = D + P * tid;
+            const float2* w = D + (D_CARRY - (T2 - 1)) + P * tid;    // d[m - k] sits at D[D_CARRY + (m - dlo) - k]
             v2f yv[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) yv[p] = v2f{0.f, 0.f};

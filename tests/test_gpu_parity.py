@@ -275,6 +275,43 @@ def test_custom_taps_zero_padded(O, FE, c4fm_1s):
     assert np.array_equal(bits(got), bits(ref))
 
 
+@pytest.mark.parametrize("nt", [(64, 64), (47, 53), (32, 41), (31, 42)])
+def test_long_taps_up_to_the_abi_ceiling(O, FE, c4fm_1s, nt):
+    """p25fe_config_t carries up to 64 taps per filter so that the reference's own p25_filts tables (src/demod.rs:27-29,
+    sizes unknown here) can be loaded: random, asymmetric tables of 64 + 64 (and odd sizes, and one tap past the build's
+    own 31 / 41) match the oracle bit for bit -- streaming host calls in ragged chunks, u8 and cf32, device ranges with a
+    history, and the fused path's dibits."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    rng = np.random.default_rng(100 + nt[0])
+    dt = (rng.standard_normal(nt[0]) * np.hanning(nt[0] + 2)[1:-1] / 6).astype(np.float32).tolist()
+    ct = (rng.standard_normal(nt[1]) * np.hanning(nt[1] + 2)[1:-1] / 6).astype(np.float32).tolist()
+    cfg = O.make_config(O.load_spec(), dt, ct)
+    iq = c4fm_1s[0]
+    ref = O.Demod(cfg).feed_cf32(iq)
+    fe = FE(decim_taps=dt, chan_taps=ct)
+    cuts = [0, 1, 17, 3276, 16384, 16385, 50001, 123456, len(iq)]
+    got = np.concatenate([fe.demod_cf32(iq[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(bits(got), bits(ref))
+    u8 = c4fm.to_u8(iq)
+    ref8 = O.Demod(cfg).feed_u8(u8)
+    fe8 = FE(decim_taps=dt, chan_taps=ct)
+    got8 = np.concatenate([fe8.demod_u8(u8[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(bits(got8), bits(ref8))
+    # device range that starts mid-stream with the history in memory
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    a0 = 100000
+    h = 448
+    bb, nb = FE(decim_taps=dt, chan_taps=ct).demod_dev(t[a0 - h:], n_hist=h, abs0=a0, offset=h)
+    assert np.array_equal(bits(bb[0, :nb].cpu().numpy()), bits(ref[len(ref) - nb:]))
+    # fused path (planar K1 of the long-tap geometry) vs the oracle's receiver on the oracle's baseband
+    dib_ref = O.Recv().feed(ref)[0]
+    dib, res = FE(decim_taps=dt, chan_taps=ct).run_dev(t)
+    n = int(parse_results(res)[0]["n_dibits"])
+    assert n == len(dib_ref) and np.array_equal(dib[0, :n].cpu().numpy(), dib_ref)
+
+
 def test_errors_are_loud(FE):
     from p25rx_amd._lib import P25feError
     fe = FE()
