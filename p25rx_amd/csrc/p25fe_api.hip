@@ -302,6 +302,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const long seg_len = (sub - SEG_HALO) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;
     if (planar && (m_begin + PLPAD < SEG_HALO || (m_begin + PLPAD) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
+    if (planar && n_out > (size_t)0x7ff00000u * 10u) return P25FE_ERR_ARG;   // symbol indices are 32-bit in the kernels: < 2^31 symbols (124 h of one channel) per call
 
     K1Args a;
     a.x = d_x;

@@ -819,3 +819,38 @@ def test_config3_full_size_end_to_end(FE):
     kk, jj, n_match, n_err = c4fm.align_dibits(got, truth)
     assert n_err == 0 and n_match > 287_000, (kk, jj, n_match, n_err)
     assert int(r["n_sync"]) >= len(truth) // 864
+
+
+@pytest.mark.gpu
+def test_sync_screen_keeps_candidates_with_wrong_sign_symbols(O, FE):
+    """K2 evaluates the exact correlation only where at most 4 of the 24 symbol-spaced samples have the wrong SIGN
+    (a necessary condition for c^2 >= 20.4 e, p25fe_recv.hip).  Build basebands whose sync words carry 1, 2 and 3
+    symbols of tiny wrong-sign amplitude (c^2 / e = 23, 22, 21: still candidates) and 4 (c^2 / e = 20 < 20.4: not one),
+    at every symbol phase, next to exact zeros and negative zeros; detections and dibits must equal the oracle's."""
+    spec = O.load_spec()
+    mask = spec["sync_sign_mask"]
+    rng = np.random.default_rng(5)
+    n = 40000
+    bb = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    bb[1000:1100] = 0.0
+    bb[1100:1200] = -0.0
+    expect = []
+    pos = 3000
+    for flips in (0, 1, 2, 3, 4, 3, 2, 1):
+        for phase in range(10):
+            s_last = pos + phase
+            bad = set(rng.choice(24, size=flips, replace=False).tolist())
+            for j in range(24):
+                g = 1.0 if (mask >> j) & 1 else -1.0
+                idx = s_last - 10 * (23 - j)
+                bb[idx - 4:idx + 5] = 0.0                                  # isolate the symbol so that the peak is at s_last
+                bb[idx] = np.float32(-1e-4 * g if j in bad else 0.3 * g)
+            expect.append(flips)
+            pos += 420
+    assert pos < n - 500
+    dib, spos, sdib = O.Recv().feed(bb)
+    # the construction does what it says: every word with <= 3 flipped symbols is detected by the oracle
+    assert len(spos) >= sum(1 for f in expect if f <= 3)
+    got = FE().slice(bb)
+    assert np.array_equal(got[1], spos) and np.array_equal(got[2], sdib)
+    assert np.array_equal(got[0], dib)
