@@ -204,13 +204,11 @@ __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((
 // ------------------------------------------------------------------------------------------
 // window loader: global -> registers, one 16-B vector per lane per load.
 //
-// Every load is unconditional and branch-free: the vector index is clamped into the range of
-// vectors that contain at least one valid sample, and samples outside [-n_hist, n_new) are
-// zeroed when the registers are written to LDS (only in boundary sub-tiles; interior ones skip
-// the masking).  A clamped vector is 16-B aligned and shares its 16 bytes with a valid sample,
-// so it can never touch an unmapped page.  (An earlier version had a second, element-wise path
-// for straddling vectors; two paths writing the same VGPRs made the compiler put
-// s_waitcnt vmcnt(0) in front of every load, serialising 13 HBM round trips per sub-tile.)
+// Every load is unconditional and branch-free (bounds-checked buffer loads, see Loader::init); samples outside
+// [-n_hist, n_new) that a straddling vector still brought in are zeroed in LDS by fixup(), which only boundary
+// windows enter.  (An earlier version had a second, element-wise path for straddling vectors; two paths writing the
+// same VGPRs made the compiler put s_waitcnt vmcnt(0) in front of every load, serialising 13 HBM round trips per
+// sub-tile.)
 // ------------------------------------------------------------------------------------------
 template <int FMT, int PK, int TX = 0> struct Loader {
     using G = Geo<PK, TX>;
@@ -223,30 +221,82 @@ template <int FMT, int PK, int TX = 0> struct Loader {
     using V = typename std::conditional<FMT == P25FE_FMT_CF32, uint4, unsigned>::type;
     V v[NV];
 
-    // base: pointer to owned sample 0 of this channel; first: index of the first window sample;
-    // i_last: last sample index this workgroup will ever need (loads past it collapse onto one cached vector)
-    __device__ __forceinline__ void load(const void* base, long first, long n_hist, long n_new, long i_last, int tid)
+    // Window loads are BUFFER loads through one descriptor per segment: the hardware bounds check returns zeros for
+    // every dword outside [descriptor base, base + num_records) and touches no memory for it, which replaces what
+    // round 1 did per vector and per sub-tile in the vector ALU (clamp the vector index with v_max / v_min, sign-extend,
+    // 64-bit add: 52 instructions for 13 loads) by ONE 32-bit add per load whose offset does not fit the 12-bit immediate.
+    //   descriptor base  = the later of (first vector of the segment's first window, vector holding sample -n_hist)
+    //   num_records      = bytes up to the last sample the segment needs (or the stream's end) -- so the prefetch past the
+    //                      segment's end costs no traffic, as the clamp onto one cached vector did;
+    //   a window that starts before the base has a negative byte offset = a huge unsigned one = out of range = zeros.
+    // (An odd n_hist leaves one invalid sample inside the base vector: fixup() zeroes it, as it does every other sample
+    // outside [-n_hist, n_new) that a straddling vector brought in.)
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    static constexpr int BPS = FMT == P25FE_FMT_CF32 ? 8 : 2;       // bytes per sample
+    static constexpr int VB = BPS * SPV;                            // bytes per vector: 16 / 4
+    __amdgpu_buffer_rsrc_t rs;
+    long base_idx;                                                  // sample index of the descriptor base (uniform, vector aligned)
+
+    // base: pointer to owned sample 0 of this channel; first0: first sample of the segment's first window;
+    // i_last: last sample index this workgroup will ever need
+    __device__ __forceinline__ void init(const void* base, long first0, long n_hist, long n_new, long i_last)
     {
-        const long v0 = first >> LOG_SPV;                           // floor division (arithmetic shift), uniform
-        const V* q = reinterpret_cast<const V*>(base) + v0;         // uniform base of the window
+        const long f_al = (first0 >> LOG_SPV) << LOG_SPV;
+        const long lo_al = ((-n_hist) >> LOG_SPV) << LOG_SPV;
+        base_idx = f_al > lo_al ? f_al : lo_al;
         const long last = i_last < n_new - 1 ? i_last : n_new - 1;
-        // clamp range relative to the window, saturated to 32 bits: one v_med3_i32 per vector
-        long lo = ((-n_hist) >> LOG_SPV) - v0;                      // vector holding sample -n_hist
-        long hi = (last >> LOG_SPV) - v0;                           // vector holding the last useful sample
-        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
-        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
-        const int lo32 = (int)lo, hi32 = (int)hi;
+        // whole vectors: the range check works on the access (a u8 dword holding `last` and one sample more would be
+        // rejected as a whole); the extra sample shares its vector, hence its page, with a valid one, and fixup() zeroes
+        // it where it lies past the stream's end
+        long bytes = ((last + 1 - base_idx + SPV - 1) >> LOG_SPV) * VB;
+        bytes = bytes < 0 ? 0 : (bytes > (1L << 30) ? (1L << 30) : bytes);
+        const uintptr_t p = reinterpret_cast<uintptr_t>(base) + (uintptr_t)(base_idx * BPS);
+        // the descriptor must be provably wave-uniform (otherwise every load becomes a waterfall loop)
+        const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)p), phi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)phi << 32) | plo), 0,
+                                               __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    }
+    // The segment's FIRST window may start before the descriptor base (stream start): its lanes' byte offsets are
+    // negative there.  The range check does not wrap a negative register offset plus a positive instruction offset
+    // back into range (it sees a huge unsigned value even when the sum is a valid byte), so this one load computes every
+    // offset in full and sends the negative ones far out of range.  Later windows of a segment start at or after the base.
+    __device__ __forceinline__ void load_first(long first, int tid)
+    {
+        const long f_al = (first >> LOG_SPV) << LOG_SPV;
+        long rel = (f_al - base_idx) * BPS;
+        rel = rel < -(1L << 30) ? -(1L << 30) : (rel > (1L << 30) ? (1L << 30) : rel);
+        const int voff = (int)rel + VB * tid;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            int r = tid + j * WV;
-            r = r < lo32 ? lo32 : r;
-            r = r > hi32 ? hi32 : r;
+            int o = voff + j * VB * WV;
+            o = o < 0 ? 0x7ffffff0 : o;
+            if constexpr (FMT == P25FE_FMT_CF32) {
+                const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+                v[j] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void load(long first, int tid)        // first >= base_idx (every window but a segment's first)
+    {
+        const long f_al = (first >> LOG_SPV) << LOG_SPV;
+        long rel = (f_al - base_idx) * BPS;                         // uniform; saturate so that the 32-bit offset cannot wrap back in range
+        rel = rel < -(1L << 30) ? -(1L << 30) : (rel > (1L << 30) ? (1L << 30) : rel);
+        const int voff = (int)rel + VB * tid;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
 #if (defined(P25FE_ABLATE) && P25FE_ABLATE == 6) || defined(P25FE_ABLATE_CACHED)     // measurement build: every window load hits one cached vector row
-            r = tid;
-            v[j] = reinterpret_cast<const V*>(base)[r];
-            continue;
+            const int o = VB * tid;
+#else
+            const int o = voff + j * VB * WV;
 #endif
-            v[j] = q[r];
+            if constexpr (FMT == P25FE_FMT_CF32) {
+                const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+                v[j] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0);
+            }
         }
     }
 
@@ -254,10 +304,13 @@ template <int FMT, int PK, int TX = 0> struct Loader {
     // ONE aligned 16-B LDS store (ds_write_b128, lane-consecutive: conflict-free).  The consumers add the 0 / 1 sample
     // shift to their read base.  (Storing at XIN - shift made the alignment unknown at compile time: every staging
     // store became a ds_write2_b64 whose 16-B lane stride is a 2-way bank conflict -- 23 % of K1's LDS cycles.)
+    // The stores are UNCONDITIONAL; samples outside [-n_hist, n_new) are zeroed afterwards by fixup(), which only
+    // boundary windows enter.  (Round 1 masked the values before storing, under `if (!interior)`: the compiler
+    // if-converted that into selects that every window executed -- 26 x (64-bit add, two 64-bit compares, two
+    // v_cndmask) = ~150 of the 900 VALU instructions per sub-tile.  Conditional LDS stores cannot be speculated, so
+    // the branch around fixup() survives.)
     __device__ __forceinline__ void store(float2* XIN, long first, long n_hist, long n_new, int tid) const
     {
-        const long first_al = (first >> LOG_SPV) << LOG_SPV;
-        const bool interior = first_al >= -n_hist && first_al + (long)NV * SPV * WV <= n_new;   // uniform
         float4* XV = reinterpret_cast<float4*>(__builtin_assume_aligned(XIN, 16));
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -271,14 +324,23 @@ template <int FMT, int PK, int TX = 0> struct Loader {
                     const unsigned pair = (v[j] >> (16 * e)) & 0xffffu;
                     s[e] = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
                 }
-                if (!interior) {
-                    const long i = first_al + SPV * (long)(tid + j * WV) + e;
-                    if (i < -n_hist || i >= n_new) s[e] = make_float2(0.f, 0.f);
-                }
             }
             // only the last round of vectors can run past the window: everything else is stored unconditionally
             if (j < NV - 1 || SPV * (tid + j * WV) + SPV <= G::XIN_N) XV[tid + j * WV] = make_float4(s[0].x, s[0].y, s[1].x, s[1].y);
         }
+    }
+    __device__ __forceinline__ void fixup(float2* XIN, long first, long n_hist, long n_new, int tid) const
+    {
+        const long first_al = (first >> LOG_SPV) << LOG_SPV;
+        if (first_al >= -n_hist && first_al + (long)NV * SPV * WV <= n_new) return;      // uniform: interior window
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < SPV; ++e) {
+                const long i = first_al + SPV * (long)(tid + j * WV) + e;
+                const int k = SPV * (tid + j * WV) + e;
+                if ((i < -n_hist || i >= n_new) && k < G::XIN_N) XIN[k] = make_float2(0.f, 0.f);
+            }
     }
 };
 
@@ -430,8 +492,12 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     typename std::conditional<DMA, DmaLoader<PK, TX>, Loader<FMT, PK, TX>>::type ld;
     long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
-    if constexpr (DMA) ld.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
-    else ld.load(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid);
+    if constexpr (DMA) {
+        ld.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
+    } else {
+        ld.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
+        ld.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+    }
     float pw = 0.f;
 
     // context carried across sub-tiles in wave-uniform registers: the last channel output and the
@@ -503,11 +569,12 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         } else {
             ld.store(XIN, first, a.n_hist, a.n_new, tid);
+            ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         }
         phase_sync();
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
-        if constexpr (!DMA) ld.load(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid);
+        if constexpr (!DMA) ld.load(first + (long)DEC * SUB, tid);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
         continue;
