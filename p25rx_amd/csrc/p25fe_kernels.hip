@@ -440,9 +440,20 @@ struct K1Args {
 #ifndef P25FE_K1_PLANAR_WPS
 #define P25FE_K1_PLANAR_WPS 2
 #endif
+// Windows in flight per wave (register-staged loader).  Measured (tools/ab.sh, same box): a second register set costs
+// the cf32 kernel a wave per SIMD (181 VGPRs -> 8 waves per CU instead of 11) and makes it 25 % SLOWER (318 vs 254 us)
+// although 45 % more bytes are in flight -- the waves' arithmetic phases, not the bytes in flight, are what covers the
+// latency there; the u8 kernel keeps 4 waves per SIMD with two sets (13 more VGPRs) and gains 10 % (200 vs 221 us).
+#ifndef P25FE_K1_PF_CF32
+#define P25FE_K1_PF_CF32 1
+#endif
+#ifndef P25FE_K1_PF_U8
+#define P25FE_K1_PF_U8 2
+#endif
 template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int LD = LD_REGS, int TX = 0>
 __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
+    constexpr int PF = (LD == LD_DMA || PK != 5 || TX != 0) ? 1 : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
     static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
     static_assert(LD == LD_REGS || FMT == P25FE_FMT_CF32, "LDS-DMA moves raw samples: cf32 only (u8 is converted on the way)");
     constexpr bool DMA = LD == LD_DMA;
@@ -489,14 +500,19 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
     for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
 
-    typename std::conditional<DMA, DmaLoader<PK, TX>, Loader<FMT, PK, TX>>::type ld;
+    using LoaderT = typename std::conditional<DMA, DmaLoader<PK, TX>, Loader<FMT, PK, TX>>::type;
+    LoaderT ld0, ld1;
     long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
     if constexpr (DMA) {
-        ld.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
+        ld0.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
     } else {
-        ld.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
-        ld.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+        ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
+        ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+        if constexpr (PF == 2) {
+            ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
+            ld1.load((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
+        }
     }
     float pw = 0.f;
 
@@ -558,8 +574,9 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         }
     };
 
-    for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB) {
-        if (dlo >= m_seg1) break;                                  // uniform
+    // One sub-tile.  `ld` holds its window (requested PF sub-tiles ago) and is refilled with the window PF sub-tiles ahead.
+    auto sub_tile = [&](auto& ld) -> bool {
+        if (dlo >= m_seg1) return false;                           // uniform
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[xsh + k] = x[first + k]
         const int xsh = (int)(first & 1);                           // window start relative to the aligned staging origin
         if constexpr (DMA) {
@@ -574,10 +591,10 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         phase_sync();
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
-        if constexpr (!DMA) ld.load(first + (long)DEC * SUB, tid);
+        if constexpr (!DMA) ld.load(first + (long)(PF * DEC) * SUB, tid);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
-        continue;
+        return true;
 #endif
         // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Lane: d[dlo + P tid + p], p = 0..P-1.
         // Output p needs x[first + 5(P tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[5 P tid + 5p + 30 - k].
@@ -607,7 +624,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         if constexpr (DMA) ld.issue(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid, XIN);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
-        continue;
+        return true;
 #endif
         // ---- stage 3: channel FIR (src/demod.rs:93). Lane: y[dlo + P tid + p] from D[P tid + p + 40 - k].
         float2 y[P];
@@ -645,7 +662,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 3
 #pragma unroll
         for (int p = 0; p < P; ++p) asm volatile("" ::"v"(y[p].x), "v"(y[p].y));     // keep the filter alive
-        continue;
+        return true;
 #endif
         // ---- stage 4: FM discriminator (src/demod.rs:109-111) on the lane's own P outputs; the sample before
         // the first one comes from lane-1 (DPP), for lane 0 from the previous sub-tile (SGPR carry)
@@ -664,7 +681,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
 #pragma unroll
         for (int p = 0; p < P; ++p) asm volatile("" ::"v"(f[p]));
-        continue;
+        return true;
 #endif
         // ---- stage 5: boxcar (src/demod.rs:114): b[m] = (fm[m] + fm[m-1] + ... + fm[m-9]) / 10, newest first.
         // fm[P tid + p - j] lives in this lane (q = p - j >= 0) or in lane - b, b = ceil(-q / P): prevf[b-1][q + b P].
@@ -704,7 +721,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             }
         }
 #if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
-        continue;
+        return true;
 #endif
         phase_sync();
         // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
@@ -729,6 +746,19 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         }
         out_rel = (int)(dlo - m_seg0);
         phase_sync();
+        return true;
+    };
+    if constexpr (PF == 1) {
+        for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB)
+            if (!sub_tile(ld0)) break;
+    } else {
+        // two register sets, two windows in flight per wave: the loop is unrolled by two so that each set keeps its registers
+        for (int it = 0; it < a.subs_per_seg; it += 2) {
+            if (!sub_tile(ld0)) break;
+            dlo += SUB;
+            if (it + 1 >= a.subs_per_seg || !sub_tile(ld1)) break;
+            dlo += SUB;
+        }
     }
     flush_outputs();
 
