@@ -3,17 +3,17 @@
 // Hot path of kchmck/p25rx re-designed for MI355X (stages of SURVEY.md section 8a):
 //   K1 k_frontend : [u8 -> cf32] -> 5:1 decimating FIR -> channel FIR -> FM discriminator ->
 //                   10-sample boxcar  == the five per-chunk loops of DemodTask::run
-//                   (src/demod.rs:82-84, 87, 93, 109-111, 114) fused into one pass over HBM.
-//   K2 k_sync     : frame-sync correlation + peak pick on the baseband (front half of
-//                   MessageReceiver::feed, src/recv.rs:207) -> event flags + per-tile summary.
-//   K3 k_scan     : per-channel scan of the tile summaries (symbol-timing anchor carry and
-//                   dibit offsets) -- the serial state of the receiver turned into a scan.
-//   K4 k_slice    : 4-level slicer at the anchored symbol instants -> dibits.
+//                   (src/demod.rs:82-84, 87, 93, 109-111, 114) fused into one pass over HBM.  Writes the baseband
+//                   either linearly (the RecvEvent::Baseband hand-off) or in the blocked polyphase layout with one sign
+//                   bit per sample on the side (the fused path: PLPAD / planar_index below).
+//   K2 k_detect, K3 k_scan, K4 k_slice (p25fe_recv.hip, included below): frame-sync detection, the receiver's serial
+//                   state as a scan, 4-level slicer -- the front half of MessageReceiver::feed (src/recv.rs:207).
 // Either side of the path (SURVEY.md section 8f / BASELINE.json config 3):
 //   K0 k_predecim   : 2.4 Msps -> 240 ksps, 80-tap 10:1 decimating FIR (config 3's extra stage).
 //   K5 k_nid        : network identifier after each frame sync, exhaustive BCH(63,16,23) search; k_chan_stats folds the
 //                     records into the reference's per-channel statistics shape (src/hub.rs:557-581).
 //   K6 k_channelise : one 2.4 Msps capture -> 192 channel streams at 240 ksps (factored 192-point DFT in registers).
+//   k_shard_resolve / k_shard_compact : carry resolution and dibit compaction across time shards (config 5).
 // K0, K1, K2, K4, K6 (everything that touches sample data): one wave per workgroup, no s_barrier, short-lived workgroups --
 // measured fastest for each of them.  K3 and K5 are small block-wide scans / searches.
 //

@@ -103,7 +103,8 @@ def test_cpp_record_replay_roundtrip_and_events(tmp_path):
 
 
 def test_scan_spans_several_lds_chunks():
-    """K3 stages 16384 tile summaries in LDS at a time: 70 M baseband samples = 34180 tiles cross a chunk boundary."""
+    """K3 stages 4096 tile summaries in LDS at a time and carries the receiver state from chunk to chunk: 70 M baseband
+    samples = 9115 tiles of 7680 = three chunks (and the linear -> polyphase conversion of a long stream)."""
     import torch
     from oracle import oracle as O
     from p25rx_amd import c4fm

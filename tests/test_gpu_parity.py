@@ -594,8 +594,8 @@ def test_channeliser_parity_and_end_to_end(O, FE):
 
 
 def test_dense_sync_events_and_noise(O, FE):
-    """Symbol receiver stress: sync words so dense that a 1024-sample tile holds several detections (K2's in-tile
-    counts, K4's event path incl. the thresholds of non-last events), timing jumps between frames, loud noise that
+    """Symbol receiver stress: sync words so dense that a 7680-sample tile holds dozens of detections (K2's sorted
+    in-tile list and counts, K4's per-detection segments and recomputed thresholds), timing jumps between frames, loud noise that
     produces candidates but no lock, and an amplitude step -- dibits, sync positions and sync dibit indices equal the
     oracle's, through the one-shot device path and through ragged streaming chunks."""
     import torch
