@@ -343,7 +343,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const Taps* dt = h->d_taps.as<Taps>();
 #define P25FE_LAUNCH_K1(PK, OM)                                                                                           \
     do {                                                                                                                  \
-        const size_t lds = Geo<PK>::LDS_BYTES;                                                                            \
+        const size_t lds = Geo<PK>::LDS_BYTES - (h->default_taps ? lds_taps_trim : 0);                                   \
         if (fmt == P25FE_FMT_CF32) {                                                                                      \
             if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK, OM>), grid, dim3(WV), lds, st, a, dt);  \
             else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK, OM>), grid, dim3(WV), lds, st, a, dt);                 \
@@ -358,6 +358,9 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);  \
         else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);                 \
     } while (0)
+    // immediate-tap kernels never touch the taps area at the end of the LDS layout: do not allocate it.  (13 376 B per
+    // wave is still 11 waves per CU: a 12th would need 13 312; trimming to that in an experiment changed nothing.)
+    constexpr size_t lds_taps_trim = sizeof(float) * (T1 + T2 + 3);
     const bool dma = h->k1_dma && fmt == P25FE_FMT_CF32 && pk == 5 && !h->long_taps;
 #define P25FE_LAUNCH_K1_LONG(OM)                                                                                          \
     do {                                                                                                                  \
