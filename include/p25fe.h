@@ -292,8 +292,8 @@ int p25fe_chan_stats_dev(p25fe_t *h, const p25fe_result_t *d_result, const p25fe
 /* Measurement hook for bench.py: when enabled, p25fe_run_dev / p25fe_shard_pass1 record HIP
  * events on the caller's stream around each kernel (K1 front end, K2 sync detect, K3 scan, K4 slice);
  * p25fe_shard_pass2 records its own slot with K3 and K4 only (ms[0], ms[1] of that slot read as 0).
- * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel
- * and the number of calls since the last read (at most the last 64 calls are kept).
+ * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel over the
+ * kept slots (at most the last 64) and, in *n_calls, how many of those slots ran K1 (= passes of the path).
  * on = 1: events around every kernel (five records per call); on = 2: around K1 only (two records; ms[1..3] read
  * as 0) -- the records themselves cost ~3 us each between kernels, which matters for a 0.38 ms step. */
 int p25fe_profile_enable(p25fe_t *h, int on);

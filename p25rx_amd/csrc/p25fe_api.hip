@@ -944,8 +944,10 @@ int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
     for (int k = 0; k < 4; ++k) ms[k] = 0.0;
     const uint64_t calls = h->prof_calls;
     const uint64_t kept = calls < (uint64_t)PROF_RING ? calls : (uint64_t)PROF_RING;
+    uint64_t n_k1 = 0;
     for (uint64_t s = 0; s < kept; ++s) {
         const unsigned m = h->prof_mask[s];                          // a slot holds the events its call recorded: all five
+        if ((m & 3u) == 3u) ++n_k1;
         for (int k = 4; k >= 0; --k)                                 // (run_dev, shard pass 1) or 2..4 (shard pass 2)
             if (m & (1u << k)) { HIPCHK(h, hipEventSynchronize(h->prof_ev[s * 5 + k])); break; }
         for (int k = 0; k < 4; ++k) {
@@ -955,7 +957,7 @@ int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
             ms[k] += t;
         }
     }
-    if (n_calls) *n_calls = kept;
+    if (n_calls) *n_calls = n_k1;          // calls that ran K1 (a shard's pass 2 has a slot of its own without one)
     h->prof_calls = 0;
     return P25FE_OK;
 }
