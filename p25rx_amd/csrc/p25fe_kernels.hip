@@ -558,7 +558,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
 #if defined(P25FE_EXP) && (P25FE_EXP & 2)      // measurement build: lane-consecutive (wrong) addresses
                 if (r >= 0 && r < seg_n) bbp_ch[(long)i_seg * SPS_ + out_rel + tid + q * WV] = outv[q];
 #else
-                if (r >= 0 && r < seg_n) row[32 * q] = outv[q];
+                if (r >= 0 && r < seg_n) row[32 * q] = outv[q];       // (non-temporal stores here: -1 % on K1, +3 % on K4: not adopted)
 #endif
             }
             // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
