@@ -639,7 +639,11 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
+#if defined(P25FE_EXP) && (P25FE_EXP & 4)      // measurement build: the channel filter's FMAs gone (upper bound of moving them off the VALU)
+                    if (k == 0) yv[p] = s;
+#else
                     if (k >= 0 && k < T2) yv[p] = cfma(tap_ch(k), s, yv[p]);
+#endif
                 }
             }
 #pragma unroll
