@@ -199,6 +199,72 @@ def run_extras(torch, dev, args, iq2, truth2):
     return out
 
 
+def bench_channels(args, torch, dist, world, rank, local, dev, staged):
+    """configs[3] over N GPUs: rank r owns a contiguous block of the channel batch (strong: the batch is fixed).  A step is
+    FrontEnd.run_dev over the local block -- the data path has no collective; the per-channel summaries are all-gathered
+    once after the timed region (the consumer's table), and checked."""
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    from p25rx_amd.sharding import ChannelShard, HostStagedComm
+    secs = 60.0 if args.seconds is None else args.seconds
+    n = int(round(secs * 240000)) // 8 * 8
+    cs = ChannelShard(rank, world, args.channels, dist,
+                      comm=HostStagedComm(dist, rank, world) if (staged and world > 1) else None)
+    iq = torch.empty((cs.n_local, n, 2), dtype=torch.float32, device=dev)
+    truths = []
+    for c in range(cs.n_local):
+        _, t = c4fm.synth_torch(n, seed=2000 + cs.c0 + c, device=dev, snr_db=30.0, out=iq[c])
+        truths.append(t)
+    fe = FrontEnd(n_channels=cs.n_local, device=local)
+    dib = res = None
+
+    def step():
+        nonlocal dib, res
+        dib, res = cs.step(fe, iq, dibits=dib, result=res)
+
+    dt = timed(torch, step, args.steps, args.warmup, dist)
+    k1, ach, _ = k1_frac(fe, torch, step, cs.n_local * n, BYTES_PER_SAMPLE_K1, reps=3)
+    cdev = torch.device("cpu") if staged else dev
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    r = parse_results(res)
+    ok = True
+    for c in (0, cs.n_local - 1):
+        nd = int(r[c]["n_dibits"])
+        got = dib[c, :nd].cpu().numpy()
+        k = min(nd, len(truths[c]) - 24)
+        ok = ok and bool(k > 0 and np.array_equal(got[:k], truths[c][24:24 + k]))
+    table = cs.gather_results(torch, res)                              # [channels, sizeof(p25fe_result_t)] on every rank
+    allr = parse_results(table)
+    ok_table = bool(len(allr) == args.channels and all(int(x["n_dibits"]) > 0 for x in allr)
+                    and np.array_equal(allr[cs.c0:cs.c1]["n_dibits"], r["n_dibits"]))
+    if dist:
+        okt = torch.tensor([1 if ok else 0, 1 if ok_table else 0], device=cdev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok, ok_table = bool(okt[0].item()), bool(okt[1].item())
+    if rank == 0:
+        total = float(n) * args.channels * args.steps
+        print(json.dumps({
+            "metric": "IQ Msamples/s through FM-demod+C4FM slice", "value": round(total / dt / 1e6, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: %d independent channels x %.0f s @ 240 ksps, channel-major, %d per rank (blocks)"
+                                   % (args.channels, secs, cs.n_local),
+                       "sharding": "channel blocks, no collective on the data path; summaries all-gathered after the timed region"
+                                   + (" (TEST HOOK: gloo through host copies, all ranks on one GPU)" if staged and world > 1 else ""),
+                       "parity_gate": "dibits == modulator symbols (first and last local channel of every rank): %s" % ok,
+                       "table_gate": "gathered per-channel table complete and in channel order: %s" % ok_table},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_frontend<cf32>",
+                         "kernel_ms": round(k1, 4), "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_K1 * cs.n_local * n}}))
+    if dist:
+        dist.destroy_process_group()
+    if not (ok and ok_table) and world == 1:
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +274,10 @@ def main():
                     help="capture length: per GPU at N = 1 / --scaling weak (default 600 = configs[1]), TOTAL at N > 1 strong "
                          "(default 3600 = configs[4])")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1 only")
+    ap.add_argument("--workload", choices=["time", "channels"], default="time",
+                    help="N > 1: 'time' = configs[4], one capture cut into time shards (default); 'channels' = configs[3], "
+                         "a 256-channel batch cut into channel blocks (no communication on the data path)")
+    ap.add_argument("--channels", type=int, default=256, help="--workload channels: size of the batch")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the dibit stream sharded (diagnostic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
@@ -237,6 +307,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.workload == "channels":
+        return bench_channels(args, torch, dist, world, rank, local, dev, staged)
     strong = world > 1 and args.scaling == "strong"
     if strong:
         total_s = 3600.0 if args.seconds is None else args.seconds

@@ -233,3 +233,25 @@ def test_bench_two_ranks_strong_split_host_staged():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
     assert d["config"]["parity_gate"].endswith("True") and d["config"]["gather_gate"].endswith("True")
     assert "ONE 60 s capture" in d["config"]["workload"] and d["value"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_channel_blocks_host_staged():
+    """config 4 over N GPUs (ChannelShard): bench.py --workload channels with two ranks on one GPU.  5 channels -> blocks
+    of 3 and 2; every rank decodes its block with the real kernels, the gathered summary table is complete."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, P25FE_BENCH_HOST_STAGED="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "channels", "--channels", "5",
+                          "--seconds", "4"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert d["n_gpus"] == 2 and "5 independent channels" in d["config"]["workload"]
+    assert d["config"]["parity_gate"].endswith("True") and d["config"]["table_gate"].endswith("True")
