@@ -145,15 +145,6 @@ __device__ __forceinline__ int wave_incl_sum(int v, int lane)
     }
     return v;
 }
-__device__ __forceinline__ long wave_incl_max(long v, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const long o = __shfl_up(v, d, 64);
-        if (lane >= d) v = o > v ? o : v;
-    }
-    return v;
-}
 __device__ __forceinline__ unsigned long long wave_incl_sum64(unsigned long long v, int lane)
 {
 #pragma unroll
@@ -376,17 +367,27 @@ struct ScanArgs {
 
 constexpr int NT3 = 512;                                     // 8 waves: 256 VGPRs each (1024 threads spilled 25 of their 128)
 constexpr int K3_CHUNK = 4096;
+static_assert((long)K3_CHUNK * EVCAP < (1L << 24) && (long)K3_CHUNK * (TSYM + EVCAP) < (1L << 40), "a chunk's counts fit the packed scan");
 
-__device__ __forceinline__ long block_incl_max(long v, long* sh, int tid, long& total)
+__device__ __forceinline__ int wave_incl_max_i(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int block_incl_max(int v, int* sh, int tid, int& total)
 {
     const int lane = tid & 63, wv = tid >> 6;
-    long inc = wave_incl_max(v, lane);
+    int inc = wave_incl_max_i(v, lane);
     if (lane == 63) sh[wv] = inc;
     __syncthreads();
-    long carry = -1, tot = -1;
+    int carry = -1, tot = -1;
 #pragma unroll
     for (int k = 0; k < NT3 / 64; ++k) {
-        const long t = sh[k];
+        const int t = sh[k];
         if (k < wv) carry = t > carry ? t : carry;
         tot = t > tot ? t : tot;
     }
@@ -416,9 +417,9 @@ __device__ __forceinline__ unsigned long long block_incl_sum(unsigned long long 
 __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
 {
     __shared__ unsigned long long TSL[K3_CHUNK];
-    __shared__ long shl[NT3 / 64];
+    __shared__ int shl[NT3 / 64];
     __shared__ unsigned long long shu[NT3 / 64];
-    __shared__ long excl_tmp[NT3 / 64];
+    __shared__ int excl_tmp[NT3 / 64];
     // carried state
     __shared__ int c_valid, c_src;
     __shared__ long c_s, c_first_event;
@@ -443,6 +444,9 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
     };
 
+    TileRec last_rec;
+    last_rec.first_event = -1; last_rec.last_s = 0; last_rec.hi = last_rec.mid = last_rec.lo = 0.f; last_rec.n_events = 0; last_rec.post_count = 0;
+    bool have_last_rec = false;
     for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
         const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
         for (int k = tid; k < cn; k += NT3) TSL[k] = tsum[c0 + k];
@@ -452,15 +456,18 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
 
         // pass 1: latest event tile inside my run -> block exclusive max
-        long last = -1;
+        int last = -1;
         for (int k = k0; k < k1; ++k) if (TSL[k] & TS_MASK) last = k;
-        long tot_max;
-        const long incl = block_incl_max(last, shl, tid, tot_max);
-        long excl = __shfl_up(incl, 1, 64);
+        int tot_max;
+        const int incl = block_incl_max(last, shl, tid, tot_max);
+        int excl = __shfl_up(incl, 1, 64);
         if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
         __syncthreads();
-        if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1L;
+        if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1;
         __syncthreads();
+        // the anchor the range will end on lives in the record of the (so far) last event tile: request it now, while the
+        // counting passes run, instead of as a dependent load after them
+        if (tid == 0 && tot_max >= 0) { last_rec = a.recs[(size_t)ch * a.n_tiles + c0 + tot_max]; have_last_rec = true; }
 
         const int cv = c_valid, csrc = c_src;
         const long cs = c_s;
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         const long cfirst = c_first_event;
 
         // phase of tile k's first sample under the anchor in force there: ph = (tile_start - s) mod 10
-        auto phase_at = [&](int k, long src, bool& v) -> unsigned {
+        auto phase_at = [&](int k, int src, bool& v) -> unsigned {
             if (src >= 0) {
                 v = true;
                 const int last_off = (int)((TSL[src] >> TS_BITS) & TS_MASK) - 1;
@@ -505,13 +512,15 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
                 }
             }
         }
-        unsigned long long tot_cnt, tot_ev;
-        const unsigned long long icnt = block_incl_sum(my_cnt, shu, tid, tot_cnt);
-        const unsigned long long iev = block_incl_sum(my_ev, shu, tid, tot_ev);
+        // one scan for both counts: dibits in the low 40 bits, detections above (a chunk holds < 2^22 / < 2^23 of them)
+        unsigned long long tot_pk;
+        const unsigned long long ipk = block_incl_sum(my_cnt | (my_ev << 40), shu, tid, tot_pk);
+        const unsigned long long icnt = ipk & ((1ull << 40) - 1), iev = ipk >> 40;
+        const unsigned long long tot_cnt = tot_pk & ((1ull << 40) - 1), tot_ev = tot_pk >> 40;
 
         // pass 3: per-tile carry-ins
         if (k0 < k1) {
-            long src = excl;
+            int src = excl;
             bool v = v0;
             unsigned ph = ph0;
             unsigned long long dc = ccnt + icnt - my_cnt, ec = cev + iev - my_ev;
@@ -562,9 +571,8 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         p25fe_anchor_t A;
         A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
         if (a.anchor_in) A = a.anchor_in[ch];
-        if (c_src >= 0) {
-            const TileRec t = a.recs[(size_t)ch * a.n_tiles + c_src];
-            A.valid = 1; A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo;
+        if (c_src >= 0 && have_last_rec) {
+            A.valid = 1; A.s = last_rec.last_s; A.hi = last_rec.hi; A.mid = last_rec.mid; A.lo = last_rec.lo;
         }
         r.anchor_out = A;
         r.first_event = c_first_event;
