@@ -444,6 +444,9 @@ struct K1Args {
 // the cf32 kernel a wave per SIMD (181 VGPRs -> 8 waves per CU instead of 11) and makes it 25 % SLOWER (318 vs 254 us)
 // although 45 % more bytes are in flight -- the waves' arithmetic phases, not the bytes in flight, are what covers the
 // latency there; the u8 kernel keeps 4 waves per SIMD with two sets (13 more VGPRs) and gains 10 % (200 vs 221 us).
+#ifndef P25FE_K1_TURNAROUND_PRIO
+#define P25FE_K1_TURNAROUND_PRIO 3
+#endif
 #ifndef P25FE_K1_PF_CF32
 #define P25FE_K1_PF_CF32 1
 #endif
@@ -585,6 +588,9 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         } else {
+#if P25FE_K1_TURNAROUND_PRIO
+            __builtin_amdgcn_s_setprio(P25FE_K1_TURNAROUND_PRIO);   // see below
+#endif
             ld.store(XIN, first, a.n_hist, a.n_new, tid);
             ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         }
@@ -592,8 +598,23 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
         if constexpr (!DMA) ld.load(first + (long)(PF * DEC) * SUB, tid);
+#if P25FE_K1_TURNAROUND_PRIO
+        // The turnaround -- window landed -> staged to LDS -> next window requested -- is the only part of the iteration during
+        // which this wave has nothing in flight; it runs at raised priority so that the other waves' FMA streams do not
+        // stretch it.  (Idle phases of the length of the arithmetic do not slow the load stream at all: 189 vs 192 us in a
+        // loads-only build with s_sleep in place of the arithmetic.)
+        if constexpr (!DMA) __builtin_amdgcn_s_setprio(0);
+#endif
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
+#if defined(P25FE_DRIFT)                            // ... with pseudo-random idle phases (units of 64 cycles) in place of the arithmetic
+        {
+            unsigned hsh = (unsigned)blockIdx.x * 2654435761u + (unsigned)(dlo & 0xffff) * 40503u;
+            hsh ^= hsh >> 13;
+            const int units = P25FE_DRIFT + (int)(hsh % (unsigned)(P25FE_DRIFT_SPREAD + 1));
+            for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(1);
+        }
+#endif
         return true;
 #endif
         // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Lane: d[dlo + P tid + p], p = 0..P-1.
