@@ -10,7 +10,7 @@ each timed over its own >= 100 ms region after the headline one (`--no-extra` sk
 N > 1 (one rank per GPU, RCCL): BASELINE.json configs[4] -- ONE 3 600 s capture cut into N contiguous time shards
 (strong scaling: the total is fixed, each rank owns 3 600 / N seconds).  A step = halo send/recv to the right neighbour
 (hidden behind K1) -> pass 1 -> all_gather of the 56-byte shard summaries -> device resolve -> pass 2 -> all_gather of
-the dibit shards + compaction into one ordered stream on every rank.  No host synchronisation inside a step.
+the dibit shards to rank 0 (point-to-point) + compaction into one ordered stream.  No host synchronisation inside a step.
 `--scaling weak` keeps 600 s per rank instead.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (K1) from HIP
@@ -278,7 +278,8 @@ def main():
                     help="N > 1: 'time' = configs[4], one capture cut into time shards (default); 'channels' = configs[3], "
                          "a 256-channel batch cut into channel blocks (no communication on the data path)")
     ap.add_argument("--channels", type=int, default=256, help="--workload channels: size of the batch")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the dibit stream sharded (diagnostic)")
+    ap.add_argument("--gather", choices=["root", "all", "none"], default="root",
+                    help="N > 1: dibit shards gathered to rank 0 (default), all-gathered, or left sharded (diagnostic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--cpu-seconds", type=float, default=600.0, help="length of the capture prefix timed on the CPU")
@@ -341,7 +342,7 @@ def main():
         summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
 
         def step():
-            ts.step_device(buf, result, summ_all, dibits, gather=not args.no_gather)
+            ts.step_device(buf, result, summ_all, dibits, gather=None if args.gather == "none" else args.gather)
 
     for _ in range(args.warmup):
         step()
@@ -384,15 +385,26 @@ def main():
                 if k > 0 and np.array_equal(got[first:first + k], truth[j:j + k]):
                     ok = True
                     break
-        if not args.no_gather:
-            # the gathered, ordered stream holds my shard's dibits at my resolved offset
+        if args.gather != "none":
+            # checksum of checksums: every rank's (length, byte sum, position-weighted sum) of its own dibits must equal
+            # what rank 0 finds at that shard's resolved offset in the gathered, ordered stream
             off = ts.d_offsets.cpu().numpy()
-            mine = ts.d_stream[int(off[rank]):int(off[rank + 1])].cpu().numpy()
-            gather_ok = bool(len(mine) == nd and np.array_equal(mine, got))
+            w = torch.arange(1, nd + 1, dtype=torch.int64, device=dev) % 65521
+            mine = dibits[0, :nd].to(torch.int64)
+            sig = torch.stack([torch.tensor(nd, dtype=torch.int64, device=dev), mine.sum(), (mine * w).sum()]).to(cdev)
+            sigs = [torch.zeros(3, dtype=torch.int64, device=cdev) for _ in range(world)]
+            dist.all_gather(sigs, sig)
+            gather_ok = True
+            if rank == 0 or args.gather == "all":
+                for r_ in range(world):
+                    seg = ts.d_stream[int(off[r_]):int(off[r_ + 1])].to(torch.int64)
+                    wr = torch.arange(1, seg.numel() + 1, dtype=torch.int64, device=dev) % 65521
+                    got_sig = [seg.numel(), int(seg.sum().item()), int((seg * wr).sum().item())]
+                    gather_ok = gather_ok and got_sig == [int(x) for x in sigs[r_].tolist()]
     if dist:
         okt = torch.tensor([1 if ok else 0, 1 if gather_ok in (None, True) else 0], device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok, gather_ok = bool(okt[0].item()), (None if args.no_gather else bool(okt[1].item()))
+        ok, gather_ok = bool(okt[0].item()), (None if args.gather == "none" else bool(okt[1].item()))
 
     if rank == 0:
         total_samples = float(n) * world * args.steps
@@ -415,13 +427,14 @@ def main():
             sharding = "none"
         elif strong:
             workload = ("configs[4]: ONE %.0f s capture (%d samples, %.3f GB) cut into %d contiguous time shards of %.1f s, "
-                        "decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather"
-                        % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0))
-            sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (%s)" % (
-                halo, "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
+                        "decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather (%s)"
+                        % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0, args.gather))
+            sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries by all_gather, dibits by %s (%s)" % (
+                halo, {"root": "point-to-point gather to rank 0", "all": "all_gather", "none": "nothing"}[args.gather],
+                "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
         else:
             workload = ("configs[4] weak-scaled: %.0f s per GPU (%d samples per rank)" % (total_s, n))
-            sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries + dibits by all_gather (RCCL)" % halo
+            sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries by all_gather, dibits gathered (RCCL)" % halo
         out = {
             "metric": "IQ Msamples/s through FM-demod+C4FM slice",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -444,7 +457,8 @@ def main():
                                                       + ("; N > 1: k_scan = pass 1 + pass 2 scans, RCCL time is in neither" if world > 1 else "")}},
         }
         if gather_ok is not None:
-            out["config"]["gather_gate"] = "gathered stream holds every shard at its resolved offset: %s" % gather_ok
+            out["config"]["gather_gate"] = ("gathered stream holds every shard at its resolved offset (length, sum and "
+                                            "position-weighted sum of every rank's dibits): %s" % gather_ok)
         if world == 1 and not args.no_cpu:
             ncpu = min(n, int(args.cpu_seconds * 240000))
             host = iq[:ncpu].cpu().numpy().view(np.complex64).reshape(-1)

@@ -9,9 +9,11 @@ TimeShard -- one long capture cut into contiguous time ranges, rank r owns [r*n,
      (p25fe_shard_pass1_main), the shard's head after the halo has arrived (p25fe_shard_pass1_finish);
   2. symbol-timing carry: every rank's 56-byte shard summary is all-gathered; a one-thread kernel resolves every
      shard's carry-in anchor and dibit offset (p25fe_shard_resolve_dev) -- no host synchronisation;
-  3. the reduced dibit stream: after pass 2 the shards' dibit buffers (n/50 bytes each) are all-gathered and compacted
-     into ONE ordered stream (p25fe_shard_compact_dev) -- what RecvTask feeds into MessageReceiver, src/recv.rs:148-150.
-     For the one-hour capture of config 5 that is 17.3 MB in total.
+  3. the reduced dibit stream: after pass 2 the shards' dibit buffers (n/50 bytes each) are GATHERED TO THE ROOT rank
+     (point-to-point, every rank has a direct xGMI link to it) and compacted there into ONE ordered stream
+     (p25fe_shard_compact_dev) -- what RecvTask feeds into MessageReceiver, src/recv.rs:148-150.  For the one-hour
+     capture of config 5 that is 17.3 MB in total.  (gather="all" all-gathers instead: the stream on every rank, at N
+     times the traffic.)
 
 ChannelShard -- a batch of independent channels (config 4): rank r takes a contiguous block of channels, no
 communication on the data path at all (one tuner = one channel in the reference, src/sdr.rs:64-65); the per-channel
@@ -51,6 +53,22 @@ class TorchComm:
     def all_gather(self, out_t, in_t):
         self.dist.all_gather_into_tensor(out_t.view(-1), in_t.reshape(-1))
 
+    def gather_to_root(self, out_t, in_t, root=0):
+        """Row r of out_t (root only) <- rank r's in_t.  Point-to-point: on MI355X every rank has a direct xGMI link to
+        the root, so the 7 shards arrive in parallel instead of travelling a ring (an all-gather moves N times the
+        bytes the one consumer needs)."""
+        d, ops = self.dist, []
+        if self.rank == root:
+            out_t[root].copy_(in_t.reshape(-1))
+            for r in range(self.world):
+                if r != root:
+                    ops.append(d.P2POp(d.irecv, out_t[r], r))
+        else:
+            ops.append(d.P2POp(d.isend, in_t.reshape(-1), root))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+
 
 class HostStagedComm(TorchComm):
     """The same exchanges through CPU copies (gloo): several ranks can then share ONE GPU."""
@@ -76,6 +94,22 @@ class HostStagedComm(TorchComm):
         o = out_t.cpu().contiguous()
         self.dist.all_gather_into_tensor(o.view(-1), in_t.cpu().contiguous().reshape(-1))
         out_t.copy_(o)
+
+    def gather_to_root(self, out_t, in_t, root=0):
+        d, ops = self.dist, []
+        if self.rank == root:
+            o = out_t.cpu().contiguous()
+            o[root].copy_(in_t.reshape(-1).cpu())
+            for r in range(self.world):
+                if r != root:
+                    ops.append(d.P2POp(d.irecv, o[r], r))
+        else:
+            ops.append(d.P2POp(d.isend, in_t.reshape(-1).cpu().contiguous(), root))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        if self.rank == root:
+            out_t.copy_(o)
 
 
 class TimeShard:
@@ -146,11 +180,12 @@ class TimeShard:
         self.d_gathered = torch.empty((self.world, self.dibit_cap), dtype=torch.uint8, device=device)
         self.d_stream = torch.empty(self.world * self.dibit_cap, dtype=torch.uint8, device=device)
 
-    def step_device(self, buf, result, summ_all, dibits, gather=True):
+    def step_device(self, buf, result, summ_all, dibits, gather="root"):
         """halo exchange (overlapped with K1) -> pass 1 -> all_gather of summaries -> k_shard_resolve -> pass 2 ->
-        all_gather of the dibit shards -> compaction, all enqueued on the current stream.  `dibits` must be a
+        gather of the dibit shards -> compaction, all enqueued on the current stream.  `dibits` must be a
         [1, dibit_cap] buffer.  Returns the device tensor of n_shards + 1 dibit offsets (read it after the timed
-        region); the ordered stream of the whole capture is self.d_stream[:offsets[-1]] on every rank."""
+        region); the ordered stream of the whole capture is self.d_stream[:offsets[-1]] on rank 0 (gather="root") or on
+        every rank (gather="all"); gather=None leaves the stream sharded."""
         h = self.halo if self.rank > 0 else 0
         view = buf[self.halo - h:]
         if self.world > 1:
@@ -167,11 +202,14 @@ class TimeShard:
         self.fe.shard_pass2(self.d_anchors[self.rank:self.rank + 1], self.bbn[self.rank], buf.device, result=result,
                             dibits=dibits)
         if gather:
-            if self.world > 1:
+            if self.world == 1:
+                self.d_gathered.copy_(dibits)
+            elif gather == "all":
                 self.comm.all_gather(self.d_gathered, dibits)
             else:
-                self.d_gathered.copy_(dibits)
-            self.fe.shard_compact_dev(self.d_gathered, self.d_offsets, self.d_stream)
+                self.comm.gather_to_root(self.d_gathered, dibits, root=0)
+            if gather == "all" or self.rank == 0:
+                self.fe.shard_compact_dev(self.d_gathered, self.d_offsets, self.d_stream)
         return self.d_offsets
 
 

@@ -171,10 +171,13 @@ def _shared_gpu_worker(rank, world, port, n_per, q):
         summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
         dibits = torch.zeros((1, ts.dibit_cap), dtype=torch.uint8, device="cuda")
         for _ in range(2):                                      # twice: scratch and profiling slots are reused
-            off = ts.step_device(buf, result, summ_all, dibits)
+            off = ts.step_device(buf, result, summ_all, dibits)             # dibits gathered to rank 0 (the default)
         total = int(off[-1])
+        root_stream = ts.d_stream[:total].cpu().numpy() if rank == 0 else None
+        ts.d_stream.zero_()
+        off = ts.step_device(buf, result, summ_all, dibits, gather="all")   # all-gather form: the stream on every rank
         q.put((rank, off.cpu().numpy().tolist(), ts.d_stream[:total].cpu().numpy(),
-               int(parse_results(result)[0]["n_dibits"])))
+               int(parse_results(result)[0]["n_dibits"]), root_stream))
     finally:
         dist.destroy_process_group()
 
@@ -204,9 +207,10 @@ def test_timeshard_step_device_two_ranks_one_gpu():
         assert p.exitcode == 0
     iq, _, _ = c4fm.synth(world * n_per / 240000.0, seed=55, snr_db=22.0, frame_dibits=900)
     ref = O.run_cf32(iq)
-    for rank, off, stream, nd in got:
+    for rank, off, stream, nd, root_stream in got:
         assert off[-1] == len(ref) and off[rank + 1] - off[rank] == nd
         assert np.array_equal(stream, ref)
+        assert rank != 0 or np.array_equal(root_stream, ref)
 
 
 @pytest.mark.timeout(300)

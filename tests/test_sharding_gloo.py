@@ -146,7 +146,12 @@ def _worker(rank, world, port, q):
             assert np.array_equal(buf[:ts.halo].numpy().view(np.complex64).reshape(-1), left)
         assert np.array_equal(fe.out, out_host)
         assert int(d_off[rank]) == off and int(d_off[-1]) == total
-        stream = ts.d_stream[:total].numpy().copy()                 # the whole capture's ordered dibit stream, on EVERY rank
+        stream = ts.d_stream[:total].numpy().copy() if rank == 0 else None    # gathered to the root (the consumer)
+        d_off2 = ts.step_device(buf, result, summ_all, dibits, gather="all")    # all-gather form: the stream on EVERY rank
+        assert d_off2.tolist() == d_off.tolist()
+        stream_all = ts.d_stream[:total].numpy().copy()
+        assert stream is None or np.array_equal(stream, stream_all)
+        stream = stream_all
         # channel shards (config 4 over N GPUs): blocks partition the batch; the summary gather keeps channel order
         from p25rx_amd.sharding import ChannelShard
         cs = ChannelShard(rank, world, 5, dist)
