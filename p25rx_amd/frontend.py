@@ -25,12 +25,12 @@ class FrontEnd:
         cfg.device = device
         cfg.n_channels = n_channels
         if decim_taps is not None:
-            cfg.n_decim_taps = len(decim_taps)
-            for i, v in enumerate(decim_taps):
+            cfg.n_decim_taps = len(decim_taps)                   # the library rejects counts above P25FE_MAX_TAPS
+            for i, v in enumerate(decim_taps[:_lib.MAX_TAPS]):
                 cfg.decim_taps[i] = v
         if chan_taps is not None:
             cfg.n_chan_taps = len(chan_taps)
-            for i, v in enumerate(chan_taps):
+            for i, v in enumerate(chan_taps[:_lib.MAX_TAPS]):
                 cfg.chan_taps[i] = v
         self.cfg = cfg
         self.C = n_channels

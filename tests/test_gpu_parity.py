@@ -313,13 +313,26 @@ def test_long_taps_up_to_the_abi_ceiling(O, FE, c4fm_1s, nt):
 
 
 def test_errors_are_loud(FE):
-    from p25rx_amd._lib import P25feError
+    from p25rx_amd._lib import ANCHOR_DTYPE, P25feError
     fe = FE()
     fe.demod_cf32(np.zeros(100, dtype=np.complex64))
     with pytest.raises(P25feError):
         fe.demod_u8(np.zeros(100, dtype=np.uint8))        # format switch inside a stream
     with pytest.raises(P25feError):
         FE(device=99)
+    with pytest.raises(P25feError):
+        FE(decim_taps=[0.1] * 65)                              # more taps than the ABI carries
+    # sharded passes out of order fail instead of working on stale scratch
+    import torch
+    t = torch.zeros((48000, 2), dtype=torch.float32, device="cuda")
+    fe2 = FE()
+    with pytest.raises(P25feError):
+        fe2.shard_pass1_finish(t, offset=0, n_hist=0, abs0=0)   # no matching shard_pass1_main
+    with pytest.raises(P25feError):
+        fe2.shard_pass2(np.zeros(1, dtype=ANCHOR_DTYPE), 9600, t.device)   # no pass 1 at all
+    fe2.shard_pass1_main(t, offset=0, n_hist=0, abs0=0)
+    with pytest.raises(P25feError):
+        fe2.shard_pass1_finish(t[:24000], offset=0, n_hist=0, abs0=0)   # a different shard than the main launch
 
 
 def test_full_size_property_60s(FE):
