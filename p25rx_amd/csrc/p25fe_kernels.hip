@@ -740,8 +740,8 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             // next sub-tile's lane 0 / 1 / ... read these: lane 63 is one lane back, lane 62 two, ...
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                if (NBACK >= 3) f_carry[2][p] = lane_bcast<WV - 3>(f[p]);
-                if (NBACK >= 2) f_carry[1][p] = lane_bcast<WV - 2>(f[p]);
+                if constexpr (NBACK >= 3) f_carry[2][p] = lane_bcast<WV - 3>(f[p]);
+                if constexpr (NBACK >= 2) f_carry[1][p] = lane_bcast<WV - 2>(f[p]);
                 f_carry[0][p] = lane_bcast<WV - 1>(f[p]);
             }
         }
