@@ -224,6 +224,10 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
         }
     }
 
+#if defined(P25FE_ABLATE_DET) && P25FE_ABLATE_DET == 1      // measurement build: the sign-bit screen alone
+    if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = (hw[0] | hw[1] | hw[2] | hw[3]) == 0x12345u ? 1ull : 0ull;
+    return;
+#endif
     // ---- exact test of the screened positions (SPEC 3.7), candidates -> peak test against their 10 neighbours
     int nh = 0;
     auto flush_hits = [&]() {
@@ -238,7 +242,11 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
                 sync_corr(v, c, e);
                 cand = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
             }
+#if defined(P25FE_ABLATE_DET) && P25FE_ABLATE_DET == 2      // measurement build: screen + exact test, no peak test
+            const unsigned long long cm = 0ull; if (cand) EVB[eo >> 5] = 1u;
+#else
             const unsigned long long cm = __ballot(cand);
+#endif
             const int nc = __popcll(cm);
             if (cand) CANDS[lane_rank(cm)] = (uint16_t)eo;
             phase_sync();
