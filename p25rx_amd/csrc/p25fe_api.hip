@@ -58,7 +58,7 @@ struct p25fe {
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
     // scratch
-    DevBuf iq_stage, bb_buf, pl_f, pl_bits, evl, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    DevBuf iq_stage, bb_buf, pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
@@ -244,7 +244,7 @@ void p25fe_destroy(p25fe_t* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->pl_f, &h->pl_bits, &h->evl, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
+    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
                       &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
@@ -395,6 +395,7 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
     HIPCHK(h, h->pl_f.ensure(C * g.floats() * sizeof(float)));
     HIPCHK(h, h->pl_bits.ensure(C * g.words() * sizeof(uint32_t)));
     HIPCHK(h, h->evl.ensure(C * g.n_tiles * EVCAP * sizeof(uint16_t)));
+    HIPCHK(h, h->evthr.ensure(C * g.n_tiles * EVTHR_N * 3 * sizeof(float)));
     HIPCHK(h, h->recs.ensure(C * g.n_tiles * sizeof(TileRec)));
     HIPCHK(h, h->tsum.ensure(C * g.n_tiles * sizeof(unsigned long long)));
     HIPCHK(h, h->outs.ensure(C * g.n_tiles * sizeof(ScanOut)));
@@ -428,7 +429,7 @@ static int launch_detect(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, hipStream_t 
     const PlanarGeo g(n_bb);
     DetArgs d;
     d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = (long)abs_bb0; d.n_tiles = (int)g.n_tiles;
-    d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>();
+    d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>(); d.evthr = h->evthr.as<float>();
     hipLaunchKernelGGL(k_detect, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
@@ -452,7 +453,7 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, const p2
     SliceArgs l;
     l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = (long)abs_bb0; l.n_tiles = n_tiles;
     l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.tsum = h->tsum.as<unsigned long long>();
-    l.evl = h->evl.as<uint16_t>(); l.anchor_in = d_anchor_in;
+    l.evl = h->evl.as<uint16_t>(); l.evthr = h->evthr.as<float>(); l.anchor_in = d_anchor_in;
     l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;

@@ -172,8 +172,11 @@ struct DetArgs {
     TileRec* recs;          // [ch][n_tiles]
     unsigned long long* tsum;   // [ch][n_tiles]
     uint16_t* evl;          // [ch][n_tiles][EVCAP] decision offsets of the tile's detections, ascending
+    float* evthr;           // [ch][n_tiles][EVTHR_N][3] slicer thresholds (hi, mid, lo) of the tile's first EVTHR_N detections
 };
 
+constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
+constexpr int K2_DCAP = 64;                                      // detections per tile whose thresholds K2 remembers (more: it recomputes)
 constexpr int K2_LANES = 60;                                     // 10 planes x 6 blocks of 4 words
 constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test
 
@@ -184,6 +187,12 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     __shared__ uint16_t EVS[EVCAP];                              // the same, sorted list
     __shared__ uint16_t CANDS[WV];
     __shared__ float CN[5][12];
+    // A candidate's thresholds (SPEC 3.8) come from the same 24 samples as its correlation: computed where those are in
+    // registers and remembered for the detections, instead of gathered again (a dependent round trip) for the summary.
+    __shared__ float CTHR[WV][3];                                // per candidate of the current round
+    __shared__ uint16_t DETE[K2_DCAP];                           // per detection: decision offset ...
+    __shared__ float DETT[K2_DCAP][3];                           // ... and thresholds
+    __shared__ unsigned DETN;
 
     const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
@@ -192,6 +201,7 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     const long pbase = t0 + PLPAD - W;                           // planar index of the position decided at tile offset 0
 
     for (int k = lane; k < TS / 32; k += WV) EVB[k] = 0u;
+    if (lane == 0) DETN = 0u;
 
     // ---- screen: hit words, bit u of hw[j] = position (word step j, bit u) has <= 4 sign mismatches
     unsigned hw[4] = {0u, 0u, 0u, 0u};
@@ -236,11 +246,13 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
             const bool act = h < nh;
             const int eo = act ? (int)HITS[h] : 0;
             bool cand = false;
+            float th_hi = 0.f, th_mid = 0.f, th_lo = 0.f;
             if (act) {
                 float c, e, v[NSYN];
                 sync_gather(f, pbase + eo, v);
                 sync_corr(v, c, e);
                 cand = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
+                if (cand) sync_thresholds(v, th_hi, th_mid, th_lo);
             }
 #if defined(P25FE_ABLATE_DET) && P25FE_ABLATE_DET == 2      // measurement build: screen + exact test, no peak test
             const unsigned long long cm = 0ull; if (cand) EVB[eo >> 5] = 1u;
@@ -248,7 +260,11 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
             const unsigned long long cm = __ballot(cand);
 #endif
             const int nc = __popcll(cm);
-            if (cand) CANDS[lane_rank(cm)] = (uint16_t)eo;
+            if (cand) {
+                const int slot = lane_rank(cm);
+                CANDS[slot] = (uint16_t)eo;
+                CTHR[slot][0] = th_hi; CTHR[slot][1] = th_mid; CTHR[slot][2] = th_lo;
+            }
             phase_sync();
             for (int cb = 0; cb < nc; cb += 5) {
                 const int q = lane / 11, d = lane - 11 * q;
@@ -266,7 +282,14 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
                     bool det = true;
 #pragma unroll
                     for (int i = 1; i <= W; ++i) det = det && (c0 > CN[q][W - i]) && (c0 >= CN[q][W + i]);
-                    if (det) atomicOr(&EVB[ec >> 5], 1u << (ec & 31));
+                    if (det) {
+                        atomicOr(&EVB[ec >> 5], 1u << (ec & 31));
+                        const unsigned di = atomicAdd(&DETN, 1u);
+                        if (di < (unsigned)K2_DCAP) {
+                            DETE[di] = (uint16_t)ec;
+                            DETT[di][0] = CTHR[cb + q][0]; DETT[di][1] = CTHR[cb + q][1]; DETT[di][2] = CTHR[cb + q][2];
+                        }
+                    }
                 }
                 phase_sync();
             }
@@ -337,11 +360,27 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     }
     post = wave_sum_i(post);
     const int first_off = EVS[0], last_off = EVS[n_ev - 1];
+    // thresholds of the first EVTHR_N detections (for K4) and of the last one (the anchor the tile hands on): looked up in
+    // the remembered table, recomputed from the planes only if the tile had more detections than the table holds
+    const int n_tab = DETN < (unsigned)K2_DCAP ? (int)DETN : K2_DCAP;
+    auto thresholds_of = [&](int eoff, float& h, float& m, float& l) {
+        const unsigned long long hit = __ballot(lane < n_tab && (int)DETE[lane < n_tab ? lane : 0] == eoff);
+        if (hit) {                                                   // uniform
+            const int i = __builtin_ctzll(hit);
+            h = DETT[i][0]; m = DETT[i][1]; l = DETT[i][2];
+        } else {
+            float v[NSYN];
+            sync_gather(f, pbase + eoff, v);                         // uniform: every lane, same window
+            sync_thresholds(v, h, m, l);
+        }
+    };
     float hi, mid, lo;
-    {
-        float v[NSYN];
-        sync_gather(f, pbase + last_off, v);                        // uniform: every lane, same window
-        sync_thresholds(v, hi, mid, lo);
+    thresholds_of(last_off, hi, mid, lo);
+    float* evthr = a.evthr + ((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3);
+    for (int k = 0; k < EVTHR_N && k < n_ev; ++k) {
+        float h, m, l;
+        thresholds_of((int)EVS[k], h, m, l);
+        if (lane == 0) { evthr[3 * k] = h; evthr[3 * k + 1] = m; evthr[3 * k + 2] = l; }
     }
     if (lane == 0) {
         TileRec rc;
@@ -603,6 +642,7 @@ struct SliceArgs {
     const TileRec* recs;
     const unsigned long long* tsum;
     const uint16_t* evl;
+    const float* evthr;         // [ch][n_tiles][EVTHR_N][3] from K2
     const p25fe_anchor_t* anchor_in;    // nullable, [ch]
     uint8_t* dibits;            // [ch][dibit_stride]
     long dibit_stride;
@@ -614,6 +654,7 @@ struct SliceArgs {
 __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
 {
     __shared__ uint16_t EV[EVCAP];
+    __shared__ float ETH[EVTHR_N * 3];
     const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
@@ -637,6 +678,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
     if (n_ev) {
         const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
         for (int k = lane; k < n_ev; k += WV) EV[k] = evl[k];
+        if (lane < EVTHR_N * 3) ETH[lane] = a.evthr[((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3) + lane];
         phase_sync();
     }
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
@@ -680,9 +722,11 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
         const int ek = EV[k];
         const int m_hi = k + 1 < n_ev ? (int)EV[k + 1] + 1 : tn;
         float h, m, l;
-        {
+        if (k < EVTHR_N) {                                          // K2 left the thresholds of the tile's first detections
+            h = ETH[3 * k]; m = ETH[3 * k + 1]; l = ETH[3 * k + 2];
+        } else {
             float v[NSYN];
-            sync_gather(f, t0 + ek - W + PLPAD, v);                 // uniform window; same arithmetic as K2
+            sync_gather(f, t0 + ek - W + PLPAD, v);                 // uniform window; same arithmetic as K2, same bits
             sync_thresholds(v, h, m, l);
         }
         if (lane == 0 && a.sync_pos && (long)(so.event_off + k) < a.sync_stride) {
