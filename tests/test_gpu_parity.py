@@ -867,3 +867,37 @@ def test_sync_screen_keeps_candidates_with_wrong_sign_symbols(O, FE):
     got = FE().slice(bb)
     assert np.array_equal(got[1], spos) and np.array_equal(got[2], sdib)
     assert np.array_equal(got[0], dib)
+
+
+@pytest.mark.gpu
+def test_run_dev_lengths_around_layout_boundaries(O, FE):
+    """The fused path's geometry has several granules: 880-output K1 segments, 320-output sub-tiles, 32-symbol blocks of
+    the polyphase layout, 7680-sample receiver tiles.  Capture lengths that end just before / on / after each of them
+    (and a few random ones), cf32 and u8: dibit count, dibits and detections equal the oracle's."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    iq_all, _, _ = c4fm.synth(1.2, seed=41, snr_db=20.0, frame_dibits=230, timing_offset=7)
+    u8_all = c4fm.to_u8(iq_all)
+    rng = np.random.default_rng(9)
+    lens = set()
+    for base_bb in (880, 320 * 3, 7680, 7680 * 2, 320 * 24, 880 * 11, 10 * 32 * 7):
+        for d in (-6, -5, -1, 0, 1, 4, 5, 11):
+            lens.add(5 * base_bb + d)
+    lens |= set(int(x) for x in rng.integers(2000, len(iq_all) - 8, size=12))
+    fe, fe8 = FE(), FE()
+    for n in sorted(lens):
+        n = max(8, min(n, len(iq_all)))
+        iq = iq_all[:n]
+        ref = O.run_cf32(iq)
+        t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+        dib, res = fe.run_dev(t)
+        r = parse_results(res)[0]
+        assert int(r["n_dibits"]) == len(ref), n
+        assert np.array_equal(dib[0, :len(ref)].cpu().numpy(), ref), n
+        if n % 97 < 40:                                          # a subset through the u8 kernel as well
+            ref8 = O.Recv().feed(O.Demod().feed_u8(u8_all[:2 * n]))[0]
+            t8 = torch.from_numpy(u8_all[:2 * n].reshape(-1, 2)).cuda()
+            d8, r8 = fe8.run_dev(t8)
+            assert int(parse_results(r8)[0]["n_dibits"]) == len(ref8), n
+            assert np.array_equal(d8[0, :len(ref8)].cpu().numpy(), ref8), n
