@@ -9,7 +9,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace p25k;
@@ -221,10 +224,10 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_LINEAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_LINEAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, LD_DMA>), Geo<5>::LDS_BYTES_DMA);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_LINEAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
@@ -272,6 +275,25 @@ static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 // --------------------------------------------------------------------------------------------
 // internal launchers
 // --------------------------------------------------------------------------------------------
+// Resident one-wave workgroups per CU of a K1 instantiation (occupancy query, cached per kernel and LDS size).
+static int k1_slots_per_cu(const void* kern, size_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({kern, lds});
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WV, lds) != hipSuccess || nb <= 0) nb = 8;
+    // the query is advisory (observed: 12 for a 13.4-KB workgroup, of which only 11 fit 160 KB): bound it by the LDS
+    const size_t lds_alloc = (lds + 511) / 512 * 512;
+    if (lds_alloc > 0 && (size_t)nb > 163840 / lds_alloc) nb = (int)(163840 / lds_alloc);
+    static const int slots_env = [] { const char* e = getenv("P25FE_K1_SLOTS"); return e ? atoi(e) : 0; }();
+    if (slots_env > 0) nb = slots_env;
+    cache[{kern, lds}] = nb;
+    return nb;
+}
+
 static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
                            hipStream_t st, const PlanarGeo* planar = nullptr, int part = 0)
@@ -327,8 +349,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         else seg_count = k_min;
         if (seg_count <= 0) return P25FE_OK;
     }
-    static const int xg_env = [] { const char* e = getenv("P25FE_XCD_GROUP"); return e ? atoi(e) : 0; }();
-    a.xcd_group = xg_env;
+    a.seg_count = (int)seg_count;
+    a.n_ch = h->C;
     a.m_begin = m_begin;
     a.power_partial = nullptr;
     a.bbp = nullptr; a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_ch_stride = 0;
@@ -340,24 +362,36 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         HIPCHK(h, h->power_partial.ensure(sizeof(float) * (size_t)h->C * (size_t)n_seg));
         a.power_partial = h->power_partial.as<float>();
     }
-    dim3 grid((unsigned)seg_count, (unsigned)h->C);
+    // One workgroup (= one wave) per resident wave slot; the kernel walks the (segment, channel) items in a grid-stride loop.
+    // P25FE_K1_PERSIST=0 (experiments): one workgroup per item, the round-1 / round-2 launch shape.
+    static const int persist_env = [] { const char* e = getenv("P25FE_K1_PERSIST"); return e ? atoi(e) : 0; }();
+    const long n_items = seg_count * (long)h->C;
+    if (n_items > 0x7fffffffL) return P25FE_ERR_ARG;
+    auto k1_grid = [&](const void* kern, size_t lds) -> dim3 {
+        long g = n_items;
+        if (persist_env > 0) {
+            const long slots = (long)k1_slots_per_cu(kern, lds) * h->n_cu * persist_env;
+            if (slots > 0 && slots < g) g = slots;
+        }
+        return dim3((unsigned)g);
+    };
     const Taps* dt = h->d_taps.as<Taps>();
 #define P25FE_LAUNCH_K1(PK, OM)                                                                                           \
     do {                                                                                                                  \
         const size_t lds = Geo<PK>::LDS_BYTES - (h->default_taps ? lds_taps_trim : 0);                                   \
         if (fmt == P25FE_FMT_CF32) {                                                                                      \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK, OM>), grid, dim3(WV), lds, st, a, dt);  \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK, OM>), grid, dim3(WV), lds, st, a, dt);                 \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK, OM>), lds), dim3(WV), lds, st, a, dt);  \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK, OM>), lds), dim3(WV), lds, st, a, dt);                 \
         } else {                                                                                                          \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, PK, OM>), grid, dim3(WV), lds, st, a, dt);    \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK, OM>), grid, dim3(WV), lds, st, a, dt);                   \
+            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK, OM>), lds), dim3(WV), lds, st, a, dt);    \
+            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK, OM>), lds), dim3(WV), lds, st, a, dt);                   \
         }                                                                                                                 \
     } while (0)
 #define P25FE_LAUNCH_K1_DMA(OM)                                                                                           \
     do {                                                                                                                  \
-        const size_t lds = Geo<5>::LDS_BYTES_DMA;                                                                         \
-        if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);  \
-        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), grid, dim3(WV), lds, st, a, dt);                 \
+        const size_t lds = P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA;                                                                     \
+        if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), lds), dim3(WV), lds, st, a, dt);  \
+        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), lds), dim3(WV), lds, st, a, dt);                 \
     } while (0)
     // immediate-tap kernels never touch the taps area at the end of the LDS layout: do not allocate it.  (13 376 B per
     // wave is still 11 waves per CU: a 12th would need 13 312; trimming to that in an experiment changed nothing.)
@@ -366,8 +400,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
 #define P25FE_LAUNCH_K1_LONG(OM)                                                                                          \
     do {                                                                                                                  \
         const size_t lds = Geo<5, 1>::LDS_BYTES;                                                                          \
-        if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_REGS, 1>), grid, dim3(WV), lds, st, a, dt); \
-        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, 5, OM, LD_REGS, 1>), grid, dim3(WV), lds, st, a, dt);    \
+        if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_REGS, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_REGS, 1>), lds), dim3(WV), lds, st, a, dt); \
+        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, 5, OM, LD_REGS, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, LD_REGS, 1>), lds), dim3(WV), lds, st, a, dt);    \
     } while (0)
     if (h->long_taps && planar) P25FE_LAUNCH_K1_LONG(OUT_PLANAR);
     else if (h->long_taps) P25FE_LAUNCH_K1_LONG(OUT_LINEAR);
@@ -1027,4 +1061,16 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
     return P25FE_OK;
 }
 
+#ifdef P25FE_K1_STAMP
+// measurement builds only: read (and clear) K1's per-phase cycle sums; out[7] = sub-tiles counted
+int p25fe_debug_k1_stamps(uint64_t out[16])
+{
+    std::vector<unsigned long long> z((size_t)p25k::K1_STAMP_SLOTS * 16, 0ull), v(z.size());
+    if (hipMemcpyFromSymbol(v.data(), HIP_SYMBOL(p25k::g_k1_stamp), v.size() * 8) != hipSuccess) return P25FE_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(p25k::g_k1_stamp), z.data(), z.size() * 8) != hipSuccess) return P25FE_ERR_HIP;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (size_t k = 0; k < v.size(); ++k) out[k & 15] += v[k];
+    return P25FE_OK;
+}
+#endif
 }  // extern "C"

@@ -86,6 +86,7 @@ template <int PK, int TX = 0> struct Geo {
     // The window cannot be overlaid: the next one is in flight into it while d, y and the outputs are produced.
     static constexpr int NVD = (XWIN + 2 + 2 * WV - 1) / (2 * WV);            // 1-KB DMA pieces per window: 13 for PK = 5
     static constexpr size_t LDS_BYTES_DMA = sizeof(float2) * (D_N + 2 * WV * NVD) + sizeof(float) * (T1 + T2 + 3);
+    static constexpr size_t LDS_BYTES_DMA2 = sizeof(float2) * (D_N + 2 * (2 * WV * NVD)) + sizeof(float) * (T1 + T2 + 3);   // two window buffers
     static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
     static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
@@ -131,10 +132,21 @@ __device__ __forceinline__ float fm_discriminate(float2 s, float2 prev)
 // section 2).  Written explicitly so that the packing does not depend on the SLP vectoriser: one build of this kernel
 // paired the imaginary parts of two different outputs instead and paid 175 v_mov_b32 per sub-tile to assemble the pairs.
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef P25FE_K1_SCALAR_FMA
+#define P25FE_K1_SCALAR_FMA 0
+#endif
 __device__ __forceinline__ v2f cfma(float tap, v2f s, v2f acc)
 {
+#if P25FE_K1_SCALAR_FMA
+    // two v_fma_f32 (2 cycles each on the 32-wide SIMD) instead of one v_pk_fma_f32; the empty asm keeps the SLP vectoriser
+    // from re-packing the pair
+    float re = __builtin_fmaf(tap, s.x, acc.x), im = __builtin_fmaf(tap, s.y, acc.y);
+    asm volatile("" : "+v"(re));
+    return v2f{re, im};
+#else
     const v2f t = {tap, tap};
     return __builtin_elementwise_fma(t, s, acc);
+#endif
 }
 
 // One complex sample from LDS as a single ds_read_b64.  The volatile 64-bit access keeps the compiler from
@@ -150,6 +162,55 @@ __device__ __forceinline__ float2 lds_read_c(const float2* p)
 {
     const v2f v = lds_read_v2(p);
     return make_float2(v.x, v.y);
+}
+
+// Software-pipelined window reads.  The FIR inner loops are chains "ds_read_b64 -> up to P packed FMAs"; scheduled by the
+// compiler (volatile reads above) only one or two reads are in flight, so every step pays most of the LDS latency
+// (64 cycles idle, several hundred with eleven waves hammering the same LDS) and the 2-3 waves of a SIMD cannot cover
+// 96 such stalls per sub-tile.  Here the reads are issued from inline asm -- which the compiler's s_waitcnt insertion does
+// not track -- DEPTH reads ahead of their use, and each use is preceded by an explicit s_waitcnt lgkmcnt(reads issued
+// after it).  LDS operations of a wave return in order, so "at most n outstanding" means everything older than the
+// last n has landed; operations the compiler interleaves on its own only make the wait stricter.
+// The wait takes the value as an in/out operand: its consumers depend on the wait, not on the issue.
+template <int OFF> __device__ __forceinline__ v2f lds_issue_b64(unsigned addr)
+{
+    v2f v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void lds_landed(v2f& v)
+{
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit field");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// Walk w[N-1], w[N-2], ..., w[0] (newest sample first = tap order 0..T-1), DEPTH reads in flight: body(j, value of w[j]).
+template <int N, int DEPTH, class Body> __device__ __forceinline__ void lds_walk_down(const float2* w, Body&& body)
+{
+    static_assert(DEPTH >= 1 && DEPTH <= 16 && DEPTH <= N, "ring depth");
+    const unsigned base = lds_addr(w);
+    v2f ring[DEPTH];
+    static_for<0, DEPTH>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        ring[i] = lds_issue_b64<8 * (N - 1 - i)>(base);
+    });
+    static_for<0, N>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int after = (N - 1 - i) < (DEPTH - 1) ? (N - 1 - i) : (DEPTH - 1);      // reads issued after read i by now
+        lds_landed<after>(ring[i % DEPTH]);
+        body(std::integral_constant<int, N - 1 - i>{}, ring[i % DEPTH]);
+        if constexpr (i + DEPTH < N) ring[i % DEPTH] = lds_issue_b64<8 * (N - 1 - (i + DEPTH))>(base);
+    });
 }
 
 // Value held by lane-1 of the wave; lane 0 receives `lane0` (DPP wave_shr:1 -- one VALU op, no LDS).
@@ -420,10 +481,11 @@ struct K1Args {
     long bb_stride;
     long n_out;             // outputs per channel
     int subs_per_seg;
-    int xcd_group;          // > 0: workgroups b, b + 8, b + 16, ... (same XCD) take xcd_group consecutive segments (see k_frontend)
+    int seg_count;          // segments per channel in this launch; work items = seg_count x n_ch, channel-major
+    int n_ch;               // channels
     int seg_first;          // first segment of this launch (a shard's head segment is launched after its halo has arrived)
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
-    float* power_partial;   // nullable: [n_channels][gridDim.x] partial sums of |y|^2
+    float* power_partial;   // nullable: [n_channels][seg_count] partial sums of |y|^2
     // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + PLPAD >= SEG_HALO,
     // (m_begin + PLPAD) % 80 == 0 and a segment length that is a multiple of 80.
     float* bbp;             // channel 0
@@ -453,14 +515,46 @@ struct K1Args {
 #ifndef P25FE_K1_PF_U8
 #define P25FE_K1_PF_U8 2
 #endif
+// window reads of the two FIRs: reads in flight ahead of their use (0 = leave the schedule to the compiler)
+#ifndef P25FE_K1_LDS_DEPTH
+#define P25FE_K1_LDS_DEPTH 8
+#endif
+// LDS-DMA loader: 1 = one window buffer (the next window is requested when the decimator releases it, ~70 % of an
+// iteration ahead), 2 = two buffers (a full iteration ahead, 29.5 KB of LDS per wave -> 5 waves per CU; measured
+// 338 / 359 us against 236 / 247 us of the register loader: the waves per CU matter more than the request distance)
+#ifndef P25FE_K1_DMA_BUFS
+#define P25FE_K1_DMA_BUFS 1
+#endif
+// Measurement builds only (-DP25FE_K1_STAMP): a wave accumulates the shader-clock time of each phase of its sub-tiles
+// and adds the sums to g_k1_stamp at its end (read through p25fe_debug_k1_stamps).  s_memtime + s_waitcnt lgkmcnt(0) per
+// stamp: the phase boundaries drain the LDS queue, which the product does not do everywhere.
+#ifdef P25FE_K1_STAMP
+constexpr int K1_STAMP_SLOTS = 8192;          // workgroup b adds into slot b % 8192: no hot address
+__device__ unsigned long long g_k1_stamp[K1_STAMP_SLOTS][16];
+#define K1_STAMP(i)                                                                   \
+    do {                                                                              \
+        unsigned long long t_;                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+        st_acc[i] += t_ - st_last;                                                    \
+        st_last = t_;                                                                 \
+    } while (0)
+#define K1_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#else
+#define K1_STAMP(i) do { } while (0)
+#define K1_PIN2(a, b) do { } while (0)
+#endif
 template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int LD = LD_REGS, int TX = 0>
 __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
-    constexpr int PF = (LD == LD_DMA || PK != 5 || TX != 0) ? 1 : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
+    constexpr int PF = (PK != 5 || TX != 0) ? 1 : LD == LD_DMA ? P25FE_K1_DMA_BUFS : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
     static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
     static_assert(LD == LD_REGS || FMT == P25FE_FMT_CF32, "LDS-DMA moves raw samples: cf32 only (u8 is converted on the way)");
     constexpr bool DMA = LD == LD_DMA;
     static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
+#ifdef P25FE_K1_STAMP
+    unsigned long long st_t0, st_r0;                                // entry: shader clock / constant 100 MHz clock
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
+#endif
     using G = Geo<PK, TX>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
@@ -470,7 +564,8 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region (register loader)
     float2* XIN = DMA ? D + G::D_N : D + D_CARRY;                   // 16-B aligned: staged with ds_write_b128 / written by the DMA
     float* OUT = reinterpret_cast<float*>(DMA ? D + D_CARRY : D + G::D_N);      // [SUB] output transpose: inside the window region / over d's front
-    float* TAPS = reinterpret_cast<float*>(DMA ? XIN + 2 * WV * G::NVD : D + D_CARRY + G::XIN_N);   // [T1 | T2], only when !CT
+    float2* XIN2 = DMA && PF == 2 ? XIN + 2 * WV * G::NVD : XIN;    // second window buffer of the double-buffered DMA form
+    float* TAPS = reinterpret_cast<float*>(DMA ? XIN2 + 2 * WV * G::NVD : D + D_CARRY + G::XIN_N);   // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
     if (!CT) {
         for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
@@ -480,25 +575,30 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
     const long seg_len = (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
-    // Workgroup -> segment.  Workgroup b runs on XCD b % 8 (observed, for speed only): inside every run of 8 G segments
-    // XCD x takes the G consecutive ones [x G, x G + G), one after the other, so that a segment's 9 % halo re-read was
-    // fetched into the SAME XCD's L2 by its left neighbour a moment ago -- while all eight XCDs still stream the same
-    // ~1 MB of the capture (whole eighths per XCD measured 4 % slower: eight far-apart DRAM streams).
-    long seg = (long)blockIdx.x + a.seg_first;
-    if (a.xcd_group > 0 && a.seg_first == 0) {
-        const long run = 8L * a.xcd_group;
-        const long full = (long)gridDim.x / run * run;              // the tail keeps the identity map
-        if (seg < full) {
-            const long x = seg & 7, k = seg >> 3;
-            seg = (k / a.xcd_group) * run + x * a.xcd_group + k % a.xcd_group;
-        }
-    }
+#ifdef P25FE_K1_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_n = 0, st_pro = 0, st_items = 0;
+#endif
+    // Work items (segment, channel) are taken in a grid-stride loop: the launch holds one workgroup per resident wave
+    // slot, wave b works on items b, b + G, b + 2 G, ... (consecutive items = consecutive segments of one channel, so at
+    // any moment the resident waves stream one compact, advancing region of the capture -- what the dispatcher's in-order
+    // hand-out of 3-sub-tile workgroups gave, without the ~4 us a wave slot stood empty between two workgroups).
+    const long n_items = (long)a.seg_count * a.n_ch;
+    for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+#ifdef P25FE_K1_STAMP
+    unsigned long long st_i0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_i0)::"memory");
+    bool st_first_sub = true;
+    ++st_items;
+#endif
+    const int ch = (int)(item / a.seg_count);
+    const long seg_rel = item - (long)ch * a.seg_count;
+    const long seg = seg_rel + a.seg_first;
     const long m_seg0 = a.m_begin + seg * seg_len;
-    if (m_seg0 >= a.n_out) return;
+    if (m_seg0 >= a.n_out) continue;
     const long m_seg1 = (m_seg0 + seg_len < a.n_out) ? m_seg0 + seg_len : a.n_out;
-    const int ch = blockIdx.y;
     const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)ch * a.ch_stride * (FMT == P25FE_FMT_CF32 ? 8 : 2);
     float* bb = a.bb + (size_t)ch * a.bb_stride;
+    phase_sync();                                                   // the previous item's LDS reads precede this item's writes
 
     // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
     for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
@@ -509,6 +609,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
     if constexpr (DMA) {
         ld0.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
+        if constexpr (PF == 2) ld0.issue(xb, (long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN2);
     } else {
         ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
         ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
@@ -578,14 +679,21 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     };
 
     // One sub-tile.  `ld` holds its window (requested PF sub-tiles ago) and is refilled with the window PF sub-tiles ahead.
-    auto sub_tile = [&](auto& ld) -> bool {
+    auto sub_tile = [&](auto& ld, float2* XIN) -> bool {
         if (dlo >= m_seg1) return false;                           // uniform
+#ifdef P25FE_K1_STAMP
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+        if (st_first_sub) { st_pro += st_last - st_i0; st_first_sub = false; }
+        ++st_n;
+#endif
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[xsh + k] = x[first + k]
         const int xsh = (int)(first & 1);                           // window start relative to the aligned staging origin
         if constexpr (DMA) {
             // the window was requested right after the previous sub-tile's decimator; everything older in the memory
             // queue (the previous outputs' stores) is older than it, so a full drain waits for nothing else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (two buffers: the other buffer's 13 DMA pieces are the newest entries of the queue and stay in flight)
+            if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NVD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         } else {
 #if P25FE_K1_TURNAROUND_PRIO
@@ -595,6 +703,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         }
         phase_sync();
+        K1_STAMP(0);                                                // window landed + staged
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
         if constexpr (!DMA) ld.load(first + (long)(PF * DEC) * SUB, tid);
@@ -605,6 +714,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         // loads-only build with s_sleep in place of the arithmetic.)
         if constexpr (!DMA) __builtin_amdgcn_s_setprio(0);
 #endif
+        K1_STAMP(1);                                                // previous outputs stored, next window requested
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
 #if defined(P25FE_DRIFT)                            // ... with pseudo-random idle phases (units of 64 cycles) in place of the arithmetic
@@ -624,6 +734,16 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             v2f acc[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p] = v2f{0.f, 0.f};
+#if P25FE_K1_LDS_DEPTH > 0
+            lds_walk_down<DEC * (P - 1) + T1, P25FE_K1_LDS_DEPTH>(w, [&](auto jc, v2f s) {   // newest to oldest => tap order 0..T1-1
+                constexpr int j = decltype(jc)::value;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int k = DEC * p + (T1 - 1) - j;
+                    if (k >= 0 && k < T1) acc[p] = cfma(tap_dec(k), s, acc[p]);
+                }
+            });
+#else
 #pragma unroll
             for (int j = DEC * (P - 1) + T1 - 1; j >= 0; --j) {    // newest to oldest => tap order 0..T1-1
                 const v2f s = lds_read_v2(w + j);
@@ -633,16 +753,22 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
                     if (k >= 0 && k < T1) acc[p] = cfma(tap_dec(k), s, acc[p]);
                 }
             }
+#endif
             // d overwrites the front of the window: every lane's window reads must be complete first.  (The compiler
             // reasons per thread and could prove a lane's own store and loads disjoint -- the fence orders the wave.)
             phase_sync();
+#ifdef P25FE_K1_STAMP
+#pragma unroll
+            for (int p = 0; p < P; ++p) K1_PIN2(acc[p].x, acc[p].y);
+            K1_STAMP(2);                                            // decimator
+#endif
 #pragma unroll
             for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = make_float2(acc[p].x, acc[p].y);
         }
         phase_sync();
         // the decimator has consumed the window (its reads fed the accumulators just stored): let the next one stream
         // into the same LDS while the channel filter, the discriminator and the boxcar run
-        if constexpr (DMA) ld.issue(xb, first + (long)DEC * SUB, a.n_hist, a.n_new, i_last, tid, XIN);
+        if constexpr (DMA) ld.issue(xb, first + (long)(PF * DEC) * SUB, a.n_hist, a.n_new, i_last, tid, XIN);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
         return true;
@@ -654,9 +780,14 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             v2f yv[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) yv[p] = v2f{0.f, 0.f};
+#if P25FE_K1_LDS_DEPTH > 0
+            lds_walk_down<(P - 1) + T2, P25FE_K1_LDS_DEPTH>(w, [&](auto jc, v2f s) {
+                constexpr int j = decltype(jc)::value;
+#else
 #pragma unroll
             for (int j = (P - 1) + T2 - 1; j >= 0; --j) {
                 const v2f s = lds_read_v2(w + j);
+#endif
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
@@ -666,7 +797,11 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
                     if (k >= 0 && k < T2) yv[p] = cfma(tap_ch(k), s, yv[p]);
 #endif
                 }
+#if P25FE_K1_LDS_DEPTH > 0
+            });
+#else
             }
+#endif
 #pragma unroll
             for (int p = 0; p < P; ++p) y[p] = make_float2(yv[p].x, yv[p].y);
             if (a.power_partial) {
@@ -680,6 +815,11 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
                 }
             }
         }
+#ifdef P25FE_K1_STAMP
+#pragma unroll
+        for (int p = 0; p < P; ++p) K1_PIN2(y[p].x, y[p].y);
+        K1_STAMP(3);                                                // d stores + channel filter
+#endif
         phase_sync();                                               // all reads of D done before its carry is rewritten
         // carry the d history to the next sub-tile (ordered before its next use by the next phase boundaries)
         for (int k = tid; k < D_CARRY; k += WV) D[k] = D[SUB + k];
@@ -702,6 +842,10 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             y_carry.x = lane_bcast<WV - 1>(y[P - 1].x);
             y_carry.y = lane_bcast<WV - 1>(y[P - 1].y);
         }
+#ifdef P25FE_K1_STAMP
+        K1_PIN2(f[0], f[1]); K1_PIN2(f[2], f[P - 2]); K1_PIN2(f[P - 1], f[0]);
+        K1_STAMP(4);                                                // d carry copy + discriminator
+#endif
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
 #pragma unroll
@@ -749,6 +893,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         return true;
 #endif
         phase_sync();
+        K1_STAMP(5);                                                // boxcar + transpose stores
         // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
         if constexpr (OM == OUT_LINEAR) {
 #pragma unroll
@@ -771,17 +916,21 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         }
         out_rel = (int)(dlo - m_seg0);
         phase_sync();
+#ifdef P25FE_K1_STAMP
+        K1_PIN2(outv[0], outv[P - 1]);
+        K1_STAMP(6);                                                // transpose reads (+ sign words)
+#endif
         return true;
     };
     if constexpr (PF == 1) {
         for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB)
-            if (!sub_tile(ld0)) break;
+            if (!sub_tile(ld0, XIN)) break;
     } else {
         // two register sets, two windows in flight per wave: the loop is unrolled by two so that each set keeps its registers
         for (int it = 0; it < a.subs_per_seg; it += 2) {
-            if (!sub_tile(ld0)) break;
+            if (!sub_tile(ld0, XIN)) break;
             dlo += SUB;
-            if (it + 1 >= a.subs_per_seg || !sub_tile(ld1)) break;
+            if (it + 1 >= a.subs_per_seg || !sub_tile(ld1, XIN2)) break;
             dlo += SUB;
         }
     }
@@ -791,8 +940,23 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
         // wave reduction of the |y|^2 partials (tree; tolerance vs the sequential fold is in the tests)
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) pw = pw + __shfl_down(pw, d, 64);
-        if (tid == 0) a.power_partial[(size_t)ch * gridDim.x + blockIdx.x] = pw;     // any order: summed by k_power_finish
+        if (tid == 0) a.power_partial[(size_t)ch * a.seg_count + seg_rel] = pw;     // any order: summed by k_power_finish
     }
+    }   // work items
+#ifdef P25FE_K1_STAMP
+    if (tid == 0) {
+        unsigned long long st_t1, st_r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1), "=s"(st_r1)::"memory");
+        unsigned long long* slot = g_k1_stamp[blockIdx.x % K1_STAMP_SLOTS];
+        for (int i = 0; i < 7; ++i) atomicAdd(&slot[i], st_acc[i]);
+        atomicAdd(&slot[7], st_n);
+        atomicAdd(&slot[8], st_pro);                                // prologues: item start -> its first sub-tile
+        atomicAdd(&slot[9], st_t1 - st_t0);                         // lifetime, shader clock
+        atomicAdd(&slot[10], st_r1 - st_r0);                        // lifetime, 100 MHz clock
+        atomicAdd(&slot[11], 1ull);                                 // workgroups
+        atomicAdd(&slot[12], st_items);                             // work items
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
