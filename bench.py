@@ -66,10 +66,14 @@ def cpu_baseline(iq_host, seconds_label):
     return out, dib
 
 
-def timed(torch, step, steps, warmup, dist=None):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+def timed(torch, step, steps, warmup, dist=None, finish=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns seconds (max over ranks).
+    `finish` (pipelined steps: FrontEnd.join_dev) runs after the K-th step, inside the timed region; the device-wide
+    synchronize that follows covers every stream, so all work of the K steps is complete when the clock stops."""
     for _ in range(warmup):
         step()
+    if finish:
+        finish()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -77,6 +81,8 @@ def timed(torch, step, steps, warmup, dist=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if finish:
+        finish()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -93,6 +99,7 @@ def k1_frac(fe, torch, step, n_samples, bytes_per_sample, reps=8):
     fe.profile_enable(1)
     for _ in range(reps):
         step()
+    fe.join_dev()
     torch.cuda.synchronize()
     kms, ncalls = fe.profile_read()
     fe.profile_enable(False)
@@ -106,6 +113,10 @@ def run_extras(torch, dev, args, iq2, truth2):
     from p25rx_amd import c4fm
     from p25rx_amd.frontend import FrontEnd, parse_results
     out = []
+    pipe = not args.no_pipeline
+
+    def run(fe, x, dib, res):
+        return fe.run_dev_pipelined(x, dibits=dib, result=res) if pipe else fe.run_dev(x, dibits=dib, result=res)
 
     def entry(name, n_samples, ms, k_name, k_ms, bps, ok, **kw):
         ach = bps * n_samples / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -128,9 +139,9 @@ def run_extras(torch, dev, args, iq2, truth2):
     dib = res = None
     def step_u8():
         nonlocal dib, res
-        dib, res = fe.run_dev(u8, dibits=dib, result=res)
+        dib, res = run(fe, u8, dib, res)
     k = steps_for(0.3)
-    dt = timed(torch, step_u8, k, 5)
+    dt = timed(torch, step_u8, k, 5, finish=fe.join_dev)
     k1, _, _ = k1_frac(fe, torch, step_u8, n, BYTES_PER_SAMPLE_K1_U8)
     entry("configs[1] as u8 I/Q pairs (the reference's input format), 1 ch x 600 s", n, dt / k * 1e3, "k_frontend<u8>", k1,
           BYTES_PER_SAMPLE_K1_U8, gate(dib, res, truth2), steps=k, note="2.8 B per sample: VALU / LDS bound, not HBM bound")
@@ -146,9 +157,9 @@ def run_extras(torch, dev, args, iq2, truth2):
     def step_c3():
         nonlocal nar, dib, res
         nar, no = fe.predecim_dev(wide, out=nar)
-        dib, res = fe.run_dev(nar[:, :no], dibits=dib, result=res)
+        dib, res = run(fe, nar[:, :no], dib, res)
     k = steps_for(0.36)
-    dt = timed(torch, step_c3, k, 5)
+    dt = timed(torch, step_c3, k, 5, finish=fe.join_dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(8):
@@ -174,9 +185,9 @@ def run_extras(torch, dev, args, iq2, truth2):
     dib = res = None
     def step_c4():
         nonlocal dib, res
-        dib, res = fe.run_dev(iq4, dibits=dib, result=res)
+        dib, res = run(fe, iq4, dib, res)
     k = steps_for(7.5)
-    dt = timed(torch, step_c4, k, 2)
+    dt = timed(torch, step_c4, k, 2, finish=fe.join_dev)
     k1, _, kms = k1_frac(fe, torch, step_c4, C * n4, BYTES_PER_SAMPLE_K1, reps=3)
     entry("configs[3]: 256 channels x 60 s, channel-major batch", C * n4, dt / k * 1e3, "k_frontend<cf32>", k1,
           BYTES_PER_SAMPLE_K1, gate(dib, res, truth4, C - 1), steps=k,
@@ -190,9 +201,9 @@ def run_extras(torch, dev, args, iq2, truth2):
     dib = res = None
     def step_c5():
         nonlocal dib, res
-        dib, res = fe.run_dev(iq5, dibits=dib, result=res)
+        dib, res = run(fe, iq5, dib, res)
     k = steps_for(1.9)
-    dt = timed(torch, step_c5, k, 2)
+    dt = timed(torch, step_c5, k, 2, finish=fe.join_dev)
     k1, _, _ = k1_frac(fe, torch, step_c5, n5, BYTES_PER_SAMPLE_K1, reps=3)
     entry("configs[4] on one GPU: 3 600 s x 1 channel, single pass", n5, dt / k * 1e3, "k_frontend<cf32>", k1,
           BYTES_PER_SAMPLE_K1, gate(dib, res, truth5), steps=k)
@@ -281,6 +292,8 @@ def main():
     ap.add_argument("--gather", choices=["root", "all", "none"], default="root",
                     help="N > 1: dibit shards gathered to rank 0 (default), all-gathered, or left sharded (diagnostic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N = 1: strictly serial steps (K1 -> K2 -> K3 -> K4 on one stream) instead of p25fe_run_dev_pipelined")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--cpu-seconds", type=float, default=600.0, help="length of the capture prefix timed on the CPU")
     args = ap.parse_args()
@@ -332,8 +345,15 @@ def main():
     if world == 1:
         dibits = torch.empty((1, cap), dtype=torch.uint8, device=dev)
 
-        def step():
-            fe.run_dev(iq, dibits=dibits, result=result)
+        if args.no_pipeline:
+            def step():
+                fe.run_dev(iq, dibits=dibits, result=result)
+        else:
+            # steps are pipelined two deep inside the library: the receive kernels (K2-K4, three short latency-bound
+            # launches) of step i run on the handle's own stream and overlap K1 of step i + 1 -- DemodTask and RecvTask
+            # are two threads joined by a channel in the reference too.  All of it completes inside the timed region.
+            def step():
+                fe.run_dev_pipelined(iq, dibits=dibits, result=result)
     else:
         from p25rx_amd.sharding import HostStagedComm, TimeShard
         ts = TimeShard(fe, rank, world, n, dist, comm=HostStagedComm(dist, rank, world) if staged else None)
@@ -346,18 +366,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    fe.join_dev()
     torch.cuda.synchronize()
     fe.profile_enable(2)            # HIP events around K1 only inside the timed region (each record costs ~3 us of gap)
-    dt = timed(torch, step, args.steps, 0, dist)
+    dt = timed(torch, step, args.steps, 0, dist, finish=fe.join_dev)
     kms, ncalls = fe.profile_read()
     # per-kernel split of the other kernels: a few extra steps OUTSIDE the timed region with events around every kernel
     fe.profile_enable(1)
     n_extra_steps = min(args.steps, 8)
     for _ in range(n_extra_steps):
         step()
+    fe.join_dev()
     torch.cuda.synchronize()
     kms_all, _ = fe.profile_read()
     fe.profile_enable(False)
+    serial_ms = None
+    if world == 1 and not args.no_pipeline:
+        # the strictly serial form of the same step (K1 -> K2 -> K3 -> K4 on one stream), for comparison; not `value`
+        ks = min(args.steps, 100)
+        t0 = time.perf_counter()
+        for _ in range(ks):
+            fe.run_dev(iq, dibits=dibits, result=result)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t0) / ks * 1e3
     cdev = torch.device("cpu") if staged else dev
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -456,6 +487,12 @@ def main():
                                               "note": "from extra steps after the timed region, HIP events around every kernel"
                                                       + ("; N > 1: k_scan = pass 1 + pass 2 scans, RCCL time is in neither" if world > 1 else "")}},
         }
+        if world == 1:
+            out["config"]["step"] = ("serial: K1 -> K2 -> K3 -> K4 on one stream" if args.no_pipeline else
+                                     "pipelined two deep (p25fe_run_dev_pipelined): K2-K4 of step i on the handle's stream overlap "
+                                     "K1 of step i + 1; join + device synchronize inside the timed region")
+            if serial_ms is not None:
+                out["config"]["serial_ms_per_step"] = round(serial_ms, 4)
         if gather_ok is not None:
             out["config"]["gather_gate"] = ("gathered stream holds every shard at its resolved offset (length, sum and "
                                             "position-weighted sum of every rank's dibits): %s" % gather_ok)

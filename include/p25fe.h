@@ -168,6 +168,19 @@ int p25fe_slice_dev(p25fe_t *h, const float *d_bb, size_t bb_stride, size_t n_hi
 int p25fe_run_dev(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n, uint8_t *d_dibits,
                   size_t dibit_stride, p25fe_result_t *d_result, void *stream);
 
+/* The same pass with the two halves of the path on two streams, for a SEQUENCE of captures (or chunks of separate
+ * tuners): stages 1-5 (K1, which is what loads the GPU) run on `stream`, stages 6-7 (sync detect, scan, slicer: three
+ * short, latency-bound launches) on a stream of the handle, so that they overlap the NEXT call's K1 -- the way
+ * DemodTask and RecvTask are two threads joined by a channel (src/demod.rs:116, src/recv.rs:140-150: the demodulator
+ * is already filling the next chunk while the receiver works on the previous one).  The receiver's scratch is double
+ * buffered; call i + 2 waits on the device for call i's receive kernels.
+ * d_dibits / d_result of a call are complete only after p25fe_join_dev has been enqueued on a stream and that stream
+ * has reached it (or after any other call on this handle that uses the receiver, which joins first). */
+int p25fe_run_dev_pipelined(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n, uint8_t *d_dibits,
+                            size_t dibit_stride, p25fe_result_t *d_result, void *stream);
+/* make `stream` wait for every receive kernel that p25fe_run_dev_pipelined has enqueued so far */
+int p25fe_join_dev(p25fe_t *h, void *stream);
+
 /* Time-sharded capture (BASELINE.json config 5): shard = owned range [abs0, abs0 + n) with
  * n_hist >= p25fe_shard_halo() samples of left context in memory (or n_hist == abs0 for the
  * first shard).  Pass 1 demodulates, detects frame syncs and fills d_result[c] with the

@@ -49,7 +49,7 @@ SYMBOLS = [
     "p25fe_default_config", "p25fe_create", "p25fe_destroy", "p25fe_strerror", "p25fe_last_hip_error",
     "p25fe_demod_u8", "p25fe_demod_cf32", "p25fe_slice", "p25fe_run_u8", "p25fe_run_cf32", "p25fe_resync",
     "p25fe_reset", "p25fe_state_size", "p25fe_state_export", "p25fe_state_import", "p25fe_demod_dev",
-    "p25fe_slice_dev", "p25fe_run_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
+    "p25fe_slice_dev", "p25fe_run_dev", "p25fe_run_dev_pipelined", "p25fe_join_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
@@ -106,6 +106,8 @@ def load():
     L.p25fe_demod_dev.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, sz, vp, vp]
     L.p25fe_slice_dev.argtypes = [vp, vp, sz, sz, sz, u64, vp, vp, sz, vp, vp, sz, vp, vp]
     L.p25fe_run_dev.argtypes = [vp, vp, C.c_int, sz, sz, vp, sz, vp, vp]
+    L.p25fe_run_dev_pipelined.argtypes = [vp, vp, C.c_int, sz, sz, vp, sz, vp, vp]
+    L.p25fe_join_dev.argtypes = [vp, vp]
     L.p25fe_shard_halo.argtypes = []
     L.p25fe_shard_halo.restype = sz
     L.p25fe_shard_pass1.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, vp]

@@ -62,6 +62,14 @@ struct p25fe {
 
     // scratch
     DevBuf iq_stage, bb_buf, pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    // p25fe_run_dev_pipelined: a second set of the receiver's scratch (the member names above always are the set of the
+    // current call; the sets are swapped per call), the stream the receive kernels run on, and the events that order
+    // K1 (caller's stream) -> K2..K4 (rx_stream) -> next K1 into the same set two calls later
+    DevBuf alt_pl_f, alt_pl_bits, alt_evl, alt_evthr, alt_recs, alt_tsum, alt_outs;
+    hipStream_t rx_stream = nullptr;
+    hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_rx[2] = {nullptr, nullptr};
+    bool rx_pending[2] = {false, false};
+    int lane = 0;
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
@@ -247,6 +255,13 @@ void p25fe_destroy(p25fe_t* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->rx_stream) { (void)hipStreamSynchronize(h->rx_stream); (void)hipStreamDestroy(h->rx_stream); }
+    for (int l = 0; l < 2; ++l) {
+        if (h->ev_k1[l]) (void)hipEventDestroy(h->ev_k1[l]);
+        if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
+    }
+    DevBuf* alt[] = {&h->alt_pl_f, &h->alt_pl_bits, &h->alt_evl, &h->alt_evthr, &h->alt_recs, &h->alt_tsum, &h->alt_outs};
+    for (DevBuf* b : alt) b->release();
     DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
                       &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
@@ -497,6 +512,7 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, const p2
     return P25FE_OK;
 }
 
+static int pipe_join(p25fe_t* h, hipStream_t st);
 // stages 6-7 on a LINEAR device baseband: planarize, detect, scan, slice
 static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
                      uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits,
@@ -504,6 +520,7 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
                      p25fe_result_t* d_result, hipStream_t st)
 {
     h->sh_valid = false;
+    if (int jrc = pipe_join(h, st)) return jrc;
     if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
         return launch_scan_slice(h, 0, abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
                                  false, st);
@@ -586,6 +603,77 @@ int p25fe_slice_dev(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hi
                      d_sync_dibit, sync_stride, d_result, (hipStream_t)stream);
 }
 
+// Every entry point that uses the receiver's scratch first makes its stream wait for receive kernels that
+// p25fe_run_dev_pipelined left running on the handle's own stream (no-op when nothing is pending).
+static int pipe_join(p25fe_t* h, hipStream_t st)
+{
+    for (int l = 0; l < 2; ++l)
+        if (h->rx_pending[l]) {
+            HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[l], 0));
+            h->rx_pending[l] = false;
+        }
+    return P25FE_OK;
+}
+
+int p25fe_join_dev(p25fe_t* h, void* stream)
+{
+    if (!h) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pipe_join(h, (hipStream_t)stream);
+}
+
+int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
+                            size_t dibit_stride, p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    h->sh_valid = false;
+    if (!h->rx_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));
+        for (int l = 0; l < 2; ++l) {
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
+        }
+    }
+    // the other scratch set becomes the current one; it was last read by the receive kernels of the call before the
+    // previous one, which this call's K1 (it overwrites the planes) has to wait for
+    std::swap(h->pl_f, h->alt_pl_f); std::swap(h->pl_bits, h->alt_pl_bits); std::swap(h->evl, h->alt_evl);
+    std::swap(h->evthr, h->alt_evthr); std::swap(h->recs, h->alt_recs); std::swap(h->tsum, h->alt_tsum);
+    std::swap(h->outs, h->alt_outs);
+    h->lane ^= 1;
+    const int lane = h->lane;
+    if (h->rx_pending[lane]) {
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[lane], 0));
+        h->rx_pending[lane] = false;
+    }
+    const size_t n_bb = p25fe_n_baseband(0, n);
+    int rc = P25FE_OK;
+    const PlanarGeo g(n_bb);
+    if (n_bb) {
+        rc = ensure_slice_scratch(h, n_bb);          // (growing a buffer frees the old one: hipFree synchronises the device)
+        if (rc) return rc;
+        prof_begin(h);
+        prof_mark(h, 0, st);
+        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g);
+        if (rc) return rc;
+        prof_mark(h, 1, st);
+    }
+    HIPCHK(h, hipEventRecord(h->ev_k1[lane], st));
+    HIPCHK(h, hipStreamWaitEvent(h->rx_stream, h->ev_k1[lane], 0));
+    if (n_bb) {
+        rc = launch_detect(h, n_bb, 0, h->rx_stream);
+        if (rc) return rc;
+        prof_mark(h, 2, h->rx_stream);
+    }
+    rc = launch_scan_slice(h, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, n_bb != 0, h->rx_stream);
+    h->prof_slot = -1;
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_rx[lane], h->rx_stream));
+    h->rx_pending[lane] = true;
+    return P25FE_OK;
+}
+
 int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
                   size_t dibit_stride, p25fe_result_t* d_result, void* stream)
 {
@@ -593,6 +681,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     h->sh_valid = false;
+    if (int jrc = pipe_join(h, st)) return jrc;
     const size_t n_bb = p25fe_n_baseband(0, n);
     if (n_bb == 0)
         return launch_scan_slice(h, 0, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st);
@@ -624,6 +713,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (do_main) h->sh_valid = false;
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int jrc = pipe_join(h, st)) return jrc;
     const size_t n_bb = p25fe_n_baseband(abs0, n);
     const uint64_t abs_bb0 = p25fe_n_baseband(0, (size_t)abs0);      // baseband samples before this shard
     int rc = ensure_slice_scratch(h, n_bb);

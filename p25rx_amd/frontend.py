@@ -159,6 +159,25 @@ class FrontEnd:
                                        dibits.stride(0), C.c_void_p(result.data_ptr()), self._stream()))
         return dibits, result
 
+    def run_dev_pipelined(self, iq, dibits=None, result=None):
+        """run_dev for a sequence of captures: the receive kernels of this call overlap the next call's K1 (they run
+        on a stream of the handle).  Outputs are complete after join_dev() + a synchronisation of the stream."""
+        import torch
+        fmt, n, stride = self._iq_view(iq)
+        cap = (n // 50 + 64 + 15) // 16 * 16
+        if dibits is None:
+            dibits = torch.empty((self.C, cap), dtype=torch.uint8, device=iq.device)
+        if result is None:
+            result = torch.empty((self.C, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=iq.device)
+        self._chk(self.L.p25fe_run_dev_pipelined(self.h, C.c_void_p(iq.data_ptr()), fmt, stride, n,
+                                                 C.c_void_p(dibits.data_ptr()), dibits.stride(0),
+                                                 C.c_void_p(result.data_ptr()), self._stream()))
+        return dibits, result
+
+    def join_dev(self):
+        """the current stream waits for every receive kernel run_dev_pipelined has enqueued"""
+        self._chk(self.L.p25fe_join_dev(self.h, self._stream()))
+
     def demod_dev(self, iq, n_hist=0, abs0=0, bb=None, want_power=False, offset=0):
         """stages 1-5 on a device range; `offset` = index of the first owned sample inside `iq` (>= n_hist)."""
         import torch

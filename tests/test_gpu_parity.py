@@ -905,3 +905,43 @@ def test_run_dev_lengths_around_layout_boundaries(O, FE):
             d8, r8 = fe8.run_dev(t8)
             assert int(parse_results(r8)[0]["n_dibits"]) == len(ref8), n
             assert np.array_equal(d8[0, :len(ref8)].cpu().numpy(), ref8), n
+
+
+@pytest.mark.gpu
+def test_run_dev_pipelined_sequence(O, FE):
+    """p25fe_run_dev_pipelined: a sequence of DIFFERENT captures (lengths from empty to 3 s, cf32 and u8) enqueued back to
+    back on one handle -- K1 of call i + 1 overlaps the receive kernels of call i, the scratch sets alternate -- gives,
+    after p25fe_join_dev, exactly the oracle's dibits for every capture; a p25fe_run_dev in the middle of the sequence
+    (it joins first) and a second round over the same handle do too."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    caps, refs = [], []
+    for k, (secs, u8) in enumerate(((3.0, False), (0.25, False), (0.00004, False), (1.7, True), (0.9, False), (2.2, True), (0.05, False))):
+        iq = c4fm.synth(max(secs, 0.01), seed=300 + k, snr_db=18.0 + k, frame_dibits=150 + 31 * k, timing_offset=3 * k)[0]
+        iq = iq[:int(secs * 240000) // 8 * 8]
+        if u8:
+            x = c4fm.to_u8(iq)
+            refs.append(O.Recv().feed(O.Demod().feed_u8(x))[0] if len(x) else np.zeros(0, np.uint8))
+            caps.append(torch.from_numpy(x.reshape(-1, 2)).cuda())
+        else:
+            refs.append(O.run_cf32(iq) if len(iq) else np.zeros(0, np.uint8))
+            caps.append(torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda())
+    fe = FE()
+    for rnd in range(2):
+        outs = [fe.run_dev_pipelined(t) for t in caps]
+        fe.join_dev()
+        torch.cuda.synchronize()
+        for k, ((dib, res), ref) in enumerate(zip(outs, refs)):
+            r = parse_results(res)[0]
+            assert int(r["n_dibits"]) == len(ref), (rnd, k)
+            assert np.array_equal(dib[0, :len(ref)].cpu().numpy(), ref), (rnd, k)
+        # an ordinary call between pipelined ones joins by itself
+        a = fe.run_dev_pipelined(caps[0])
+        b = fe.run_dev(caps[4])
+        c = fe.run_dev_pipelined(caps[3])
+        fe.join_dev()
+        torch.cuda.synchronize()
+        for (dib, res), ref in ((a, refs[0]), (b, refs[4]), (c, refs[3])):
+            assert int(parse_results(res)[0]["n_dibits"]) == len(ref)
+            assert np.array_equal(dib[0, :len(ref)].cpu().numpy(), ref)
