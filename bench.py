@@ -95,7 +95,8 @@ def steps_for(ms_guess, min_ms=120.0, lo=5, hi=2000):
 
 
 def k1_frac(fe, torch, step, n_samples, bytes_per_sample, reps=8):
-    """Dominant-kernel time from the library's HIP events (on the launch stream), over a few extra steps."""
+    """Dominant-kernel time from the library's HIP events (on the launch stream), over a few extra SERIAL steps
+    (the extras' ms_per_step is that of pipelined steps; the kernel split is that of the kernels alone)."""
     fe.profile_enable(1)
     for _ in range(reps):
         step()
@@ -142,7 +143,7 @@ def run_extras(torch, dev, args, iq2, truth2):
         dib, res = run(fe, u8, dib, res)
     k = steps_for(0.3)
     dt = timed(torch, step_u8, k, 5, finish=fe.join_dev)
-    k1, _, _ = k1_frac(fe, torch, step_u8, n, BYTES_PER_SAMPLE_K1_U8)
+    k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(u8, dibits=dib, result=res), n, BYTES_PER_SAMPLE_K1_U8)
     entry("configs[1] as u8 I/Q pairs (the reference's input format), 1 ch x 600 s", n, dt / k * 1e3, "k_frontend<u8>", k1,
           BYTES_PER_SAMPLE_K1_U8, gate(dib, res, truth2), steps=k, note="2.8 B per sample: VALU / LDS bound, not HBM bound")
     del u8, fe
@@ -188,7 +189,7 @@ def run_extras(torch, dev, args, iq2, truth2):
         dib, res = run(fe, iq4, dib, res)
     k = steps_for(7.5)
     dt = timed(torch, step_c4, k, 2, finish=fe.join_dev)
-    k1, _, kms = k1_frac(fe, torch, step_c4, C * n4, BYTES_PER_SAMPLE_K1, reps=3)
+    k1, _, kms = k1_frac(fe, torch, lambda: fe.run_dev(iq4, dibits=dib, result=res), C * n4, BYTES_PER_SAMPLE_K1, reps=3)
     entry("configs[3]: 256 channels x 60 s, channel-major batch", C * n4, dt / k * 1e3, "k_frontend<cf32>", k1,
           BYTES_PER_SAMPLE_K1, gate(dib, res, truth4, C - 1), steps=k,
           receiver_share=round((kms[1] + kms[2] + kms[3]) / max(sum(kms), 1e-9), 4))
@@ -204,7 +205,7 @@ def run_extras(torch, dev, args, iq2, truth2):
         dib, res = run(fe, iq5, dib, res)
     k = steps_for(1.9)
     dt = timed(torch, step_c5, k, 2, finish=fe.join_dev)
-    k1, _, _ = k1_frac(fe, torch, step_c5, n5, BYTES_PER_SAMPLE_K1, reps=3)
+    k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(iq5, dibits=dib, result=res), n5, BYTES_PER_SAMPLE_K1, reps=3)
     entry("configs[4] on one GPU: 3 600 s x 1 channel, single pass", n5, dt / k * 1e3, "k_frontend<cf32>", k1,
           BYTES_PER_SAMPLE_K1, gate(dib, res, truth5), steps=k)
     return out
@@ -375,7 +376,10 @@ def main():
     fe.profile_enable(1)
     n_extra_steps = min(args.steps, 8)
     for _ in range(n_extra_steps):
-        step()
+        if world == 1:
+            fe.run_dev(iq, dibits=dibits, result=result)            # serial form: the split is that of the kernels alone
+        else:
+            step()
     fe.join_dev()
     torch.cuda.synchronize()
     kms_all, _ = fe.profile_read()
@@ -484,7 +488,7 @@ def main():
                          "other_kernels_ms": {"k_detect": round(kms_all[1] / n_extra_steps, 4),
                                               "k_scan": round(kms_all[2] / n_extra_steps, 4),
                                               "k_slice": round(kms_all[3] / n_extra_steps, 4),
-                                              "note": "from extra steps after the timed region, HIP events around every kernel"
+                                              "note": "from extra SERIAL steps after the timed region, HIP events around every kernel"
                                                       + ("; N > 1: k_scan = pass 1 + pass 2 scans, RCCL time is in neither" if world > 1 else "")}},
         }
         if world == 1:

@@ -54,7 +54,6 @@ struct p25fe {
     int n_cu = 256;
     Taps taps;
     int k1_p = 5;                          // FIR outputs per thread
-    bool k1_dma = false;                   // P25FE_K1_DMA=1: cf32 windows by LDS-DMA instead of register staging (measured slower)
     bool default_taps = true;              // taps == p25fe_spec.h tables bit for bit -> immediate-coefficient kernels
     bool long_taps = false;                // more than P25FE_T1 / P25FE_T2 taps -> the 64 / 64 geometry (Geo<5, 1>)
     DevBuf d_taps;                         // device copy for the generic kernels
@@ -214,8 +213,6 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     {
         const char* pv = getenv("P25FE_K1_P");            // tuning knob: FIR outputs per lane (5 default, 3)
         h->k1_p = (pv && atoi(pv) == 3) ? 3 : 5;
-        const char* dv = getenv("P25FE_K1_DMA");
-        h->k1_dma = dv && atoi(dv) == 1;
     }
     auto set_lds = [&](const void* f, size_t bytes) {
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -228,14 +225,10 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     P25FE_FOR_K1(5)
     P25FE_FOR_K1(3)
 #undef P25FE_FOR_K1
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_LINEAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR, LD_REGS, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_LINEAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, LD_DMA>), (P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA));
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_LINEAR, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR, 1>), Geo<5, 1>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
@@ -402,30 +395,20 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
             else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK, OM>), lds), dim3(WV), lds, st, a, dt);                   \
         }                                                                                                                 \
     } while (0)
-#define P25FE_LAUNCH_K1_DMA(OM)                                                                                           \
-    do {                                                                                                                  \
-        const size_t lds = P25FE_K1_DMA_BUFS == 2 ? Geo<5>::LDS_BYTES_DMA2 : Geo<5>::LDS_BYTES_DMA;                                                                     \
-        if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OM, LD_DMA>), lds), dim3(WV), lds, st, a, dt);  \
-        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_DMA>), lds), dim3(WV), lds, st, a, dt);                 \
-    } while (0)
     // immediate-tap kernels never touch the taps area at the end of the LDS layout: do not allocate it.  (13 376 B per
     // wave is still 11 waves per CU: a 12th would need 13 312; trimming to that in an experiment changed nothing.)
     constexpr size_t lds_taps_trim = sizeof(float) * (T1 + T2 + 3);
-    const bool dma = h->k1_dma && fmt == P25FE_FMT_CF32 && pk == 5 && !h->long_taps;
 #define P25FE_LAUNCH_K1_LONG(OM)                                                                                          \
     do {                                                                                                                  \
         const size_t lds = Geo<5, 1>::LDS_BYTES;                                                                          \
-        if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_REGS, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, LD_REGS, 1>), lds), dim3(WV), lds, st, a, dt); \
-        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, 5, OM, LD_REGS, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, LD_REGS, 1>), lds), dim3(WV), lds, st, a, dt);    \
+        if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), lds), dim3(WV), lds, st, a, dt); \
+        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), lds), dim3(WV), lds, st, a, dt);    \
     } while (0)
     if (h->long_taps && planar) P25FE_LAUNCH_K1_LONG(OUT_PLANAR);
     else if (h->long_taps) P25FE_LAUNCH_K1_LONG(OUT_LINEAR);
-    else if (dma && planar) P25FE_LAUNCH_K1_DMA(OUT_PLANAR);
-    else if (dma) P25FE_LAUNCH_K1_DMA(OUT_LINEAR);
     else if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
     else if (pk == 3) P25FE_LAUNCH_K1(3, OUT_LINEAR);
     else P25FE_LAUNCH_K1(5, OUT_LINEAR);
-#undef P25FE_LAUNCH_K1_DMA
 #undef P25FE_LAUNCH_K1_LONG
 #undef P25FE_LAUNCH_K1
     HIPCHK(h, hipGetLastError());
@@ -630,7 +613,11 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     hipStream_t st = (hipStream_t)stream;
     h->sh_valid = false;
     if (!h->rx_stream) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));
+        // highest priority: the receive kernels are a few thousand short waves and one single-workgroup scan that should
+        // not queue behind K1's 32 000 workgroups (measured: no difference in the step time, 0.3005 vs 0.3001 ms)
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi));
         for (int l = 0; l < 2; ++l) {
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));

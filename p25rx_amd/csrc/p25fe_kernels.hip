@@ -82,11 +82,6 @@ template <int PK, int TX = 0> struct Geo {
     // workgroups fit a CU's 160 KB instead of 9 (occupancy is what bounds the overlap of HBM, LDS and VALU work).
     static constexpr size_t LDS_BYTES = sizeof(float2) * (D_CARRY + XIN_N) + sizeof(float) * (T1 + T2 + 3);
     static_assert(sizeof(float2) * XIN_N >= sizeof(float2) * SUB + sizeof(float) * SUB, "d and the transpose fit the window region");
-    // LDS-DMA variant (LD_DMA below): [d carry 40 | d SUB (the output transpose overlays its front)][window: NVD KB][taps].
-    // The window cannot be overlaid: the next one is in flight into it while d, y and the outputs are produced.
-    static constexpr int NVD = (XWIN + 2 + 2 * WV - 1) / (2 * WV);            // 1-KB DMA pieces per window: 13 for PK = 5
-    static constexpr size_t LDS_BYTES_DMA = sizeof(float2) * (D_N + 2 * WV * NVD) + sizeof(float) * (T1 + T2 + 3);
-    static constexpr size_t LDS_BYTES_DMA2 = sizeof(float2) * (D_N + 2 * (2 * WV * NVD)) + sizeof(float) * (T1 + T2 + 3);   // two window buffers
     static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
     static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
@@ -406,57 +401,6 @@ template <int FMT, int PK, int TX = 0> struct Loader {
 };
 
 // ------------------------------------------------------------------------------------------
-// window loader, LDS-DMA form (cf32 only): global -> LDS directly (global_load_lds_dwordx4: each lane supplies a global
-// address, the 64 x 16 B land lane-consecutively at a wave-uniform LDS address -- exactly the staging layout of
-// Loader::store).  No staging registers (52 VGPRs) and no ds_write_b128 pass (13 per sub-tile at ~13 cycles each of the
-// CU's VGPR -> LDS path: 45 us of the kernel's 207 us of arithmetic-side time, measured with tools/ablate.sh).  The same
-// clamped, branch-free addresses as above; samples outside [-n_hist, n_new) are zeroed in LDS after the data has landed
-// (boundary sub-tiles only).
-// ------------------------------------------------------------------------------------------
-constexpr int LD_REGS = 0, LD_DMA = 1;
-template <int PK, int TX = 0> struct DmaLoader {
-    using G = Geo<PK, TX>;
-    static constexpr int NV = G::NVD;
-    __device__ __forceinline__ void issue(const void* base, long first, long n_hist, long n_new, long i_last, int tid, float2* XIN) const
-    {
-        const long v0 = first >> 1;
-        const uint4* q = reinterpret_cast<const uint4*>(base) + v0;
-        const long last = i_last < n_new - 1 ? i_last : n_new - 1;
-        long lo = ((-n_hist) >> 1) - v0;
-        long hi = (last >> 1) - v0;
-        lo = lo < -(1L << 30) ? -(1L << 30) : (lo > (1L << 30) ? (1L << 30) : lo);
-        hi = hi < -(1L << 30) ? -(1L << 30) : (hi > (1L << 30) ? (1L << 30) : hi);
-        const int lo32 = (int)lo, hi32 = (int)hi;
-        typedef __attribute__((address_space(3))) char* lds_ptr;
-        typedef const __attribute__((address_space(1))) void* glb_ptr;
-        lds_ptr dst = (lds_ptr)XIN;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            int r = tid + j * WV;
-            r = r < lo32 ? lo32 : r;
-            r = r > hi32 ? hi32 : r;
-#if (defined(P25FE_ABLATE) && P25FE_ABLATE == 6) || defined(P25FE_ABLATE_CACHED)
-            __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const uint4*>(base) + tid), dst + 1024 * j, 16, 0, 0);
-            continue;
-#endif
-            __builtin_amdgcn_global_load_lds((glb_ptr)(q + r), dst + 1024 * j, 16, 0, 0);
-        }
-    }
-    __device__ __forceinline__ void fixup(float2* XIN, long first, long n_hist, long n_new, int tid) const
-    {
-        const long first_al = (first >> 1) << 1;
-        if (first_al >= -n_hist && first_al + (long)NV * 2 * WV <= n_new) return;      // uniform: interior window
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const long i = first_al + 2 * (long)(tid + j * WV) + e;
-                if (i < -n_hist || i >= n_new) XIN[2 * (tid + j * WV) + e] = make_float2(0.f, 0.f);
-            }
-    }
-};
-
-// ------------------------------------------------------------------------------------------
 // K1: fused front end.  One wave walks `subs_per_seg` consecutive sub-tiles of one channel.
 //   * the next sub-tile's input window is prefetched into registers while the current one is
 //     processed; it reaches LDS (time-linear cf32) at the top of the next iteration;
@@ -496,7 +440,7 @@ struct K1Args {
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
 // registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
-// Register budget of the planar / DMA variants: minimum waves per SIMD the kernel is compiled for.  Same-box A/B
+// Register budget of the planar variants: minimum waves per SIMD the kernel is compiled for.  Same-box A/B
 // (tools/ab.sh, 3 processes x 30 launches): with 3 the planar kernel is allocated the SAME 146 VGPRs as with 2 but is
 // scheduled differently and ran 300 us instead of 272 us.
 #ifndef P25FE_K1_PLANAR_WPS
@@ -519,12 +463,6 @@ struct K1Args {
 #ifndef P25FE_K1_LDS_DEPTH
 #define P25FE_K1_LDS_DEPTH 8
 #endif
-// LDS-DMA loader: 1 = one window buffer (the next window is requested when the decimator releases it, ~70 % of an
-// iteration ahead), 2 = two buffers (a full iteration ahead, 29.5 KB of LDS per wave -> 5 waves per CU; measured
-// 338 / 359 us against 236 / 247 us of the register loader: the waves per CU matter more than the request distance)
-#ifndef P25FE_K1_DMA_BUFS
-#define P25FE_K1_DMA_BUFS 1
-#endif
 // Measurement builds only (-DP25FE_K1_STAMP): a wave accumulates the shader-clock time of each phase of its sub-tiles
 // and adds the sums to g_k1_stamp at its end (read through p25fe_debug_k1_stamps).  s_memtime + s_waitcnt lgkmcnt(0) per
 // stamp: the phase boundaries drain the LDS queue, which the product does not do everywhere.
@@ -543,13 +481,11 @@ __device__ unsigned long long g_k1_stamp[K1_STAMP_SLOTS][16];
 #define K1_STAMP(i) do { } while (0)
 #define K1_PIN2(a, b) do { } while (0)
 #endif
-template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int LD = LD_REGS, int TX = 0>
-__global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
+__global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
-    constexpr int PF = (PK != 5 || TX != 0) ? 1 : LD == LD_DMA ? P25FE_K1_DMA_BUFS : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
+    constexpr int PF = (PK != 5 || TX != 0) ? 1 : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
     static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
-    static_assert(LD == LD_REGS || FMT == P25FE_FMT_CF32, "LDS-DMA moves raw samples: cf32 only (u8 is converted on the way)");
-    constexpr bool DMA = LD == LD_DMA;
     static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
 #ifdef P25FE_K1_STAMP
     unsigned long long st_t0, st_r0;                                // entry: shader clock / constant 100 MHz clock
@@ -562,10 +498,9 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     constexpr int T1 = G::T1, T2 = G::T2, D_CARRY = G::D_CARRY;      // this instantiation's tap counts (shadow the build's)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region (register loader)
-    float2* XIN = DMA ? D + G::D_N : D + D_CARRY;                   // 16-B aligned: staged with ds_write_b128 / written by the DMA
-    float* OUT = reinterpret_cast<float*>(DMA ? D + D_CARRY : D + G::D_N);      // [SUB] output transpose: inside the window region / over d's front
-    float2* XIN2 = DMA && PF == 2 ? XIN + 2 * WV * G::NVD : XIN;    // second window buffer of the double-buffered DMA form
-    float* TAPS = reinterpret_cast<float*>(DMA ? XIN2 + 2 * WV * G::NVD : D + D_CARRY + G::XIN_N);   // [T1 | T2], only when !CT
+    float2* XIN = D + D_CARRY;                                      // 16-B aligned: staged with ds_write_b128
+    float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose: inside the window region
+    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2], only when !CT
     const int tid = threadIdx.x;
     if (!CT) {
         for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
@@ -603,20 +538,15 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
     for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
 
-    using LoaderT = typename std::conditional<DMA, DmaLoader<PK, TX>, Loader<FMT, PK, TX>>::type;
+    using LoaderT = Loader<FMT, PK, TX>;
     LoaderT ld0, ld1;
     long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
-    if constexpr (DMA) {
-        ld0.issue(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN);
-        if constexpr (PF == 2) ld0.issue(xb, (long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), a.n_hist, a.n_new, i_last, tid, XIN2);
-    } else {
-        ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
-        ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
-        if constexpr (PF == 2) {
-            ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
-            ld1.load((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
-        }
+    ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
+    ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+    if constexpr (PF == 2) {
+        ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
+        ld1.load((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
     }
     float pw = 0.f;
 
@@ -679,7 +609,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     };
 
     // One sub-tile.  `ld` holds its window (requested PF sub-tiles ago) and is refilled with the window PF sub-tiles ahead.
-    auto sub_tile = [&](auto& ld, float2* XIN) -> bool {
+    auto sub_tile = [&](auto& ld) -> bool {
         if (dlo >= m_seg1) return false;                           // uniform
 #ifdef P25FE_K1_STAMP
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -688,31 +618,22 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
 #endif
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[xsh + k] = x[first + k]
         const int xsh = (int)(first & 1);                           // window start relative to the aligned staging origin
-        if constexpr (DMA) {
-            // the window was requested right after the previous sub-tile's decimator; everything older in the memory
-            // queue (the previous outputs' stores) is older than it, so a full drain waits for nothing else
-            // (two buffers: the other buffer's 13 DMA pieces are the newest entries of the queue and stay in flight)
-            if constexpr (PF == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NVD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
-        } else {
 #if P25FE_K1_TURNAROUND_PRIO
-            __builtin_amdgcn_s_setprio(P25FE_K1_TURNAROUND_PRIO);   // see below
+        __builtin_amdgcn_s_setprio(P25FE_K1_TURNAROUND_PRIO);       // see below
 #endif
-            ld.store(XIN, first, a.n_hist, a.n_new, tid);
-            ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
-        }
+        ld.store(XIN, first, a.n_hist, a.n_new, tid);
+        ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         phase_sync();
         K1_STAMP(0);                                                // window landed + staged
         flush_outputs();                                            // previous sub-tile's outputs (lane-predicated)
         // unconditional prefetch: past the segment's end the clamp makes every lane read one cached vector
-        if constexpr (!DMA) ld.load(first + (long)(PF * DEC) * SUB, tid);
+        ld.load(first + (long)(PF * DEC) * SUB, tid);
 #if P25FE_K1_TURNAROUND_PRIO
         // The turnaround -- window landed -> staged to LDS -> next window requested -- is the only part of the iteration during
         // which this wave has nothing in flight; it runs at raised priority so that the other waves' FMA streams do not
         // stretch it.  (Idle phases of the length of the arithmetic do not slow the load stream at all: 189 vs 192 us in a
         // loads-only build with s_sleep in place of the arithmetic.)
-        if constexpr (!DMA) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
 #endif
         K1_STAMP(1);                                                // previous outputs stored, next window requested
 
@@ -766,9 +687,6 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
             for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = make_float2(acc[p].x, acc[p].y);
         }
         phase_sync();
-        // the decimator has consumed the window (its reads fed the accumulators just stored): let the next one stream
-        // into the same LDS while the channel filter, the discriminator and the boxcar run
-        if constexpr (DMA) ld.issue(xb, first + (long)(PF * DEC) * SUB, a.n_hist, a.n_new, i_last, tid, XIN);
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
         return true;
@@ -924,13 +842,13 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR || LD == LD_DMA ? P25FE_K1_PL
     };
     if constexpr (PF == 1) {
         for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB)
-            if (!sub_tile(ld0, XIN)) break;
+            if (!sub_tile(ld0)) break;
     } else {
         // two register sets, two windows in flight per wave: the loop is unrolled by two so that each set keeps its registers
         for (int it = 0; it < a.subs_per_seg; it += 2) {
-            if (!sub_tile(ld0, XIN)) break;
+            if (!sub_tile(ld0)) break;
             dlo += SUB;
-            if (it + 1 >= a.subs_per_seg || !sub_tile(ld1, XIN2)) break;
+            if (it + 1 >= a.subs_per_seg || !sub_tile(ld1)) break;
             dlo += SUB;
         }
     }

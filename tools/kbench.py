@@ -22,18 +22,11 @@ iq8 = None
 if any(m.endswith("u8") for m in modes):
     iq8 = torch.clamp(torch.round((iq + 1.0) * 127.5), 0, 255).to(torch.uint8)
 fe = FrontEnd(n_channels=C)
-os.environ["P25FE_K1_DMA"] = "1"          # second handle: LDS-DMA K1 loader (modes with suffix _d)
-fe_r = FrontEnd(n_channels=C)
-os.environ.pop("P25FE_K1_DMA")
 bb = None
 def step(m):
     global bb
     if m == "lin":
         bb, _ = fe.demod_dev(iq, bb=bb)
-    elif m == "lin_d":
-        bb, _ = fe_r.demod_dev(iq, bb=bb)
-    elif m == "run_d":
-        fe_r.run_dev(iq)
     elif m == "lin_u8":
         bb, _ = fe.demod_dev(iq8, bb=bb)
     elif m == "run":
