@@ -945,3 +945,33 @@ def test_run_dev_pipelined_sequence(O, FE):
         for (dib, res), ref in ((a, refs[0]), (b, refs[4]), (c, refs[3])):
             assert int(parse_results(res)[0]["n_dibits"]) == len(ref)
             assert np.array_equal(dib[0, :len(ref)].cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_run_dev_pipelined_channel_batches(O, FE):
+    """The pipelined entry point on a 4-channel handle: two different batches (different lengths: the scratch is resized
+    between calls) alternate three times; every channel of every call equals the oracle's dibits."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    C = 4
+    batches, refs = [], []
+    for b, secs in enumerate((0.8, 1.3)):
+        chans = [c4fm.synth(secs, seed=500 + 10 * b + c, snr_db=16.0 + 2 * c, frame_dibits=120 + 40 * c, timing_offset=c)[0] for c in range(C)]
+        n = min(len(x) for x in chans) // 8 * 8
+        arr = np.stack([x[:n] for x in chans])
+        refs.append([O.run_cf32(arr[c]) for c in range(C)])
+        batches.append(torch.from_numpy(arr.view(np.float32).reshape(C, n, 2)).cuda())
+    fe = FE(n_channels=C)
+    outs = []
+    for rnd in range(3):
+        for b in (0, 1):
+            outs.append((b, fe.run_dev_pipelined(batches[b])))
+    fe.join_dev()
+    torch.cuda.synchronize()
+    for b, (dib, res) in outs:
+        r = parse_results(res)
+        for c in range(C):
+            nd = int(r[c]["n_dibits"])
+            assert nd == len(refs[b][c]), (b, c)
+            assert np.array_equal(dib[c, :nd].cpu().numpy(), refs[b][c]), (b, c)

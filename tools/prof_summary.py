@@ -12,8 +12,11 @@ def short(k):
         if "p25k::" + s in k:
             return s
     return None
-for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
-    print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extra :", os.path.relpath(f, d))
+for sub, what in (("stats", "(pipelined steps, the bench's default: the receive kernels overlap the next K1 and wait for wave slots, "
+                               "so their durations here are not their running times)"),
+                  ("stats_serial", "--no-pipeline (serial steps: every kernel alone on the chip)")):
+  for f in glob.glob(os.path.join(d, sub, "**", "*kernel_stats.csv"), recursive=True):
+    print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extra", what, ":", os.path.relpath(f, d))
     for r in csv.DictReader(open(f)):
         if short(r.get("Name", "")):
             print("  %-12s calls %4s  avg %10.1f ns  min %9s  max %9s  pct %s" % (
