@@ -376,12 +376,11 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const long n_items = seg_count * (long)h->C;
     if (n_items > 0x7fffffffL) return P25FE_ERR_ARG;
     auto k1_grid = [&](const void* kern, size_t lds) -> dim3 {
-        long g = n_items;
         if (persist_env > 0) {
             const long slots = (long)k1_slots_per_cu(kern, lds) * h->n_cu * persist_env;
-            if (slots > 0 && slots < g) g = slots;
+            if (slots > 0 && slots < n_items && slots != seg_count) return dim3((unsigned)slots);
         }
-        return dim3((unsigned)g);
+        return dim3((unsigned)seg_count, (unsigned)h->C);             // one workgroup per item
     };
     const Taps* dt = h->d_taps.as<Taps>();
 #define P25FE_LAUNCH_K1(PK, OM)                                                                                           \

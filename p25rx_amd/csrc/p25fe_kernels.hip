@@ -517,16 +517,19 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
     // slot, wave b works on items b, b + G, b + 2 G, ... (consecutive items = consecutive segments of one channel, so at
     // any moment the resident waves stream one compact, advancing region of the capture -- what the dispatcher's in-order
     // hand-out of 3-sub-tile workgroups gave, without the ~4 us a wave slot stood empty between two workgroups).
+    // (The default launch is one workgroup per item on a (segment, channel) grid: no division for the channel index.)
     const long n_items = (long)a.seg_count * a.n_ch;
-    for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const bool grid2d = gridDim.x == (unsigned)a.seg_count;         // uniform: one workgroup per item, blockIdx.y = channel
+    for (long item = grid2d ? (long)blockIdx.y * a.seg_count + blockIdx.x : (long)blockIdx.x; item < n_items;
+         item += grid2d ? n_items : (long)gridDim.x) {
 #ifdef P25FE_K1_STAMP
     unsigned long long st_i0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_i0)::"memory");
     bool st_first_sub = true;
     ++st_items;
 #endif
-    const int ch = (int)(item / a.seg_count);
-    const long seg_rel = item - (long)ch * a.seg_count;
+    const int ch = grid2d ? (int)blockIdx.y : (int)((unsigned)item / (unsigned)a.seg_count);
+    const long seg_rel = grid2d ? (long)blockIdx.x : item - (long)ch * a.seg_count;
     const long seg = seg_rel + a.seg_first;
     const long m_seg0 = a.m_begin + seg * seg_len;
     if (m_seg0 >= a.n_out) continue;
