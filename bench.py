@@ -391,7 +391,9 @@ def main():
         step()
     fe.join_dev()
     torch.cuda.synchronize()
-    fe.profile_enable(2)            # HIP events around K1 only inside the timed region (each record costs ~3 us of gap)
+    # HIP events around K1 inside the timed region, on every 8th step (each record is one more packet between two
+    # kernels, ~4 us): ~50 live samples of K1's duration spread over the 400 steps
+    fe.profile_enable(3 if world == 1 else 2)
     dt = timed(torch, step, args.steps, 0, dist, finish=fe.join_dev)
     kms, ncalls = fe.profile_read()
     # per-kernel split of the other kernels: a few extra steps OUTSIDE the timed region with events around every kernel

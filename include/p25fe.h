@@ -308,7 +308,8 @@ int p25fe_chan_stats_dev(p25fe_t *h, const p25fe_result_t *d_result, const p25fe
  * p25fe_profile_read synchronises those events and returns the summed milliseconds per kernel over the
  * kept slots (at most the last 64) and, in *n_calls, how many of those slots ran K1 (= passes of the path).
  * on = 1: events around every kernel (five records per call); on = 2: around K1 only (two records; ms[1..3] read
- * as 0) -- the records themselves cost ~3 us each between kernels, which matters for a 0.38 ms step. */
+ * as 0) -- the records themselves cost ~4 us each between kernels, which matters for a 0.28 ms step; on = 3: as 2, but
+ * only every 8th call carries the two records (the kept slots then span the last 512 calls). */
 int p25fe_profile_enable(p25fe_t *h, int on);
 int p25fe_profile_read(p25fe_t *h, double ms[4], uint64_t *n_calls);
 

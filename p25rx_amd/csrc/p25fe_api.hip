@@ -83,6 +83,7 @@ struct p25fe {
     std::vector<hipEvent_t> prof_ev;
     std::vector<uint8_t> prof_mask;        // per slot: which of its five events were recorded
     uint64_t prof_calls = 0;
+    uint64_t prof_seq = 0;                 // level 3: calls seen (every PROF_SAMPLE-th is recorded)
     int prof_slot = -1;                    // slot being recorded by the current call
     // shard context between pass1 and pass2 (the planar baseband and the tile summaries stay in the scratch buffers;
     // every other entry point that touches them clears sh_nbb, so a stale pass 2 fails instead of slicing garbage)
@@ -107,6 +108,7 @@ struct PlanarGeo {
 };
 
 constexpr int PROF_RING = 64;
+constexpr int PROF_SAMPLE = 8;
 
 #define HIPCHK(h, expr)                                                        \
     do {                                                                       \
@@ -269,12 +271,15 @@ void p25fe_destroy(p25fe_t* h)
 // --------------------------------------------------------------------------------------------
 static void prof_begin(p25fe_t* h)
 {
+    // level 3: only every PROF_SAMPLE-th call carries events (the two records around K1 are two more packets between
+    // consecutive kernels, ~4 us each)
+    if (h->prof_on && h->prof_level == 3 && (h->prof_seq++ % PROF_SAMPLE) != 0) { h->prof_slot = -1; return; }
     h->prof_slot = h->prof_on ? (int)(h->prof_calls++ % PROF_RING) : -1;
     if (h->prof_slot >= 0) h->prof_mask[(size_t)h->prof_slot] = 0;
 }
 static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 {
-    if (h->prof_slot >= 0 && (idx <= 1 || h->prof_level == 1)) {    // level 2: only the two events around K1
+    if (h->prof_slot >= 0 && (idx <= 1 || h->prof_level == 1)) {    // levels 2, 3: only the two events around K1
         if (hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st) == hipSuccess)
             h->prof_mask[(size_t)h->prof_slot] |= (uint8_t)(1u << idx);
     }
@@ -618,6 +623,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(h, hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi));
         for (int l = 0; l < 2; ++l) {
+            // (hipEventDisableSystemFence / hipEventReleaseToDevice on these events: no measurable difference)
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
         }
@@ -1045,8 +1051,9 @@ int p25fe_profile_enable(p25fe_t* h, int on)
         for (auto& e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
     }
     h->prof_on = on != 0;
-    h->prof_level = on == 2 ? 2 : 1;
+    h->prof_level = on == 2 ? 2 : (on == 3 ? 3 : 1);
     h->prof_calls = 0;
+    h->prof_seq = 0;
     return P25FE_OK;
 }
 

@@ -276,7 +276,7 @@ class FrontEnd:
         return out
 
     def profile_enable(self, on=True):
-        """True / 1: events around every kernel; 2: around K1 only; False / 0: off."""
+        """True / 1: events around every kernel; 2: around K1 only; 3: around K1 on every 8th call; False / 0: off."""
         self._chk(self.L.p25fe_profile_enable(self.h, int(on)))
 
     def profile_read(self):
