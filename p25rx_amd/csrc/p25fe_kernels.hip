@@ -208,6 +208,86 @@ template <int N, int DEPTH, class Body> __device__ __forceinline__ void lds_walk
     });
 }
 
+// The same walk with the reads in groups of G and ONE s_waitcnt per group (two groups of registers: group g + 1 is
+// requested before group g is waited for).  A wave issues about one instruction of any kind per 5 cycles (a lone wave
+// per CU needs 6 600 cycles for the ~1 300 instructions of a sub-tile), and the per-read s_waitcnt -- plus the s_nop
+// the compiler puts behind every inline-asm statement that defines a VALU operand -- were 190 of them.
+template <int G, int AFTER> __device__ __forceinline__ void lds_landed_group(v2f (&r)[G])
+{
+    static_assert(G == 8 || G == 6 || G == 4, "group size");
+    static_assert(AFTER >= 0 && AFTER <= 15, "lgkmcnt is a 4-bit field");
+    if constexpr (G == 8)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(AFTER));
+    else if constexpr (G == 6)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(AFTER));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(AFTER));
+}
+template <int N, int G, class Body> __device__ __forceinline__ void lds_walk_down_grouped(const float2* w, Body&& body)
+{
+    constexpr int NG = (N + G - 1) / G;                             // groups; the last one may be short
+    const unsigned base = lds_addr(w);
+    v2f ra[G], rb[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) ra[k] = rb[k] = v2f{0.f, 0.f};
+    auto issue = [&](auto gc, v2f (&r)[G]) {
+        constexpr int g = decltype(gc)::value;
+        static_for<0, G>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, i = g * G + k;
+            if constexpr (i < N) r[k] = lds_issue_b64<8 * (N - 1 - i)>(base);
+        });
+    };
+    auto consume = [&](auto gc, v2f (&r)[G]) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int next = (g + 1 < NG) ? ((g + 2) * G <= N ? G : N - (g + 1) * G) : 0;     // reads of group g + 1, issued after group g
+        lds_landed_group<G, next>(r);
+        static_for<0, G>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, i = g * G + k;
+            if constexpr (i < N) body(std::integral_constant<int, N - 1 - i>{}, r[k]);
+        });
+    };
+    issue(std::integral_constant<int, 0>{}, ra);
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g % 2 == 0) {
+            if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{}, rb);
+            consume(gc, ra);
+        } else {
+            if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{}, ra);
+            consume(gc, rb);
+        }
+    });
+}
+
+// window reads of the two FIRs: reads in flight ahead of their use (0 = leave the schedule to the compiler)
+#ifndef P25FE_K1_LDS_DEPTH
+#define P25FE_K1_LDS_DEPTH 8
+#endif
+// > 0: reads in groups of this many with one s_waitcnt per group (takes precedence over P25FE_K1_LDS_DEPTH)
+#ifndef P25FE_K1_LDS_GROUP
+#define P25FE_K1_LDS_GROUP 8
+#endif
+// body(j, w[j]) for j = N-1 .. 0 in the form the build selects
+// (GROUPED = false: the kernels with caller-supplied taps, whose broadcast tap reads from LDS interleave with the
+// window reads anyway and whose register budget -- 147 VGPRs -- has no room for the second group)
+template <int N, bool GROUPED, class Body> __device__ __forceinline__ void lds_walk(const float2* w, Body&& body)
+{
+#if P25FE_K1_LDS_GROUP > 0
+    if constexpr (GROUPED) {
+        lds_walk_down_grouped<N, P25FE_K1_LDS_GROUP>(w, body);
+        return;
+    }
+#endif
+#if P25FE_K1_LDS_DEPTH > 0
+    lds_walk_down<N, P25FE_K1_LDS_DEPTH>(w, body);
+#else
+    static_for<0, N>([&](auto ic) {
+        constexpr int j = N - 1 - decltype(ic)::value;
+        body(std::integral_constant<int, j>{}, lds_read_v2(w + j));       // compiler-scheduled (volatile) reads
+    });
+#endif
+}
+
 // Value held by lane-1 of the wave; lane 0 receives `lane0` (DPP wave_shr:1 -- one VALU op, no LDS).
 __device__ __forceinline__ float wave_shr1(float v, float lane0)
 {
@@ -459,10 +539,6 @@ struct K1Args {
 #ifndef P25FE_K1_PF_U8
 #define P25FE_K1_PF_U8 2
 #endif
-// window reads of the two FIRs: reads in flight ahead of their use (0 = leave the schedule to the compiler)
-#ifndef P25FE_K1_LDS_DEPTH
-#define P25FE_K1_LDS_DEPTH 8
-#endif
 // Measurement builds only (-DP25FE_K1_STAMP): a wave accumulates the shader-clock time of each phase of its sub-tiles
 // and adds the sums to g_k1_stamp at its end (read through p25fe_debug_k1_stamps).  s_memtime + s_waitcnt lgkmcnt(0) per
 // stamp: the phase boundaries drain the LDS queue, which the product does not do everywhere.
@@ -658,8 +734,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
             v2f acc[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p] = v2f{0.f, 0.f};
-#if P25FE_K1_LDS_DEPTH > 0
-            lds_walk_down<DEC * (P - 1) + T1, P25FE_K1_LDS_DEPTH>(w, [&](auto jc, v2f s) {   // newest to oldest => tap order 0..T1-1
+            lds_walk<DEC * (P - 1) + T1, CT>(w, [&](auto jc, v2f s) {   // newest to oldest => tap order 0..T1-1
                 constexpr int j = decltype(jc)::value;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
@@ -667,17 +742,6 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
                     if (k >= 0 && k < T1) acc[p] = cfma(tap_dec(k), s, acc[p]);
                 }
             });
-#else
-#pragma unroll
-            for (int j = DEC * (P - 1) + T1 - 1; j >= 0; --j) {    // newest to oldest => tap order 0..T1-1
-                const v2f s = lds_read_v2(w + j);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const int k = DEC * p + (T1 - 1) - j;
-                    if (k >= 0 && k < T1) acc[p] = cfma(tap_dec(k), s, acc[p]);
-                }
-            }
-#endif
             // d overwrites the front of the window: every lane's window reads must be complete first.  (The compiler
             // reasons per thread and could prove a lane's own store and loads disjoint -- the fence orders the wave.)
             phase_sync();
@@ -701,14 +765,8 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
             v2f yv[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) yv[p] = v2f{0.f, 0.f};
-#if P25FE_K1_LDS_DEPTH > 0
-            lds_walk_down<(P - 1) + T2, P25FE_K1_LDS_DEPTH>(w, [&](auto jc, v2f s) {
+            lds_walk<(P - 1) + T2, CT>(w, [&](auto jc, v2f s) {
                 constexpr int j = decltype(jc)::value;
-#else
-#pragma unroll
-            for (int j = (P - 1) + T2 - 1; j >= 0; --j) {
-                const v2f s = lds_read_v2(w + j);
-#endif
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
@@ -718,11 +776,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
                     if (k >= 0 && k < T2) yv[p] = cfma(tap_ch(k), s, yv[p]);
 #endif
                 }
-#if P25FE_K1_LDS_DEPTH > 0
             });
-#else
-            }
-#endif
 #pragma unroll
             for (int p = 0; p < P; ++p) y[p] = make_float2(yv[p].x, yv[p].y);
             if (a.power_partial) {
