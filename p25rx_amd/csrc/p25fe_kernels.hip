@@ -668,7 +668,9 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
-#if defined(P25FE_EXP) && (P25FE_EXP & 2)      // measurement build: lane-consecutive (wrong) addresses
+#if defined(P25FE_EXP) && (P25FE_EXP & 8)      // measurement build: no baseband stores at all (what the write stream costs)
+                asm volatile("" ::"v"(outv[q]), "v"(r));
+#elif defined(P25FE_EXP) && (P25FE_EXP & 2)    // measurement build: lane-consecutive (wrong) addresses
                 if (r >= 0 && r < seg_n) bbp_ch[(long)i_seg * SPS_ + out_rel + tid + q * WV] = outv[q];
 #else
                 if (r >= 0 && r < seg_n) row[32 * q] = outv[q];       // (non-temporal stores here: -1 % on K1, +3 % on K4: not adopted)
