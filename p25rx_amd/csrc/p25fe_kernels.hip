@@ -1223,6 +1223,7 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
     const unsigned step2 = (CZ_C1 * nm) % (unsigned)CZ_M;       // index step of the rotation from c to c + 12
     unsigned idx1 = 0;                                          // (c1 * nm) mod 192
     float2* yb = reinterpret_cast<float2*>(a.y) + m;
+    const bool odd = (lane & 1) != 0;
 
     // c1 in groups of CZ_G (a rolled loop: the c1-dependent twiddles come from CZ_TW by scalar loads): the 80 products
     // a[p] = h[p] x[n - p] are re-formed from LDS once per group (window position 79 + 10 lane - p -> phase
@@ -1230,8 +1231,18 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
 #if defined(P25FE_ABLATE6)                          // measurement build (tools/k6_variants.sh): the store stream alone
     {
         const float2 xv = lds_read_c(X + lane);
+#if P25FE_ABLATE6 == 2                              // ... as 16-byte stores: a lane pair writes two instants of two rows
+        float4* const y4 = reinterpret_cast<float4*>(yb - (lane & 1));
+#pragma unroll 1
+        for (int c = 0; c < CZ_M; c += 2) {
+            typedef float __attribute__((ext_vector_type(4))) f32x4;
+            f32x4 ov; ov.x = xv.x + (float)c; ov.y = xv.y; ov.z = xv.x; ov.w = xv.y;
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(reinterpret_cast<float2*>(y4) + (size_t)(c + (lane & 1)) * a.y_stride));
+        }
+#else
 #pragma unroll 1
         for (int c = 0; c < CZ_M; ++c) yb[(size_t)c * a.y_stride] = make_float2(xv.x + (float)c, xv.y);
+#endif
         return;
     }
 #endif
@@ -1282,18 +1293,32 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
         for (int e = 0; e < 4; ++e) {
             cz_bf4(BB[q][4 * e], BB[q][4 * e + 1], BB[q][4 * e + 2], BB[q][4 * e + 3]);                 // slot 4 e + f <- Y[e + 4 f]
             unsigned ix = idx[e];
+            float2 o4[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const float2 rot = ROT[ix];
                 const float2 yv = BB[q][4 * e + f];
-                const float2 o = make_float2(__builtin_fmaf(-yv.y, rot.y, yv.x * rot.x), __builtin_fmaf(yv.y, rot.x, yv.x * rot.y));
-                {   // streaming store (nt): 22 GB of output per minute of capture never fit a cache; measured +4.5 %.
-                    // Rows are padded to whole tiles: no predicate.
-                    typedef float __attribute__((ext_vector_type(2))) f32x2;
-                    f32x2 ov; ov.x = o.x; ov.y = o.y;
-                    __builtin_nontemporal_store(ov, reinterpret_cast<f32x2*>(yb + (size_t)(c1 + CZ_C1 * (e + 4 * f)) * a.y_stride));
-                }
+                o4[f] = make_float2(__builtin_fmaf(-yv.y, rot.y, yv.x * rot.x), __builtin_fmaf(yv.y, rot.x, yv.x * rot.y));
                 ix += step8; ix = ix >= (unsigned)CZ_M ? ix - CZ_M : ix;
+            }
+            // Streaming stores (nt: 22 GB of output per minute of capture never fit a cache; measured +4.5 %), 16 bytes per
+            // lane: the lanes of a pair swap one value each (DPP quad_perm [1,0,3,2]) so that the even lane writes instants
+            // (m, m + 1) of channel row f and the odd lane instants (m - 1, m) of row f + 1 -- half as many store
+            // instructions for the same 512 contiguous bytes per row (the store-only build: 0.416 against 0.458 ms per
+            // 1.44e7 input samples).  Rows are padded to whole tiles: no predicate.
+#pragma unroll
+            for (int f = 0; f < 4; f += 2) {
+                const float2 mine = odd ? o4[f + 1] : o4[f];        // what this lane keeps (its own instant)
+                const float2 give = odd ? o4[f] : o4[f + 1];        // what its partner needs
+                float2 got;
+                got.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give.x), 0xB1, 0xf, 0xf, true));
+                got.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give.y), 0xB1, 0xf, 0xf, true));
+                typedef float __attribute__((ext_vector_type(4))) f32x4;
+                f32x4 ov;
+                ov.x = odd ? got.x : mine.x; ov.y = odd ? got.y : mine.y;      // instant m - 1 (odd lane) / m (even lane)
+                ov.z = odd ? mine.x : got.x; ov.w = odd ? mine.y : got.y;      // instant m (odd lane) / m + 1 (even lane)
+                const int c = c1 + CZ_C1 * (e + 4 * (f + (odd ? 1 : 0)));
+                __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(yb - (odd ? 1 : 0) + (size_t)c * a.y_stride));
             }
         }
         idx1 += nm; idx1 = idx1 >= (unsigned)CZ_M ? idx1 - CZ_M : idx1;
