@@ -975,3 +975,25 @@ def test_run_dev_pipelined_channel_batches(O, FE):
             nd = int(r[c]["n_dibits"])
             assert nd == len(refs[b][c]), (b, c)
             assert np.array_equal(dib[c, :nd].cpu().numpy(), refs[b][c]), (b, c)
+
+
+@pytest.mark.gpu
+def test_profile_hook_levels(FE):
+    """p25fe_profile_enable: level 1 records every kernel of every call, level 2 only K1, level 3 only K1 and only on
+    every 8th call; p25fe_profile_read reports how many of the kept slots ran K1."""
+    import torch
+    from p25rx_amd import c4fm
+    iq = c4fm.synth(0.5, seed=9, snr_db=20.0)[0]
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    fe = FE()
+    for level, calls, want in ((1, 5, 5), (2, 6, 6), (3, 32, 4), (3, 9, 2)):
+        fe.profile_enable(level)
+        for _ in range(calls):
+            fe.run_dev_pipelined(t) if level == 3 else fe.run_dev(t)
+        fe.join_dev()
+        torch.cuda.synchronize()
+        ms, n = fe.profile_read()
+        assert n == want, (level, calls, n)
+        assert ms[0] > 0.0
+        assert (ms[1] > 0.0 and ms[3] > 0.0) if level == 1 else (ms[1] == 0.0 and ms[2] == 0.0 and ms[3] == 0.0)
+    fe.profile_enable(False)
