@@ -539,6 +539,14 @@ struct K1Args {
 #ifndef P25FE_K1_PF_CF32
 #define P25FE_K1_PF_CF32 1
 #endif
+// planar baseband rows as non-temporal stores: the 115 MB of a pass are read back sparsely (one plane in ten by K4, a
+// few windows by K2) and only evict the window stream from L2 / Infinity Cache on their way out.  Round 2, first half:
+// "-1 % on K1, +3 % on K4: not adopted"; with the receive kernels overlapped by the next K1 the trade is the other way
+// round: pipelined step 0.270 / 0.270 / 0.275 against 0.278 / 0.283 / 0.282 ms (three interleaved bench runs, one box),
+// K1 0.259 against 0.259 - 0.270, K4 0.0155 against 0.0150.
+#ifndef P25FE_K1_NT_STORES
+#define P25FE_K1_NT_STORES 1
+#endif
 #ifndef P25FE_K1_PF_U8
 #define P25FE_K1_PF_U8 2
 #endif
@@ -676,7 +684,11 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
 #elif defined(P25FE_EXP) && (P25FE_EXP & 2)    // measurement build: lane-consecutive (wrong) addresses
                 if (r >= 0 && r < seg_n) bbp_ch[(long)i_seg * SPS_ + out_rel + tid + q * WV] = outv[q];
 #else
-                if (r >= 0 && r < seg_n) row[32 * q] = outv[q];       // (non-temporal stores here: -1 % on K1, +3 % on K4: not adopted)
+#if P25FE_K1_NT_STORES
+                if (r >= 0 && r < seg_n) __builtin_nontemporal_store(outv[q], row + 32 * q);
+#else
+                if (r >= 0 && r < seg_n) row[32 * q] = outv[q];
+#endif
 #endif
             }
             // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
