@@ -346,6 +346,10 @@ __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((
 // same VGPRs made the compiler put s_waitcnt vmcnt(0) in front of every load, serialising 13 HBM round trips per
 // sub-tile.)
 // ------------------------------------------------------------------------------------------
+// cache policy bits of the window loads (buffer-load aux: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef P25FE_K1_LD_AUX
+#define P25FE_K1_LD_AUX 0
+#endif
 template <int FMT, int PK, int TX = 0> struct Loader {
     using G = Geo<PK, TX>;
     // A lane's vector always holds TWO samples -- 16 B of cf32 or 4 B of u8 pairs -- which become one 16-B LDS store,
@@ -410,10 +414,10 @@ template <int FMT, int PK, int TX = 0> struct Loader {
             int o = voff + j * VB * WV;
             o = o < 0 ? 0x7ffffff0 : o;
             if constexpr (FMT == P25FE_FMT_CF32) {
-                const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+                const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, P25FE_K1_LD_AUX);
                 v[j] = make_uint4(t.x, t.y, t.z, t.w);
             } else {
-                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, P25FE_K1_LD_AUX);
             }
         }
     }
@@ -431,10 +435,10 @@ template <int FMT, int PK, int TX = 0> struct Loader {
             const int o = voff + j * VB * WV;
 #endif
             if constexpr (FMT == P25FE_FMT_CF32) {
-                const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+                const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, P25FE_K1_LD_AUX);
                 v[j] = make_uint4(t.x, t.y, t.z, t.w);
             } else {
-                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, P25FE_K1_LD_AUX);
             }
         }
     }
