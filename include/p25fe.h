@@ -175,7 +175,9 @@ int p25fe_run_dev(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_
  * is already filling the next chunk while the receiver works on the previous one).  The receiver's scratch is double
  * buffered; call i + 2 waits on the device for call i's receive kernels.
  * d_dibits / d_result of a call are complete only after p25fe_join_dev has been enqueued on a stream and that stream
- * has reached it (or after any other call on this handle that uses the receiver, which joins first). */
+ * has reached it (or after any other call on this handle that uses the receiver, which joins first).  Consecutive calls
+ * may name the same output buffers (their receive kernels run in call order on one stream); d_iq must stay unchanged
+ * until `stream` has passed the call (K1 is the only reader). */
 int p25fe_run_dev_pipelined(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n, uint8_t *d_dibits,
                             size_t dibit_stride, p25fe_result_t *d_result, void *stream);
 /* make `stream` wait for every receive kernel that p25fe_run_dev_pipelined has enqueued so far */
