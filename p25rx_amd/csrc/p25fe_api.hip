@@ -332,8 +332,9 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const int t1 = h->long_taps ? TMAX : T1;
     const long sub = (long)WV * pk;
     static const long subs_env = [] { const char* e = getenv("P25FE_SUBS"); return e ? atol(e) : 0L; }();
-    // (round 2: the VALU-bound u8 kernel prefers longer segments -- less halo recomputed: 3 -> 239, 6 -> 231 us, same box)
-    long subs = subs_env > 0 ? subs_env : (fmt == P25FE_FMT_U8 ? 6 : 3);
+    // (round 2: the instruction-bound u8 kernel prefers longer segments -- less halo recomputed: 3 -> 239, 6 -> 231 us on one
+    // box; with the final build 4 -> 222 / 216, 6 -> 217 / 215, 9 -> 212 / 209, 12 -> 216 / 205 us under rocprofv3)
+    long subs = subs_env > 0 ? subs_env : (fmt == P25FE_FMT_U8 ? 9 : 3);
     if (subs > 32768) subs = 32768;
     const long seg_len = (sub - SEG_HALO) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;
