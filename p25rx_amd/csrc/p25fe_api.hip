@@ -621,8 +621,12 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
         // highest priority: the receive kernels are a few thousand short waves and one single-workgroup scan that should
         // not queue behind K1's 32 000 workgroups (measured: no difference in the step time, 0.3005 vs 0.3001 ms)
         int prio_lo = 0, prio_hi = 0;
-        HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(h, hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi));
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+            (void)hipGetLastError();
+            h->rx_stream = nullptr;
+            HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));     // any non-blocking stream will do
+        }
         for (int l = 0; l < 2; ++l) {
             // (hipEventDisableSystemFence / hipEventReleaseToDevice on these events: no measurable difference)
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
