@@ -259,3 +259,61 @@ def test_bench_two_ranks_channel_blocks_host_staged():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert d["n_gpus"] == 2 and "5 independent channels" in d["config"]["workload"]
     assert d["config"]["parity_gate"].endswith("True") and d["config"]["table_gate"].endswith("True")
+
+
+def _rccl_world1_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.sharding import TorchComm
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        comm = TorchComm(dist, 0, 1)
+        item = RESULT_DTYPE.itemsize
+        summ = torch.arange(item, dtype=torch.uint8, device="cuda").reshape(1, item)
+        out = torch.zeros((1, item), dtype=torch.uint8, device="cuda")
+        comm.all_gather(out, summ)                                  # all_gather_into_tensor on uint8 views: RCCL
+        dib = (torch.arange(4096, device="cuda") % 4).to(torch.uint8).reshape(1, -1)
+        gathered = torch.zeros((1, 4096), dtype=torch.uint8, device="cuda")
+        comm.all_gather(gathered, dib)
+        root = torch.zeros((1, 4096), dtype=torch.uint8, device="cuda")
+        comm.gather_to_root(root, dib)                              # world 1: the root's own row
+        works = comm.halo_start(dib, dib)                           # no neighbours: nothing to do
+        comm.halo_wait(works)
+        # the point-to-point calls of halo_start / gather_to_root (batched P2POp isend + irecv), looped back to this rank:
+        # a halo-sized slice of a cf32 capture and a dibit row
+        cap = torch.arange(2 * 40000, dtype=torch.float32, device="cuda").reshape(-1, 2)
+        halo_in = torch.zeros((1728, 2), dtype=torch.float32, device="cuda")
+        row = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, cap[-1728:], 0), dist.P2POp(dist.irecv, halo_in, 0)]):
+            w.wait()
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, dib.reshape(-1), 0), dist.P2POp(dist.irecv, row, 0)]):
+            w.wait()
+        dist.barrier()
+        torch.cuda.synchronize()
+        q.put((bool(torch.equal(out, summ)), bool(torch.equal(gathered, dib)), bool(torch.equal(root, dib)), len(works),
+               bool(torch.equal(halo_in, cap[-1728:])), bool(torch.equal(row, dib.reshape(-1)))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_world1_collectives():
+    """The collectives of the multi-GPU step on the REAL backend (nccl = RCCL), as far as one GPU allows: process group
+    of one rank, all_gather_into_tensor of the shard summary and of a dibit buffer as uint8 device tensors, the root's
+    own row of the point-to-point gather, barrier, and the batched isend / irecv of the halo exchange and of the dibit
+    gather looped back to the same rank (RCCL allows send / recv to self inside a group).  What one GPU cannot show is a
+    transfer over xGMI: the two-rank logic is covered by gloo."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res == (True, True, True, 0, True, True)
