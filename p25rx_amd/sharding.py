@@ -123,6 +123,7 @@ class TimeShard:
             raise ValueError("n_per_rank must be a multiple of 8 samples (shard cut points stay 16-byte aligned)")
         self.fe, self.rank, self.world, self.n, self.dist = fe, rank, world, n_per_rank, dist
         self.comm = comm if comm is not None else (TorchComm(dist, rank, world) if dist is not None else None)
+        self.always_comm = False         # tests: take the collective path at world = 1 too (RCCL on a one-GPU box)
         self.halo = int(fe.shard_halo())
         self.abs0 = rank * n_per_rank
         from .frontend import n_baseband
@@ -188,7 +189,8 @@ class TimeShard:
         every rank (gather="all"); gather=None leaves the stream sharded."""
         h = self.halo if self.rank > 0 else 0
         view = buf[self.halo - h:]
-        if self.world > 1:
+        multi = self.world > 1 or (self.comm is not None and self.always_comm)
+        if multi:
             works = self.comm.halo_start(buf[self.n:], buf[:self.halo])
             self.fe.shard_pass1_main(view, offset=h, n_hist=h, abs0=self.abs0)     # needs no halo
             self.comm.halo_wait(works)
@@ -202,7 +204,7 @@ class TimeShard:
         self.fe.shard_pass2(self.d_anchors[self.rank:self.rank + 1], self.bbn[self.rank], buf.device, result=result,
                             dibits=dibits)
         if gather:
-            if self.world == 1:
+            if not multi:
                 self.d_gathered.copy_(dibits)
             elif gather == "all":
                 self.comm.all_gather(self.d_gathered, dibits)

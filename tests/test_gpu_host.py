@@ -317,3 +317,58 @@ def test_rccl_backend_world1_collectives():
     p.join(60)
     assert p.exitcode == 0
     assert res == (True, True, True, 0, True, True)
+
+
+def _rccl_world1_step_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from p25rx_amd import c4fm
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    from p25rx_amd.sharding import TimeShard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))    # as bench.py does for N > 1
+    try:
+        iq = c4fm.synth(2.0, seed=77, snr_db=22.0, frame_dibits=400)[0]
+        n = len(iq) // 8 * 8
+        fe = FrontEnd()
+        ts = TimeShard(fe, 0, 1, n, dist)
+        ts.always_comm = True
+        ts.setup_device(torch, "cuda")
+        buf = ts.alloc(torch, "cuda", torch.float32)
+        buf[ts.halo:] = torch.from_numpy(iq[:n].view(np.float32).reshape(-1, 2)).cuda()
+        result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        summ_all = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        dibits = torch.zeros((1, ts.dibit_cap), dtype=torch.uint8, device="cuda")
+        oks = []
+        ref, rres = FrontEnd().run_dev(buf[ts.halo:])
+        nref = int(parse_results(rres)[0]["n_dibits"])
+        for gather in ("root", "all", "root"):
+            ts.d_stream.zero_()
+            off = ts.step_device(buf, result, summ_all, dibits, gather=gather)     # no host synchronisation inside
+            torch.cuda.synchronize()
+            total = int(off[-1])
+            oks.append(total == nref and bool(torch.equal(ts.d_stream[:total], ref[0, :nref])))
+        q.put(oks)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_timeshard_step_device_rccl_world1():
+    """The multi-GPU step with its collectives on the real backend (RCCL), one rank: pass 1 main / finish, the summary
+    all_gather, the device resolve, pass 2, the dibit gather (to the root, and as all_gather) and the compaction run as
+    they do for N > 1 -- enqueued without a host synchronisation between library kernels and RCCL operations -- and the
+    gathered stream equals the single-pass dibits."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_step_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res == [True, True, True]
