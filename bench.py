@@ -30,9 +30,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_SAMPLE_K1 = 8.0 + 0.8  # algorithmic: 8 B cf32 read + 4 B baseband written per 5 samples
+VALU_PEAK_TFLOPS = 157.3         # fp32 vector peak (MI355X_MICROARCH.md)
+# algorithmic bytes per input IQ sample of the fused path = 8 B read + 1 dibit byte per 50
+# samples written.  The 0.8 B / sample polyphase baseband that K1 hands to K2 / K4 is this design's INTERMEDIATE, not an
+# output: it is traffic, not algorithmic bytes.  (K1 priced alone on what it reads and writes, 8.8 B, is reported beside
+# it as `k1_alone`.)
+BYTES_PER_SAMPLE = 8.02
+BYTES_PER_SAMPLE_U8 = 2.02
+BYTES_PER_SAMPLE_K1 = 8.0 + 0.8
 BYTES_PER_SAMPLE_K1_U8 = 2.0 + 0.8
-PMC_FILE = os.path.join("profiles", "r02_k1_pmc.json")
+# arithmetic of SPEC section 3 per input sample (flops: an fma = 2): decimator 31 taps x 2 components / 5, channel filter
+# 41 x 2 / 5, discriminator (4 + division + 8-term Horner + selects ~ 30) / 5, boxcar 10 / 5, u8 -> f32 2 x 2
+FLOPS_PER_SAMPLE = (2 * 2 * 31 + 2 * 2 * 41 + 30 + 10) / 5.0
+FLOPS_PER_SAMPLE_U8 = FLOPS_PER_SAMPLE + 4.0
+PMC_FILES = [os.path.join("profiles", "r03_k1_pmc.json"), os.path.join("profiles", "r02_k1_pmc.json")]
+PREWARM_MS = 150.0               # untimed steps before the W warm-up steps: the chip reaches its steady clock / power state
 
 
 def cpu_baseline(iq_host, seconds_label):
@@ -165,9 +177,14 @@ def run_extras(torch, dev, args, iq2, truth2):
         dib, res = run(fe, u8, dib, res)
     k = steps_for(0.3)
     dt = timed(torch, step_u8, k, 5, finish=fe.join_dev)
-    k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(u8, dibits=dib, result=res), n, BYTES_PER_SAMPLE_K1_U8)
+    k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(u8, dibits=dib, result=res), n, BYTES_PER_SAMPLE_U8)
+    tfl = FLOPS_PER_SAMPLE_U8 * n / (k1 * 1e-3) / 1e12 if k1 > 0 else 0.0
     entry("configs[1] as u8 I/Q pairs (the reference's input format), 1 ch x 600 s", n, dt / k * 1e3, "k_frontend<u8>", k1,
-          BYTES_PER_SAMPLE_K1_U8, gate(dib, res, truth2), steps=k, note="2.8 B per sample: VALU / LDS bound, not HBM bound")
+          BYTES_PER_SAMPLE_U8, gate(dib, res, truth2), steps=k,
+          roofline={"bound": "valu", "achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tfl / VALU_PEAK_TFLOPS, 4), "flops_per_sample": FLOPS_PER_SAMPLE_U8,
+                    "note": "2.02 B per sample leaves HBM idle: this format is priced on the fp32 vector pipe (SPEC section 3's "
+                            "arithmetic, an fma = 2 flops); instruction mix in profiles/r03_pmc_u8.txt"})
     del u8, fe
 
     # ---- configs[2]: 2.4 Msps front end, 60 s = 1.44e8 samples -> stage 0 (10:1, 80 taps) -> K1..K4
@@ -193,7 +210,7 @@ def run_extras(torch, dev, args, iq2, truth2):
     nd = int(parse_results(res)[0]["n_dibits"])
     al = c4fm.align_dibits(dib[0, :nd].cpu().numpy(), truth3)
     entry("configs[2]: 2.4 Msps x 60 s -> 10:1 pre-decimator -> FIR + FM + slice, end to end", wide.shape[0], dt / k * 1e3,
-          "k_predecim", k0_ms, 8.8, al is not None and al[3] == 0 and al[2] > 287000, steps=k)
+          "k_predecim", k0_ms, 8.002, al is not None and al[3] == 0 and al[2] > 287000, steps=k)
     del wide, nar, fe
 
     # ---- configs[3]: 256 independent channels x 60 s, channel-major (29.5 GB)
@@ -211,9 +228,9 @@ def run_extras(torch, dev, args, iq2, truth2):
         dib, res = run(fe, iq4, dib, res)
     k = steps_for(7.5)
     dt = timed(torch, step_c4, k, 2, finish=fe.join_dev)
-    k1, _, kms = k1_frac(fe, torch, lambda: fe.run_dev(iq4, dibits=dib, result=res), C * n4, BYTES_PER_SAMPLE_K1, reps=3)
+    k1, _, kms = k1_frac(fe, torch, lambda: fe.run_dev(iq4, dibits=dib, result=res), C * n4, BYTES_PER_SAMPLE, reps=3)
     entry("configs[3]: 256 channels x 60 s, channel-major batch", C * n4, dt / k * 1e3, "k_frontend<cf32>", k1,
-          BYTES_PER_SAMPLE_K1, gate(dib, res, truth4, C - 1), steps=k,
+          BYTES_PER_SAMPLE, gate(dib, res, truth4, C - 1), steps=k,
           receiver_share=round((kms[1] + kms[2] + kms[3]) / max(sum(kms), 1e-9), 4))
     del iq4, fe, dib, res
 
@@ -227,9 +244,9 @@ def run_extras(torch, dev, args, iq2, truth2):
         dib, res = run(fe, iq5, dib, res)
     k = steps_for(1.9)
     dt = timed(torch, step_c5, k, 2, finish=fe.join_dev)
-    k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(iq5, dibits=dib, result=res), n5, BYTES_PER_SAMPLE_K1, reps=3)
+    k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(iq5, dibits=dib, result=res), n5, BYTES_PER_SAMPLE, reps=3)
     entry("configs[4] on one GPU: 3 600 s x 1 channel, single pass", n5, dt / k * 1e3, "k_frontend<cf32>", k1,
-          BYTES_PER_SAMPLE_K1, gate(dib, res, truth5), steps=k)
+          BYTES_PER_SAMPLE, gate(dib, res, truth5), steps=k)
     return out
 
 
@@ -257,7 +274,7 @@ def bench_channels(args, torch, dist, world, rank, local, dev, staged):
         dib, res = cs.step(fe, iq, dibits=dib, result=res)
 
     dt = timed(torch, step, args.steps, args.warmup, dist)
-    k1, ach, _ = k1_frac(fe, torch, step, cs.n_local * n, BYTES_PER_SAMPLE_K1, reps=3)
+    k1, ach, _ = k1_frac(fe, torch, step, cs.n_local * n, BYTES_PER_SAMPLE, reps=3)
     cdev = torch.device("cpu") if staged else dev
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -292,7 +309,7 @@ def bench_channels(args, torch, dist, world, rank, local, dev, staged):
                        "table_gate": "gathered per-channel table complete and in channel order: %s" % ok_table},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_frontend<cf32>",
-                         "kernel_ms": round(k1, 4), "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_K1 * cs.n_local * n}}))
+                         "kernel_ms": round(k1, 4), "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * cs.n_local * n}}))
     if dist:
         dist.destroy_process_group()
     if not (ok and ok_table) and world == 1:
@@ -387,13 +404,23 @@ def main():
         def step():
             ts.step_device(buf, result, summ_all, dibits, gather=None if args.gather == "none" else args.gather)
 
+    # untimed pre-warm (not part of W or K): the chip needs ~100 ms of this load to settle at its power-limited clock; the
+    # driver's `--steps 20 --warmup 5` is a 6 ms timed region behind 1.5 ms of warm-up and otherwise times the clock ramp
+    t_pw = time.perf_counter()
+    n_prewarm = 0
+    while (time.perf_counter() - t_pw) * 1e3 < PREWARM_MS:
+        for _ in range(16):
+            step()
+        fe.join_dev()
+        torch.cuda.synchronize()
+        n_prewarm += 16
     for _ in range(args.warmup):
         step()
     fe.join_dev()
     torch.cuda.synchronize()
-    # HIP events around K1 inside the timed region, on every 8th step (each record is one more packet between two
-    # kernels, ~4 us): ~50 live samples of K1's duration spread over the 400 steps
-    fe.profile_enable(3 if world == 1 else 2)
+    # K1's begin / end events ride on its own dispatch (hipExtLaunchKernelGGL: no extra packet between two kernels) --
+    # on every step when there are at most 64 of them (the ring holds 64 slots), otherwise on every 8th, spread over the run
+    fe.profile_enable(2 if (world > 1 or args.steps <= 64) else 3)
     dt = timed(torch, step, args.steps, 0, dist, finish=fe.join_dev)
     kms, ncalls = fe.profile_read()
     # per-kernel split of the other kernels: a few extra steps OUTSIDE the timed region with events around every kernel
@@ -469,17 +496,19 @@ def main():
         total_samples = float(n) * world * args.steps
         value = total_samples / dt / 1e6
         k1_ms = kms[0] / max(ncalls, 1)
-        achieved = BYTES_PER_SAMPLE_K1 * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        achieved = BYTES_PER_SAMPLE * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        achieved_k1_alone = BYTES_PER_SAMPLE_K1 * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, PMC_FILE)
-        if world == 1 and abs(total_s - 600.0) < 1e-9 and os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-                traffic_source = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, collected in "
-                                  "a SEPARATE run (tools/prof.sh), not by this process" % PMC_FILE)
-            except Exception:
-                traffic = None
+        if world == 1 and abs(total_s - 600.0) < 1e-9:
+            for pmc_file in PMC_FILES:
+                try:
+                    with open(os.path.join(ROOT, pmc_file)) as f:
+                        traffic = json.load(f).get("hbm_bytes_per_launch")
+                    traffic_source = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, collected in "
+                                      "a SEPARATE run (tools/prof.sh), not by this process" % pmc_file)
+                    break
+                except Exception:
+                    traffic = None
         if world == 1:
             workload = ("configs[1]: 1 channel x %.0f s synthetic C4FM cf32 IQ @ 240 ksps (%d samples, %.3f GB), decimating "
                         "FIR + FM + boxcar + sync + 4-level slice" % (total_s, n, n * 8 / 1e9))
@@ -504,8 +533,14 @@ def main():
                        "parity_gate": "dibits == modulator symbols: %s" % ok},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_frontend<cf32>", "kernel_ms": round(k1_ms, 4),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_K1 * n,
+                         "traffic_ratio": (round(traffic / (BYTES_PER_SAMPLE * n), 4) if traffic else None),
+                         "kernel": "k_frontend<cf32>", "kernel_ms": round(k1_ms, 4), "kernel_ms_samples": int(ncalls),
+                         "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
+                         "k1_alone": {"bytes_per_sample": BYTES_PER_SAMPLE_K1, "achieved": round(achieved_k1_alone, 1),
+                                      "frac": round(achieved_k1_alone / HBM_PEAK_GBPS, 4),
+                                      "note": "K1 priced on what it reads AND writes (8 B in + 0.8 B polyphase baseband out); "
+                                              "the baseband is an intermediate of this design, so `frac` above uses SURVEY 8(d)'s 8.02 B"},
                          "whole_step": {"algorithmic_bytes_per_sample": 8.02,
                                         "achieved": round(8.02 * n * world * args.steps / dt / 1e9, 1),
                                         "frac_of_peak_x_gpus": round(8.02 * n * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)},
@@ -516,6 +551,7 @@ def main():
                                                       + ("; N > 1: k_scan = pass 1 + pass 2 scans, RCCL time is in neither" if world > 1 else "")}},
         }
         if world == 1:
+            out["config"]["prewarm"] = "%d untimed steps (>= %.0f ms) before the W warm-up steps" % (n_prewarm, PREWARM_MS)
             out["config"]["step"] = ("serial: K1 -> K2 -> K3 -> K4 on one stream" if args.no_pipeline else
                                      "pipelined two deep (p25fe_run_dev_pipelined): K2-K4 of step i on the handle's stream overlap "
                                      "K1 of step i + 1; join + device synchronize inside the timed region")

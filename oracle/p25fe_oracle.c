@@ -310,7 +310,7 @@ static size_t demod_tail(p25o_demod *d, cf32 *samples, size_t n, float *bb, floa
         samples[i] = fir_eval(&d->bandpass);
     }
     if (power)
-        *power = len ? p25o_power_dbm(samples, len, 1.0f) : 0.0f;/* :97     */
+        *power = p25o_power_dbm(samples, len, 1.0f);             /* :97; an empty chunk folds to 0 / 0 = NaN, as the reference's does */
     for (size_t i = 0; i < len; i++)                             /* :109-111 */
         bb[i] = fm_feed(&d->cfg, &d->fm_prev, samples[i]);
     for (size_t i = 0; i < len; i++)                             /* :114    */

@@ -5,6 +5,7 @@
 // No CPU compute path exists here: every entry point either runs the HIP kernels or fails.
 #include "p25fe_kernels.hip"
 
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -22,7 +23,7 @@ namespace {
 constexpr size_t HISTPAD = 448;      // >= HIST_IQ_MAX (432 with 64 + 64 taps), multiple of 8: keeps 16-B alignment for u8 and cf32
 static_assert(HISTPAD >= (size_t)HIST_IQ_MAX && HISTPAD % 8 == 0, "stream history covers the longest filters");
 constexpr size_t BBPAD = 256;        // >= HIST_BB (240), multiple of 4
-constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 1568
+constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 5 * 256 + 448 = 1728 samples (13.8 KB of cf32)
 constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
 
 struct DevBuf {
@@ -43,6 +44,17 @@ struct DevBuf {
 };
 
 inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// Kernel launch with optional events ATTACHED TO THE DISPATCH (hipExtLaunchKernelGGL): the start / stop events are
+// signalled by the kernel's own AQL packet, where hipEventRecord would put one more barrier packet (and its release) in
+// front of the next kernel of the stream.
+template <class... Args, class... Act>
+inline void launch_ev(void (*kern)(Args...), dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t e0, hipEvent_t e1,
+                      Act... args)
+{
+    if (e0 || e1) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, st, e0, e1, 0u, Args(args)...);
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, Args(args)...);
+}
 inline size_t fmt_bytes(int fmt) { return fmt == P25FE_FMT_CF32 ? 8 : 2; }
 
 }  // namespace
@@ -68,7 +80,11 @@ struct p25fe {
     hipStream_t rx_stream = nullptr;
     hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_rx[2] = {nullptr, nullptr};
     bool rx_pending[2] = {false, false};
+    hipStream_t rx_joined[2] = {nullptr, nullptr};   // stream that has already been made to wait for ev_rx[l] (valid while rx_pending[l])
+    bool rx_joined_any[2] = {false, false};
     int lane = 0;
+    bool ext_events = true;                // events ride on the kernel dispatches (hipExtLaunchKernelGGL) instead of separate records
+    int rx_cus = 0;                        // > 0: the receive stream is confined to this many CUs (hipExtStreamCreateWithCUMask)
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
@@ -215,6 +231,12 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     {
         const char* pv = getenv("P25FE_K1_P");            // tuning knob: FIR outputs per lane (5 default, 3)
         h->k1_p = (pv && atoi(pv) == 3) ? 3 : 5;
+        // measurement knobs of the two-stream form: events attached to the dispatches (default) or
+        // recorded separately; CUs the receive stream is confined to (0 = no mask)
+        const char* ee = getenv("P25FE_EXT_EVENTS");
+        h->ext_events = !(ee && atoi(ee) == 0);
+        const char* rc_ = getenv("P25FE_RX_CUS");
+        h->rx_cus = rc_ ? atoi(rc_) : 0;
     }
     auto set_lds = [&](const void* f, size_t bytes) {
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -280,9 +302,20 @@ static void prof_begin(p25fe_t* h)
 static void prof_mark(p25fe_t* h, int idx, hipStream_t st)
 {
     if (h->prof_slot >= 0 && (idx <= 1 || h->prof_level == 1)) {    // levels 2, 3: only the two events around K1
+        if (idx <= 1 && h->ext_events) return;                      // K1's pair rides on its dispatch: prof_k1_events
         if (hipEventRecord(h->prof_ev[(size_t)h->prof_slot * 5 + idx], st) == hipSuccess)
             h->prof_mask[(size_t)h->prof_slot] |= (uint8_t)(1u << idx);
     }
+}
+// The pair of events of the current profiling slot for K1's own dispatch (null when this call is not sampled): the
+// kernel's begin / end time stamps, no extra packet on the stream.
+static void prof_k1_events(p25fe_t* h, hipEvent_t* e0, hipEvent_t* e1)
+{
+    *e0 = *e1 = nullptr;
+    if (h->prof_slot < 0 || !h->ext_events) return;
+    *e0 = h->prof_ev[(size_t)h->prof_slot * 5 + 0];
+    *e1 = h->prof_ev[(size_t)h->prof_slot * 5 + 1];
+    h->prof_mask[(size_t)h->prof_slot] |= 3u;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -309,8 +342,10 @@ static int k1_slots_per_cu(const void* kern, size_t lds)
 
 static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
-                           hipStream_t st, const PlanarGeo* planar = nullptr, int part = 0)
+                           hipStream_t st, const PlanarGeo* planar = nullptr, int part = 0, hipEvent_t ev0 = nullptr,
+                           hipEvent_t ev1 = nullptr)
 {
+    // ev0 / ev1 (nullable): events attached to K1's dispatch (begin / end of the kernel)
     // part: 0 = every segment; 1 = only the segments whose input window lies inside the owned samples (a shard's main
     // launch, runs while the halo is still on the wire); 2 = the others (the shard's head, after the halo has arrived)
     if (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) return P25FE_ERR_ARG;
@@ -393,11 +428,11 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     do {                                                                                                                  \
         const size_t lds = Geo<PK>::LDS_BYTES - (h->default_taps ? lds_taps_trim : 0);                                   \
         if (fmt == P25FE_FMT_CF32) {                                                                                      \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, true, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK, OM>), lds), dim3(WV), lds, st, a, dt);  \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK, OM>), lds), dim3(WV), lds, st, a, dt);                 \
+            if (h->default_taps) launch_ev(k_frontend<P25FE_FMT_CF32, true, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);  \
+            else launch_ev(k_frontend<P25FE_FMT_CF32, false, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);                 \
         } else {                                                                                                          \
-            if (h->default_taps) hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, true, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK, OM>), lds), dim3(WV), lds, st, a, dt);    \
-            else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, PK, OM>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK, OM>), lds), dim3(WV), lds, st, a, dt);                   \
+            if (h->default_taps) launch_ev(k_frontend<P25FE_FMT_U8, true, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);    \
+            else launch_ev(k_frontend<P25FE_FMT_U8, false, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);                   \
         }                                                                                                                 \
     } while (0)
     // immediate-tap kernels never touch the taps area at the end of the LDS layout: do not allocate it.  (13 376 B per
@@ -406,8 +441,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
 #define P25FE_LAUNCH_K1_LONG(OM)                                                                                          \
     do {                                                                                                                  \
         const size_t lds = Geo<5, 1>::LDS_BYTES;                                                                          \
-        if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), lds), dim3(WV), lds, st, a, dt); \
-        else hipLaunchKernelGGL((k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), lds), dim3(WV), lds, st, a, dt);    \
+        if (fmt == P25FE_FMT_CF32) launch_ev(k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), lds), dim3(WV), lds, st, ev0, ev1, a, dt); \
+        else launch_ev(k_frontend<P25FE_FMT_U8, false, 5, OM, 1>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);    \
     } while (0)
     if (h->long_taps && planar) P25FE_LAUNCH_K1_LONG(OUT_PLANAR);
     else if (h->long_taps) P25FE_LAUNCH_K1_LONG(OUT_LINEAR);
@@ -475,18 +510,21 @@ static int launch_detect(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, hipStream_t 
 // K3 (+ K4 when do_slice) on the summaries of launch_detect
 static int launch_scan_slice(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in,
                              uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit,
-                             size_t sync_stride, p25fe_result_t* d_result, bool do_slice, hipStream_t st)
+                             size_t sync_stride, p25fe_result_t* d_result, bool do_slice, hipStream_t st,
+                             hipEvent_t ev_done = nullptr)
 {
+    // ev_done (nullable): attached to the LAST kernel this function launches (its completion = the receive side is done)
     const PlanarGeo g(n_bb);
     const int n_tiles = n_bb ? (int)g.n_tiles : 0;
     ScanArgs c;
     c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>();
     c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
     c.n_baseband = n_bb;
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, c);
+    const bool slice = do_slice && n_tiles != 0;
+    launch_ev(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 3, st);
-    if (!do_slice || n_tiles == 0) { prof_mark(h, 4, st); return P25FE_OK; }
+    if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
     SliceArgs l;
     l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = (long)abs_bb0; l.n_tiles = n_tiles;
     l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.tsum = h->tsum.as<unsigned long long>();
@@ -494,10 +532,17 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, const p2
     l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
-    hipLaunchKernelGGL(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, l);
+    launch_ev(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, l);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 4, st);
     return P25FE_OK;
+}
+
+// every entry point that overwrites the receiver's scratch: a shard's pass-1 context is gone
+static void shard_invalidate(p25fe_t* h)
+{
+    h->sh_valid = false;
+    h->sh_main_nbb = (size_t)-1;             // a later p25fe_shard_pass1_finish must not pair with a main launch whose planes are gone
 }
 
 static int pipe_join(p25fe_t* h, hipStream_t st);
@@ -507,7 +552,7 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
                      size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
                      p25fe_result_t* d_result, hipStream_t st)
 {
-    h->sh_valid = false;
+    shard_invalidate(h);
     if (int jrc = pipe_join(h, st)) return jrc;
     if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
         return launch_scan_slice(h, 0, abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
@@ -595,10 +640,12 @@ int p25fe_slice_dev(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_hi
 // p25fe_run_dev_pipelined left running on the handle's own stream (no-op when nothing is pending).
 static int pipe_join(p25fe_t* h, hipStream_t st)
 {
+    // The events stay pending until the lane is reused: a later call on ANOTHER stream must wait too (the receive
+    // kernels may still be running and share the scratch with whatever that call launches).
     for (int l = 0; l < 2; ++l)
-        if (h->rx_pending[l]) {
+        if (h->rx_pending[l] && !(h->rx_joined_any[l] && h->rx_joined[l] == st)) {
             HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[l], 0));
-            h->rx_pending[l] = false;
+            h->rx_joined[l] = st; h->rx_joined_any[l] = true;
         }
     return P25FE_OK;
 }
@@ -616,19 +663,32 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    h->sh_valid = false;
+    shard_invalidate(h);
     if (!h->rx_stream) {
-        // highest priority: the receive kernels are a few thousand short waves and one single-workgroup scan that should
-        // not queue behind K1's 32 000 workgroups (measured: no difference in the step time, 0.3005 vs 0.3001 ms)
-        int prio_lo = 0, prio_hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
-            (void)hipGetLastError();
-            h->rx_stream = nullptr;
-            HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));     // any non-blocking stream will do
+        if (h->rx_cus > 0) {
+            // The receive kernels are a few thousand short one-wave workgroups and one single-workgroup scan.  Left free they
+            // take wave slots, LDS and memory-pipe time from K1 on EVERY CU (K1 measured 12 % slower under overlap in round
+            // 2's driver run); confined to a few CUs they cost K1 at most that share of the chip while they run.
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int ncu = h->n_cu < 256 ? h->n_cu : 256;
+            const int want = h->rx_cus < ncu ? h->rx_cus : ncu;
+            // spread over the XCDs: CU c of the mask numbering sits on XCD c % 8 (workgroups are handed out the same way)
+            for (int k = 0; k < want; ++k) mask[k / 32] |= 1u << (k % 32);
+            if (hipExtStreamCreateWithCUMask(&h->rx_stream, (uint32_t)((ncu + 31) / 32), mask) != hipSuccess) {
+                (void)hipGetLastError();
+                h->rx_stream = nullptr;
+            }
+        }
+        if (!h->rx_stream) {
+            int prio_lo = 0, prio_hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+                (void)hipGetLastError();
+                h->rx_stream = nullptr;
+                HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));     // any non-blocking stream will do
+            }
         }
         for (int l = 0; l < 2; ++l) {
-            // (hipEventDisableSystemFence / hipEventReleaseToDevice on these events: no measurable difference)
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
         }
@@ -641,32 +701,43 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     h->lane ^= 1;
     const int lane = h->lane;
     if (h->rx_pending[lane]) {
-        HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[lane], 0));
+        if (!(h->rx_joined_any[lane] && h->rx_joined[lane] == st)) HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[lane], 0));
         h->rx_pending[lane] = false;
     }
+    h->rx_joined_any[lane] = false;
     const size_t n_bb = p25fe_n_baseband(0, n);
     int rc = P25FE_OK;
     const PlanarGeo g(n_bb);
+    hipEvent_t k1_done = h->ev_k1[lane];
+    bool k1_done_attached = false;
     if (n_bb) {
         rc = ensure_slice_scratch(h, n_bb);          // (growing a buffer frees the old one: hipFree synchronises the device)
         if (rc) return rc;
         prof_begin(h);
         prof_mark(h, 0, st);
-        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g);
+        hipEvent_t e0, e1;
+        prof_k1_events(h, &e0, &e1);
+        if (h->ext_events) {
+            if (e1) k1_done = e1;                    // a sampled call: the profiling stop event doubles as "K1 done"
+            else e1 = k1_done;
+            k1_done_attached = true;
+        }
+        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g, 0, e0, e1);
         if (rc) return rc;
         prof_mark(h, 1, st);
     }
-    HIPCHK(h, hipEventRecord(h->ev_k1[lane], st));
-    HIPCHK(h, hipStreamWaitEvent(h->rx_stream, h->ev_k1[lane], 0));
+    if (!k1_done_attached) HIPCHK(h, hipEventRecord(k1_done, st));
+    HIPCHK(h, hipStreamWaitEvent(h->rx_stream, k1_done, 0));
     if (n_bb) {
         rc = launch_detect(h, n_bb, 0, h->rx_stream);
         if (rc) return rc;
         prof_mark(h, 2, h->rx_stream);
     }
-    rc = launch_scan_slice(h, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, n_bb != 0, h->rx_stream);
+    rc = launch_scan_slice(h, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, n_bb != 0, h->rx_stream,
+                           h->ext_events ? h->ev_rx[lane] : nullptr);
     h->prof_slot = -1;
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_rx[lane], h->rx_stream));
+    if (!h->ext_events) HIPCHK(h, hipEventRecord(h->ev_rx[lane], h->rx_stream));
     h->rx_pending[lane] = true;
     return P25FE_OK;
 }
@@ -677,7 +748,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    h->sh_valid = false;
+    shard_invalidate(h);
     if (int jrc = pipe_join(h, st)) return jrc;
     const size_t n_bb = p25fe_n_baseband(0, n);
     if (n_bb == 0)
@@ -687,9 +758,11 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     const PlanarGeo g(n_bb);
     prof_begin(h);
     prof_mark(h, 0, st);
+    hipEvent_t e0, e1;
+    prof_k1_events(h, &e0, &e1);
     // K1 writes the baseband straight into the polyphase layout (+ sign planes); the 240 history positions in front
     // of the stream come out as the zeros of a fresh DemodTask (outputs of an all-zero input)
-    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g);
+    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g, 0, e0, e1);
     if (rc) return rc;
     prof_mark(h, 1, st);
     rc = launch_detect(h, n_bb, 0, st);
@@ -707,7 +780,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
                             p25fe_result_t* d_result, hipStream_t st, bool do_main, bool do_finish)
 {
     if (!h || !d_iq || (do_finish && !d_result)) return P25FE_ERR_ARG;
-    if (do_main) h->sh_valid = false;
+    if (do_main) shard_invalidate(h);
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (int jrc = pipe_join(h, st)) return jrc;
@@ -721,8 +794,12 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
         prof_begin(h);
         prof_mark(h, 0, st);
         if (n_bb) {
+            // K1's event pair rides on THIS launch: with the split form it times the main launch alone (the head segment
+            // that follows the halo wait is one workgroup), so an RCCL wait between the two is not in K1's figure
+            hipEvent_t e0, e1;
+            prof_k1_events(h, &e0, &e1);
             rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g,
-                                 do_finish ? 0 : 1);
+                                 do_finish ? 0 : 1, e0, e1);
             if (rc) return rc;
         }
         h->sh_main_nbb = n_bb; h->sh_main_abs0 = abs0;
@@ -983,8 +1060,9 @@ int p25fe_run_cf32(p25fe_t* h, const float* iq, size_t n_samples, uint8_t* dibit
 int p25fe_nid_dev(p25fe_t* h, const uint8_t* d_dibits, size_t n_dibits, const uint64_t* d_sync_dibit,
                   const int64_t* d_sync_pos, size_t n_sync, p25fe_nid_t* d_out, void* stream)
 {
-    if (!h || !d_dibits || !d_sync_dibit || !d_out) return P25FE_ERR_ARG;
+    if (!h) return P25FE_ERR_ARG;
     if (n_sync == 0) return P25FE_OK;
+    if (!d_dibits || !d_sync_dibit || !d_out) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_nid, dim3((unsigned)n_sync), dim3(256), 0, (hipStream_t)stream, d_dibits,
                        (unsigned long long)n_dibits, reinterpret_cast<const unsigned long long*>(d_sync_dibit),
@@ -997,8 +1075,9 @@ int p25fe_nid_dev(p25fe_t* h, const uint8_t* d_dibits, size_t n_dibits, const ui
 int p25fe_nid(p25fe_t* h, const uint8_t* dibits, size_t n_dibits, const uint64_t* sync_dibit, const int64_t* sync_pos,
               size_t n_sync, p25fe_nid_t* out)
 {
-    if (!h || (!dibits && n_dibits) || !sync_dibit || !out) return P25FE_ERR_ARG;
-    if (n_sync == 0) return P25FE_OK;
+    if (!h) return P25FE_ERR_ARG;
+    if (n_sync == 0) return P25FE_OK;                               // a capture without a frame sync: nothing to decode (empty vectors hand over null pointers)
+    if ((!dibits && n_dibits) || !sync_dibit || !out) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     DevBuf d_dib, d_sd, d_sp, d_out;
     int rc = P25FE_OK;
@@ -1077,7 +1156,11 @@ int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
         for (int k = 0; k < 4; ++k) {
             if ((m & (3u << k)) != (3u << k)) continue;
             float t = 0.f;
-            HIPCHK(h, hipEventElapsedTime(&t, h->prof_ev[s * 5 + k], h->prof_ev[s * 5 + k + 1]));
+            if (hipEventElapsedTime(&t, h->prof_ev[s * 5 + k], h->prof_ev[s * 5 + k + 1]) != hipSuccess) {
+                (void)hipGetLastError();                             // a slot whose launch had nothing to do (empty part of a shard)
+                if (k == 0 && n_k1) --n_k1;
+                continue;
+            }
             ms[k] += t;
         }
     }

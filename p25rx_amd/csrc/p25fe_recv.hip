@@ -645,7 +645,7 @@ struct SliceArgs {
     const float* evthr;         // [ch][n_tiles][EVTHR_N][3] from K2
     const p25fe_anchor_t* anchor_in;    // nullable, [ch]
     uint8_t* dibits;            // [ch][dibit_stride]
-    long dibit_stride;
+    long dibit_stride;          // row stride AND per-channel capacity: dibits past it are counted (K3) but not stored
     int64_t* sync_pos;          // nullable
     uint64_t* sync_dibit;       // nullable
     long sync_stride;
@@ -682,6 +682,10 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
         phase_sync();
     }
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
+    // room left in this channel's row from the tile's first dibit on (<= 0: the row is full).  A receiver that re-anchors
+    // on every sync word follows the transmitter's symbol clock, so a range can hold more than n / 10 dibits (up to
+    // n / (W + 1) under dense detections): the count in p25fe_result_t stays exact, the stores stop at the capacity.
+    const long room = a.dibit_stride - (long)so.dibit_off;
 
     // instants m in [m_lo, m_hi) (tile-local) that are congruent to the anchor: first one at m_lo + off
     auto emit = [&](int off, int m_lo, int m_hi, float h, float m, float l, int rank) -> int {
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = j0 + q * WV + lane;
-                if (j < count) dst[j] = slice_dibit(v[q], h, m, l);
+                if (j < count && rank + j < room) dst[j] = slice_dibit(v[q], h, m, l);
             }
         }
         return count;
