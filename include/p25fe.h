@@ -43,7 +43,8 @@ extern "C" {
 #endif
 
 #define P25FE_MAX_TAPS 64
-#define P25FE_ABI_VERSION 2        /* 2: p25fe_shard_resolve* write n_shards + 1 offsets */
+#define P25FE_ABI_VERSION 3        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
+                                      flags in p25fe_result_t, p25fe_resync_at_dev, symbol_clock argument of p25fe_shard_resolve */
 
 typedef enum p25fe_status {
     P25FE_OK = 0,
@@ -73,7 +74,16 @@ typedef struct p25fe_config {
     int32_t n_chan_taps;
     float decim_taps[P25FE_MAX_TAPS];    /* 240k -> 48k anti-alias, tap 0 multiplies the newest sample */
     float chan_taps[P25FE_MAX_TAPS];     /* 48 kHz channel-select low-pass */
+    int32_t symbol_clock;                /* P25FE_CLOCK_FIXED (0, default): symbol instants at a fixed 10-sample stride from the last
+                                            sync word, the receiver structure of the reference; P25FE_CLOCK_TRACKING (1): docs/SPEC.md
+                                            3.8b -- the stride is the measured interval between the last two sync words over its
+                                            symbol count, instants are read by 4-tap interpolation, the receiver runs 2 samples
+                                            behind the baseband */
+    int32_t reserved;
 } p25fe_config_t;
+
+#define P25FE_CLOCK_FIXED 0
+#define P25FE_CLOCK_TRACKING 1
 
 typedef struct p25fe p25fe_t;
 
@@ -82,6 +92,7 @@ typedef struct p25fe_anchor {
     int64_t s;                           /* absolute baseband index of the sync word's last symbol */
     float hi, mid, lo;                   /* slicer thresholds derived from that sync word */
     int32_t valid;
+    int32_t period_d, period_n;          /* symbol period period_d / period_n samples (10 / 1 unless the clock tracks; 0 / 0 reads as 10 / 1) */
 } p25fe_anchor_t;
 
 /* Per-channel summary of one processed range (device or host memory, see each call). */
@@ -92,7 +103,16 @@ typedef struct p25fe_result {
     p25fe_anchor_t anchor_out;           /* anchor after the range */
     int64_t first_event;                 /* baseband index at which the range's first own detection is decided (s + W), -1 if none */
     uint64_t n_dibits_after_first;       /* dibits governed by the range's own detections */
+    /* what p25fe_shard_resolve needs beyond that when the clock tracks or lock is dropped inside ranges: */
+    int64_t carry_end;                   /* index from which the carry-in anchor no longer governs (first_event + 1, or the first lock
+                                            drop if that comes first); -1: it governs the whole range */
+    int64_t first_seg_end;               /* end (exclusive) of the interval the first own detection governs */
+    uint32_t flags;                      /* P25FE_RES_* */
+    uint32_t reserved;
 } p25fe_result_t;
+#define P25FE_RES_FIRST_TRACKS_CARRY 1u  /* no lock drop between the range's start and its first detection: with a tracking clock that
+                                            detection takes its period from the carry-in (n_dibits_after_first assumed 10 / 1) */
+#define P25FE_RES_OUT_PERIOD_FROM_CARRY 2u /* anchor_out's period is that same interval (the range has one detection, nothing else) */
 
 void p25fe_default_config(p25fe_config_t *cfg);
 int p25fe_create(const p25fe_config_t *cfg, p25fe_t **out);
@@ -128,6 +148,14 @@ int p25fe_run_cf32(p25fe_t *h, const float *iq, size_t n_samples, uint8_t *dibit
 
 /* MessageReceiver::resync (src/recv.rs:136, 179): drop symbol lock at the current position. */
 int p25fe_resync(p25fe_t *h);
+/* The same for device-resident ranges, where "the current position" lies INSIDE the range (RecvTask handles
+ * RecvEvent::SetControlFreq between two baseband chunks, src/recv.rs:127-137; a resident capture spans many): the NEXT
+ * call on this handle that runs the receiver (p25fe_slice_dev, p25fe_run_dev, p25fe_run_dev_pipelined,
+ * p25fe_shard_pass1 / _finish + the p25fe_shard_pass2 that follows) drops lock before each listed sample -- exactly as
+ * if resync() had been called between feeding samples q - 1 and q.  d_idx: device array, n_idx ascending ABSOLUTE
+ * baseband indices per channel, channel c at d_idx + c * idx_stride (pad a shorter list with INT64_MAX); it must stay
+ * valid and unchanged until that call's kernels have run.  n_idx = 0 cancels.  The list is consumed by that call. */
+int p25fe_resync_at_dev(p25fe_t *h, const int64_t *d_idx, size_t n_idx, size_t idx_stride);
 /* Forget all stream state (a new DemodTask + MessageReceiver). */
 int p25fe_reset(p25fe_t *h);
 
@@ -158,7 +186,11 @@ size_t p25fe_n_predecim(uint64_t abs0, size_t n);
 
 /* stages 6-7 on device baseband.  d_bb points at the first owned sample; n_hist_bb valid
  * samples precede it; abs_bb0 is its absolute index; d_anchor_in (nullable = no lock) is the
- * carry-in per channel.  d_result[c] is filled per channel. */
+ * carry-in per channel.  d_result[c] is filled per channel.
+ * dibit_stride (here and in every *_dev call) is the row stride AND the per-channel capacity of d_dibits: a receiver
+ * that re-anchors on every sync word follows the transmitter's symbol clock, so a range of n baseband samples can hold
+ * more than n / 10 dibits (n / 6 at most, under back-to-back detections).  d_result[c].n_dibits is always the exact
+ * count; dibits past the capacity are not stored (n_dibits > dibit_stride tells the caller so). */
 int p25fe_slice_dev(p25fe_t *h, const float *d_bb, size_t bb_stride, size_t n_hist_bb, size_t n_bb,
                     uint64_t abs_bb0, const p25fe_anchor_t *d_anchor_in, uint8_t *d_dibits, size_t dibit_stride,
                     int64_t *d_sync_pos, uint64_t *d_sync_dibit, size_t sync_stride, p25fe_result_t *d_result,
@@ -212,9 +244,9 @@ int p25fe_shard_pass1_finish(p25fe_t *h, const void *d_iq, int fmt, size_t ch_st
 /* Host-side combine: summaries[r] for r = 0..n_shards-1 in time order (one channel) ->
  * anchor_in[r] (n_shards entries) and dibit_offset[r] (n_shards + 1 entries: shard r's dibits occupy
  * [dibit_offset[r], dibit_offset[r + 1]) of the whole stream, the last entry is the total).
- * Pure integer/struct logic, no device work. */
+ * Pure integer/struct logic, no device work.  symbol_clock: the handles' p25fe_config_t.symbol_clock. */
 int p25fe_shard_resolve(const p25fe_result_t *summaries, const uint64_t *shard_bb0, const uint64_t *shard_bb_n,
-                        size_t n_shards, p25fe_anchor_t *anchor_in, uint64_t *dibit_offset);
+                        size_t n_shards, int symbol_clock, p25fe_anchor_t *anchor_in, uint64_t *dibit_offset);
 
 /* Same combine on the device (one tiny kernel, no host synchronisation): all arrays are device pointers, e.g. the
  * all-gathered summaries; writes n_shards anchors and n_shards + 1 offsets; pass d_anchor_in + rank to p25fe_shard_pass2. */

@@ -28,6 +28,8 @@ class Config(C.Structure):
         ("pi", C.c_float), ("half_pi", C.c_float),
         ("inv_npos", C.c_float), ("inv_nneg", C.c_float), ("rho2_n", C.c_float),
         ("e_min", C.c_float), ("slice_frac", C.c_float),
+        ("symbol_clock", C.c_int32), ("clk_lookahead", C.c_int32), ("clk_tol_shift", C.c_int32), ("clk_dmax_log2", C.c_int32),
+        ("clk_interp", C.c_float * 256),
     ]
 
 
@@ -36,9 +38,14 @@ def load_spec(path=SPEC_JSON):
         return json.load(f)
 
 
-def make_config(spec=None, decim_taps=None, chan_taps=None):
+def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0):
     s = spec or load_spec()
     c = Config()
+    c.symbol_clock = symbol_clock
+    c.clk_lookahead, c.clk_tol_shift, c.clk_dmax_log2 = s["clk_lookahead"], s["clk_tol_shift"], s["clk_dmax_log2"]
+    for q, row in enumerate(s["clk_interp"]):
+        for k, v in enumerate(row):
+            c.clk_interp[4 * q + k] = v
     c.decim, c.sps, c.boxcar, c.peak_w = s["decim"], s["sps"], s["boxcar_len"], s["sync_peak_w"]
     dt = list(s["decim_taps"] if decim_taps is None else decim_taps)
     ct = list(s["chan_taps"] if chan_taps is None else chan_taps)

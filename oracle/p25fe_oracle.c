@@ -48,6 +48,11 @@ typedef struct {
     float fm_gain, u8_scale, boxcar_scale;
     float pi, half_pi;
     float inv_npos, inv_nneg, rho2_n, e_min, slice_frac;
+    /* SPEC 3.8b (tracking symbol clock; the reference's receiver has a fixed 10-sample stride, symbol_clock = 0) */
+    int32_t symbol_clock;                /* 0: fixed stride (SPEC 3.8), 1: period tracked from sync word to sync word */
+    int32_t clk_lookahead;               /* samples the receiver runs behind the baseband in mode 1 (2) */
+    int32_t clk_tol_shift, clk_dmax_log2;
+    float clk_interp[64 * 4];            /* cubic-Lagrange weights of the samples at -1, 0, +1, +2, row q: mu = q / 64 */
 } p25o_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -397,6 +402,11 @@ typedef struct {
     int anchor_valid;
     int64_t anchor_s;
     float hi, mid, lo;
+    /* symbol clock of the anchor in force: instants at anchor_s + j * per_d / per_n, j = 1, 2, ...  (10 / 1 in mode 0) */
+    int64_t per_d, per_n, next_j, next_i;
+    int next_q;
+    int prev_valid;             /* a detection since the last lock drop: the next sync-to-sync interval is a period estimate */
+    int64_t prev_s;
     uint64_t n_dibits;
 } p25o_recv;
 
@@ -404,29 +414,44 @@ p25o_recv *p25o_recv_create(const p25o_config *cfg)
 {
     p25o_recv *r = calloc(1, sizeof *r);
     r->cfg = *cfg;
+    r->per_d = cfg->sps; r->per_n = 1;
     return r;
 }
 
 void p25o_recv_destroy(p25o_recv *r) { free(r); }
 
-/* MessageReceiver::resync (src/recv.rs:136, 179): drop lock. */
-void p25o_recv_resync(p25o_recv *r) { r->anchor_valid = 0; }
+/* MessageReceiver::resync (src/recv.rs:136, 179): drop lock (and with it the clock estimate). */
+void p25o_recv_resync(p25o_recv *r) { r->anchor_valid = 0; r->prev_valid = 0; }
 
 static inline float bget(const p25o_recv *r, int64_t n) { return n < 0 ? 0.0f : r->b[n & (RING - 1)]; }
 static inline float cget(const p25o_recv *r, int64_t n) { return n < 0 ? 0.0f : r->c[n & (RING - 1)]; }
 
+/* position of instant next_j of the current anchor: integer part and interpolation phase (SPEC 3.8b) */
+static inline void clock_advance(p25o_recv *r)
+{
+    const int64_t num = r->next_j * r->per_d;
+    r->next_i = r->anchor_s + num / r->per_n;
+    r->next_q = (int)(((num % r->per_n) * 64) / r->per_n);
+}
+
 /* Feed n baseband samples (the `for &s in samples.iter()` loop of src/recv.rs:148-150).
  * Writes dibits (one per byte, values 0..3) and sync events (sample position of the sync
- * word's last symbol; index of the first dibit after it). Returns 0, or -1 on overflow. */
+ * word's last symbol; index of the first dibit after it). Returns 0, or -1 on overflow.
+ * Mode 1 (SPEC 3.8b) is the same loop run `clk_lookahead` samples behind the input: index u = t - L is processed when
+ * sample t arrives, so that the 4-tap interpolation around an instant in [u, u + 1) has its two right-hand samples. */
 int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, size_t cap, size_t *n_dibits,
                    int64_t *sync_pos, uint64_t *sync_dibit, size_t sync_cap, size_t *n_sync)
 {
     const p25o_config *g = &r->cfg;
     const int W = g->peak_w, S = g->sps;
+    const int track = g->symbol_clock != 0;
+    const int L = track ? g->clk_lookahead : 0;
     size_t nd = 0, ns = 0;
     for (size_t i = 0; i < n; i++) {
-        const int64_t t = r->t;
-        r->b[t & (RING - 1)] = bb[i];
+        r->b[r->t & (RING - 1)] = bb[i];
+        const int64_t t = r->t - L;               /* index processed now */
+        r->t++;
+        if (t < 0) continue;
         float c = 0.0f, e = 0.0f;
         for (int j = 0; j < P25O_SYNC_DIBITS; j++) {
             float v = bget(r, t - (int64_t)S * (P25O_SYNC_DIBITS - 1 - j));
@@ -436,13 +461,24 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
         r->c[t & (RING - 1)] = c;
         r->cand[t & (RING - 1)] = (c > 0.0f) && (e >= g->e_min) && (c * c >= g->rho2_n * e);
 
-        /* 1. slice instant t under the latest detection s with s + W < t */
-        if (r->anchor_valid && (t - r->anchor_s) % S == 0) {
-            float v = bb[i];
+        /* 1. slice the instant whose integer position is t, under the latest detection s with s + W < t */
+        if (r->anchor_valid && t == r->next_i) {
+            float v;
+            if (track) {
+                const float *w = g->clk_interp + 4 * r->next_q;
+                v = w[0] * bget(r, t - 1);
+                v = fmaf(w[1], bget(r, t), v);
+                v = fmaf(w[2], bget(r, t + 1), v);
+                v = fmaf(w[3], bget(r, t + 2), v);
+            } else {
+                v = bget(r, t);
+            }
             uint8_t d = v >= r->hi ? 1 : v >= r->mid ? 0 : v >= r->lo ? 2 : 3;
             if (nd >= cap) return -1;
             dibits[nd++] = d;
             r->n_dibits++;
+            r->next_j++;
+            clock_advance(r);
         }
         /* 2. decide detection at m = t - W (needs c[m-W .. m+W] = c[.. t]) */
         const int64_t m = t - W;
@@ -463,8 +499,21 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
                 float span = (P - N) * 0.5f;
                 float dlt = span * g->slice_frac;
                 r->mid = mid; r->hi = mid + dlt; r->lo = mid - dlt;
+                /* SPEC 3.8b: the interval from the previous sync word, if lock was held throughout and it is a
+                 * plausible whole number of symbols, is the period estimate D / N; otherwise the nominal 10 / 1 */
+                r->per_d = S; r->per_n = 1;
+                if (track && r->prev_valid) {
+                    const int64_t dd = m - r->prev_s, nn = (dd + S / 2) / S;
+                    const int64_t err = dd > S * nn ? dd - S * nn : S * nn - dd;
+                    if (nn >= 1 && dd <= ((int64_t)1 << g->clk_dmax_log2) && (err << g->clk_tol_shift) <= S * nn) {
+                        r->per_d = dd; r->per_n = nn;
+                    }
+                }
+                r->prev_s = m; r->prev_valid = 1;
                 r->anchor_s = m;
                 r->anchor_valid = 1;
+                r->next_j = 1;
+                clock_advance(r);
                 if (ns < sync_cap) {
                     if (sync_pos) sync_pos[ns] = m;
                     if (sync_dibit) sync_dibit[ns] = r->n_dibits;
@@ -472,7 +521,6 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
                 ns++;
             }
         }
-        r->t++;
     }
     *n_dibits = nd;
     if (n_sync) *n_sync = ns;

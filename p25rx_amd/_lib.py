@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libp25fe.so")
 MAX_TAPS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 FMT_CF32, FMT_U8 = 0, 1
 
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -20,21 +20,26 @@ OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM = 0, -1
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_channels", C.c_int32),
                 ("n_decim_taps", C.c_int32), ("n_chan_taps", C.c_int32),
-                ("decim_taps", C.c_float * MAX_TAPS), ("chan_taps", C.c_float * MAX_TAPS)]
+                ("decim_taps", C.c_float * MAX_TAPS), ("chan_taps", C.c_float * MAX_TAPS),
+                ("symbol_clock", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Anchor(C.Structure):
-    _fields_ = [("s", C.c_int64), ("hi", C.c_float), ("mid", C.c_float), ("lo", C.c_float), ("valid", C.c_int32)]
+    _fields_ = [("s", C.c_int64), ("hi", C.c_float), ("mid", C.c_float), ("lo", C.c_float), ("valid", C.c_int32),
+                ("period_d", C.c_int32), ("period_n", C.c_int32)]
 
 
 class Result(C.Structure):
     _fields_ = [("n_baseband", C.c_uint64), ("n_dibits", C.c_uint64), ("n_sync", C.c_uint64),
-                ("anchor_out", Anchor), ("first_event", C.c_int64), ("n_dibits_after_first", C.c_uint64)]
+                ("anchor_out", Anchor), ("first_event", C.c_int64), ("n_dibits_after_first", C.c_uint64),
+                ("carry_end", C.c_int64), ("first_seg_end", C.c_int64), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-ANCHOR_DTYPE = np.dtype([("s", "<i8"), ("hi", "<f4"), ("mid", "<f4"), ("lo", "<f4"), ("valid", "<i4")])
+ANCHOR_DTYPE = np.dtype([("s", "<i8"), ("hi", "<f4"), ("mid", "<f4"), ("lo", "<f4"), ("valid", "<i4"),
+                         ("period_d", "<i4"), ("period_n", "<i4")])
 RESULT_DTYPE = np.dtype([("n_baseband", "<u8"), ("n_dibits", "<u8"), ("n_sync", "<u8"), ("anchor_out", ANCHOR_DTYPE),
-                         ("first_event", "<i8"), ("n_dibits_after_first", "<u8")])
+                         ("first_event", "<i8"), ("n_dibits_after_first", "<u8"), ("carry_end", "<i8"),
+                         ("first_seg_end", "<i8"), ("flags", "<u4"), ("reserved", "<u4")])
 NID_DTYPE = np.dtype([("raw", "<u8"), ("sync_pos", "<i8"), ("nac", "<u2"), ("duid", "u1"), ("n_errors", "u1"),
                       ("valid", "<i4")])
 assert NID_DTYPE.itemsize == 24
@@ -53,7 +58,7 @@ SYMBOLS = [
     "p25fe_shard_resolve", "p25fe_n_baseband", "p25fe_profile_enable", "p25fe_profile_read",
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
-    "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev",
+    "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
 ]
 
 
@@ -115,7 +120,8 @@ def load():
     L.p25fe_shard_pass1_finish.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp, vp]
     L.p25fe_shard_compact_dev.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
     L.p25fe_shard_pass2.argtypes = [vp, vp, vp, sz, vp, vp]
-    L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.p25fe_shard_resolve.argtypes = [vp, vp, vp, sz, C.c_int, vp, vp]
+    L.p25fe_resync_at_dev.argtypes = [vp, vp, sz, sz]
     L.p25fe_shard_resolve_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_nid_dev.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp]
     L.p25fe_nid.argtypes = [vp, vp, sz, vp, vp, sz, vp]

@@ -86,11 +86,14 @@ def make_dibits(n_dibits, seed, frame_dibits=864, nid=None):
     return d
 
 
-def modulate(dibits, snr_db=30.0, seed=0, freq_offset_hz=0.0, amplitude=0.5, timing_offset=0, lead_symbols=4):
+def modulate(dibits, snr_db=30.0, seed=0, freq_offset_hz=0.0, amplitude=0.5, timing_offset=0, lead_symbols=4,
+             clock_ppm=0.0):
     """dibits -> cf32 IQ at 240 ksps.  Returns (iq, info).
 
     info['symbol_center_iq'][k] = IQ sample index of the centre of symbol k (before any
     receiver delay).  `timing_offset` shifts the whole waveform by that many IQ samples.
+    `clock_ppm`: the receiver's sample clock runs that many ppm FAST relative to the transmitter's symbol clock (a
+    symbol then lasts 50 (1 + ppm 1e-6) received samples): the phase trajectory is resampled before the noise is added.
     """
     dibits = np.asarray(dibits, dtype=np.uint8)
     sym = DIBIT_TO_SYMBOL[dibits]
@@ -105,6 +108,11 @@ def modulate(dibits, snr_db=30.0, seed=0, freq_offset_hz=0.0, amplitude=0.5, tim
     # the boxcar in the receiver integrates frequency, so `shaped` is the frequency in units
     freq = shaped * DEV_HZ_PER_UNIT / SPS_IQ * 1.0 + freq_offset_hz
     phase = 2.0 * np.pi * np.cumsum(freq) / FS_IQ
+    if clock_ppm:
+        k = 1.0 + clock_ppm * 1e-6
+        t = np.arange(int(len(phase) * k)) / k                   # receiver sample m looks at transmitter time m / k
+        phase = np.interp(t, np.arange(len(phase)), phase)
+        centers = centers * k
     iq = amplitude * np.exp(1j * phase)
     if snr_db is not None:
         rng = np.random.Generator(np.random.PCG64(seed + 0x5EED))

@@ -71,12 +71,18 @@ struct p25fe {
     DevBuf d_taps;                         // device copy for the generic kernels
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
+    int track = 0;                         // p25fe_config_t.symbol_clock (docs/SPEC.md 3.8b)
+    long look = 0;                         // samples the receiver runs behind the baseband (2 with the tracking clock)
+    // lock drops for the next receiver-running call (p25fe_resync_at_dev); consumed by it
+    const long* rs_idx = nullptr;
+    size_t rs_n = 0, rs_stride = 0;
     // scratch
     DevBuf iq_stage, bb_buf, pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    DevBuf gsum, gouts, evg;               // general receiver only (tracking clock / lock drops): allocated on first use
     // p25fe_run_dev_pipelined: a second set of the receiver's scratch (the member names above always are the set of the
     // current call; the sets are swapped per call), the stream the receive kernels run on, and the events that order
     // K1 (caller's stream) -> K2..K4 (rx_stream) -> next K1 into the same set two calls later
-    DevBuf alt_pl_f, alt_pl_bits, alt_evl, alt_evthr, alt_recs, alt_tsum, alt_outs;
+    DevBuf alt_pl_f, alt_pl_bits, alt_evl, alt_evthr, alt_recs, alt_tsum, alt_outs, alt_gsum, alt_gouts, alt_evg;
     hipStream_t rx_stream = nullptr;
     hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_rx[2] = {nullptr, nullptr};
     bool rx_pending[2] = {false, false};
@@ -107,7 +113,8 @@ struct p25fe {
     size_t sh_main_nbb = (size_t)-1;       // shard whose main K1 launch is out, waiting for p25fe_shard_pass1_finish
     uint64_t sh_main_abs0 = 0;
     size_t sh_nbb = 0;
-    uint64_t sh_abs_bb0 = 0;
+    long sh_abs_bb0 = 0;
+    bool sh_gen = false;                   // pass 1 ran the general receiver (pass 2 reads its summaries)
 };
 
 // geometry of the planar scratch for n_bb owned baseband samples (p25fe_recv.hip: Planar)
@@ -189,7 +196,7 @@ int p25fe_reset(p25fe_t* h)
     h->abs_iq = 0;
     h->fmt_locked = -1;
     h->abs_bb = 0;
-    h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0});
+    h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0, SPS, 1});
     h->total_dibits.assign((size_t)h->C, 0);
     HIPCHK(h, hipMemsetAsync(h->hist_iq.p, 0, (size_t)h->C * HISTPAD * 8, h->stream));
     HIPCHK(h, hipMemsetAsync(h->tail_bb.p, 0, (size_t)h->C * BBPAD * sizeof(float), h->stream));
@@ -202,7 +209,8 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     if (!cfg || !out) return P25FE_ERR_ARG;
     *out = nullptr;
     if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_channels > 65535 /* grid.y */ || cfg->n_decim_taps < 1 ||
-        cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_MAX_TAPS)
+        cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_MAX_TAPS ||
+        (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING))
         return P25FE_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
@@ -216,6 +224,8 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     if (!h) return P25FE_ERR_NOMEM;
     h->cfg = *cfg;
     h->C = cfg->n_channels;
+    h->track = cfg->symbol_clock;
+    h->look = cfg->symbol_clock ? CLK_L : 0;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     memset(&h->taps, 0, sizeof h->taps);                 // zero padding at the old end is bit-neutral
     memcpy(h->taps.dec, cfg->decim_taps, sizeof(float) * (size_t)cfg->n_decim_taps);
@@ -277,7 +287,8 @@ void p25fe_destroy(p25fe_t* h)
         if (h->ev_k1[l]) (void)hipEventDestroy(h->ev_k1[l]);
         if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
     }
-    DevBuf* alt[] = {&h->alt_pl_f, &h->alt_pl_bits, &h->alt_evl, &h->alt_evthr, &h->alt_recs, &h->alt_tsum, &h->alt_outs};
+    DevBuf* alt[] = {&h->alt_pl_f, &h->alt_pl_bits, &h->alt_evl, &h->alt_evthr, &h->alt_recs, &h->alt_tsum, &h->alt_outs,
+                     &h->alt_gsum, &h->alt_gouts, &h->alt_evg, &h->gsum, &h->gouts, &h->evg};
     for (DevBuf* b : alt) b->release();
     DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
                       &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
@@ -373,7 +384,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     if (subs > 32768) subs = 32768;
     const long seg_len = (sub - SEG_HALO) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;
-    if (planar && (m_begin + PLPAD < SEG_HALO || (m_begin + PLPAD) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
+    const long pl_shift = PLPAD + h->look;       // the general receiver sees the range h->look samples late (p25fe_recv.hip)
+    if (planar && (m_begin + pl_shift < SEG_HALO || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
     if (planar && n_out > (size_t)0x7ff00000u * 10u) return P25FE_ERR_ARG;   // symbol indices are 32-bit in the kernels: < 2^31 symbols (124 h of one channel) per call
 
     K1Args a;
@@ -402,7 +414,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.n_ch = h->C;
     a.m_begin = m_begin;
     a.power_partial = nullptr;
-    a.bbp = nullptr; a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_ch_stride = 0;
+    a.bbp = nullptr; a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_ch_stride = 0; a.pl_shift = (int)pl_shift;
     if (planar) {
         a.bbp = h->pl_f.as<float>(); a.bbp_ch_stride = (long)planar->floats();
         a.bits = h->pl_bits.as<uint8_t>(); a.bits_ch_stride = (long)(4 * planar->words());
@@ -471,7 +483,29 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
     HIPCHK(h, h->recs.ensure(C * g.n_tiles * sizeof(TileRec)));
     HIPCHK(h, h->tsum.ensure(C * g.n_tiles * sizeof(unsigned long long)));
     HIPCHK(h, h->outs.ensure(C * g.n_tiles * sizeof(ScanOut)));
+    if (h->track || h->rs_n) {                                       // the general receiver's summaries and carry-ins
+        HIPCHK(h, h->gsum.ensure(C * g.n_tiles * sizeof(TileSumG)));
+        HIPCHK(h, h->gouts.ensure(C * g.n_tiles * sizeof(ScanOutG)));
+        HIPCHK(h, h->evg.ensure(C * g.n_tiles * EVCAP * sizeof(uint16_t)));
+    }
     return P25FE_OK;
+}
+
+// The receiver options of the call being enqueued.  h->rs_* (p25fe_resync_at_dev) is consumed by the call that runs the
+// sync detection; a shard keeps its copy for pass 2.
+struct RecvCall {
+    bool gen = false;
+    RecvOpt opt;
+};
+static RecvCall recv_call(const p25fe_t* h)
+{
+    RecvCall c;
+    c.opt.track = h->track;
+    c.opt.n_resync = (int)h->rs_n;
+    c.opt.resync = h->rs_idx;
+    c.opt.resync_stride = (long)h->rs_stride;
+    c.gen = h->track != 0 || h->rs_n != 0;
+    return c;
 }
 
 static Planar planar_view(const p25fe_t* h, const PlanarGeo& g)
@@ -490,43 +524,67 @@ static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, siz
     a.bb = d_bb; a.bb_stride = (long)bb_stride; a.n_hist = (long)n_hist_bb; a.n = (long)n_bb;
     a.f = h->pl_f.as<float>(); a.f_ch = (long)g.floats();
     a.bits = h->pl_bits.as<uint32_t>(); a.bits_ch = (long)g.words(); a.n_blocks = (long)g.n_blocks;
+    a.shift = (int)h->look;
     hipLaunchKernelGGL(k_planarize, dim3((unsigned)((g.n_blocks + 1) / 2), (unsigned)h->C), dim3(WV * SPS), 0, st, a);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
 
-// K2 on the planar scratch
-static int launch_detect(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, hipStream_t st)
+// K2 on the planar scratch.  abs_bb0: absolute index of the first PROCESSED sample (owned sample 0 minus h->look).
+static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc)
 {
     const PlanarGeo g(n_bb);
     DetArgs d;
-    d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = (long)abs_bb0; d.n_tiles = (int)g.n_tiles;
+    d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = abs_bb0; d.n_tiles = (int)g.n_tiles;
     d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>(); d.evthr = h->evthr.as<float>();
-    hipLaunchKernelGGL(k_detect, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
+    d.opt = rc.opt; d.gsum = h->gsum.as<TileSumG>(); d.evg = h->evg.as<uint16_t>();
+    if (rc.gen) hipLaunchKernelGGL(k_detect<true>, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
+    else hipLaunchKernelGGL(k_detect<false>, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
 
 // K3 (+ K4 when do_slice) on the summaries of launch_detect
-static int launch_scan_slice(p25fe_t* h, size_t n_bb, uint64_t abs_bb0, const p25fe_anchor_t* d_anchor_in,
+static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_anchor_t* d_anchor_in,
                              uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit,
                              size_t sync_stride, p25fe_result_t* d_result, bool do_slice, hipStream_t st,
-                             hipEvent_t ev_done = nullptr)
+                             const RecvCall& rc, hipEvent_t ev_done = nullptr)
 {
     // ev_done (nullable): attached to the LAST kernel this function launches (its completion = the receive side is done)
     const PlanarGeo g(n_bb);
     const int n_tiles = n_bb ? (int)g.n_tiles : 0;
+    const bool slice = do_slice && n_tiles != 0;
+    if (rc.gen) {
+        ScanArgsG c;
+        c.gsum = h->gsum.as<TileSumG>(); c.recs = h->recs.as<TileRec>(); c.outs = h->gouts.as<ScanOutG>();
+        c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
+        c.n_baseband = n_bb; c.track = h->track;
+        launch_ev(k_scan_g, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
+        HIPCHK(h, hipGetLastError());
+        prof_mark(h, 3, st);
+        if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
+        SliceArgsG l;
+        l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = abs_bb0; l.n_tiles = n_tiles;
+        l.outs = h->gouts.as<ScanOutG>(); l.gsum = h->gsum.as<TileSumG>(); l.recs = h->recs.as<TileRec>();
+        l.evl = h->evl.as<uint16_t>(); l.evg = h->evg.as<uint16_t>(); l.evthr = h->evthr.as<float>(); l.anchor_in = d_anchor_in;
+        l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
+        l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
+        l.sync_stride = (long)sync_stride; l.track = h->track;
+        launch_ev(k_slice_g, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, l);
+        HIPCHK(h, hipGetLastError());
+        prof_mark(h, 4, st);
+        return P25FE_OK;
+    }
     ScanArgs c;
     c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>();
-    c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = (long)abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
+    c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
     c.n_baseband = n_bb;
-    const bool slice = do_slice && n_tiles != 0;
     launch_ev(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 3, st);
     if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
     SliceArgs l;
-    l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = (long)abs_bb0; l.n_tiles = n_tiles;
+    l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = abs_bb0; l.n_tiles = n_tiles;
     l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.tsum = h->tsum.as<unsigned long long>();
     l.evl = h->evl.as<uint16_t>(); l.evthr = h->evthr.as<float>(); l.anchor_in = d_anchor_in;
     l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
@@ -554,18 +612,21 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
 {
     shard_invalidate(h);
     if (int jrc = pipe_join(h, st)) return jrc;
-    if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
-        return launch_scan_slice(h, 0, abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
-                                 false, st);
-    int rc = ensure_slice_scratch(h, n_bb);
+    const long view0 = (long)abs_bb0 - h->look;          // first processed index: the tracking clock runs h->look samples late
+    int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
+    const RecvCall rcall = recv_call(h);
+    h->rs_n = 0;                                         // the lock drops belong to this call
+    if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
+        return launch_scan_slice(h, 0, view0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
+                                 false, st, rcall);
     rc = launch_planarize(h, d_bb, bb_stride, n_hist_bb, n_bb, st);
     if (rc) return rc;
-    rc = launch_detect(h, n_bb, abs_bb0, st);
+    rc = launch_detect(h, n_bb, view0, st, rcall);
     if (rc) return rc;
     prof_mark(h, 2, st);
-    return launch_scan_slice(h, n_bb, abs_bb0, d_anchor_in, d_dibits, dibit_stride, d_sync_pos, d_sync_dibit,
-                             sync_stride, d_result, true, st);
+    return launch_scan_slice(h, n_bb, view0, d_anchor_in, d_dibits, dibit_stride, d_sync_pos, d_sync_dibit,
+                             sync_stride, d_result, true, st, rcall);
 }
 
 extern "C" {
@@ -698,6 +759,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     std::swap(h->pl_f, h->alt_pl_f); std::swap(h->pl_bits, h->alt_pl_bits); std::swap(h->evl, h->alt_evl);
     std::swap(h->evthr, h->alt_evthr); std::swap(h->recs, h->alt_recs); std::swap(h->tsum, h->alt_tsum);
     std::swap(h->outs, h->alt_outs);
+    std::swap(h->gsum, h->alt_gsum); std::swap(h->gouts, h->alt_gouts); std::swap(h->evg, h->alt_evg);
     h->lane ^= 1;
     const int lane = h->lane;
     if (h->rx_pending[lane]) {
@@ -710,9 +772,11 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     const PlanarGeo g(n_bb);
     hipEvent_t k1_done = h->ev_k1[lane];
     bool k1_done_attached = false;
+    rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);   // (growing a buffer frees the old one: hipFree synchronises the device)
+    if (rc) return rc;
+    const RecvCall rcall = recv_call(h);
+    h->rs_n = 0;
     if (n_bb) {
-        rc = ensure_slice_scratch(h, n_bb);          // (growing a buffer frees the old one: hipFree synchronises the device)
-        if (rc) return rc;
         prof_begin(h);
         prof_mark(h, 0, st);
         hipEvent_t e0, e1;
@@ -722,19 +786,19 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
             else e1 = k1_done;
             k1_done_attached = true;
         }
-        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g, 0, e0, e1);
+        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
         if (rc) return rc;
         prof_mark(h, 1, st);
     }
     if (!k1_done_attached) HIPCHK(h, hipEventRecord(k1_done, st));
     HIPCHK(h, hipStreamWaitEvent(h->rx_stream, k1_done, 0));
     if (n_bb) {
-        rc = launch_detect(h, n_bb, 0, h->rx_stream);
+        rc = launch_detect(h, n_bb, -h->look, h->rx_stream, rcall);
         if (rc) return rc;
         prof_mark(h, 2, h->rx_stream);
     }
-    rc = launch_scan_slice(h, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, n_bb != 0, h->rx_stream,
-                           h->ext_events ? h->ev_rx[lane] : nullptr);
+    rc = launch_scan_slice(h, n_bb, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, n_bb != 0, h->rx_stream,
+                           rcall, h->ext_events ? h->ev_rx[lane] : nullptr);
     h->prof_slot = -1;
     if (rc) return rc;
     if (!h->ext_events) HIPCHK(h, hipEventRecord(h->ev_rx[lane], h->rx_stream));
@@ -751,10 +815,12 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     shard_invalidate(h);
     if (int jrc = pipe_join(h, st)) return jrc;
     const size_t n_bb = p25fe_n_baseband(0, n);
-    if (n_bb == 0)
-        return launch_scan_slice(h, 0, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st);
-    int rc = ensure_slice_scratch(h, n_bb);
+    int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
+    const RecvCall rcall = recv_call(h);
+    h->rs_n = 0;
+    if (n_bb == 0)
+        return launch_scan_slice(h, 0, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st, rcall);
     const PlanarGeo g(n_bb);
     prof_begin(h);
     prof_mark(h, 0, st);
@@ -762,13 +828,13 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     prof_k1_events(h, &e0, &e1);
     // K1 writes the baseband straight into the polyphase layout (+ sign planes); the 240 history positions in front
     // of the stream come out as the zeros of a fresh DemodTask (outputs of an all-zero input)
-    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g, 0, e0, e1);
+    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
     if (rc) return rc;
     prof_mark(h, 1, st);
-    rc = launch_detect(h, n_bb, 0, st);
+    rc = launch_detect(h, n_bb, -h->look, st, rcall);
     if (rc) return rc;
     prof_mark(h, 2, st);
-    rc = launch_scan_slice(h, n_bb, 0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st);
+    rc = launch_scan_slice(h, n_bb, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall);
     h->prof_slot = -1;
     return rc;
 }
@@ -785,8 +851,8 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (int jrc = pipe_join(h, st)) return jrc;
     const size_t n_bb = p25fe_n_baseband(abs0, n);
-    const uint64_t abs_bb0 = p25fe_n_baseband(0, (size_t)abs0);      // baseband samples before this shard
-    int rc = ensure_slice_scratch(h, n_bb);
+    const long abs_bb0 = (long)p25fe_n_baseband(0, (size_t)abs0) - h->look;      // first processed baseband index of this shard
+    int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
     const PlanarGeo g(n_bb);
     // the receiver's 240 history samples are recomputed from the IQ halo (zeros before the start of the stream)
@@ -798,7 +864,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
             // that follows the halo wait is one workgroup), so an RCCL wait between the two is not in K1's figure
             hipEvent_t e0, e1;
             prof_k1_events(h, &e0, &e1);
-            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g,
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g,
                                  do_finish ? 0 : 1, e0, e1);
             if (rc) return rc;
         }
@@ -808,20 +874,22 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (!do_main) {
         if (h->sh_main_nbb != n_bb || h->sh_main_abs0 != abs0) return P25FE_ERR_ARG;     // finish without its main launch
         if (n_bb) {
-            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB, nullptr, 0, nullptr, st, &g, 2);
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g, 2);
             if (rc) return rc;
         }
     }
     prof_mark(h, 1, st);
+    const RecvCall rcall = recv_call(h);
+    h->rs_n = 0;
     if (n_bb) {
-        rc = launch_detect(h, n_bb, abs_bb0, st);
+        rc = launch_detect(h, n_bb, abs_bb0, st, rcall);
         if (rc) return rc;
     }
     prof_mark(h, 2, st);
-    rc = launch_scan_slice(h, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0, d_result, false, st);
+    rc = launch_scan_slice(h, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0, d_result, false, st, rcall);
     h->prof_slot = -1;
     if (rc) return rc;
-    h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0;
+    h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0; h->sh_gen = rcall.gen;
     h->sh_main_nbb = (size_t)-1;
     return P25FE_OK;
 }
@@ -851,17 +919,19 @@ int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_
     HIPCHK(h, hipSetDevice(h->cfg.device));
     prof_begin(h);
     prof_mark(h, 2, (hipStream_t)stream);
+    RecvCall rcall = recv_call(h);
+    rcall.gen = h->sh_gen;                               // K3 / K4 read what pass 1's K2 left (the lock drops are in its summaries)
     const int rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr,
-                                     0, d_result, true, (hipStream_t)stream);
+                                     0, d_result, true, (hipStream_t)stream, rcall);
     h->prof_slot = -1;
     return rc;
 }
 
 int p25fe_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
-                        size_t n_shards, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
+                        size_t n_shards, int symbol_clock, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {
     if (!summaries || !shard_bb0 || !shard_bb_n || !anchor_in || !dibit_offset) return P25FE_ERR_ARG;
-    shard_resolve_impl(summaries, shard_bb0, shard_bb_n, (int)n_shards, anchor_in, dibit_offset);
+    shard_resolve_impl(summaries, shard_bb0, shard_bb_n, (int)n_shards, symbol_clock, anchor_in, dibit_offset);
     return P25FE_OK;
 }
 
@@ -872,7 +942,7 @@ int p25fe_shard_resolve_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const
     if (!h || !d_summaries || !d_shard_bb0 || !d_shard_bb_n || !d_anchor_in || !d_dibit_offset) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_summaries, d_shard_bb0, d_shard_bb_n,
-                       (int)n_shards, d_anchor_in, d_dibit_offset);
+                       (int)n_shards, h->track, d_anchor_in, d_dibit_offset);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
@@ -967,7 +1037,7 @@ static int stream_slice_staged(p25fe_t* h, size_t n_bb, size_t bb_stride, uint8_
     float* base = h->bb_buf.as<float>();
     HIPCHK(h, hipMemcpy2DAsync(base, bb_stride * sizeof(float), h->tail_bb.p, BBPAD * sizeof(float),
                                BBPAD * sizeof(float), C, hipMemcpyDeviceToDevice, st));
-    const size_t max_d = n_bb / SPS + 2;
+    const size_t max_d = n_bb / (W + 1) + 2;             // hard ceiling: detections, hence re-anchors, are at least W + 1 samples apart
     const size_t dstride = round_up(max_d, 16);
     HIPCHK(h, h->dibits.ensure(C * dstride));
     const size_t sstride = sync_cap;
@@ -983,10 +1053,12 @@ static int stream_slice_staged(p25fe_t* h, size_t n_bb, size_t bb_stride, uint8_
     if (rc) return rc;
     std::vector<p25fe_result_t> res(C);
     HIPCHK(h, hipMemcpyAsync(res.data(), h->results.p, sizeof(p25fe_result_t) * C, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (size_t c = 0; c < C; ++c)
+        if (res[c].n_dibits > cap) return P25FE_ERR_CAPACITY;    // before any receiver state moves: the call can be repeated with more room
     // roll the tail: last BBPAD samples of [tail | new]
     HIPCHK(h, hipMemcpy2DAsync(h->tail_bb.p, BBPAD * sizeof(float), base + n_bb, bb_stride * sizeof(float),
                                BBPAD * sizeof(float), C, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipStreamSynchronize(st));
     for (size_t c = 0; c < C; ++c) {
         if (res[c].n_dibits)
             HIPCHK(h, hipMemcpyAsync(dibits + c * cap, h->dibits.as<uint8_t>() + c * dstride, res[c].n_dibits,
@@ -1172,7 +1244,17 @@ int p25fe_profile_read(p25fe_t* h, double ms[4], uint64_t* n_calls)
 int p25fe_resync(p25fe_t* h)
 {
     if (!h) return P25FE_ERR_ARG;
-    for (auto& a : h->anchor) a.valid = 0;
+    for (auto& a : h->anchor) a.valid = 0;      // lock and, with it, the clock estimate (the next sync word starts from 10 / 1)
+    return P25FE_OK;
+}
+
+int p25fe_resync_at_dev(p25fe_t* h, const int64_t* d_idx, size_t n_idx, size_t idx_stride)
+{
+    if (!h || (n_idx && !d_idx) || n_idx > 0x7fffffffu || (h->C > 1 && n_idx && idx_stride < n_idx)) return P25FE_ERR_ARG;
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    h->rs_idx = reinterpret_cast<const long*>(d_idx);
+    h->rs_n = n_idx;
+    h->rs_stride = idx_stride;
     return P25FE_OK;
 }
 

@@ -523,6 +523,8 @@ struct K1Args {
     long bbp_ch_stride;     // floats per channel (a whole number of blocks)
     uint8_t* bits;          // channel 0, addressed by byte
     long bits_ch_stride;    // bytes per channel
+    int pl_shift;           // output m sits at planar position m + pl_shift: PLPAD, or PLPAD + 2 when the receiver runs with
+                            // the tracking clock's lookahead (p25fe_recv.hip); (m_begin + pl_shift) % 80 == 0
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
     float* const bb_seg = OM == OUT_LINEAR ? bb + m_seg0 : nullptr;
     // planar: lane = (half h = tid >> 5, symbol tid & 31) holds, in outv[q], plane 5 h + q of the sub-tile's 32 symbols
     const int pl_sym = tid & 31, pl_h5 = (tid >> 5) * 5;
-    const int i_seg = OM == OUT_PLANAR ? (int)((m_seg0 + PLPAD) / SPS_) : 0;     // symbol index of the segment's first output (multiple of 8)
+    const int i_seg = OM == OUT_PLANAR ? (int)((m_seg0 + a.pl_shift) / SPS_) : 0;     // symbol index of the segment's first output (multiple of 8)
     float* const bbp_ch = OM == OUT_PLANAR ? a.bbp + (size_t)ch * a.bbp_ch_stride : nullptr;
     uint8_t* const bits_ch = OM == OUT_PLANAR ? a.bits + (size_t)ch * a.bits_ch_stride : nullptr;
     unsigned bitsv = 0u;                                            // lanes 0..39: byte (tid & 3) of plane (tid >> 2)
@@ -1482,20 +1484,44 @@ __global__ __launch_bounds__(256) void k_chan_stats(const p25fe_result_t* result
 // shard that has an event of its own, and its dibit offset adds the closed-form count of instants that the carry-in
 // governs before the shard's first own event.  Shared by the host entry point and the one-thread device kernel.
 __host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summaries, const uint64_t* shard_bb0,
-                                                    const uint64_t* shard_bb_n, int n_shards, p25fe_anchor_t* anchor_in,
-                                                    uint64_t* dibit_offset)
+                                                    const uint64_t* shard_bb_n, int n_shards, int symbol_clock,
+                                                    p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {
+    // With the tracking clock (SPEC 3.8b) a shard that owns baseband [lo, hi) processes [lo - L, hi - L), and the first
+    // own detection of a shard takes its period from the carry-in, which pass 1 did not know: its share of
+    // n_dibits_after_first (counted at the nominal 10 / 1) is replaced by the count under the real clock.
+    const bool track = symbol_clock != 0;
+    const long L = track ? CLK_L : 0;
     p25fe_anchor_t cur;
-    cur.s = 0; cur.hi = cur.mid = cur.lo = 0.f; cur.valid = 0;
+    cur.s = 0; cur.hi = cur.mid = cur.lo = 0.f; cur.valid = 0; cur.period_d = SPS; cur.period_n = 1;
     uint64_t off = 0;
     for (int r = 0; r < n_shards; ++r) {
         anchor_in[r] = cur;
         dibit_offset[r] = off;
-        const long lo = (long)shard_bb0[r], hi = (long)(shard_bb0[r] + shard_bb_n[r]);
-        const long pre_hi = summaries[r].first_event >= 0 ? (long)summaries[r].first_event + 1 : hi;
-        const uint64_t pre = cur.valid ? (uint64_t)count_instants(cur.s, lo, pre_hi) : 0;
-        off += pre + (summaries[r].first_event >= 0 ? summaries[r].n_dibits_after_first : 0);
-        if (summaries[r].first_event >= 0) cur = summaries[r].anchor_out;
+        const p25fe_result_t& R = summaries[r];
+        const long lo = (long)shard_bb0[r] - L, hi = (long)(shard_bb0[r] + shard_bb_n[r]) - L;
+        const long pre_hi = R.carry_end >= 0 ? (long)R.carry_end : hi;
+        const uint64_t pre = cur.valid ? (uint64_t)clock_count(cur.s, cur.period_d, cur.period_n, lo, pre_hi) : 0;
+        uint64_t own = R.first_event >= 0 ? R.n_dibits_after_first : 0;
+        const bool tracks = track && (R.flags & P25FE_RES_FIRST_TRACKS_CARRY) && cur.valid;
+        if (R.first_event >= 0 && tracks) {
+            const long s0 = (long)R.first_event - W;
+            int D0, N0;
+            clock_period(true, true, cur.s, s0, D0, N0);
+            own = own - (uint64_t)clock_count(s0, SPS, 1, s0 + W + 1, (long)R.first_seg_end) +
+                  (uint64_t)clock_count(s0, D0, N0, s0 + W + 1, (long)R.first_seg_end);
+        }
+        off += pre + own;
+        if (R.carry_end >= 0) {                                   // the shard has an event: the carry changes
+            if (R.anchor_out.valid) {
+                p25fe_anchor_t nxt = R.anchor_out;
+                if (nxt.period_n <= 0 || nxt.period_d <= 0) { nxt.period_d = SPS; nxt.period_n = 1; }
+                if (R.flags & P25FE_RES_OUT_PERIOD_FROM_CARRY) clock_period(track, tracks, cur.s, nxt.s, nxt.period_d, nxt.period_n);
+                cur = nxt;
+            } else {
+                cur.valid = 0;
+            }
+        }
     }
     dibit_offset[n_shards] = off;            // total: shard r holds offset[r + 1] - offset[r] dibits
 }
@@ -1514,10 +1540,10 @@ __global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, 
 }
 
 __global__ void k_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
-                                int n_shards, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
+                                int n_shards, int symbol_clock, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        shard_resolve_impl(summaries, shard_bb0, shard_bb_n, n_shards, anchor_in, dibit_offset);
+        shard_resolve_impl(summaries, shard_bb0, shard_bb_n, n_shards, symbol_clock, anchor_in, dibit_offset);
 }
 
 }  // namespace p25k

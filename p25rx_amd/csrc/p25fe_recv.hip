@@ -81,6 +81,74 @@ __host__ __device__ inline long count_instants(long s, long lo, long hi)
     return k1 >= k0 ? k1 - k0 + 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// General receiver (SPEC 3.8b tracking symbol clock, and lock drops inside a range -- MessageReceiver::resync,
+// src/recv.rs:136, 179, at given sample indices).  The fixed-stride receiver without lock drops keeps the kernels
+// below as they were (packed 8-byte tile summaries, phase arithmetic modulo 10); everything else runs the *_g forms.
+//
+// A detection at s has a symbol clock: instants at s + floor(j D / N), j = 1, 2, ..., D / N = 10 / 1 or the interval from
+// the previous sync word over its (rounded) symbol count.  It governs the instants with index in [s + W + 1, end),
+// end = the next detection's decision index + 1 or the next lock drop.  In mode 1 the receiver runs L = 2 samples
+// behind the baseband (the 4-tap interpolation around an instant in [i, i + 1) reads i - 1 .. i + 2): a range that
+// owns baseband [a, b) processes indices [a - L, b - L) -- the kernels simply see a range that starts L samples
+// earlier (K1 / k_planarize write sample m at planar position m + L + PLPAD); a lock drop before sample q kills the
+// instants with index >= q - L.
+// ------------------------------------------------------------------------------------------
+constexpr int CLK_L = P25FE_CLK_LOOKAHEAD;
+
+__host__ __device__ inline void clock_period(bool track, bool prev_valid, long s_prev, long s_new, int& D, int& N)
+{
+    D = SPS; N = 1;
+    if (track && prev_valid) {
+        const long dd = s_new - s_prev, nn = (dd + SPS / 2) / SPS;
+        const long err = dd > SPS * nn ? dd - SPS * nn : SPS * nn - dd;
+        if (nn >= 1 && dd <= (1L << P25FE_CLK_DMAX_LOG2) && (err << P25FE_CLK_TOL_SHIFT) <= SPS * nn) { D = (int)dd; N = (int)nn; }
+    }
+}
+// number of instants j >= 1 of a clock (D, N) with floor(j D / N) < x
+__host__ __device__ inline long clock_J(long x, int D, int N) { return x > 0 ? (x * (long)N - 1) / (long)D : 0; }
+// instants of the detection (s, D, N) with index in [lo, hi) that it governs (index > s + W)
+__host__ __device__ inline long clock_count(long s, int D, int N, long lo, long hi)
+{
+    if (lo < s + W + 1) lo = s + W + 1;
+    if (hi <= lo) return 0;
+    return clock_J(hi - s, D, N) - clock_J(lo - s, D, N);
+}
+
+struct RecvOpt {
+    int track;                  // SPEC 3.8b
+    int n_resync;               // lock drops per channel
+    const long* resync;         // [ch][resync_stride] ascending absolute baseband indices q (lock dropped before sample q); nullable
+    long resync_stride;
+};
+// first kill index f = q - L >= x of a channel's lock drops (LONG_MAX if none); L = the mode's lookahead
+__device__ __forceinline__ long first_kill(const RecvOpt& o, int ch, long x)
+{
+    if (o.n_resync == 0) return 0x7fffffffffffffffL;
+    const long* r = o.resync + (size_t)ch * o.resync_stride;
+    const long key = x + (o.track ? CLK_L : 0);
+    int lo = 0, hi = o.n_resync;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (r[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo < o.n_resync ? r[lo] - (o.track ? CLK_L : 0) : 0x7fffffffffffffffL;
+}
+
+// Per-tile summary of the general receiver (K2 -> K3 / K4), 32 bytes
+struct TileSumG {
+    unsigned pre_end1;          // (tile offset from which the carry-in anchor no longer governs) + 1; 0: the tile has no event of any kind
+    unsigned first1;            // first own detection's decision offset + 1; 0: none
+    unsigned end0;              // tile offset (exclusive) at which the first detection's governed interval ends
+    unsigned last1;             // last own detection's decision offset + 1
+    unsigned n_det_flags;       // detections (low 16 bits) | flags << 16
+    unsigned post_rest;         // instants governed by own detections 1 .. n_det - 1 (their clocks are known inside the tile)
+    int out_D, out_N;           // clock of the last detection, if G_OUT_PERIOD_KNOWN
+};
+constexpr unsigned G_FIRST_TRACKS = 1u;       // no lock drop between the tile's start and its first detection
+constexpr unsigned G_OUT_VALID = 2u;          // the tile ends locked on its last detection
+constexpr unsigned G_OUT_PERIOD_KNOWN = 4u;   // ... whose clock does not depend on the carry-in
+
 __device__ __forceinline__ unsigned char slice_dibit(float v, float hi, float mid, float lo)
 {
     return v >= hi ? 1 : v >= mid ? 0 : v >= lo ? 2 : 3;
@@ -173,6 +241,10 @@ struct DetArgs {
     unsigned long long* tsum;   // [ch][n_tiles]
     uint16_t* evl;          // [ch][n_tiles][EVCAP] decision offsets of the tile's detections, ascending
     float* evthr;           // [ch][n_tiles][EVTHR_N][3] slicer thresholds (hi, mid, lo) of the tile's first EVTHR_N detections
+    // general receiver only (k_detect<true>)
+    RecvOpt opt;
+    TileSumG* gsum;         // [ch][n_tiles]
+    uint16_t* evg;          // [ch][n_tiles][EVCAP] per detection: end offset of its governed interval | (tracks its predecessor) << 15
 };
 
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
@@ -180,7 +252,7 @@ constexpr int K2_DCAP = 64;                                      // detections p
 constexpr int K2_LANES = 60;                                     // 10 planes x 6 blocks of 4 words
 constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test
 
-__global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
+template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 3 : 4) void k_detect(DetArgs a)
 {
     __shared__ uint16_t HITS[K2_HCAP];
     __shared__ unsigned EVB[TS / 32];                            // detections of the tile, bit = decision offset
@@ -328,12 +400,20 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     }
     const int incl = wave_incl_sum(cnt, lane);
     const int n_ev = __shfl(incl, WV - 1, 64);
+    long kill0 = 0x7fffffffffffffffL;                            // GEN: first lock drop at or after the tile's start
+    if constexpr (GEN) kill0 = first_kill(a.opt, ch, a.abs0 + t0);
     if (n_ev == 0) {
         if (lane == 0) {
             TileRec rc;
             rc.first_event = -1; rc.last_s = -1; rc.hi = rc.mid = rc.lo = 0.f; rc.n_events = 0; rc.post_count = 0;
             a.recs[(size_t)ch * a.n_tiles + tile] = rc;
             a.tsum[(size_t)ch * a.n_tiles + tile] = 0ull;
+            if constexpr (GEN) {
+                TileSumG g;
+                g.pre_end1 = kill0 < a.abs0 + t0 + tn ? (unsigned)(kill0 - (a.abs0 + t0)) + 1u : 0u;   // a lock drop alone ends the carry-in
+                g.first1 = 0u; g.end0 = 0u; g.last1 = 0u; g.n_det_flags = 0u; g.post_rest = 0u; g.out_D = SPS; g.out_N = 1;
+                a.gsum[(size_t)ch * a.n_tiles + tile] = g;
+            }
         }
         return;
     }
@@ -360,6 +440,54 @@ __global__ __launch_bounds__(WV, 4) void k_detect(DetArgs a)
     }
     post = wave_sum_i(post);
     const int first_off = EVS[0], last_off = EVS[n_ev - 1];
+    if constexpr (GEN) {
+        // per detection k: where its governed interval ends (the next detection's decision index + 1, the next lock drop or
+        // the tile's end) and whether detection k + 1 may take its period from the interval s_k -> s_{k+1} (no drop between)
+        __shared__ uint16_t ENDO[EVCAP];
+        __shared__ uint8_t TRK[EVCAP];
+        const long T0 = a.abs0 + t0, TE = T0 + tn;
+        for (int k = lane; k < n_ev; k += WV) {
+            const long ek = T0 + EVS[k];
+            const long f = first_kill(a.opt, ch, ek + 1);
+            const long nxt = k + 1 < n_ev ? T0 + EVS[k + 1] + 1 : TE;
+            ENDO[k] = (uint16_t)((f < nxt ? f : nxt) - T0);
+            if (k + 1 < n_ev) TRK[k + 1] = f >= nxt ? 1 : 0;
+        }
+        if (lane == 0) TRK[0] = kill0 > T0 + first_off ? 1 : 0;
+        phase_sync();
+        uint16_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+        long rest = 0;
+        for (int k = lane; k < n_ev; k += WV) {
+            evg[k] = (uint16_t)(ENDO[k] | (TRK[k] << 15));
+            if (k >= 1) {
+                const long sk = T0 + EVS[k] - W, sp = T0 + EVS[k - 1] - W;
+                int D, N;
+                clock_period(a.opt.track != 0, TRK[k] != 0, sp, sk, D, N);
+                rest += clock_count(sk, D, N, sk + W + 1, T0 + ENDO[k]);
+            }
+        }
+        rest = (long)wave_sum_i((int)rest);
+        if (lane == 0) {
+            TileSumG g;
+            const long pe = kill0 < T0 + first_off + 1 ? kill0 : T0 + first_off + 1;
+            g.pre_end1 = (unsigned)(pe - T0) + 1u;
+            g.first1 = (unsigned)first_off + 1u;
+            g.end0 = ENDO[0];
+            g.last1 = (unsigned)last_off + 1u;
+            unsigned fl = TRK[0] ? G_FIRST_TRACKS : 0u;
+            if ((int)ENDO[n_ev - 1] == tn) fl |= G_OUT_VALID;
+            g.out_D = SPS; g.out_N = 1;
+            if (n_ev >= 2) {
+                fl |= G_OUT_PERIOD_KNOWN;
+                clock_period(a.opt.track != 0, TRK[n_ev - 1] != 0, T0 + EVS[n_ev - 2] - W, T0 + last_off - W, g.out_D, g.out_N);
+            } else if (!a.opt.track || !TRK[0]) {
+                fl |= G_OUT_PERIOD_KNOWN;                          // nominal period: nothing to take it from
+            }
+            g.n_det_flags = (unsigned)n_ev | (fl << 16);
+            g.post_rest = (unsigned)rest;
+            a.gsum[(size_t)ch * a.n_tiles + tile] = g;
+        }
+    }
     // thresholds of the first EVTHR_N detections (for K4) and of the last one (the anchor the tile hands on): looked up in
     // the remembered table, recomputed from the planes only if the tile had more detections than the table holds
     const int n_tab = DETN < (unsigned)K2_DCAP ? (int)DETN : K2_DCAP;
@@ -479,7 +607,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
     ScanOut* outs = a.outs + (size_t)ch * a.n_tiles;
     if (tid == 0) {
         p25fe_anchor_t A;
-        A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
+        A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f; A.period_d = SPS; A.period_n = 1;
         if (a.anchor_in) A = a.anchor_in[ch];
         c_valid = A.valid; c_s = A.s; c_src = -1;
         c_cnt = 0; c_ev = 0; c_first_event = -1; c_base_first = 0;
@@ -621,9 +749,13 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         if (c_src >= 0 && have_last_rec) {
             A.valid = 1; A.s = last_rec.last_s; A.hi = last_rec.hi; A.mid = last_rec.mid; A.lo = last_rec.lo;
         }
+        A.period_d = SPS; A.period_n = 1;                          // fixed stride (the tracking clock runs k_scan_g)
         r.anchor_out = A;
         r.first_event = c_first_event;
         r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
+        r.carry_end = c_first_event >= 0 ? c_first_event + 1 : -1;
+        r.first_seg_end = -1;                                      // only the tracking clock's resolve needs it
+        r.flags = 0u; r.reserved = 0u;
         a.result[ch] = r;
     }
 }
@@ -744,6 +876,334 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// K3 / K4 of the general receiver (tracking clock and / or lock drops inside the range).
+//
+// The receiver's state at a tile's first sample is the state after the latest tile that has an event (a detection or a
+// lock drop).  That state is: locked or not; if locked, the last detection's position and clock.  The clock of a tile's
+// LAST detection is known inside the tile unless that detection is the tile's only event and tracks the carry-in --
+// then it is the interval from the previous detection, i.e. from the event tile BEFORE: the state depends on the two
+// latest event tiles, never on more.  So one "latest two" scan gives every tile its carry-in, each tile's dibit count
+// follows independently in closed form (clock_count: two 64-bit divisions per anchor and interval), and a prefix sum
+// gives the offsets.
+// ------------------------------------------------------------------------------------------
+struct ScanOutG {               // per (channel, tile) carry-in written by k_scan_g
+    long s;                     // position of the detection in force at the tile's first sample
+    unsigned long long dibit_off;
+    int src;                    // tile whose record holds that detection's thresholds; -1: the range's anchor_in; -2: not locked
+    unsigned event_off;
+    int D, N;                   // its clock
+};
+
+struct ScanArgsG {
+    const TileSumG* gsum;
+    const TileRec* recs;
+    ScanOutG* outs;
+    int n_tiles;
+    long n;
+    long abs0;                          // absolute index of the first PROCESSED sample (owned sample 0 minus the lookahead)
+    const p25fe_anchor_t* anchor_in;    // nullable, [ch]
+    p25fe_result_t* result;             // [ch]
+    unsigned long long n_baseband;
+    int track;
+};
+
+struct Top2 { int a, b; };              // latest and second-latest event tile, -1: none
+__device__ __forceinline__ Top2 top2_merge(Top2 l, Top2 r)      // r is later than l
+{
+    Top2 o;
+    if (r.a < 0) return l;
+    o.a = r.a;
+    o.b = r.b >= 0 ? r.b : l.a;
+    return o;
+}
+__device__ __forceinline__ Top2 top2_shfl_up(Top2 v, int d)
+{
+    Top2 o;
+    o.a = __shfl_up(v.a, d, 64); o.b = __shfl_up(v.b, d, 64);
+    return o;
+}
+
+struct CState { int valid; long s; int D, N; int src; };
+
+__global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
+{
+    __shared__ unsigned CNT[K3_CHUNK], PRE[K3_CHUNK];
+    __shared__ Top2 sh2[NT3 / 64];
+    __shared__ unsigned long long shu[NT3 / 64];
+    __shared__ Top2 c_top;                                         // latest two event tiles before the chunk (global indices)
+    __shared__ unsigned long long c_cnt, c_ev, c_base_first;
+    __shared__ long c_first_event, c_carry_end, c_first_seg_end;
+    __shared__ unsigned c_flags;
+
+    const int tid = threadIdx.x, ch = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    const TileSumG* gsum = a.gsum + (size_t)ch * a.n_tiles;
+    const TileRec* recs = a.recs + (size_t)ch * a.n_tiles;
+    ScanOutG* outs = a.outs + (size_t)ch * a.n_tiles;
+    p25fe_anchor_t Ain;
+    Ain.valid = 0; Ain.s = 0; Ain.hi = Ain.mid = Ain.lo = 0.f; Ain.period_d = SPS; Ain.period_n = 1;
+    if (a.anchor_in) Ain = a.anchor_in[ch];
+    if (Ain.period_n <= 0 || Ain.period_d <= 0) { Ain.period_d = SPS; Ain.period_n = 1; }
+    const bool track = a.track != 0;
+    if (tid == 0) {
+        c_top.a = c_top.b = -1;
+        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_flags = 0u;
+    }
+    __syncthreads();
+
+    // state after event tile t1 (t2: the event tile before it, -1: the range's carry-in)
+    auto state_after = [&](int t1, int t2) -> CState {
+        CState st;
+        if (t1 < 0) { st.valid = Ain.valid; st.s = Ain.s; st.D = Ain.period_d; st.N = Ain.period_n; st.src = Ain.valid ? -1 : -2; return st; }
+        const TileSumG g = gsum[t1];
+        const unsigned fl = g.n_det_flags >> 16;
+        if (!(fl & G_OUT_VALID)) { st.valid = 0; st.s = 0; st.D = SPS; st.N = 1; st.src = -2; return st; }
+        st.valid = 1; st.src = t1; st.s = recs[t1].last_s;
+        if (fl & G_OUT_PERIOD_KNOWN) { st.D = g.out_D; st.N = g.out_N; return st; }
+        bool pv; long ps;
+        if (t2 >= 0) { pv = ((gsum[t2].n_det_flags >> 16) & G_OUT_VALID) != 0; ps = pv ? recs[t2].last_s : 0; }
+        else { pv = Ain.valid != 0; ps = Ain.s; }
+        clock_period(track, pv, ps, st.s, st.D, st.N);
+        return st;
+    };
+    auto tile_len = [&](int k) -> int {
+        const long rem = a.n - (long)k * TS;
+        return rem < TS ? (int)rem : TS;
+    };
+
+    for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
+        const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
+        const int per = (cn + NT3 - 1) / NT3;
+        const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
+        // ---- latest two event tiles of my run -> exclusive scan
+        Top2 mine; mine.a = mine.b = -1;
+        for (int k = k0; k < k1; ++k)
+            if (gsum[c0 + k].pre_end1) { mine.b = mine.a; mine.a = c0 + k; }
+        Top2 inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const Top2 o = top2_shfl_up(inc, d);
+            if (lane >= d) inc = top2_merge(o, inc);
+        }
+        if (lane == 63) sh2[wv] = inc;
+        __syncthreads();
+        Top2 carry = c_top;
+        for (int k = 0; k < wv; ++k) carry = top2_merge(carry, sh2[k]);
+        Top2 exc = top2_shfl_up(inc, 1);
+        if (lane == 0) { exc.a = exc.b = -1; }
+        exc = top2_merge(carry, exc);                              // latest two event tiles before my run
+        Top2 tot = c_top;
+        for (int k = 0; k < NT3 / 64; ++k) tot = top2_merge(tot, sh2[k]);
+        __syncthreads();
+
+        // ---- dibits / detections of every tile of my run
+        unsigned long long my_cnt = 0, my_ev = 0;
+        {
+            Top2 t2 = exc;
+            CState st = state_after(t2.a, t2.b);
+            for (int k = k0; k < k1; ++k) {
+                const TileSumG g = gsum[c0 + k];
+                const long T0 = a.abs0 + (long)(c0 + k) * TS, TE = T0 + tile_len(c0 + k);
+                const long pre_hi = g.pre_end1 ? T0 + (long)g.pre_end1 - 1 : TE;
+                const unsigned pre = st.valid ? (unsigned)clock_count(st.s, st.D, st.N, T0, pre_hi) : 0u;
+                unsigned tot_k = pre;
+                if (g.first1) {
+                    const long s0 = T0 + (long)g.first1 - 1 - W;
+                    int D0, N0;
+                    clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && st.valid, st.s, s0, D0, N0);
+                    tot_k += (unsigned)clock_count(s0, D0, N0, s0 + W + 1, T0 + g.end0) + g.post_rest;
+                }
+                PRE[k] = pre; CNT[k] = tot_k;
+                my_cnt += tot_k; my_ev += g.n_det_flags & 0xffffu;
+                if (g.pre_end1) { t2.b = t2.a; t2.a = c0 + k; st = state_after(t2.a, t2.b); }
+            }
+        }
+        unsigned long long tot_pk;
+        const unsigned long long ipk = block_incl_sum(my_cnt | (my_ev << 40), shu, tid, tot_pk);
+        // ---- carry-ins
+        {
+            unsigned long long dc = c_cnt + (ipk & ((1ull << 40) - 1)) - my_cnt, ec = c_ev + (ipk >> 40) - my_ev;
+            Top2 t2 = exc;
+            CState st = state_after(t2.a, t2.b);
+            for (int k = k0; k < k1; ++k) {
+                const TileSumG g = gsum[c0 + k];
+                ScanOutG o;
+                o.s = st.s; o.dibit_off = dc; o.src = st.src; o.event_off = (unsigned)ec; o.D = st.D; o.N = st.N;
+                outs[c0 + k] = o;
+                if (g.pre_end1 && t2.a < 0) {                      // the range's first event tile (one thread finds it)
+                    const long T0 = a.abs0 + (long)(c0 + k) * TS;
+                    c_carry_end = T0 + (long)g.pre_end1 - 1;
+                }
+                if (g.first1 && c_first_event < 0) {
+                    // the range's first detection: the one tile with detections and none before it (every earlier event
+                    // tile holds lock drops only) -- exactly one thread gets here with ec == 0
+                    if (ec == 0) {
+                        const long T0 = a.abs0 + (long)(c0 + k) * TS;
+                        c_first_event = T0 + (long)g.first1 - 1;
+                        c_first_seg_end = T0 + g.end0;
+                        c_base_first = dc + PRE[k];
+                        unsigned fl = 0u;
+                        if (((g.n_det_flags >> 16) & G_FIRST_TRACKS) && t2.a < 0) fl |= 1u;      // no lock drop between the range's start and it
+                        c_flags = fl;
+                    }
+                }
+                dc += CNT[k]; ec += g.n_det_flags & 0xffffu;
+                if (g.pre_end1) { t2.b = t2.a; t2.a = c0 + k; st = state_after(t2.a, t2.b); }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            c_top = tot;
+            c_cnt += tot_pk & ((1ull << 40) - 1);
+            c_ev += tot_pk >> 40;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const CState st = state_after(c_top.a, c_top.b);
+        p25fe_result_t r;
+        r.n_baseband = a.n_baseband;
+        r.n_dibits = c_cnt;
+        r.n_sync = c_ev;
+        p25fe_anchor_t A = Ain;
+        if (st.src >= 0) {
+            const TileRec t = recs[st.src];
+            A.valid = 1; A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo; A.period_d = st.D; A.period_n = st.N;
+        } else if (st.src == -2) {
+            A.valid = 0;
+        }
+        r.anchor_out = A;
+        r.first_event = c_first_event;
+        r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
+        r.carry_end = c_carry_end;
+        r.first_seg_end = c_first_seg_end;
+        unsigned fl = c_flags;
+        // the clock the range ends on was taken from the carry-in: its only event is one tracking detection
+        if (st.src >= 0 && c_top.b < 0 && !((gsum[c_top.a].n_det_flags >> 16) & G_OUT_PERIOD_KNOWN)) fl |= 2u;
+        r.flags = fl; r.reserved = 0u;
+        a.result[ch] = r;
+    }
+}
+
+struct SliceArgsG {
+    Planar pl;
+    long n;
+    long abs0;
+    int n_tiles;
+    const ScanOutG* outs;
+    const TileSumG* gsum;
+    const TileRec* recs;
+    const uint16_t* evl;
+    const uint16_t* evg;
+    const float* evthr;
+    const p25fe_anchor_t* anchor_in;
+    uint8_t* dibits;
+    long dibit_stride;
+    int64_t* sync_pos;
+    uint64_t* sync_dibit;
+    long sync_stride;
+    int track;
+};
+
+__global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
+{
+    __shared__ uint16_t EV[EVCAP], EG[EVCAP];
+    __shared__ float ETH[EVTHR_N * 3];
+    __shared__ float CI[P25FE_CLK_PHASES * 4];
+    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
+    const long t0 = (long)tile * TS;
+    const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
+    const ScanOutG so = a.outs[(size_t)ch * a.n_tiles + tile];
+    const TileSumG g = a.gsum[(size_t)ch * a.n_tiles + tile];
+    const int n_ev = (int)(g.n_det_flags & 0xffffu);
+    const bool track = a.track != 0;
+
+    int valid = 0;
+    float hi = 0.f, mid = 0.f, lo = 0.f;
+    if (so.src >= 0) {
+        const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
+        valid = 1; hi = t.hi; mid = t.mid; lo = t.lo;
+    } else if (so.src == -1 && a.anchor_in) {
+        const p25fe_anchor_t A = a.anchor_in[ch];
+        valid = A.valid; hi = A.hi; mid = A.mid; lo = A.lo;
+    }
+    if (!valid && n_ev == 0) return;
+    if (track) for (int k = lane; k < P25FE_CLK_PHASES * 4; k += WV) CI[k] = P25FE_CLK_INTERP[k];
+    if (n_ev) {
+        const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+        const uint16_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+        for (int k = lane; k < n_ev; k += WV) { EV[k] = evl[k]; EG[k] = evg[k]; }
+        if (lane < EVTHR_N * 3) ETH[lane] = a.evthr[((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3) + lane];
+    }
+    phase_sync();
+    uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
+    const long room = a.dibit_stride - (long)so.dibit_off;
+    const long T0 = a.abs0 + t0, TE = T0 + tn;
+
+    // instants of the clock (s, D, N) with index in [lo_, hi_) that it governs
+    auto emit = [&](long s, int D, int N, long lo_, long hi_, float h, float m, float l, int rank) -> int {
+        if (lo_ < s + W + 1) lo_ = s + W + 1;
+        if (hi_ <= lo_) return 0;
+        const long j_lo = clock_J(lo_ - s, D, N) + 1, j_hi = clock_J(hi_ - s, D, N);     // inclusive
+        const int count = (int)(j_hi - j_lo + 1);
+        uint8_t* dst = out + rank;
+        for (int j0 = 0; j0 < count; j0 += WV) {
+            const int idx = j0 + lane;
+            if (idx < count) {
+                const long num = (j_lo + idx) * (long)D;
+                long i; int q = 0;
+                if (N == 1) { i = s + num; }
+                else { const long qu = num / N; i = s + qu; q = (int)(((num - qu * N) * P25FE_CLK_PHASES) / N); }
+                const long p = i - a.abs0 + PLPAD;                 // planar position of the instant's integer sample
+                float v;
+                if (track) {
+                    float b[4];
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq) {
+                        const long pp = p - 1 + tq;
+                        const long sy = pp / SPS;
+                        b[tq] = f[planar_index(sy, (int)(pp - sy * SPS))];
+                    }
+                    const float* w = CI + 4 * q;
+                    v = w[0] * b[0];
+                    v = __builtin_fmaf(w[1], b[1], v);
+                    v = __builtin_fmaf(w[2], b[2], v);
+                    v = __builtin_fmaf(w[3], b[3], v);
+                } else {
+                    const long sy = p / SPS;
+                    v = f[planar_index(sy, (int)(p - sy * SPS))];
+                }
+                if (rank + idx < room) dst[idx] = slice_dibit(v, h, m, l);
+            }
+        }
+        return count;
+    };
+
+    int rank = 0;
+    if (valid) rank += emit(so.s, so.D, so.N, T0, g.pre_end1 ? T0 + (long)g.pre_end1 - 1 : TE, hi, mid, lo, 0);
+    for (int k = 0; k < n_ev; ++k) {
+        const long ek = T0 + EV[k], sk = ek - W;
+        const unsigned eg = EG[k];
+        int D, N;
+        if (k == 0) clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && valid, so.s, sk, D, N);
+        else clock_period(track, (eg >> 15) != 0, T0 + EV[k - 1] - W, sk, D, N);
+        float h, m, l;
+        if (k < EVTHR_N) {
+            h = ETH[3 * k]; m = ETH[3 * k + 1]; l = ETH[3 * k + 2];
+        } else {
+            float v[NSYN];
+            sync_gather(f, t0 + EV[k] - W + PLPAD, v);
+            sync_thresholds(v, h, m, l);
+        }
+        if (lane == 0 && a.sync_pos && (long)(so.event_off + k) < a.sync_stride) {
+            a.sync_pos[(size_t)ch * a.sync_stride + so.event_off + k] = sk;
+            a.sync_dibit[(size_t)ch * a.sync_stride + so.event_off + k] = so.dibit_off + (unsigned long long)rank;
+        }
+        rank += emit(sk, D, N, ek + 1, T0 + (long)(eg & 0x7fffu), h, m, l, rank);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // linear baseband -> planes + sign bits (entry points that receive a 48 kHz float stream).  Workgroup = 10 waves,
 // wave r fills 64 symbols of plane r: the ten waves read the same 2.5 KB of the linear stream (L1), every plane row
 // is written as one contiguous 256-byte store, and the ballot of the sign bits is the plane's 64-bit word.
@@ -758,14 +1218,15 @@ struct PlanarizeArgs {
     uint32_t* bits;
     long bits_ch;
     long n_blocks;          // blocks per channel
+    int shift;              // sample m goes to planar position m + shift + PLPAD (the general receiver's lookahead)
 };
 
 __global__ __launch_bounds__(WV * SPS) void k_planarize(PlanarizeArgs a)
 {
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6, ch = blockIdx.y;
     const long i = (long)blockIdx.x * WV + lane;                    // two blocks per workgroup
-    const long m = SPS * i + r - PLPAD;
-    const long hist = a.n_hist < HIST_BB ? a.n_hist : HIST_BB;
+    const long m = SPS * i + r - PLPAD - a.shift;
+    const long hist = a.n_hist < HIST_BB + a.shift ? a.n_hist : HIST_BB + a.shift;
     const float v = (m >= -hist && m < a.n) ? a.bb[(size_t)ch * a.bb_stride + m] : 0.0f;
     const bool in = (i >> 5) < a.n_blocks;
     if (in) a.f[(size_t)ch * a.f_ch + planar_index(i, r)] = v;

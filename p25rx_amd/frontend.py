@@ -19,11 +19,13 @@ def _p(a):
 
 
 class FrontEnd:
-    def __init__(self, n_channels=1, device=0, decim_taps=None, chan_taps=None):
+    def __init__(self, n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_clock=0):
         self.L = _lib.load()
         cfg = _lib.default_config()
         cfg.device = device
         cfg.n_channels = n_channels
+        cfg.symbol_clock = symbol_clock                          # 0: fixed stride (the reference's receiver), 1: SPEC 3.8b
+        self.symbol_clock = symbol_clock
         if decim_taps is not None:
             cfg.n_decim_taps = len(decim_taps)                   # the library rejects counts above P25FE_MAX_TAPS
             for i, v in enumerate(decim_taps[:_lib.MAX_TAPS]):
@@ -107,6 +109,21 @@ class FrontEnd:
 
     def reset(self):
         self._chk(self.L.p25fe_reset(self.h))
+
+    def resync_at_dev(self, idx):
+        """Lock drops for the NEXT receiver-running device call: idx = int64 device tensor [n] or [C, n] of ascending absolute
+        baseband indices (lock is dropped before each); None / empty cancels.  The tensor is kept alive by the wrapper."""
+        if idx is None or idx.numel() == 0:
+            self._rs = None
+            self._chk(self.L.p25fe_resync_at_dev(self.h, None, 0, 0))
+            return
+        import torch
+        assert idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()
+        if idx.dim() == 1:
+            idx = idx.unsqueeze(0).expand(self.C, -1).contiguous() if self.C > 1 else idx.unsqueeze(0)
+        assert idx.shape[0] == self.C
+        self._rs = idx
+        self._chk(self.L.p25fe_resync_at_dev(self.h, C.c_void_p(idx.data_ptr()), idx.shape[1], idx.stride(0)))
 
     def state_export(self):
         n = C.c_size_t(0)
@@ -363,7 +380,7 @@ class FrontEnd:
         n = len(summaries)
         anc = np.zeros(n, dtype=ANCHOR_DTYPE)
         off = np.zeros(n + 1, dtype=np.uint64)                   # [n] = total dibits of the capture
-        self._chk(self.L.p25fe_shard_resolve(_p(summaries), _p(bb0), _p(bbn), n, _p(anc), _p(off)))
+        self._chk(self.L.p25fe_shard_resolve(_p(summaries), _p(bb0), _p(bbn), n, self.symbol_clock, _p(anc), _p(off)))
         return anc, off
 
 

@@ -31,7 +31,7 @@ def test_header_symbols_all_exported(lib):
 
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
-    assert cfg.abi_version == lib.ABI_VERSION == 2 and cfg.n_channels == 1
+    assert cfg.abi_version == lib.ABI_VERSION == 3 and cfg.n_channels == 1 and cfg.symbol_clock == 0
     assert cfg.n_decim_taps == spec["t1"] and cfg.n_chan_taps == spec["t2"]
     assert np.array_equal(np.array(cfg.decim_taps[:spec["t1"]], dtype=np.float32), np.array(spec["decim_taps"], dtype=np.float32))
     assert np.array_equal(np.array(cfg.chan_taps[:spec["t2"]], dtype=np.float32), np.array(spec["chan_taps"], dtype=np.float32))
@@ -74,22 +74,41 @@ def test_shard_resolve_host_logic(lib):
     bb0 = np.array([0, 1000, 2000, 3000], dtype=np.uint64)
     bbn = np.array([1000, 1000, 1000, 1000], dtype=np.uint64)
     # shard 0: first event decided at 307 (s = 302), 69 dibits after it; shard 1: no sync; shard 2: re-anchors
-    summ[0]["first_event"], summ[0]["n_dibits_after_first"] = 307, 69
-    summ[0]["anchor_out"] = (302, 0.2, 0.0, -0.2, 1)
-    summ[1]["first_event"] = -1
-    summ[2]["first_event"], summ[2]["n_dibits_after_first"] = 2508, 49
-    summ[2]["anchor_out"] = (2503, 0.3, 0.1, -0.1, 1)
-    summ[3]["first_event"] = -1
+    summ[0]["first_event"], summ[0]["n_dibits_after_first"], summ[0]["carry_end"] = 307, 69, 308
+    summ[0]["anchor_out"] = (302, 0.2, 0.0, -0.2, 1, 10, 1)
+    summ[1]["first_event"] = summ[1]["carry_end"] = -1
+    summ[2]["first_event"], summ[2]["n_dibits_after_first"], summ[2]["carry_end"] = 2508, 49, 2509
+    summ[2]["anchor_out"] = (2503, 0.3, 0.1, -0.1, 1, 10, 1)
+    summ[3]["first_event"] = summ[3]["carry_end"] = -1
     anc = np.zeros(4, dtype=A)
     off = np.zeros(5, dtype=np.uint64)                         # n_shards + 1: the last entry is the capture's total
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, p(anc), p(off)) == 0
+    assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, 0, p(anc), p(off)) == 0
     assert anc["valid"].tolist() == [0, 1, 1, 1] and anc["s"].tolist()[1:] == [302, 302, 2503]
     inst = lambda s, lo, hi: len([n for n in range(lo, hi) if n > s and (n - s) % 10 == 0])
     exp1 = 69
     exp2 = exp1 + inst(302, 1000, 2000)
     exp3 = exp2 + inst(302, 2000, 2509) + 49
     assert off.tolist() == [0, exp1, exp2, exp3, exp3 + inst(2503, 3000, 4000)]
+    # a lock drop inside shard 1 (MessageReceiver::resync at sample 1500, no sync word after it): the carry of shard 0
+    # governs up to 1499, shards 2's own detection re-acquires
+    summ[1]["carry_end"] = 1500
+    assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, 0, p(anc), p(off)) == 0
+    assert anc["valid"].tolist() == [0, 1, 0, 1]
+    e2 = exp1 + inst(302, 1000, 1500)
+    assert off.tolist() == [0, exp1, e2, e2 + 49, e2 + 49 + inst(2503, 3000, 4000)]
+    # tracking clock: shard 2's one detection takes its period from the carry-in (2503 - 302 = 2201 -> 220 symbols, a
+    # period of 2201 / 220), which replaces the 10 / 1 that pass 1 assumed for its 49 dibits
+    summ[1]["carry_end"] = -1
+    summ[2]["first_seg_end"] = 3000 - 2
+    summ[2]["flags"] = 3                                      # FIRST_TRACKS_CARRY | OUT_PERIOD_FROM_CARRY
+    assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, 1, p(anc), p(off)) == 0
+    assert (int(anc["period_d"][3]), int(anc["period_n"][3])) == (2201, 220)
+    instq = lambda s, d, n, lo, hi: len([j for j in range(1, 2000) if lo <= s + (j * d) // n < hi and s + (j * d) // n > s + 5])
+    t1 = 69                                                   # shard 0 ends 2 samples early: it owns [-2, 998)
+    t2 = t1 + instq(302, 10, 1, 998, 1998)
+    t3 = t2 + instq(302, 10, 1, 1998, 2509) + 49 - instq(2503, 10, 1, 2509, 2998) + instq(2503, 2201, 220, 2509, 2998)
+    assert off.tolist() == [0, t1, t2, t3, t3 + instq(2503, 2201, 220, 2998, 3998)]
 
 
 def test_cpp_host_driver_built_and_fails_loudly_without_gpu(lib, tmp_path):

@@ -1,0 +1,235 @@
+"""GPU parity tests of the general symbol receiver: the tracking symbol clock (docs/SPEC.md 3.8b -- north_star's
+"symbol-clock interpolator") and lock drops INSIDE device-resident ranges (MessageReceiver::resync, src/recv.rs:136, 179,
+at given sample indices).  Everything is compared with the CPU oracle bit for bit: dibits, sync positions, sync dibit
+indices."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def FE():
+    from p25rx_amd.frontend import FrontEnd
+    return FrontEnd
+
+
+def oracle_recv(O, bb, mode, resync=()):
+    """The oracle's receiver over bb with resync() called before each listed sample index."""
+    r = O.Recv(O.make_config(symbol_clock=mode))
+    outs, o = [], 0
+    for q in sorted(resync):
+        q = min(max(int(q), 0), len(bb))
+        outs.append(r.feed(bb[o:q]))
+        r.resync()
+        o = q
+    outs.append(r.feed(bb[o:]))
+    return (np.concatenate([x[0] for x in outs]), np.concatenate([x[1] for x in outs]),
+            np.concatenate([x[2] for x in outs]).astype(np.uint64))          # (sync_dibit already counts the receiver's total)
+
+
+def dev_slice(fe, bb, resync=None, sync_cap=4096):
+    import torch
+    from p25rx_amd.frontend import parse_results
+    t = torch.from_numpy(np.ascontiguousarray(bb)).cuda()
+    if resync is not None:
+        fe.resync_at_dev(torch.tensor(sorted(int(q) for q in resync), dtype=torch.int64, device="cuda"))
+    dib, res, sp, sd = fe.slice_dev(t, len(bb), sync_cap=sync_cap)
+    r = parse_results(res)[0]
+    nd, ns = int(r["n_dibits"]), int(r["n_sync"])
+    return dib[0, :nd].cpu().numpy(), sp[0, :ns].cpu().numpy(), sd[0, :ns].cpu().numpy().astype(np.uint64), r
+
+
+def same(got, ref, what=""):
+    for k, name in enumerate(("dibits", "sync_pos", "sync_dibit")):
+        assert len(got[k]) == len(ref[k]), "%s %s: %d vs %d" % (what, name, len(got[k]), len(ref[k]))
+        assert np.array_equal(got[k], ref[k]), "%s %s differ" % (what, name)
+
+
+@pytest.mark.parametrize("ppm,frame", [(100.0, 3000), (-100.0, 3000), (35.0, 8640), (0.0, 864)])
+def test_tracking_clock_device_matches_oracle(O, FE, ppm, frame):
+    """Mode 1 on a capture with a sample-clock error: the device receiver (linear baseband in, and the fused IQ path whose K1
+    writes the planes two samples late) equals the oracle; every frame after the first decodes to the modulator's dibits."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    iq, truth, _ = c4fm.synth(4 * frame / 4800.0 + 0.3, seed=21, snr_db=30.0, frame_dibits=frame, clock_ppm=ppm)
+    iq = iq[:len(iq) // 8 * 8]
+    bb = O.Demod().feed_cf32(iq)
+    ref = oracle_recv(O, bb, 1)
+    assert len(ref[1]) >= 5
+    fe = FE(symbol_clock=1)
+    got = dev_slice(fe, bb)
+    same(got, ref, "slice_dev")
+    for k in range(1, len(ref[2]) - 1):                              # locked frames are error free
+        assert np.array_equal(ref[0][int(ref[2][k]):int(ref[2][k + 1])], truth[frame * k + 24:frame * (k + 1) + 24])
+    r = got[3]
+    a = r["anchor_out"]
+    if ppm:
+        assert int(a["period_n"]) == frame and abs(int(a["period_d"]) - frame * 10 * (1 + ppm * 1e-6)) <= 1.5
+    else:
+        assert (int(a["period_d"]), int(a["period_n"])) in ((10, 1), (frame * 10, frame))
+    # fused: IQ -> dibits in one pass
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    dib, res = fe.run_dev(t)
+    nd = int(parse_results(res)[0]["n_dibits"])
+    assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
+    # streaming through the host entry points, ragged chunks, state (anchor + clock) carried in the handle
+    fe2, rng = FE(symbol_clock=1), np.random.default_rng(3)
+    parts, o = [], 0
+    sizes = [1, 1, 2, 3, 239, 240, 241, 242, 243]
+    while o < len(bb):
+        n = sizes.pop(0) if sizes else int(rng.integers(1, 12000))
+        parts.append(fe2.slice(bb[o:o + n]))
+        o += n
+    same([np.concatenate([p[k] for p in parts]) for k in range(3)], ref, "streaming")
+    fe3 = FE(symbol_clock=1)
+    got3 = np.concatenate([fe3.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)])
+    assert np.array_equal(got3, ref[0])
+
+
+def test_tracking_clock_on_a_nominal_clock_equals_the_fixed_stride(O, FE, c4fm_1s):
+    bb = O.Demod().feed_cf32(c4fm_1s[0])
+    fix, trk = dev_slice(FE(), bb), dev_slice(FE(symbol_clock=1), bb)
+    n = len(trk[0])
+    assert len(fix[0]) - 1 <= n <= len(fix[0]) and np.array_equal(trk[0], fix[0][:n])
+    assert np.array_equal(trk[1], fix[1]) and np.array_equal(trk[2], fix[2])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_dense_events_general_receiver(O, FE, mode):
+    """Dozens of detections per tile, with and without lock drops between them, under both clocks."""
+    from p25rx_amd import c4fm
+    rng = np.random.default_rng(78)
+    pieces = []
+    for fd, snr, amp, toff in ((26, 25.0, 0.5, 0), (140, 14.0, 0.25, 3), (31, 30.0, 0.1, 41), (1200, 25.0, 0.4, 7)):
+        pieces.append(c4fm.synth(0.6, seed=300 + fd, snr_db=snr, frame_dibits=fd, amplitude=amp, timing_offset=toff)[0])
+        pieces.append((0.3 * (rng.standard_normal(5003) + 1j * rng.standard_normal(5003))).astype(np.complex64))
+    bb = O.Demod().feed_cf32(np.concatenate(pieces))
+    ref0 = oracle_recv(O, bb, mode)
+    assert len(ref0[1]) > 200
+    same(dev_slice(FE(symbol_clock=mode), bb, resync=[len(bb) + 1000]), ref0, "no drops")     # (a drop past the end: the general kernels run in mode 0 too)
+    # lock drops: right at decision indices of dense detections, between them, many in one tile, duplicates
+    sp = ref0[1]
+    drops = [int(sp[10]) + 5, int(sp[10]) + 6, int(sp[11]) + 4, int(sp[40]) + 5 + 2 * mode, int(sp[41]) + 6 + 2 * mode,
+             int(sp[41]) + 6 + 2 * mode, int(sp[90]) + 100] + [int(x) for x in rng.integers(0, len(bb), size=60)]
+    ref = oracle_recv(O, bb, mode, drops)
+    same(dev_slice(FE(symbol_clock=mode), bb, resync=drops), ref, "60 drops")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_resync_inside_device_ranges(O, FE, mode):
+    """MessageReceiver::resync at sample indices inside ONE device range (src/recv.rs:127-137, 179): at a sync word's
+    decision index, one sample either side, inside an event-free tile, on tile boundaries, at 0, past the end."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    iq, truth, _ = c4fm.synth(2.5, seed=5, snr_db=28.0)
+    iq = iq[:len(iq) // 8 * 8]
+    bb = O.Demod().feed_cf32(iq)
+    L = 2 * mode
+    free = oracle_recv(O, bb, mode)
+    sp = [int(x) for x in free[1]]
+    assert len(sp) >= 13
+    e = [s + 5 for s in sp]                                          # decision indices (s + W)
+    tile = 7680
+    quiet = [t for t in range(len(bb) // tile) if not any(t * tile <= x + L < (t + 1) * tile for x in e)]
+    assert quiet
+    cases = {
+        "at the decision index": [e[2] + L], "one before": [e[2] + L - 1], "one after": [e[2] + L + 1], "two after": [e[2] + L + 2],
+        "event-free tile": [quiet[0] * tile + 3000], "tile boundary": [2 * tile], "tile boundary + 1": [2 * tile + 1],
+        "tile boundary - 1": [3 * tile - 1], "at zero": [0], "at one": [1], "last sample": [len(bb) - 1], "past the end": [len(bb) + 50],
+        "inside a sync word": [sp[4] - 100], "several": [e[1] + L, e[3] + L + 1, quiet[0] * tile + 10, quiet[0] * tile + 11, e[7] + L - 1, 9 * tile],
+    }
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    for name, drops in cases.items():
+        ref = oracle_recv(O, bb, mode, drops)
+        fe = FE(symbol_clock=mode)
+        same(dev_slice(fe, bb, resync=drops), ref, name)
+        assert len(ref[0]) < len(free[0]) or name in ("past the end", "last sample", "at zero", "at one")
+        # the list is consumed by the call: the next one on the handle runs free
+        same(dev_slice(fe, bb), free, name + " (next call)")
+        # fused path
+        fe.resync_at_dev(torch.tensor(sorted(drops), dtype=torch.int64, device="cuda"))
+        dib, res = fe.run_dev(t)
+        nd = int(parse_results(res)[0]["n_dibits"])
+        assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0]), name + " (run_dev)"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_time_shards_with_tracking_clock_and_lock_drops(O, FE, mode):
+    """Config 5's shard / resolve / pass 2 with the general receiver: carry-in clocks across shards, a shard whose only
+    event is a lock drop, a shard with one detection that takes its period from the previous shard."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results, n_baseband
+    iq, _, _ = c4fm.synth(3.0, seed=34, snr_db=24.0, frame_dibits=1500, clock_ppm=80.0 if mode else 0.0)
+    iq = iq[:len(iq) // 8 * 8]
+    bb = O.Demod().feed_cf32(iq)
+    free = oracle_recv(O, bb, mode)
+    sp = [int(x) for x in free[1]]
+    drops = [sp[3] + 5 + 2 * mode, 100000 // 5 + 4000, 310006 // 5 + 50, 310006 // 5 + 60]
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    for rs in ([], drops):
+        ref = oracle_recv(O, bb, mode, rs)
+        fe = FE(symbol_clock=mode)
+        halo = fe.shard_halo()
+        cuts = [0, 100004, 100004 + 3002, 200008, 310006, 400000, len(iq)]
+        fes = [FE(symbol_clock=mode) for _ in range(len(cuts) - 1)]
+        d_rs = torch.tensor(sorted(rs), dtype=torch.int64, device="cuda") if rs else None
+        summ, bb0, bbn = [], [], []
+        for r in range(len(cuts) - 1):
+            a, b = cuts[r], cuts[r + 1]
+            h = min(a, halo)
+            fes[r].resync_at_dev(d_rs)
+            if r % 2:
+                fes[r].shard_pass1_main(t[a - h:b], offset=h, n_hist=h, abs0=a)
+                res = fes[r].shard_pass1_finish(t[a - h:b], offset=h, n_hist=h, abs0=a)
+            else:
+                res = fes[r].shard_pass1(t[a - h:b], offset=h, n_hist=h, abs0=a)
+            summ.append(parse_results(res)[0])
+            bb0.append(n_baseband(0, a))
+            bbn.append(n_baseband(a, b - a))
+        anc, off = fe.shard_resolve(np.array(summ), bb0, bbn)
+        out = []
+        for r in range(len(cuts) - 1):
+            dib, res = fes[r].shard_pass2(anc[r:r + 1], bbn[r], t.device)
+            k = int(parse_results(res)[0]["n_dibits"])
+            assert off[r] == sum(len(x) for x in out), "shard %d offset" % r
+            out.append(dib[0, :k].cpu().numpy())
+        got = np.concatenate(out)
+        assert int(off[-1]) == len(got) == len(ref[0]) and np.array_equal(got, ref[0]), "drops %s" % rs
+        summ_t = torch.from_numpy(np.frombuffer(np.array(summ).tobytes(), dtype=np.uint8).copy()).view(len(summ), -1).cuda()
+        d_anc, d_off = fe.shard_resolve_dev(summ_t, torch.tensor(bb0, dtype=torch.int64, device="cuda"),
+                                            torch.tensor(bbn, dtype=torch.int64, device="cuda"))
+        assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), off) and d_anc.cpu().numpy().tobytes() == anc.tobytes()
+
+
+def test_dibit_row_capacity_is_a_hard_bound(O, FE, c4fm_1s):
+    """dibit_stride is the capacity: a row too short for the range's dibits is filled to the brim, the count stays exact,
+    nothing is written past the row (a clock offset makes a range hold more than n / 10 dibits)."""
+    import ctypes as C
+    import torch
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.frontend import parse_results
+    bb = O.Demod().feed_cf32(c4fm_1s[0])
+    ref = O.Recv().feed(bb)[0]
+    fe = FE()
+    t = torch.from_numpy(bb).cuda()
+    for cap in (0, 1, 777, len(ref) - 1, len(ref), len(ref) + 5):
+        buf = torch.full((cap + 4096,), 0xEE, dtype=torch.uint8, device="cuda")
+        res = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        fe._chk(fe.L.p25fe_slice_dev(fe.h, C.c_void_p(t.data_ptr()), len(bb), 0, len(bb), 0, None,
+                                     C.c_void_p(buf.data_ptr() + 2048), cap, None, None, 0, C.c_void_p(res.data_ptr()),
+                                     fe._stream()))
+        assert int(parse_results(res)[0]["n_dibits"]) == len(ref)
+        got = buf.cpu().numpy()
+        k = min(cap, len(ref))
+        assert np.array_equal(got[2048:2048 + k], ref[:k])
+        assert np.all(got[:2048] == 0xEE) and np.all(got[2048 + k:] == 0xEE), "cap %d" % cap

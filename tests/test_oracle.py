@@ -259,3 +259,58 @@ def test_channeliser_oracle(spec):
     f_est = np.angle(np.sum(seg[1:] * np.conj(seg[:-1]))) * 240000 / (2 * np.pi)
     assert abs(f_est - d) < 1.0
     assert np.abs(yt[(c + 40) % 192, 100:]).max() < 1e-3             # 500 kHz away: stop band of the prototype
+
+
+# ---- SPEC 3.8b: tracking symbol clock (north_star's "symbol-clock interpolator") -----------------------------------
+def frames_ok(dib, sdib, truth, frame):
+    """Per sync event k: the dibits it governs (up to the next event) against the modulator's symbols that follow
+    sync word k (its own 24 dibits are not emitted: the detection is decided at the word's last symbol)."""
+    ok = []
+    for k in range(len(sdib) - 1):
+        got = dib[int(sdib[k]):int(sdib[k + 1])]
+        want = truth[frame * k + 24:frame * (k + 1) + 24]
+        ok.append(len(got) == len(want) and np.array_equal(got, want))
+    return ok
+
+
+def test_tracking_clock_equals_fixed_stride_on_a_nominal_clock(c4fm_1s):
+    """Sync words exactly 8640 samples apart give the period 8640 / 864 = 10 / 1: phase 0 of the interpolator is the
+    identity row, so mode 1 emits the same dibits and events as the reference-shaped fixed stride (2 samples later)."""
+    iq, truth, _ = c4fm_1s
+    bb = O.Demod().feed_cf32(iq)
+    ref = O.Recv().feed(bb)
+    trk = O.Recv(O.make_config(symbol_clock=1)).feed(bb)
+    n = len(trk[0])
+    assert len(ref[0]) - 1 <= n <= len(ref[0]) and np.array_equal(trk[0], ref[0][:n])     # the last instant may wait for its lookahead
+    assert np.array_equal(trk[1], ref[1]) and np.array_equal(trk[2], ref[2])
+
+
+@pytest.mark.parametrize("ppm,frame", [(100.0, 3000), (-100.0, 3000), (35.0, 8640)])
+def test_tracking_clock_follows_a_sample_clock_error(ppm, frame):
+    """+-100 ppm with 0.625 s between sync words, 35 ppm with 1.8 s: the fixed stride walks 3 samples off the eye inside a
+    frame and loses symbols (the integrate-and-dump eye closes at ~1.7 samples for a +3 -> -3 transition); with the
+    period taken from the previous sync-to-sync interval every frame after the first decodes to the modulator's dibits.
+    (The symbol count of an interval is round(interval / 10): unambiguous while ppm x interval + the +-1 sample jitter
+    of two detections stays below 5 samples -- the limit of ANY scheme that infers the count from the gap alone,
+    interpolation between consecutive sync words included; 100 ppm x 1.8 s = 8.6 samples is beyond it.)"""
+    n_frames = 5
+    iq, truth, _ = c4fm.synth((n_frames - 1) * frame / 4800.0 + 0.3, seed=21, snr_db=30.0, frame_dibits=frame, clock_ppm=ppm)
+    bb = O.Demod().feed_cf32(iq)
+    fix = O.Recv().feed(bb)
+    trk = O.Recv(O.make_config(symbol_clock=1)).feed(bb)
+    assert len(trk[1]) == len(fix[1]) == n_frames and np.array_equal(trk[1], fix[1])
+    d = np.diff(trk[1])
+    assert np.all(np.abs(d - frame * 10 * (1 + ppm * 1e-6)) <= 1.5)           # the intervals the period estimates come from
+    ok_fix, ok_trk = frames_ok(*fix[::2], truth, frame), frames_ok(*trk[::2], truth, frame)
+    assert not any(ok_fix)                                                     # every frame of the fixed stride is damaged
+    assert not ok_trk[0] and all(ok_trk[1:])                                   # first frame: no estimate yet; then locked
+    # chunk invariance holds in mode 1 too (any chunking, state carried)
+    r = O.Recv(O.make_config(symbol_clock=1))
+    rng = np.random.default_rng(5)
+    outs, off = [], 0
+    while off < len(bb):
+        n = int(rng.integers(1, 5000))
+        outs.append(r.feed(bb[off:off + n]))
+        off += n
+    for q in range(3):
+        assert np.array_equal(np.concatenate([o[q] for o in outs]), trk[q])

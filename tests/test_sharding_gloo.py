@@ -49,11 +49,12 @@ class OracleShardFE:
         st = r.state()
         summ = np.zeros(1, dtype=self._lib.RESULT_DTYPE)
         summ["n_baseband"] = nb
-        summ["first_event"] = -1
+        summ["first_event"] = summ["carry_end"] = -1
         if len(spos):
             summ["first_event"] = spos[0] + base + self.W
+            summ["carry_end"] = summ["first_event"] + 1
             summ["n_dibits_after_first"] = len(dib)
-            summ["anchor_out"] = (st["s"] + base, st["hi"], st["mid"], st["lo"], 1)
+            summ["anchor_out"] = (st["s"] + base, st["hi"], st["mid"], st["lo"], 1, 10, 1)
         out = torch.from_numpy(np.frombuffer(summ.tobytes(), dtype=np.uint8).copy()).view(1, -1)
         if result is not None:
             result.copy_(out)
@@ -83,7 +84,7 @@ class OracleShardFE:
         anc = np.zeros(n, dtype=self._lib.ANCHOR_DTYPE)
         off = np.zeros(n + 1, dtype=np.uint64)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        assert L.p25fe_shard_resolve(p(summaries), p(bb0), p(bbn), n, p(anc), p(off)) == 0
+        assert L.p25fe_shard_resolve(p(summaries), p(bb0), p(bbn), n, 0, p(anc), p(off)) == 0
         return anc, off
 
     def shard_resolve_dev(self, summ_all, d_bb0, d_bbn, anchors=None, offsets=None):

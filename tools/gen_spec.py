@@ -28,6 +28,10 @@ nid        : network identifier that follows the frame sync: 16 data bits (NAC 1
              code word + 1 extra bit; generator polynomial 6331141367235453 (octal, TIA-102.BAAA).  This script
              verifies that g(x) has degree 47, divides x^63 + 1 and gives minimum weight 23 (it refuses otherwise).
 sync       : P25 frame sync word 0x5575F5FF77FF (TIA-102.BAAA), dibit 01 -> +3, 11 -> -3.
+clock      : tracking symbol clock (SPEC 3.8b): 64 x 4 table of cubic-Lagrange interpolation weights for the samples at
+             -1, 0, +1, +2 around a fractional instant mu = q / 64 (row 0 is exactly 0, 1, 0, 0, so that a period of exactly
+             10 samples reproduces the fixed-stride receiver bit for bit); lookahead 2 samples; a sync-to-sync interval
+             D = 10 N + r is accepted as a period estimate D / N when |r| * 1024 <= 10 N and D <= 2^24.
 """
 import json
 import os
@@ -46,6 +50,18 @@ SPS = 10                      # baseband samples per symbol (48000 / 4800)
 SYNC_WORD = 0x5575F5FF77FF    # 48 bits, 24 dibits
 SYNC_DIBITS = 24
 NID_GEN_POLY = int("6331141367235453", 8)
+CLK_PHASES, CLK_TAPS, CLK_LOOKAHEAD, CLK_TOL_SHIFT, CLK_DMAX_LOG2 = 64, 4, 2, 10, 24
+
+
+def interp_table():
+    rows = []
+    for q in range(CLK_PHASES):
+        mu = q / float(CLK_PHASES)
+        rows.append([-mu * (mu - 1.0) * (mu - 2.0) / 6.0, (mu + 1.0) * (mu - 1.0) * (mu - 2.0) / 2.0,
+                     -(mu + 1.0) * mu * (mu - 2.0) / 2.0, (mu + 1.0) * mu * (mu - 1.0) / 6.0])
+    t = np.array(rows, dtype=np.float64)
+    assert np.allclose(t.sum(axis=1), 1.0) and list(t[0]) == [0.0, 1.0, 0.0, 0.0]
+    return t.astype(np.float32)
 
 
 def kaiser_sinc(ntaps, cutoff_hz, fs, beta):
@@ -151,6 +167,8 @@ def main():
         "chz_w": [[float(np.float32(np.round(np.cos(2 * np.pi * k / CHZ_M), 15))),     # quarter turns exactly 0 / +-1
                    float(np.float32(np.round(np.sin(2 * np.pi * k / CHZ_M), 15)))] for k in range(CHZ_M)],
         "nid_gen_poly": NID_GEN_POLY, "nid_rows": nid_rows, "nid_t": 11, "nid_status_pos": 35,
+        "clk_phases": CLK_PHASES, "clk_lookahead": CLK_LOOKAHEAD, "clk_tol_shift": CLK_TOL_SHIFT, "clk_dmax_log2": CLK_DMAX_LOG2,
+        "clk_interp": [[float(v) for v in row] for row in interp_table()],
     }
 
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
@@ -207,6 +225,11 @@ def main():
     h.append("\n/* channeliser (SPEC 3.11): e^{+j 2 pi k / 192} as (cos, sin) pairs, k = 0..191 */\n")
     h.append("#define P25FE_CHZ_CHANNELS %d       /* 2.4 Msps / 12.5 kHz raster */\n" % CHZ_M)
     h.append(arr("P25FE_CHZ_W", [v for pair in spec["chz_w"] for v in pair]))
+    h.append("\n/* tracking symbol clock (SPEC 3.8b): cubic-Lagrange weights of the samples at -1, 0, +1, +2 for mu = q / 64 */\n")
+    h.append("#define P25FE_CLK_PHASES %d\n#define P25FE_CLK_LOOKAHEAD %d     /* samples the receiver runs behind the baseband */\n" % (CLK_PHASES, CLK_LOOKAHEAD))
+    h.append("#define P25FE_CLK_TOL_SHIFT %d    /* interval 10 N + r accepted as a period when |r| << shift <= 10 N */\n" % CLK_TOL_SHIFT)
+    h.append("#define P25FE_CLK_DMAX_LOG2 %d    /* ... and the interval is at most 2^24 samples */\n" % CLK_DMAX_LOG2)
+    h.append(arr("P25FE_CLK_INTERP", [v for row in interp_table() for v in row]))
     h.append("\n#endif /* P25FE_SPEC_H */\n")
     os.makedirs(os.path.join(ROOT, "include"), exist_ok=True)
     with open(os.path.join(ROOT, "include", "p25fe_spec.h"), "w") as f:
