@@ -408,12 +408,18 @@ def main():
     # driver's `--steps 20 --warmup 5` is a 6 ms timed region behind 1.5 ms of warm-up and otherwise times the clock ramp
     t_pw = time.perf_counter()
     n_prewarm = 0
-    while (time.perf_counter() - t_pw) * 1e3 < PREWARM_MS:
-        for _ in range(16):
+    if world == 1:
+        while (time.perf_counter() - t_pw) * 1e3 < PREWARM_MS:
+            for _ in range(16):
+                step()
+            fe.join_dev()
+            torch.cuda.synchronize()
+            n_prewarm += 16
+    elif not staged:
+        n_prewarm = 256                                           # N > 1: the same count on every rank (the steps hold collectives)
+        for _ in range(n_prewarm):
             step()
-        fe.join_dev()
         torch.cuda.synchronize()
-        n_prewarm += 16
     for _ in range(args.warmup):
         step()
     fe.join_dev()

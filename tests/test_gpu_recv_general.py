@@ -152,7 +152,8 @@ def test_resync_inside_device_ranges(O, FE, mode):
         ref = oracle_recv(O, bb, mode, drops)
         fe = FE(symbol_clock=mode)
         same(dev_slice(fe, bb, resync=drops), ref, name)
-        assert len(ref[0]) < len(free[0]) or name in ("past the end", "last sample", "at zero", "at one")
+        if name in ("event-free tile", "several", "inside a sync word", "tile boundary"):
+            assert len(ref[0]) < len(free[0])                        # symbols between the drop and the next sync word are lost
         # the list is consumed by the call: the next one on the handle runs free
         same(dev_slice(fe, bb), free, name + " (next call)")
         # fused path
