@@ -22,7 +22,7 @@ namespace {
 
 constexpr size_t HISTPAD = 448;      // >= HIST_IQ_MAX (432 with 64 + 64 taps), multiple of 8: keeps 16-B alignment for u8 and cf32
 static_assert(HISTPAD >= (size_t)HIST_IQ_MAX && HISTPAD % 8 == 0, "stream history covers the longest filters");
-constexpr size_t BBPAD = 256;        // >= HIST_BB (240), multiple of 4
+constexpr size_t BBPAD = 256;        // >= HIST_BB (240) + the tracking clock's lookahead, multiple of 4
 constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 5 * 256 + 448 = 1728 samples (13.8 KB of cf32)
 constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
 
@@ -43,7 +43,42 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// pinned host memory that the device reads and writes in place (the streaming entry points' staging and result buffers)
+struct PinBuf {
+    void* p = nullptr;          // host view
+    void* dp = nullptr;         // device view of the same bytes
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        e = hipHostGetDevicePointer(&dp, p, 0);
+        if (e != hipSuccess) { (void)hipHostFree(p); p = dp = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = dp = nullptr; cap = 0; }
+};
+
 inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// carve `bytes` (rounded up to 64) out of a pinned arena; returns the host pointer, *dev = the device view
+struct Arena {
+    char* hp; char* dp; size_t off = 0;
+    Arena(const PinBuf& b) : hp(static_cast<char*>(b.p)), dp(static_cast<char*>(b.dp)) {}
+    template <class T> T* take(size_t count, T** dev)
+    {
+        T* r = reinterpret_cast<T*>(hp + off);
+        *dev = reinterpret_cast<T*>(dp + off);
+        off += round_up(count * sizeof(T), 64);
+        return r;
+    }
+};
+
+
 
 // Kernel launch with optional events ATTACHED TO THE DISPATCH (hipExtLaunchKernelGGL): the start / stop events are
 // signalled by the kernel's own AQL packet, where hipEventRecord would put one more barrier packet (and its release) in
@@ -58,6 +93,8 @@ inline void launch_ev(void (*kern)(Args...), dim3 grid, dim3 block, size_t lds, 
 inline size_t fmt_bytes(int fmt) { return fmt == P25FE_FMT_CF32 ? 8 : 2; }
 
 }  // namespace
+
+static_assert(BBPAD == (size_t)TAILN && BBPAD >= (size_t)HIST_BB + CLK_L, "baseband tail kept between calls");
 
 struct p25fe {
     p25fe_config_t cfg;
@@ -77,7 +114,8 @@ struct p25fe {
     const long* rs_idx = nullptr;
     size_t rs_n = 0, rs_stride = 0;
     // scratch
-    DevBuf iq_stage, bb_buf, pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, power_out, results, anchors, dibits, sync_pos, sync_dibit;
+    DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, chunk_cnt;
+    PinBuf hin, hbb, hout;                 // streaming entry points: staged input ([history | new] IQ, [tail | new] baseband), results
     DevBuf gsum, gouts, evg;               // general receiver only (tracking clock / lock drops): allocated on first use
     // p25fe_run_dev_pipelined: a second set of the receiver's scratch (the member names above always are the set of the
     // current call; the sets are swapped per call), the stream the receive kernels run on, and the events that order
@@ -94,9 +132,9 @@ struct p25fe {
     // stream state (per channel, channel-major in the device buffers)
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
-    DevBuf hist_iq;                        // [C][HISTPAD] raw samples
+    std::vector<char> hist_iq;             // [C][SHARD_HALO] raw samples (8 bytes reserved per sample), host side
     uint64_t abs_bb = 0;                   // baseband samples consumed by the slicer
-    DevBuf tail_bb;                        // [C][BBPAD] floats
+    std::vector<float> tail_bb;            // [C][BBPAD], host side
     std::vector<p25fe_anchor_t> anchor;    // [C]
     std::vector<uint64_t> total_dibits;    // [C]
     // profiling ring: PROF_RING calls x 5 events (before K1, after K1, K2, K3, K4)
@@ -178,29 +216,16 @@ size_t p25fe_n_baseband(uint64_t abs0, size_t n)
 
 size_t p25fe_shard_halo(void) { return SHARD_HALO; }
 
-static int state_alloc(p25fe_t* h)
-{
-    const size_t C = (size_t)h->C;
-    HIPCHK(h, h->hist_iq.ensure(C * HISTPAD * 8));
-    HIPCHK(h, h->tail_bb.ensure(C * BBPAD * sizeof(float)));
-    HIPCHK(h, h->anchors.ensure(C * sizeof(p25fe_anchor_t)));
-    HIPCHK(h, h->results.ensure(C * sizeof(p25fe_result_t)));
-    HIPCHK(h, h->power_out.ensure(C * sizeof(float)));
-    return P25FE_OK;
-}
-
 int p25fe_reset(p25fe_t* h)
 {
     if (!h) return P25FE_ERR_ARG;
-    HIPCHK(h, hipSetDevice(h->cfg.device));
     h->abs_iq = 0;
     h->fmt_locked = -1;
     h->abs_bb = 0;
     h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0, SPS, 1});
     h->total_dibits.assign((size_t)h->C, 0);
-    HIPCHK(h, hipMemsetAsync(h->hist_iq.p, 0, (size_t)h->C * HISTPAD * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->tail_bb.p, 0, (size_t)h->C * BBPAD * sizeof(float), h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->hist_iq.assign((size_t)h->C * SHARD_HALO * 8, 0);
+    h->tail_bb.assign((size_t)h->C * BBPAD, 0.f);
     return P25FE_OK;
 }
 
@@ -267,11 +292,16 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_CF32, true, 0>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_CF32, false, 0>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_U8, true, 0>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_U8, false, 0>), Geo<5>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_CF32, false, 1>), Geo<5, 1>::LDS_BYTES);
+    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_U8, false, 1>), Geo<5, 1>::LDS_BYTES);
     if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); h->d_taps.release(); delete h; return P25FE_ERR_HIP; }
-    int rc = state_alloc(h);
-    if (rc == P25FE_OK) rc = p25fe_reset(h);
+    int rc = p25fe_reset(h);
     if (rc != P25FE_OK) { p25fe_destroy(h); return rc; }
     *out = h;
     return P25FE_OK;
@@ -290,9 +320,9 @@ void p25fe_destroy(p25fe_t* h)
     DevBuf* alt[] = {&h->alt_pl_f, &h->alt_pl_bits, &h->alt_evl, &h->alt_evthr, &h->alt_recs, &h->alt_tsum, &h->alt_outs,
                      &h->alt_gsum, &h->alt_gouts, &h->alt_evg, &h->gsum, &h->gouts, &h->evg};
     for (DevBuf* b : alt) b->release();
-    DevBuf* bufs[] = {&h->iq_stage, &h->bb_buf, &h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->power_out,
-                      &h->results, &h->anchors, &h->dibits, &h->sync_pos, &h->sync_dibit, &h->hist_iq, &h->tail_bb, &h->d_taps};
+    DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
+    h->hin.release(); h->hbb.release(); h->hout.release();
     for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -351,11 +381,19 @@ static int k1_slots_per_cu(const void* kern, size_t lds)
     return nb;
 }
 
+static int ensure_chunk_scratch(p25fe_t* h)
+{
+    if (h->chunk_cnt.p) return P25FE_OK;
+    HIPCHK(h, h->chunk_cnt.ensure(sizeof(unsigned) * (size_t)h->C));
+    HIPCHK(h, hipMemsetAsync(h->chunk_cnt.p, 0, sizeof(unsigned) * (size_t)h->C, h->stream));
+    return P25FE_OK;
+}
 static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
                            hipStream_t st, const PlanarGeo* planar = nullptr, int part = 0, hipEvent_t ev0 = nullptr,
-                           hipEvent_t ev1 = nullptr)
+                           hipEvent_t ev1 = nullptr, const ChunkRecvArgs* chunk = nullptr)
 {
+    // chunk (nullable, planar only): launch k_chunk -- K1 plus the one-tile receiver run by each channel's last workgroup
     // ev0 / ev1 (nullable): events attached to K1's dispatch (begin / end of the kernel)
     // part: 0 = every segment; 1 = only the segments whose input window lies inside the owned samples (a shard's main
     // launch, runs while the halo is still on the wire); 2 = the others (the shard's head, after the halo has arrived)
@@ -381,6 +419,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     // (round 2: the instruction-bound u8 kernel prefers longer segments -- less halo recomputed: 3 -> 239, 6 -> 231 us on one
     // box; with the final build 4 -> 222 / 216, 6 -> 217 / 215, 9 -> 212 / 209, 12 -> 216 / 205 us under rocprofv3)
     long subs = subs_env > 0 ? subs_env : (fmt == P25FE_FMT_U8 ? 9 : 3);
+    if (chunk) subs = 1;                                            // a chunk is latency: every sub-tile its own workgroup
     if (subs > 32768) subs = 32768;
     const long seg_len = (sub - SEG_HALO) + (subs - 1) * sub;
     const long n_seg = (total + seg_len - 1) / seg_len;
@@ -456,6 +495,30 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         if (fmt == P25FE_FMT_CF32) launch_ev(k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), lds), dim3(WV), lds, st, ev0, ev1, a, dt); \
         else launch_ev(k_frontend<P25FE_FMT_U8, false, 5, OM, 1>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);    \
     } while (0)
+    if (chunk) {
+        if (!planar || part) return P25FE_ERR_ARG;
+        int rc = ensure_chunk_scratch(h);
+        if (rc) return rc;
+        ChunkTail t;
+        t.r = *chunk; t.counter = h->chunk_cnt.as<unsigned>(); t.wg_per_ch = (int)seg_count;
+        const dim3 grid((unsigned)seg_count, (unsigned)h->C);
+        if (h->long_taps) {
+            const size_t lds = Geo<5, 1>::LDS_BYTES;
+            if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_chunk<P25FE_FMT_CF32, false, 1>), grid, dim3(WV), lds, st, a, dt, t);
+            else hipLaunchKernelGGL((k_chunk<P25FE_FMT_U8, false, 1>), grid, dim3(WV), lds, st, a, dt, t);
+        } else {
+            const size_t lds = Geo<5>::LDS_BYTES;
+            if (fmt == P25FE_FMT_CF32) {
+                if (h->default_taps) hipLaunchKernelGGL((k_chunk<P25FE_FMT_CF32, true, 0>), grid, dim3(WV), lds, st, a, dt, t);
+                else hipLaunchKernelGGL((k_chunk<P25FE_FMT_CF32, false, 0>), grid, dim3(WV), lds, st, a, dt, t);
+            } else {
+                if (h->default_taps) hipLaunchKernelGGL((k_chunk<P25FE_FMT_U8, true, 0>), grid, dim3(WV), lds, st, a, dt, t);
+                else hipLaunchKernelGGL((k_chunk<P25FE_FMT_U8, false, 0>), grid, dim3(WV), lds, st, a, dt, t);
+            }
+        }
+        HIPCHK(h, hipGetLastError());
+        return P25FE_OK;
+    }
     if (h->long_taps && planar) P25FE_LAUNCH_K1_LONG(OUT_PLANAR);
     else if (h->long_taps) P25FE_LAUNCH_K1_LONG(OUT_LINEAR);
     else if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
@@ -960,34 +1023,40 @@ int p25fe_shard_compact_dev(p25fe_t* h, const uint8_t* d_gathered, size_t cap, c
 }
 
 // --------------------------------------------------------------------------------------------
-// streaming with host buffers
+// streaming with host buffers: the bodies of DemodTask::run / RecvTask::run, one chunk per call
+//
+// All stream state (IQ history, baseband tail, anchors, counters) lives in HOST memory; input is staged in pinned,
+// device-visible memory as [history | new samples] and read by the kernels over PCIe (zero copy: a 32 768-byte chunk is
+// one latency, not a DMA command); results are written by the kernels straight into pinned memory.  A call is
+// launches + ONE synchronisation, and for a chunk of at most one tile (the reference's 16 384-sample buffer gives
+// 3 276 / 3 277 baseband samples) ONE launch: k_chunk / k_recv_chunk.
 // --------------------------------------------------------------------------------------------
-// Stage [history | new] per channel on the device, run K1, roll the history.
-static int stream_demod(p25fe_t* h, const void* iq, int fmt, size_t n, float* d_bb_out, size_t bb_stride,
-                        float* d_power, size_t* n_out)
+// [history | new] per channel in h->hin; returns the staging geometry
+struct Staged { size_t stride, n_hist; char* host; const char* dev; };
+static int stage_iq(p25fe_t* h, const void* iq, int fmt, size_t n, Staged* s)
 {
     if (h->fmt_locked >= 0 && h->fmt_locked != fmt && h->abs_iq > 0) return P25FE_ERR_FORMAT;
-    h->fmt_locked = fmt;
     const size_t C = (size_t)h->C, eb = fmt_bytes(fmt);
-    const size_t stride = HISTPAD + round_up(n, 8) + 8;              // samples, multiple of 8
-    HIPCHK(h, h->iq_stage.ensure(C * stride * eb));
-    char* stage = h->iq_stage.as<char>();
-    hipStream_t st = h->stream;
-    HIPCHK(h, hipMemcpy2DAsync(stage, stride * eb, h->hist_iq.p, HISTPAD * eb, HISTPAD * eb, C,
-                               hipMemcpyDeviceToDevice, st));
-    if (n)
-        HIPCHK(h, hipMemcpy2DAsync(stage + HISTPAD * eb, stride * eb, iq, n * eb, n * eb, C, hipMemcpyHostToDevice, st));
-    const size_t n_hist = h->abs_iq < HISTPAD ? (size_t)h->abs_iq : HISTPAD;
-    const size_t nb = p25fe_n_baseband(h->abs_iq, n);
-    int rc = launch_frontend(h, stage + HISTPAD * eb, fmt, stride, n_hist, n, h->abs_iq, 0, d_bb_out, bb_stride,
-                             d_power, st);
-    if (rc) return rc;
-    // new history = last HISTPAD samples of [history | new]
-    HIPCHK(h, hipMemcpy2DAsync(h->hist_iq.p, HISTPAD * eb, stage + n * eb, stride * eb, HISTPAD * eb, C,
-                               hipMemcpyDeviceToDevice, st));
-    h->abs_iq += n;
-    *n_out = nb;
+    s->stride = SHARD_HALO + round_up(n, 8) + 8;                     // samples, multiple of 8: owned sample 0 stays 16-B aligned
+    HIPCHK(h, h->hin.ensure(C * s->stride * eb));
+    s->host = static_cast<char*>(h->hin.p);
+    s->dev = static_cast<const char*>(h->hin.dp);
+    s->n_hist = h->abs_iq < SHARD_HALO ? (size_t)h->abs_iq : SHARD_HALO;
+    for (size_t c = 0; c < C; ++c) {
+        char* row = s->host + c * s->stride * eb;
+        memcpy(row, h->hist_iq.data() + c * SHARD_HALO * 8, SHARD_HALO * eb);
+        if (n) memcpy(row + SHARD_HALO * eb, static_cast<const char*>(iq) + c * n * eb, n * eb);
+    }
     return P25FE_OK;
+}
+// the call succeeded: the last SHARD_HALO samples of [history | new] become the history
+static void commit_iq(p25fe_t* h, int fmt, size_t n, const Staged& s)
+{
+    const size_t C = (size_t)h->C, eb = fmt_bytes(fmt);
+    for (size_t c = 0; c < C; ++c)
+        memcpy(h->hist_iq.data() + c * SHARD_HALO * 8, s.host + (c * s.stride + n) * eb, SHARD_HALO * eb);
+    h->fmt_locked = fmt;
+    h->abs_iq += n;
 }
 
 static int demod_host(p25fe_t* h, const void* iq, int fmt, size_t n, float* bb, size_t bb_cap, size_t* n_out,
@@ -998,19 +1067,23 @@ static int demod_host(p25fe_t* h, const void* iq, int fmt, size_t n, float* bb, 
     const size_t nb = p25fe_n_baseband(h->abs_iq, n);
     if (nb > bb_cap) return P25FE_ERR_CAPACITY;
     const size_t C = (size_t)h->C;
-    const size_t bb_stride = round_up(nb + 4, 4);
-    HIPCHK(h, h->bb_buf.ensure(C * bb_stride * sizeof(float)));
-    size_t got = 0;
-    int rc = stream_demod(h, iq, fmt, n, h->bb_buf.as<float>(), bb_stride, power_dbm ? h->power_out.as<float>() : nullptr,
-                          &got);
+    Staged sg;
+    int rc = stage_iq(h, iq, fmt, n, &sg);
     if (rc) return rc;
-    if (got)
-        HIPCHK(h, hipMemcpy2DAsync(bb, bb_cap * sizeof(float), h->bb_buf.p, bb_stride * sizeof(float),
-                                   got * sizeof(float), C, hipMemcpyDeviceToHost, h->stream));
-    if (power_dbm)
-        HIPCHK(h, hipMemcpyAsync(power_dbm, h->power_out.p, sizeof(float) * C, hipMemcpyDeviceToHost, h->stream));
+    const size_t bb_stride = round_up(nb + 4, 4);
+    HIPCHK(h, h->hout.ensure(C * bb_stride * sizeof(float) + 64 * (C + 2)));
+    Arena ar(h->hout);
+    float *d_bb, *d_pw;
+    float* h_bb = ar.take<float>(C * bb_stride, &d_bb);
+    float* h_pw = ar.take<float>(C, &d_pw);
+    rc = launch_frontend(h, sg.dev + SHARD_HALO * fmt_bytes(fmt), fmt, sg.stride, sg.n_hist, n, h->abs_iq, 0, d_bb, bb_stride,
+                         power_dbm ? d_pw : nullptr, h->stream);
+    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    *n_out = got;
+    for (size_t c = 0; c < C; ++c) memcpy(bb + c * bb_cap, h_bb + c * bb_stride, nb * sizeof(float));
+    if (power_dbm) memcpy(power_dbm, h_pw, sizeof(float) * C);
+    commit_iq(h, fmt, n, sg);
+    *n_out = nb;
     return P25FE_OK;
 }
 
@@ -1027,62 +1100,65 @@ int p25fe_demod_cf32(p25fe_t* h, const float* iq, size_t n_samples, float* bb, s
     return demod_host(h, iq, P25FE_FMT_CF32, n_samples, bb, bb_cap, n_out, power_dbm);
 }
 
-// Slice n_bb new baseband samples that already sit at bb_buf + BBPAD (per channel, stride bb_stride);
-// the tail of the previous call is copied in front of them.  Copies results to the host.
-static int stream_slice_staged(p25fe_t* h, size_t n_bb, size_t bb_stride, uint8_t* dibits, size_t cap, size_t* n_dibits,
-                               int64_t* sync_pos, uint64_t* sync_dibit, size_t sync_cap, size_t* n_sync)
+// Pinned outputs of one receiver call: per channel a result record, the carry-in anchor, a dibit row and (optionally) the
+// sync event rows; plus the baseband tail the fused path hands back.
+struct RecvOut {
+    p25fe_result_t *res, *d_res;
+    p25fe_anchor_t *anc, *d_anc;
+    uint8_t *dib, *d_dib;
+    int64_t *spos, *d_spos;
+    uint64_t *sdib, *d_sdib;
+    float *tail, *d_tail;
+    size_t dstride, sstride;
+};
+static int recv_out(p25fe_t* h, size_t n_bb, size_t sync_cap, RecvOut* o)
 {
     const size_t C = (size_t)h->C;
-    hipStream_t st = h->stream;
-    float* base = h->bb_buf.as<float>();
-    HIPCHK(h, hipMemcpy2DAsync(base, bb_stride * sizeof(float), h->tail_bb.p, BBPAD * sizeof(float),
-                               BBPAD * sizeof(float), C, hipMemcpyDeviceToDevice, st));
-    const size_t max_d = n_bb / (W + 1) + 2;             // hard ceiling: detections, hence re-anchors, are at least W + 1 samples apart
-    const size_t dstride = round_up(max_d, 16);
-    HIPCHK(h, h->dibits.ensure(C * dstride));
-    const size_t sstride = sync_cap;
-    if (sync_cap) {
-        HIPCHK(h, h->sync_pos.ensure(C * sstride * sizeof(int64_t)));
-        HIPCHK(h, h->sync_dibit.ensure(C * sstride * sizeof(uint64_t)));
-    }
-    HIPCHK(h, hipMemcpyAsync(h->anchors.p, h->anchor.data(), sizeof(p25fe_anchor_t) * C, hipMemcpyHostToDevice, st));
-    const size_t hist = h->abs_bb < BBPAD ? (size_t)h->abs_bb : BBPAD;
-    int rc = dev_slice(h, base + BBPAD, bb_stride, hist, n_bb, h->abs_bb, h->anchors.as<p25fe_anchor_t>(),
-                       h->dibits.as<uint8_t>(), dstride, sync_cap ? h->sync_pos.as<int64_t>() : nullptr,
-                       sync_cap ? h->sync_dibit.as<uint64_t>() : nullptr, sstride, h->results.as<p25fe_result_t>(), st);
-    if (rc) return rc;
-    std::vector<p25fe_result_t> res(C);
-    HIPCHK(h, hipMemcpyAsync(res.data(), h->results.p, sizeof(p25fe_result_t) * C, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    o->dstride = round_up(n_bb / (W + 1) + 2, 16);                   // hard ceiling: detections, hence re-anchors, are at least W + 1 samples apart
+    o->sstride = sync_cap;
+    const size_t bytes = C * (sizeof(p25fe_result_t) + sizeof(p25fe_anchor_t) + o->dstride + 16 * sync_cap + TAILN * sizeof(float)) + 64 * 8;
+    HIPCHK(h, h->hout.ensure(bytes));
+    Arena ar(h->hout);
+    o->res = ar.take<p25fe_result_t>(C, &o->d_res);
+    o->anc = ar.take<p25fe_anchor_t>(C, &o->d_anc);
+    o->dib = ar.take<uint8_t>(C * o->dstride, &o->d_dib);
+    o->spos = ar.take<int64_t>(C * sync_cap, &o->d_spos);
+    o->sdib = ar.take<uint64_t>(C * sync_cap, &o->d_sdib);
+    o->tail = ar.take<float>(C * TAILN, &o->d_tail);
+    memcpy(o->anc, h->anchor.data(), sizeof(p25fe_anchor_t) * C);
+    return P25FE_OK;
+}
+// after the synchronisation: capacity check, copy-out, receiver state
+static int recv_finish(p25fe_t* h, const RecvOut& o, size_t n_bb, uint8_t* dibits, size_t cap, size_t* n_dibits, int64_t* sync_pos,
+                       uint64_t* sync_dibit, size_t sync_cap, size_t* n_sync)
+{
+    const size_t C = (size_t)h->C;
     for (size_t c = 0; c < C; ++c)
-        if (res[c].n_dibits > cap) return P25FE_ERR_CAPACITY;    // before any receiver state moves: the call can be repeated with more room
-    // roll the tail: last BBPAD samples of [tail | new]
-    HIPCHK(h, hipMemcpy2DAsync(h->tail_bb.p, BBPAD * sizeof(float), base + n_bb, bb_stride * sizeof(float),
-                               BBPAD * sizeof(float), C, hipMemcpyDeviceToDevice, st));
+        if (o.res[c].n_dibits > cap) return P25FE_ERR_CAPACITY;      // before any state moves: the call can be repeated with more room
     for (size_t c = 0; c < C; ++c) {
-        if (res[c].n_dibits)
-            HIPCHK(h, hipMemcpyAsync(dibits + c * cap, h->dibits.as<uint8_t>() + c * dstride, res[c].n_dibits,
-                                     hipMemcpyDeviceToHost, st));
-        const size_t ns = res[c].n_sync < sync_cap ? (size_t)res[c].n_sync : sync_cap;
-        if (ns && sync_pos)
-            HIPCHK(h, hipMemcpyAsync(sync_pos + c * sync_cap, h->sync_pos.as<int64_t>() + c * sstride,
-                                     ns * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        if (ns && sync_dibit)
-            HIPCHK(h, hipMemcpyAsync(sync_dibit + c * sync_cap, h->sync_dibit.as<uint64_t>() + c * sstride,
-                                     ns * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    }
-    HIPCHK(h, hipStreamSynchronize(st));
-    for (size_t c = 0; c < C; ++c) {
-        const size_t ns = res[c].n_sync < sync_cap ? (size_t)res[c].n_sync : sync_cap;
+        const p25fe_result_t& r = o.res[c];
+        memcpy(dibits + c * cap, o.dib + c * o.dstride, (size_t)r.n_dibits);
+        const size_t ns = r.n_sync < sync_cap ? (size_t)r.n_sync : sync_cap;
+        if (ns && sync_pos) memcpy(sync_pos + c * sync_cap, o.spos + c * o.sstride, ns * sizeof(int64_t));
         if (sync_dibit)
-            for (size_t k = 0; k < ns; ++k) sync_dibit[c * sync_cap + k] += h->total_dibits[c];
-        n_dibits[c] = (size_t)res[c].n_dibits;
-        if (n_sync) n_sync[c] = (size_t)res[c].n_sync;
-        h->anchor[c] = res[c].anchor_out;
-        h->total_dibits[c] += res[c].n_dibits;
+            for (size_t k = 0; k < ns; ++k) sync_dibit[c * sync_cap + k] = o.sdib[c * o.sstride + k] + h->total_dibits[c];
+        n_dibits[c] = (size_t)r.n_dibits;
+        if (n_sync) n_sync[c] = (size_t)r.n_sync;
+        h->anchor[c] = r.anchor_out;
+        h->total_dibits[c] += r.n_dibits;
     }
     h->abs_bb += n_bb;
     return P25FE_OK;
+}
+
+static void chunk_recv_args(p25fe_t* h, const RecvOut& o, size_t n_bb, long view0, bool want_sync, bool want_tail, ChunkRecvArgs* c)
+{
+    const PlanarGeo g(n_bb);
+    c->pl = planar_view(h, g); c->n = (long)n_bb; c->abs0 = view0;
+    c->recs = h->recs.as<TileRec>(); c->tsum = h->tsum.as<unsigned long long>(); c->evl = h->evl.as<uint16_t>(); c->evthr = h->evthr.as<float>();
+    c->anchor_in = o.d_anc; c->result = o.d_res; c->dibits = o.d_dib; c->dibit_stride = (long)o.dstride;
+    c->sync_pos = want_sync ? o.d_spos : nullptr; c->sync_dibit = want_sync ? o.d_sdib : nullptr; c->sync_stride = (long)o.sstride;
+    c->tail = want_tail ? o.d_tail : nullptr; c->look = (int)h->look; c->n_baseband = n_bb;
 }
 
 int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits, int64_t* sync_pos,
@@ -1094,12 +1170,58 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
     if (n == 0) { for (size_t c = 0; c < C; ++c) { n_dibits[c] = 0; if (n_sync) n_sync[c] = 0; } return P25FE_OK; }
-    if (cap < n / SPS + 1) return P25FE_ERR_CAPACITY;               // worst case, checked before any state moves
+    if (cap < n / SPS + 1) return P25FE_ERR_CAPACITY;               // worst case of an undisturbed lock, checked before any state moves
+    shard_invalidate(h);
+    if (int jrc = pipe_join(h, h->stream)) return jrc;
+    // stage [tail | new] per channel
     const size_t bb_stride = round_up(BBPAD + n + 4, 4);
-    HIPCHK(h, h->bb_buf.ensure(C * bb_stride * sizeof(float)));
-    HIPCHK(h, hipMemcpy2DAsync(h->bb_buf.as<float>() + BBPAD, bb_stride * sizeof(float), bb, n * sizeof(float),
-                               n * sizeof(float), C, hipMemcpyHostToDevice, h->stream));
-    return stream_slice_staged(h, n, bb_stride, dibits, cap, n_dibits, sync_pos, sync_dibit, sync_cap, n_sync);
+    HIPCHK(h, h->hbb.ensure(C * bb_stride * sizeof(float)));
+    float* hb = static_cast<float*>(h->hbb.p);
+    const float* db = static_cast<const float*>(h->hbb.dp);
+    for (size_t c = 0; c < C; ++c) {
+        memcpy(hb + c * bb_stride, h->tail_bb.data() + c * BBPAD, BBPAD * sizeof(float));
+        memcpy(hb + c * bb_stride + BBPAD, bb + c * n, n * sizeof(float));
+    }
+    RecvOut o;
+    int rc = recv_out(h, n, sync_cap, &o);
+    if (rc) return rc;
+    rc = ensure_slice_scratch(h, n);
+    if (rc) return rc;
+    const size_t hist = h->abs_bb < BBPAD ? (size_t)h->abs_bb : BBPAD;
+    const long view0 = (long)h->abs_bb - h->look;
+    if (!h->track && n <= (size_t)TS) {
+        RecvChunkArgs a;
+        chunk_recv_args(h, o, n, view0, sync_cap != 0, false, &a.r);
+        const PlanarGeo g(n);
+        a.bb = db + BBPAD; a.bb_stride = (long)bb_stride; a.n_hist = (long)hist;
+        a.f = h->pl_f.as<float>(); a.bits = h->pl_bits.as<uint32_t>(); a.n_blocks = (long)g.n_blocks;
+        hipLaunchKernelGGL(k_recv_chunk, dim3((unsigned)C), dim3(WV), 0, h->stream, a);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        const RecvCall rcall = recv_call(h);
+        rc = launch_planarize(h, db + BBPAD, bb_stride, hist, n, h->stream);
+        if (rc) return rc;
+        rc = launch_detect(h, n, view0, h->stream, rcall);
+        if (rc) return rc;
+        rc = launch_scan_slice(h, n, view0, o.d_anc, o.d_dib, o.dstride, sync_cap ? o.d_spos : nullptr,
+                               sync_cap ? o.d_sdib : nullptr, o.sstride, o.d_res, true, h->stream, rcall);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    rc = recv_finish(h, o, n, dibits, cap, n_dibits, sync_pos, sync_dibit, sync_cap, n_sync);
+    if (rc) return rc;
+    for (size_t c = 0; c < C; ++c)                                   // the tail: last BBPAD samples of [tail | new]
+        memcpy(h->tail_bb.data() + c * BBPAD, hb + c * bb_stride + n, BBPAD * sizeof(float));
+    return P25FE_OK;
+}
+
+// launch of the fused chunk kernel: K1 (planar) + receiver tail
+static int launch_chunk(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                        const ChunkRecvArgs& r)
+{
+    const PlanarGeo g(p25fe_n_baseband(abs0, n));
+    return launch_frontend(h, d_x, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, h->stream, &g, 0,
+                           nullptr, nullptr, &r);
 }
 
 static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits)
@@ -1108,14 +1230,59 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
     const size_t nb = p25fe_n_baseband(h->abs_iq, n);
-    if (cap < nb / SPS + 1) return P25FE_ERR_CAPACITY;              // worst case, checked before any state moves
-    const size_t bb_stride = round_up(BBPAD + nb + 4, 4);
-    HIPCHK(h, h->bb_buf.ensure(C * bb_stride * sizeof(float)));
-    size_t got = 0;
-    int rc = stream_demod(h, iq, fmt, n, h->bb_buf.as<float>() + BBPAD, bb_stride, nullptr, &got);
+    if (cap < nb / SPS + 1) return P25FE_ERR_CAPACITY;              // worst case of an undisturbed lock, checked before any state moves
+    shard_invalidate(h);
+    if (int jrc = pipe_join(h, h->stream)) return jrc;
+    Staged sg;
+    int rc = stage_iq(h, iq, fmt, n, &sg);
     if (rc) return rc;
-    if (got == 0) { for (size_t c = 0; c < C; ++c) n_dibits[c] = 0; return P25FE_OK; }
-    return stream_slice_staged(h, got, bb_stride, dibits, cap, n_dibits, nullptr, nullptr, 0, nullptr);
+    if (nb == 0) {                                                  // fewer than five new samples: only the filters' history moves
+        commit_iq(h, fmt, n, sg);
+        for (size_t c = 0; c < C; ++c) n_dibits[c] = 0;
+        return P25FE_OK;
+    }
+    RecvOut o;
+    rc = recv_out(h, nb, 0, &o);
+    if (rc) return rc;
+    rc = ensure_slice_scratch(h, nb);
+    if (rc) return rc;
+    const size_t eb = fmt_bytes(fmt);
+    const long view0 = (long)h->abs_bb - h->look;
+    const PlanarGeo g(nb);
+    ChunkRecvArgs cr;
+    chunk_recv_args(h, o, nb, view0, false, true, &cr);
+    if (!h->track && nb <= (size_t)TS) {
+        rc = launch_chunk(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, cr);
+        if (rc) return rc;
+    } else {
+        // the baseband stays in HBM; the receiver's history is recomputed from the IQ history, like a shard's from its halo
+        const RecvCall rcall = recv_call(h);
+        rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)HIST_BB - h->look, nullptr, 0,
+                             nullptr, h->stream, &g);
+        if (rc) return rc;
+        rc = launch_detect(h, nb, view0, h->stream, rcall);
+        if (rc) return rc;
+        rc = launch_scan_slice(h, nb, view0, o.d_anc, o.d_dib, o.dstride, nullptr, nullptr, 0, o.d_res, true, h->stream, rcall);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tail_extract, dim3((unsigned)C), dim3(WV), 0, h->stream, cr);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    rc = recv_finish(h, o, nb, dibits, cap, n_dibits, nullptr, nullptr, 0, nullptr);
+    if (rc) return rc;
+    commit_iq(h, fmt, n, sg);
+    // baseband tail for a later p25fe_slice on this handle: the newest TAILN samples, those older than what the planes hold
+    // (a very short chunk) come from the previous tail
+    for (size_t c = 0; c < C; ++c) {
+        float* t = h->tail_bb.data() + c * BBPAD;
+        float merged[BBPAD];
+        for (size_t j = 0; j < (size_t)BBPAD; ++j) {
+            const long m = (long)nb - (long)BBPAD + (long)j;        // index relative to this call's first baseband sample
+            merged[j] = m >= -(long)(HIST_BB + h->look) ? o.tail[c * TAILN + j] : t[j + nb];
+        }
+        memcpy(t, merged, sizeof merged);
+    }
+    return P25FE_OK;
 }
 
 int p25fe_run_u8(p25fe_t* h, const uint8_t* iq, size_t n_bytes, uint8_t* dibits, size_t cap, size_t* n_dibits)
@@ -1259,7 +1426,7 @@ int p25fe_resync_at_dev(p25fe_t* h, const int64_t* d_idx, size_t n_idx, size_t i
 }
 
 // --------------------------------------------------------------------------------------------
-// state blob: header | hist_iq raw | tail_bb | anchors | totals
+// state blob: header | IQ history raw | baseband tail | anchors | totals
 // --------------------------------------------------------------------------------------------
 struct StateHeader {
     uint32_t magic, abi;
@@ -1271,7 +1438,7 @@ int p25fe_state_size(const p25fe_t* h, size_t* n)
 {
     if (!h || !n) return P25FE_ERR_ARG;
     const size_t C = (size_t)h->C;
-    *n = sizeof(StateHeader) + C * HISTPAD * 8 + C * BBPAD * sizeof(float) + C * sizeof(p25fe_anchor_t) + C * sizeof(uint64_t);
+    *n = sizeof(StateHeader) + C * SHARD_HALO * 8 + C * BBPAD * sizeof(float) + C * sizeof(p25fe_anchor_t) + C * sizeof(uint64_t);
     return P25FE_OK;
 }
 
@@ -1282,14 +1449,12 @@ int p25fe_state_export(const p25fe_t* hc, void* buf, size_t cap, size_t* n)
     if (!h || !buf || p25fe_state_size(h, &need)) return P25FE_ERR_ARG;
     if (n) *n = need;
     if (cap < need) return P25FE_ERR_CAPACITY;
-    HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
     char* p = static_cast<char*>(buf);
     StateHeader hd = {STATE_MAGIC, P25FE_ABI_VERSION, h->C, h->fmt_locked, h->abs_iq, h->abs_bb};
     memcpy(p, &hd, sizeof hd); p += sizeof hd;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(p, h->hist_iq.p, C * HISTPAD * 8, hipMemcpyDeviceToHost)); p += C * HISTPAD * 8;
-    HIPCHK(h, hipMemcpy(p, h->tail_bb.p, C * BBPAD * sizeof(float), hipMemcpyDeviceToHost)); p += C * BBPAD * sizeof(float);
+    memcpy(p, h->hist_iq.data(), C * SHARD_HALO * 8); p += C * SHARD_HALO * 8;       // the streaming state is host-side
+    memcpy(p, h->tail_bb.data(), C * BBPAD * sizeof(float)); p += C * BBPAD * sizeof(float);
     memcpy(p, h->anchor.data(), C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);
     memcpy(p, h->total_dibits.data(), C * sizeof(uint64_t));
     return P25FE_OK;
@@ -1303,11 +1468,9 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
     StateHeader hd;
     memcpy(&hd, p, sizeof hd); p += sizeof hd;
     if (hd.magic != STATE_MAGIC || hd.abi != P25FE_ABI_VERSION || hd.n_channels != h->C) return P25FE_ERR_ARG;
-    HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(h->hist_iq.p, p, C * HISTPAD * 8, hipMemcpyHostToDevice)); p += C * HISTPAD * 8;
-    HIPCHK(h, hipMemcpy(h->tail_bb.p, p, C * BBPAD * sizeof(float), hipMemcpyHostToDevice)); p += C * BBPAD * sizeof(float);
+    memcpy(h->hist_iq.data(), p, C * SHARD_HALO * 8); p += C * SHARD_HALO * 8;
+    memcpy(h->tail_bb.data(), p, C * BBPAD * sizeof(float)); p += C * BBPAD * sizeof(float);
     memcpy(h->anchor.data(), p, C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);
     memcpy(h->total_dibits.data(), p, C * sizeof(uint64_t));
     h->fmt_locked = hd.fmt_locked; h->abs_iq = hd.abs_iq; h->abs_bb = hd.abs_bb;

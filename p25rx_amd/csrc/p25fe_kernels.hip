@@ -575,7 +575,7 @@ __device__ unsigned long long g_k1_stamp[K1_STAMP_SLOTS][16];
 #define K1_PIN2(a, b) do { } while (0)
 #endif
 template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
-__global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+__device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __restrict__ gtaps)
 {
     constexpr int PF = (PK != 5 || TX != 0) ? 1 : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
     static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
@@ -955,6 +955,12 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<P
         atomicAdd(&slot[12], st_items);                             // work items
     }
 #endif
+}
+
+template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
+__global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+{
+    frontend_body<FMT, CT, PK, OM, TX>(a, gtaps);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1477,6 +1483,34 @@ __global__ __launch_bounds__(256) void k_chan_stats(const p25fe_result_t* result
         o.bch.size = 63; o.bch.reserved = 0;
         stats[ch] = o;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// One launch per streaming chunk (the body of DemodTask::run + the sample loop of RecvTask::run for one buffer of the
+// reader, src/demod.rs:70-117, src/recv.rs:145-150): K1's workgroups write the planes of a range of at most one tile; the
+// LAST of a channel's workgroups to finish (agent-scope release, ticket, agent-scope acquire: cdna_hip_programming.md
+// guideline 16) runs the receiver for that channel and writes the results where the host reads them.
+// ------------------------------------------------------------------------------------------
+struct ChunkTail {
+    ChunkRecvArgs r;
+    unsigned* counter;          // [ch], zero between launches
+    int wg_per_ch;
+};
+
+template <int FMT, bool CT, int TX>
+__global__ __launch_bounds__(WV, 2) void k_chunk(K1Args a, const Taps* __restrict__ gtaps, ChunkTail t)
+{
+    frontend_body<FMT, CT, 5, OUT_PLANAR, TX>(a, gtaps);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the compiler may drop the wait behind the write-back
+    unsigned ticket = 0u;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&t.counter[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket != (unsigned)t.wg_per_ch - 1u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) t.counter[blockIdx.y] = 0u;               // the next launch (a kernel boundary later) starts from zero
+    recv_one_tile(t.r, (int)blockIdx.y);
 }
 
 // Carry resolution across time shards (BASELINE.json config 5): the same "latest anchor wins" rule as K3, one level

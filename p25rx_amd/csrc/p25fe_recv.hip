@@ -252,7 +252,7 @@ constexpr int K2_DCAP = 64;                                      // detections p
 constexpr int K2_LANES = 60;                                     // 10 planes x 6 blocks of 4 words
 constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test
 
-template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 3 : 4) void k_detect(DetArgs a)
+template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a, const int tile, const int ch)
 {
     __shared__ uint16_t HITS[K2_HCAP];
     __shared__ unsigned EVB[TS / 32];                            // detections of the tile, bit = decision offset
@@ -266,7 +266,7 @@ template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 3 : 4) void k_detect(
     __shared__ float DETT[K2_DCAP][3];                           // ... and thresholds
     __shared__ unsigned DETN;
 
-    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
@@ -520,6 +520,11 @@ template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 3 : 4) void k_detect(
         a.recs[(size_t)ch * a.n_tiles + tile] = rc;
         a.tsum[(size_t)ch * a.n_tiles + tile] = pack_tsum(first_off, last_off, n_ev, post);
     }
+}
+
+template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 3 : 4) void k_detect(DetArgs a)
+{
+    detect_tile<GEN>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -783,29 +788,18 @@ struct SliceArgs {
     long sync_stride;
 };
 
-__global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
+// so: the tile's carry-in record; u: its packed summary; (valid, s_abs, hi, mid, lo): the anchor in force at its first sample
+__device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, const int ch, const ScanOut so,
+                                           const unsigned long long u, const int valid, const long s_abs, const float hi,
+                                           const float mid, const float lo)
 {
     __shared__ uint16_t EV[EVCAP];
     __shared__ float ETH[EVTHR_N * 3];
-    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
-    const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
-    const unsigned long long u = a.tsum[(size_t)ch * a.n_tiles + tile];
     const int n_ev = (int)((u >> (2 * TS_BITS)) & TS_MASK);
-
-    // carry-in anchor
-    int valid = 0;
-    long s_abs = 0;
-    float hi = 0.f, mid = 0.f, lo = 0.f;
-    if (so.src >= 0) {
-        const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
-        valid = 1; s_abs = t.last_s; hi = t.hi; mid = t.mid; lo = t.lo;
-    } else if (a.anchor_in) {
-        const p25fe_anchor_t A = a.anchor_in[ch];
-        valid = A.valid; s_abs = A.s; hi = A.hi; mid = A.mid; lo = A.lo;
-    }
     if (!valid && n_ev == 0) return;                                // nothing decided yet: no instants
     if (n_ev) {
         const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
@@ -873,6 +867,25 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
         // instants n > e_k with n = s_k + 10 j: the first is s_k + 10 = e_k + 5
         rank += emit(SPS - W - 1, ek + 1, m_hi, h, m, l, rank);
     }
+}
+
+__global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
+{
+    const int tile = blockIdx.x, ch = blockIdx.y;
+    const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
+    const unsigned long long u = a.tsum[(size_t)ch * a.n_tiles + tile];
+    // carry-in anchor
+    int valid = 0;
+    long s_abs = 0;
+    float hi = 0.f, mid = 0.f, lo = 0.f;
+    if (so.src >= 0) {
+        const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
+        valid = 1; s_abs = t.last_s; hi = t.hi; mid = t.mid; lo = t.lo;
+    } else if (a.anchor_in) {
+        const p25fe_anchor_t A = a.anchor_in[ch];
+        valid = A.valid; s_abs = A.s; hi = A.hi; mid = A.mid; lo = A.lo;
+    }
+    slice_tile(a, tile, ch, so, u, valid, s_abs, hi, mid, lo);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1201,6 +1214,133 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
         }
         rank += emit(sk, D, N, ek + 1, T0 + (long)(eg & 0x7fffu), h, m, l, rank);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming chunks (the reference's unit of work: one 32 768-byte read of the dongle = 3 276 / 3 277 baseband samples,
+// src/consts.rs:6-8, src/demod.rs:87-90): a range of at most ONE tile runs the whole receiver -- sync detection, the
+// (trivial) scan, the slicer -- in one wave, with the carry-in anchor read from and every result written to host-visible
+// memory, so that a chunk costs one kernel launch and one synchronisation instead of five launches and six copies.
+// Fixed-stride clock only (the tracking clock and in-range lock drops take the general kernels).
+// ------------------------------------------------------------------------------------------
+constexpr int TAILN = 256;                                          // newest baseband samples handed back to the host (>= HIST_BB + CLK_L)
+
+struct ChunkRecvArgs {
+    Planar pl;                  // planar scratch holding the range (written by K1 or by planarize_one below)
+    long n;                     // processed baseband samples per channel, <= TS
+    long abs0;                  // absolute index of the first one
+    TileRec* recs;              // [ch] one tile of K2's scratch per channel
+    unsigned long long* tsum;   // [ch]
+    uint16_t* evl;              // [ch][EVCAP]
+    float* evthr;               // [ch][EVTHR_N][3]
+    const p25fe_anchor_t* anchor_in;    // [ch]
+    p25fe_result_t* result;     // [ch]
+    uint8_t* dibits;            // [ch][dibit_stride]
+    long dibit_stride;
+    int64_t* sync_pos;          // nullable
+    uint64_t* sync_dibit;
+    long sync_stride;
+    float* tail;                // nullable: [ch][TAILN] newest baseband samples of the range, oldest first (entries older than the
+                                // recomputed history are left untouched)
+    int look;                   // baseband sample m of the range sits at planar position m + look + PLPAD
+    unsigned long long n_baseband;
+};
+
+// every lane's global stores of the wave are visible to every lane's later loads (one wave: same CU, same L1)
+__device__ __forceinline__ void wave_global_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// the newest TAILN baseband samples of the range, read back from the planes (what a later p25fe_slice call on the handle
+// needs as its history): owned sample m sits at planar position m + look + PLPAD, K1 wrote m >= -(HIST_BB + look)
+__device__ __forceinline__ void tail_extract(const ChunkRecvArgs& c, const int ch)
+{
+    if (!c.tail) return;
+    const float* f = c.pl.f + (size_t)ch * c.pl.f_ch;
+    for (int j = (int)threadIdx.x; j < TAILN; j += WV) {
+        const long m = c.n - TAILN + j;
+        if (m >= -(long)(HIST_BB + c.look)) {
+            const long pp = m + c.look + PLPAD;
+            const long sy = pp / SPS;
+            c.tail[(size_t)ch * TAILN + j] = f[planar_index(sy, (int)(pp - sy * SPS))];
+        }
+    }
+}
+__global__ __launch_bounds__(WV) void k_tail_extract(ChunkRecvArgs c) { tail_extract(c, (int)blockIdx.x); }
+
+__device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int ch)
+{
+    const int lane = threadIdx.x;
+    DetArgs d;
+    d.pl = c.pl; d.n = c.n; d.abs0 = c.abs0; d.n_tiles = 1;
+    d.recs = c.recs; d.tsum = c.tsum; d.evl = c.evl; d.evthr = c.evthr;
+    d.opt.track = 0; d.opt.n_resync = 0; d.opt.resync = nullptr; d.opt.resync_stride = 0; d.gsum = nullptr; d.evg = nullptr;
+    detect_tile<false>(d, 0, ch);
+    wave_global_sync();
+    // the scan of a one-tile range
+    const TileRec rc = c.recs[ch];
+    const unsigned long long u = c.tsum[ch];
+    p25fe_anchor_t A = c.anchor_in[ch];
+    if (A.period_n <= 0 || A.period_d <= 0) { A.period_d = SPS; A.period_n = 1; }
+    const bool own = rc.n_events > 0;
+    const unsigned long long pre = A.valid ? (unsigned long long)count_instants(A.s, c.abs0, own ? rc.first_event + 1 : c.abs0 + c.n) : 0ull;
+    if (lane == 0) {
+        p25fe_result_t r;
+        r.n_baseband = c.n_baseband;
+        r.n_dibits = pre + (own ? (unsigned long long)rc.post_count : 0ull);
+        r.n_sync = own ? (unsigned long long)rc.n_events : 0ull;
+        p25fe_anchor_t out = A;
+        if (own) { out.valid = 1; out.s = rc.last_s; out.hi = rc.hi; out.mid = rc.mid; out.lo = rc.lo; out.period_d = SPS; out.period_n = 1; }
+        r.anchor_out = out;
+        r.first_event = own ? rc.first_event : -1;
+        r.n_dibits_after_first = own ? (unsigned long long)rc.post_count : 0ull;
+        r.carry_end = own ? rc.first_event + 1 : -1;
+        r.first_seg_end = -1; r.flags = 0u; r.reserved = 0u;
+        c.result[ch] = r;
+    }
+    SliceArgs l;
+    l.pl = c.pl; l.n = c.n; l.abs0 = c.abs0; l.n_tiles = 1;
+    l.outs = nullptr; l.recs = c.recs; l.tsum = c.tsum; l.evl = c.evl; l.evthr = c.evthr; l.anchor_in = c.anchor_in;
+    l.dibits = c.dibits; l.dibit_stride = c.dibit_stride;
+    l.sync_pos = (c.sync_pos && c.sync_dibit) ? c.sync_pos : nullptr; l.sync_dibit = c.sync_dibit; l.sync_stride = c.sync_stride;
+    ScanOut so;
+    so.src = -1; so.event_off = 0u; so.dibit_off = 0ull;
+    slice_tile(l, 0, ch, so, u, A.valid, A.s, A.hi, A.mid, A.lo);
+    tail_extract(c, ch);
+}
+
+// p25fe_slice for a chunk of at most one tile: planarize (one wave walks the ten planes), then the receiver.
+struct RecvChunkArgs {
+    ChunkRecvArgs r;
+    const float* bb;            // owned baseband sample 0 of channel 0 (host-visible staging: [tail | new])
+    long bb_stride;
+    long n_hist;                // valid samples before it
+    float* f;                   // planar scratch, writable view of r.pl
+    uint32_t* bits;
+    long n_blocks;
+};
+
+__global__ __launch_bounds__(WV, 4) void k_recv_chunk(RecvChunkArgs a)
+{
+    const int lane = threadIdx.x, ch = blockIdx.x;
+    const long hist = a.n_hist < HIST_BB + a.r.look ? a.n_hist : HIST_BB + a.r.look;
+    const float* bb = a.bb + (size_t)ch * a.bb_stride;
+    float* f = a.f + (size_t)ch * a.r.pl.f_ch;
+    uint32_t* bits = a.bits + (size_t)ch * a.r.pl.bits_ch;
+    // symbols that hold data (whole 64-symbol strides; planes past the range are never decided on: K2 drops positions >= tn)
+    long n_sym = ((a.r.n + a.r.look + PLPAD + SPS - 1) / SPS + WV - 1) / WV * WV;
+    if (n_sym > a.n_blocks * 32) n_sym = a.n_blocks * 32;
+    for (long i0 = 0; i0 < n_sym; i0 += WV) {
+        const long i = i0 + lane;
+#pragma unroll
+        for (int r = 0; r < SPS; ++r) {
+            const long m = SPS * i + r - PLPAD - a.r.look;
+            const float v = (m >= -hist && m < a.r.n + a.r.look) ? bb[m] : 0.0f;
+            f[planar_index(i, r)] = v;
+            const unsigned long long sg = __ballot(__float_as_int(v) < 0);
+            if ((lane & 31) == 0) bits[(i >> 5) * SPS + r] = (unsigned)(sg >> (lane & 32));
+        }
+    }
+    wave_global_sync();
+    recv_one_tile(a.r, ch);
 }
 
 // ------------------------------------------------------------------------------------------
