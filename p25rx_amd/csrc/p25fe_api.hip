@@ -23,7 +23,9 @@ namespace {
 constexpr size_t HISTPAD = 448;      // >= HIST_IQ_MAX (432 with 64 + 64 taps), multiple of 8: keeps 16-B alignment for u8 and cf32
 static_assert(HISTPAD >= (size_t)HIST_IQ_MAX && HISTPAD % 8 == 0, "stream history covers the longest filters");
 constexpr size_t BBPAD = 256;        // >= HIST_BB (240) + the tracking clock's lookahead, multiple of 4
-constexpr size_t SHARD_HALO = DEC * BBPAD + HISTPAD;   // 5 * 256 + 448 = 1728 samples (13.8 KB of cf32)
+constexpr size_t SHARD_HALO = 2048;                     // samples (16 KB of cf32): K1 recomputes one block (320 + 2) of baseband history in front of a
+                                                       // shard and needs 73 decimator outputs and 63 samples in front of that with 64-tap tables
+static_assert(SHARD_HALO >= (size_t)(DEC * (PLPAD + CLK_L + HALO_Y + TMAX - 1) + TMAX) && SHARD_HALO % 8 == 0, "shard halo");
 constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
 
 struct DevBuf {
@@ -421,10 +423,11 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     long subs = subs_env > 0 ? subs_env : (fmt == P25FE_FMT_U8 ? 9 : 3);
     if (chunk) subs = 1;                                            // a chunk is latency: every sub-tile its own workgroup
     if (subs > 32768) subs = 32768;
-    const long seg_len = (sub - SEG_HALO) + (subs - 1) * sub;
+    const long seg_len = subs * sub;
+    const long nd = HALO_Y + (h->long_taps ? TMAX : T2) - 1;       // decimator outputs the segment prologue computes in front of a segment
     const long n_seg = (total + seg_len - 1) / seg_len;
     const long pl_shift = PLPAD + h->look;       // the general receiver sees the range h->look samples late (p25fe_recv.hip)
-    if (planar && (m_begin + pl_shift < SEG_HALO || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
+    if (planar && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % PL_BLK != 0 || seg_len % PL_BLK != 0)) return P25FE_ERR_ARG;
     if (planar && n_out > (size_t)0x7ff00000u * 10u) return P25FE_ERR_ARG;   // symbol indices are 32-bit in the kernels: < 2^31 symbols (124 h of one channel) per call
 
     K1Args a;
@@ -441,10 +444,10 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     long seg_count = n_seg;
     if (part) {
         if (d_power_dbm) return P25FE_ERR_ARG;
-        // segment k reads input from o0 + 5 (m_begin + k seg_len - SEG_HALO) - (T1 - 1) on
+        // segment k reads input from o0 + 5 (m_begin + k seg_len - nd) - (T1 - 1) on
         const long o0 = (long)((4 + 5 - abs0 % 5) % 5);
         long k_min = 0;
-        while (k_min < n_seg && o0 + DEC * (m_begin + k_min * seg_len - SEG_HALO) - (t1 - 1) < 0) ++k_min;
+        while (k_min < n_seg && o0 + DEC * (m_begin + k_min * seg_len - nd) - (t1 - 1) < 0) ++k_min;
         if (part == 1) { a.seg_first = (int)k_min; seg_count = n_seg - k_min; }
         else seg_count = k_min;
         if (seg_count <= 0) return P25FE_OK;
@@ -849,7 +852,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
             else e1 = k1_done;
             k1_done_attached = true;
         }
-        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
+        rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
         if (rc) return rc;
         prof_mark(h, 1, st);
     }
@@ -891,7 +894,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     prof_k1_events(h, &e0, &e1);
     // K1 writes the baseband straight into the polyphase layout (+ sign planes); the 240 history positions in front
     // of the stream come out as the zeros of a fresh DemodTask (outputs of an all-zero input)
-    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
+    rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
     if (rc) return rc;
     prof_mark(h, 1, st);
     rc = launch_detect(h, n_bb, -h->look, st, rcall);
@@ -927,7 +930,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
             // that follows the halo wait is one workgroup), so an RCCL wait between the two is not in K1's figure
             hipEvent_t e0, e1;
             prof_k1_events(h, &e0, &e1);
-            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g,
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g,
                                  do_finish ? 0 : 1, e0, e1);
             if (rc) return rc;
         }
@@ -937,7 +940,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (!do_main) {
         if (h->sh_main_nbb != n_bb || h->sh_main_abs0 != abs0) return P25FE_ERR_ARG;     // finish without its main launch
         if (n_bb) {
-            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, st, &g, 2);
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 2);
             if (rc) return rc;
         }
     }
@@ -1220,7 +1223,7 @@ static int launch_chunk(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, 
                         const ChunkRecvArgs& r)
 {
     const PlanarGeo g(p25fe_n_baseband(abs0, n));
-    return launch_frontend(h, d_x, fmt, ch_stride, n_hist, n, abs0, -(long)HIST_BB - h->look, nullptr, 0, nullptr, h->stream, &g, 0,
+    return launch_frontend(h, d_x, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, h->stream, &g, 0,
                            nullptr, nullptr, &r);
 }
 
@@ -1257,7 +1260,7 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     } else {
         // the baseband stays in HBM; the receiver's history is recomputed from the IQ history, like a shard's from its halo
         const RecvCall rcall = recv_call(h);
-        rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)HIST_BB - h->look, nullptr, 0,
+        rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)PLPAD - h->look, nullptr, 0,
                              nullptr, h->stream, &g);
         if (rc) return rc;
         rc = launch_detect(h, nb, view0, h->stream, rcall);

@@ -42,11 +42,12 @@ constexpr int BOX = P25FE_BOXCAR;
 constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9])
 constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50 (the build's own tap counts; Geo<PK, 1> has its own)
 constexpr int TMAX = P25FE_MAX_TAPS;         // 64: tap-count ceiling of the ABI (p25fe_config_t), the generic kernels' geometry
-// Outputs recomputed (and dropped) at the start of every segment.  HALO_D = 50 would do for the arithmetic; 80 = one
-// byte of every sign-bit plane (8 symbols x 10 samples), so that with segment lengths that are multiples of 80 every
-// sub-tile starts on a byte boundary of the polyphase layout below and no two workgroups ever share a byte.
-constexpr int SEG_HALO = 80;
-static_assert(SEG_HALO >= HALO_Y + (TMAX - 1) && SEG_HALO % 80 == 0, "segment halo covers the filter memory (64 taps too) and is byte-aligned per plane");
+// A segment (the consecutive sub-tiles one workgroup walks) needs, in front of its first output, the HALO_Y + (T2 - 1)
+// decimator outputs its first channel-filter / discriminator / boxcar results depend on.  Rounds 1-2 recomputed 80 whole
+// OUTPUTS there and dropped them (a quarter of a sub-tile of arithmetic and of input per 880 outputs); round 3 computes
+// just those d's, the 10 channel outputs and 9 discriminator values behind them in a short prologue (K1 below), so
+// that every sub-tile yields 320 outputs and -- with ranges that start on a block boundary of the layout below -- IS one
+// 1280-byte block: whole 128-byte rows, one 32-bit sign word per plane.
 
 // Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
 // 240 history samples of the receiver at m = -240..-1), sample p belongs to plane r = p % 10 at symbol index i = p / 10.
@@ -56,8 +57,8 @@ static_assert(SEG_HALO >= HALO_Y + (TMAX - 1) && SEG_HALO % 80 == 0, "segment ha
 // A locked 4800 Bd slicer reads one plane: 128 contiguous bytes per 32 symbols; a 24-symbol sync window is 96 bytes
 // in at most two pieces; the sign words (1/32 of the baseband) are all the frame-sync screen has to touch.
 constexpr int SPS_ = P25FE_SPS;
-constexpr int PLPAD = 320;                   // >= 240 + SEG_HALO, multiple of 320 (owned sample 0 = bit 0 of word 1)
-static_assert(PLPAD % 320 == 0 && PLPAD >= 240 + SEG_HALO, "planar pad");
+constexpr int PLPAD = 320;                   // one block of history in front of owned sample 0 (= bit 0 of word 1); K1 starts at position 0
+static_assert(PLPAD % 320 == 0 && PLPAD >= 240 + 2, "planar pad holds the receiver's history");
 constexpr int OUT_LINEAR = 0, OUT_PLANAR = 1;
 constexpr int PL_BLK = 32 * P25FE_SPS;       // floats per block
 __host__ __device__ inline long planar_index(long i, int r) { return (i >> 5) * PL_BLK + r * 32 + (i & 31); }
@@ -350,14 +351,14 @@ __device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((
 #ifndef P25FE_K1_LD_AUX
 #define P25FE_K1_LD_AUX 0
 #endif
-template <int FMT, int PK, int TX = 0> struct Loader {
+template <int FMT, int PK, int TX = 0, int NVX = 0> struct Loader {
     using G = Geo<PK, TX>;
     // A lane's vector always holds TWO samples -- 16 B of cf32 or 4 B of u8 pairs -- which become one 16-B LDS store,
     // lane-consecutive and therefore conflict-free.  (u8 used to load 16 B = 8 samples per lane: the 64-B lane stride of
     // the resulting ds_write_b128 is a 4-way bank conflict in every 8-lane group and cost 20 % of the kernel.)
     static constexpr int LOG_SPV = 1;
     static constexpr int SPV = 1 << LOG_SPV;
-    static constexpr int NV = (G::XWIN + SPV + SPV * WV - 1) / (SPV * WV);   // vectors per lane: 13 for PK = 5
+    static constexpr int NV = NVX ? NVX : (G::XWIN + SPV + SPV * WV - 1) / (SPV * WV);   // vectors per lane: 13 for PK = 5 (NVX: the segment prologue's short window)
     using V = typename std::conditional<FMT == P25FE_FMT_CF32, uint4, unsigned>::type;
     V v[NV];
 
@@ -381,9 +382,6 @@ template <int FMT, int PK, int TX = 0> struct Loader {
     // i_last: last sample index this workgroup will ever need
     __device__ __forceinline__ void init(const void* base, long first0, long n_hist, long n_new, long i_last)
     {
-#if defined(P25FE_EXP) && (P25FE_EXP & 16)     // measurement build (wrong results): the halo in front of a segment is not read (zeros, no traffic)
-        first0 += DEC * SEG_HALO;
-#endif
         const long f_al = (first0 >> LOG_SPV) << LOG_SPV;
         const long lo_al = ((-n_hist) >> LOG_SPV) << LOG_SPV;
         base_idx = f_al > lo_al ? f_al : lo_al;
@@ -517,23 +515,25 @@ struct K1Args {
     int seg_first;          // first segment of this launch (a shard's head segment is launched after its halo has arrived)
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
     float* power_partial;   // nullable: [n_channels][seg_count] partial sums of |y|^2
-    // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + PLPAD >= SEG_HALO,
-    // (m_begin + PLPAD) % 80 == 0 and a segment length that is a multiple of 80.
+    // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + pl_shift >= 0 and a
+    // multiple of 320: every sub-tile is one block of the layout.
     float* bbp;             // channel 0
     long bbp_ch_stride;     // floats per channel (a whole number of blocks)
     uint8_t* bits;          // channel 0, addressed by byte
     long bits_ch_stride;    // bytes per channel
     int pl_shift;           // output m sits at planar position m + pl_shift: PLPAD, or PLPAD + 2 when the receiver runs with
-                            // the tracking clock's lookahead (p25fe_recv.hip); (m_begin + pl_shift) % 80 == 0
+                            // the tracking clock's lookahead (p25fe_recv.hip); (m_begin + pl_shift) % 320 == 0
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
 // registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
-// Register budget of the planar variants: minimum waves per SIMD the kernel is compiled for.  Same-box A/B
-// (tools/ab.sh, 3 processes x 30 launches): with 3 the planar kernel is allocated the SAME 146 VGPRs as with 2 but is
-// scheduled differently and ran 300 us instead of 272 us.
+// Register budget of the planar variants: minimum waves per SIMD the kernel is compiled for.  Round 2 (segment halo of
+// 80 recomputed outputs): bound 3 and bound 2 were both allocated 146 VGPRs, the bound-3 schedule ran 300 us against 272.
+// Round 3 (segment prologue): unbounded the cf32 kernel takes 174 VGPRs = 2 waves per SIMD and runs 0.264 ms; bound to 3
+// it takes 168 with two 8-byte spills OUTSIDE the sub-tile loop (item setup -> after the prologue / after the loop) and
+// runs 0.257 - 0.261 ms against 0.254 - 0.256 of the round-2 kernel on the same box (tools/k1_ab.sh).
 #ifndef P25FE_K1_PLANAR_WPS
-#define P25FE_K1_PLANAR_WPS 2
+#define P25FE_K1_PLANAR_WPS 3
 #endif
 // Windows in flight per wave (register-staged loader).  Measured (tools/ab.sh, same box): a second register set costs
 // the cf32 kernel a wave per SIMD (181 VGPRs -> 8 waves per CU instead of 11) and makes it 25 % SLOWER (318 vs 254 us)
@@ -602,7 +602,14 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     auto tap_dec = [&](int k) -> float { return CT ? P25FE_DEFAULT_DECIM_TAPS[k] : TAPS[k]; };
     auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
-    const long seg_len = (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
+    const long seg_len = (long)a.subs_per_seg * SUB;
+    // segment prologue: the ND decimator outputs in front of the segment, from a window of PWIN input samples
+    constexpr int ND = HALO_Y + (T2 - 1);                           // 50 (73 with 64-tap tables)
+    constexpr int PWIN = DEC * (ND - 1) + T1;                       // 276 (424)
+    constexpr int NVP = (PWIN + 2 + 2 * WV - 1) / (2 * WV);         // 16-B vectors per lane: 3 (4)
+    constexpr int PBASE = 2 * WV * NVP;                             // the d's are parked behind the staged prologue window
+    constexpr int NDL = (ND + WV - 1) / WV;                         // d's per lane: 1 (2)
+    static_assert(PBASE + ND <= G::XIN_N && D_CARRY <= ND, "prologue scratch fits the window region");
 #ifdef P25FE_K1_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_n = 0, st_pro = 0, st_items = 0;
 #endif
@@ -631,18 +638,22 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     float* bb = a.bb + (size_t)ch * a.bb_stride;
     phase_sync();                                                   // the previous item's LDS reads precede this item's writes
 
-    // zero the d carry (its garbage would only reach never-stored outputs, but keep it tidy)
-    for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
-
     using LoaderT = Loader<FMT, PK, TX>;
+    using LoaderP = Loader<FMT, PK, TX, NVP>;
     LoaderT ld0, ld1;
-    long dlo = m_seg0 - SEG_HALO;                                  // first d index of this sub-tile
+    LoaderP lp;
+    long dlo = m_seg0;                                             // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
-    ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
+    const long pfirst = (long)a.o0 + DEC * (m_seg0 - ND) - (T1 - 1);     // first input sample of the prologue window
+    ld0.init(xb, pfirst, a.n_hist, a.n_new, i_last);
+    lp.rs = ld0.rs; lp.base_idx = ld0.base_idx;
+    // one HBM round trip for the prologue window and the first sub-tile's window (both may start before the descriptor's base
+    // at the start of a stream: load_first sends those lanes out of range = zeros)
+    lp.load_first(pfirst, tid);
     ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
     if constexpr (PF == 2) {
         ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
-        ld1.load((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
+        ld1.load_first((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
     }
     float pw = 0.f;
 
@@ -650,10 +661,60 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     // fm values of the last NBACK lanes of the previous sub-tile
     float2 y_carry = make_float2(0.f, 0.f);
     float f_carry[NBACK][P];
+    {
+        // ---- prologue: d[m_seg0 - ND .. m_seg0) on lanes 0 .. ND-1, y[m_seg0 - 10 .. m_seg0) and the discriminator values
+        // behind them on lanes 0..9 -- the state a receiver that had run through the previous segment would hand over.
+        // Same tap order and single accumulators as the sub-tiles (SPEC 3.2 - 3.4): the same bits.
+        float2* const PD_ = XIN + PBASE;
+        lp.store(XIN, pfirst, a.n_hist, a.n_new, tid);
+        lp.fixup(XIN, pfirst, a.n_hist, a.n_new, tid);
+        phase_sync();
+        const int pxsh = (int)(pfirst & 1);
+        v2f dacc[NDL];
 #pragma unroll
-    for (int b = 0; b < NBACK; ++b)
+        for (int r = 0; r < NDL; ++r) {
+            dacc[r] = v2f{0.f, 0.f};
+            const int l = tid + WV * r;
+            if (NDL == 1 || l < ND) {                               // (one d per lane: the 14 surplus lanes compute on staged zeros / garbage, never stored)
+                const float2* w = XIN + pxsh + DEC * l;             // lane stride 5 complex = 10 dwords: conflict-free ds_read_b64
+                lds_walk<T1, CT>(w, [&](auto jc, v2f sv) {           // newest to oldest => tap order 0..T1-1
+                    constexpr int j = decltype(jc)::value;
+                    dacc[r] = cfma(tap_dec(T1 - 1 - j), sv, dacc[r]);
+                });
+            }
+        }
 #pragma unroll
-        for (int p = 0; p < P; ++p) f_carry[b][p] = 0.f;
+        for (int r = 0; r < NDL; ++r) {
+            const int l = tid + WV * r;
+            if (l < ND) PD_[l] = make_float2(dacc[r].x, dacc[r].y);
+        }
+        phase_sync();
+        v2f yv = v2f{0.f, 0.f};
+        if (tid < HALO_Y) {
+            const float2* w = PD_ + (ND - HALO_Y) - (T2 - 1) + tid; // d[m - k] = w[T2 - 1 - k] for m = m_seg0 - 10 + tid
+            lds_walk<T2, CT>(w, [&](auto jc, v2f sv) {
+                constexpr int j = decltype(jc)::value;
+                yv = cfma(tap_ch(T2 - 1 - j), sv, yv);
+            });
+        }
+        float2 yp;
+        yp.x = wave_shr1(yv.x, 0.f);
+        yp.y = wave_shr1(yv.y, 0.f);
+        const float fmv = fm_discriminate(make_float2(yv.x, yv.y), yp);     // lane l: fm[m_seg0 - 10 + l], l = 1..9 (lane 0: unused)
+        y_carry.x = lane_bcast<HALO_Y - 1>(yv.x);
+        y_carry.y = lane_bcast<HALO_Y - 1>(yv.y);
+        static_for<0, NBACK>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            static_for<0, P>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                constexpr int l = HALO_Y - (b + 1) * P + p;          // f_carry[b][p] = fm of lane 63 - b, output p, of the sub-tile before
+                if constexpr (l >= 1) f_carry[b][p] = lane_bcast<l>(fmv);
+                else f_carry[b][p] = 0.f;                            // further back than the boxcar reaches
+            });
+        });
+        for (int k = tid; k < D_CARRY; k += WV) D[k] = PD_[ND - D_CARRY + k];
+        phase_sync();
+    }
 
     // Outputs are kept in registers for one sub-tile and stored at the top of the next one, BEFORE the
     // prefetch loads are issued: vmcnt counts loads and stores in one in-order queue, so stores issued
@@ -667,10 +728,10 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     float* const bb_seg = OM == OUT_LINEAR ? bb + m_seg0 : nullptr;
     // planar: lane = (half h = tid >> 5, symbol tid & 31) holds, in outv[q], plane 5 h + q of the sub-tile's 32 symbols
     const int pl_sym = tid & 31, pl_h5 = (tid >> 5) * 5;
-    const int i_seg = OM == OUT_PLANAR ? (int)((m_seg0 + a.pl_shift) / SPS_) : 0;     // symbol index of the segment's first output (multiple of 8)
+    const int i_seg = OM == OUT_PLANAR ? (int)((m_seg0 + a.pl_shift) / SPS_) : 0;     // symbol index of the segment's first output (multiple of 32)
     float* const bbp_ch = OM == OUT_PLANAR ? a.bbp + (size_t)ch * a.bbp_ch_stride : nullptr;
     uint8_t* const bits_ch = OM == OUT_PLANAR ? a.bits + (size_t)ch * a.bits_ch_stride : nullptr;
-    unsigned bitsv = 0u;                                            // lanes 0..39: byte (tid & 3) of plane (tid >> 2)
+    unsigned bitsv = 0u;                                            // lanes 0..9: the sign word of plane tid
     auto flush_outputs = [&]() {
         if constexpr (OM == OUT_LINEAR) {
 #pragma unroll
@@ -679,16 +740,14 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
                 if (r >= 0 && r < seg_n) bb_seg[r] = outv[q];
             }
         } else {
-            const int i_sub = i_seg + out_rel / SPS_;               // symbol index of the sub-tile (multiple of 8, >= 0)
-            const int i = i_sub + pl_sym;
-            float* const row = bbp_ch + (size_t)(i >> 5) * PL_BLK + (i & 31) + 32 * pl_h5;
+            // a sub-tile is one block of the layout: ten 128-byte rows and ten sign words
+            const int blk = (i_seg >> 5) + out_rel / SUB;
+            float* const row = bbp_ch + (size_t)blk * PL_BLK + pl_sym + 32 * pl_h5;
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
 #if defined(P25FE_EXP) && (P25FE_EXP & 8)      // measurement build: no baseband stores at all (what the write stream costs)
                 asm volatile("" ::"v"(outv[q]), "v"(r));
-#elif defined(P25FE_EXP) && (P25FE_EXP & 2)    // measurement build: lane-consecutive (wrong) addresses
-                if (r >= 0 && r < seg_n) bbp_ch[(long)i_seg * SPS_ + out_rel + tid + q * WV] = outv[q];
 #else
 #if P25FE_K1_NT_STORES
                 if (r >= 0 && r < seg_n) __builtin_nontemporal_store(outv[q], row + 32 * q);
@@ -697,16 +756,11 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #endif
 #endif
             }
-            // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
-            // either wholly inside the segment or wholly halo (the range's last byte may carry bits past n_out: unread)
-            const int r0 = out_rel + 8 * SPS_ * (tid & 3) + (tid >> 2);
-            const int ib = i_sub + 8 * (tid & 3);
-#if defined(P25FE_EXP) && (P25FE_EXP & 1)      // measurement build: no sign planes
-            if (false)
-#else
-            if (tid < 4 * SPS_ && r0 >= 0 && r0 < seg_n)
+            // lane j < 10 holds plane j's 32 sign bits of the sub-tile (the range's last word may carry bits past n_out: unread)
+#if !(defined(P25FE_EXP) && (P25FE_EXP & 1))   // (measurement build: no sign planes)
+            if (tid < SPS_ && out_rel >= 0 && out_rel < seg_n)
+                reinterpret_cast<unsigned*>(bits_ch)[(size_t)blk * SPS_ + tid] = bitsv;
 #endif
-                bits_ch[((size_t)(ib >> 5) * SPS_ + (tid >> 2)) * 4 + ((ib >> 3) & 3)] = (uint8_t)bitsv;
         }
     };
 
@@ -909,8 +963,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #if !(defined(P25FE_EXP) && (P25FE_EXP & 1))
             w = lanes_from_ballots(sg);                              // lane q: word of plane q, lane q + 5: plane q + 5
 #endif
-            const unsigned pw_ = lane_gather(w, tid >> 2);          // lane j <- word of plane j >> 2
-            bitsv = (pw_ >> (8 * (tid & 3))) & 0xffu;
+            bitsv = w;
         }
         out_rel = (int)(dlo - m_seg0);
         phase_sync();

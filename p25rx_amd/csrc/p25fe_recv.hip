@@ -29,7 +29,7 @@ constexpr int SPS = P25FE_SPS;
 constexpr int NSYN = P25FE_SYNC_DIBITS;
 constexpr int SYNC_SPAN = P25FE_SYNC_SPAN;                   // 230
 constexpr int HIST_BB = SYNC_SPAN + 2 * W;                   // 240: baseband history the receiver needs
-static_assert(SPS == SPS_ && PLPAD >= HIST_BB + SEG_HALO, "planar layout matches the receiver");
+static_assert(SPS == SPS_ && PLPAD >= HIST_BB + P25FE_CLK_LOOKAHEAD, "planar layout matches the receiver");
 
 constexpr int TSYM = 768;                                    // symbols of every plane per tile (24 words of sign bits)
 constexpr int TS = TSYM * SPS;                               // 7680 baseband samples (decision indices) per tile
