@@ -1,0 +1,308 @@
+// p25fe_rccl.cpp -- include/p25fe_rccl.h: the time-sharded step (BASELINE.json config 5) over RCCL, behind the C ABI.
+// Host code only (the kernels are libp25fe.so's); built into libp25fe_rccl.so, which links libp25fe.so and librccl.so.
+#include "p25fe_rccl.h"
+
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int RING = 64;                  // steps whose exchange events are kept for p25fe_shard_comm_ms
+constexpr size_t SHM_HALO_MAX = 4096 * 8; // bytes of one halo slot in the test hook's shared segment
+
+// TEST HOOK: the collectives through a POSIX shared-memory segment (every rank on the same GPU).  Layout: a sense-
+// reversing barrier, one halo slot, one summary slot and one dibit row per rank.
+struct ShmHdr {
+    std::atomic<unsigned> arrived;
+    std::atomic<unsigned> phase;
+    unsigned world;
+    unsigned pad;
+    unsigned long long row_bytes;
+};
+struct Shm {
+    ShmHdr* hd = nullptr;
+    char* base = nullptr;
+    size_t bytes = 0;
+    char* halo(int r) const { return base + sizeof(ShmHdr) + (size_t)r * SHM_HALO_MAX; }
+    char* summ(int r) const { return base + sizeof(ShmHdr) + (size_t)hd->world * SHM_HALO_MAX + (size_t)r * sizeof(p25fe_result_t); }
+    char* row(int r) const
+    {
+        return base + sizeof(ShmHdr) + (size_t)hd->world * (SHM_HALO_MAX + sizeof(p25fe_result_t)) + (size_t)r * hd->row_bytes;
+    }
+    void barrier() const
+    {
+        const unsigned ph = hd->phase.load(std::memory_order_acquire);
+        if (hd->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == hd->world) {
+            hd->arrived.store(0, std::memory_order_relaxed);
+            hd->phase.store(ph + 1, std::memory_order_release);
+        } else {
+            while (hd->phase.load(std::memory_order_acquire) == ph) usleep(50);
+        }
+    }
+};
+
+}  // namespace
+
+struct p25fe_shard {
+    p25fe_t* h = nullptr;
+    int rank = 0, world = 1;
+    size_t n = 0, halo = 0, cap = 0;
+    bool staged = false;
+    ncclComm_t comm = nullptr;
+    Shm shm;
+    hipStream_t cs = nullptr;             // the halo exchange runs beside K1
+    hipEvent_t e_fork = nullptr, e_join = nullptr;
+    hipEvent_t ev[RING][6];               // halo begin / end, all-gather begin / end, gather begin / end
+    uint64_t steps = 0, read_from = 0;
+    std::vector<uint64_t> bb0, bbn;
+    p25fe_result_t* d_summ = nullptr;
+    uint64_t *d_bb0 = nullptr, *d_bbn = nullptr, *d_off = nullptr;
+    p25fe_anchor_t* d_anc = nullptr;
+    uint8_t *d_gathered = nullptr, *d_stream = nullptr;
+    char* d_loop = nullptr;               // one-rank RCCL group (tests on a 1-GPU box): where the halo loops back to
+};
+
+#define HCHK(x) do { if ((x) != hipSuccess) return P25FE_ERR_HIP; } while (0)
+#define NCHK(x) do { if ((x) != ncclSuccess) return P25FE_ERR_HIP; } while (0)
+
+extern "C" {
+
+int p25fe_rccl_unique_id(void* id128)
+{
+    static_assert(sizeof(ncclUniqueId) <= P25FE_RCCL_ID_BYTES, "id size");
+    if (!id128) return P25FE_ERR_ARG;
+    ncclUniqueId id;
+    NCHK(ncclGetUniqueId(&id));
+    memset(id128, 0, P25FE_RCCL_ID_BYTES);
+    memcpy(id128, &id, sizeof id);
+    return P25FE_OK;
+}
+
+size_t p25fe_shard_dibit_cap(const p25fe_shard_t* s) { return s ? s->cap : 0; }
+
+void p25fe_shard_destroy(p25fe_shard_t* s)
+{
+    if (!s) return;
+    if (s->cs) { (void)hipStreamSynchronize(s->cs); (void)hipStreamDestroy(s->cs); }
+    if (s->comm) (void)ncclCommDestroy(s->comm);
+    if (s->e_fork) (void)hipEventDestroy(s->e_fork);
+    if (s->e_join) (void)hipEventDestroy(s->e_join);
+    for (auto& row : s->ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+    void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_anc, s->d_gathered, s->d_stream, s->d_loop};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (s->shm.base) munmap(s->shm.base, s->shm.bytes);
+    delete s;
+}
+
+int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_t n_per_rank, p25fe_shard_t** out)
+{
+    if (!h || !out || world < 1 || rank < 0 || rank >= world || n_per_rank == 0 || (n_per_rank % 8) != 0) return P25FE_ERR_ARG;
+    *out = nullptr;
+    p25fe_shard_t* s = new (std::nothrow) p25fe_shard;
+    if (!s) return P25FE_ERR_NOMEM;
+    for (auto& row : s->ev) for (hipEvent_t& e : row) e = nullptr;
+    s->h = h; s->rank = rank; s->world = world; s->n = n_per_rank; s->halo = p25fe_shard_halo();
+    size_t bbmax = 0;
+    for (int r = 0; r < world; ++r) {
+        s->bb0.push_back(p25fe_n_baseband(0, (size_t)r * n_per_rank));
+        s->bbn.push_back(p25fe_n_baseband((uint64_t)r * n_per_rank, n_per_rank));
+        if (s->bbn.back() > bbmax) bbmax = (size_t)s->bbn.back();
+    }
+    // a receiver that re-anchors on every sync word follows the TRANSMITTER's symbol clock: proportional slack (200 ppm)
+    s->cap = ((bbmax / 10 + bbmax / 50000 + 64) + 15) / 16 * 16;
+    int rc = P25FE_OK;
+    auto fail = [&](int code) { p25fe_shard_destroy(s); return code; };
+    if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess) return fail(P25FE_ERR_HIP);
+    if (hipEventCreateWithFlags(&s->e_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->e_join, hipEventDisableTiming) != hipSuccess) return fail(P25FE_ERR_HIP);
+    for (auto& row : s->ev) for (hipEvent_t& e : row) if (hipEventCreate(&e) != hipSuccess) return fail(P25FE_ERR_HIP);
+    const size_t W = (size_t)world;
+    if (hipMalloc(&s->d_summ, W * sizeof(p25fe_result_t)) != hipSuccess || hipMalloc(&s->d_bb0, W * 8) != hipSuccess ||
+        hipMalloc(&s->d_bbn, W * 8) != hipSuccess || hipMalloc(&s->d_off, (W + 1) * 8) != hipSuccess ||
+        hipMalloc(&s->d_anc, W * sizeof(p25fe_anchor_t)) != hipSuccess || hipMalloc(&s->d_gathered, W * s->cap) != hipSuccess ||
+        hipMalloc(&s->d_stream, W * s->cap) != hipSuccess)
+        return fail(P25FE_ERR_NOMEM);
+    if (hipMemcpy(s->d_bb0, s->bb0.data(), W * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->d_bbn, s->bbn.data(), W * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(P25FE_ERR_HIP);
+    if (world > 1 || id128) {
+        if (id128) {
+            ncclUniqueId id;
+            memcpy(&id, id128, sizeof id);
+            if (ncclCommInitRank(&s->comm, world, id, rank) != ncclSuccess) return fail(P25FE_ERR_HIP);
+            if (world == 1 && hipMalloc(&s->d_loop, s->halo * 8) != hipSuccess) return fail(P25FE_ERR_NOMEM);
+        } else {
+            const char* name = getenv("P25FE_SHARD_SHM");
+            if (!name || s->halo * 8 > SHM_HALO_MAX) return fail(P25FE_ERR_ARG);
+            s->staged = true;
+            s->shm.bytes = sizeof(ShmHdr) + W * (SHM_HALO_MAX + sizeof(p25fe_result_t) + s->cap);
+            const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)s->shm.bytes) != 0) { if (fd >= 0) close(fd); return fail(P25FE_ERR_ARG); }
+            void* p = mmap(nullptr, s->shm.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p == MAP_FAILED) return fail(P25FE_ERR_NOMEM);
+            s->shm.base = static_cast<char*>(p);
+            s->shm.hd = reinterpret_cast<ShmHdr*>(p);          // a fresh segment is zero-filled: barrier state starts at 0
+            s->shm.hd->world = (unsigned)world;
+            s->shm.hd->row_bytes = s->cap;
+        }
+    }
+    (void)rc;
+    *out = s;
+    return P25FE_OK;
+}
+
+int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
+{
+    if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8)) return P25FE_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t eb = fmt == P25FE_FMT_CF32 ? 8 : 2;
+    char* buf = static_cast<char*>(d_buf);
+    char* owned = buf + s->halo * eb;
+    const size_t n_hist = s->rank > 0 ? s->halo : 0;
+    const uint64_t abs0 = (uint64_t)s->rank * s->n;
+    hipEvent_t* ev = s->ev[s->steps % RING];
+    const bool multi = s->world > 1 || s->comm != nullptr;
+    int rc;
+    if (multi) {
+        // ---- 1. halo: my last `halo` samples -> rank + 1, rank - 1's -> the front of my buffer, beside K1's main launch
+        if (s->staged) {
+            HCHK(hipStreamSynchronize(st));
+            if (s->rank + 1 < s->world) HCHK(hipMemcpy(s->shm.halo(s->rank), buf + s->n * eb, s->halo * eb, hipMemcpyDeviceToHost));
+            s->shm.barrier();
+            if (s->rank > 0) HCHK(hipMemcpy(buf, s->shm.halo(s->rank - 1), s->halo * eb, hipMemcpyHostToDevice));
+            s->shm.barrier();
+            rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
+            if (rc) return rc;
+        } else {
+            HCHK(hipEventRecord(s->e_fork, st));                 // the exchange may not overtake earlier users of the buffers
+            HCHK(hipStreamWaitEvent(s->cs, s->e_fork, 0));
+            HCHK(hipEventRecord(ev[0], s->cs));
+            NCHK(ncclGroupStart());
+            if (s->rank + 1 < s->world) NCHK(ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, s->comm, s->cs));
+            if (s->rank > 0) NCHK(ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, s->comm, s->cs));
+            if (s->world == 1) {                                 // one-rank group (tests on a 1-GPU box): loop the halo back
+                NCHK(ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
+                NCHK(ncclRecv(s->d_loop, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
+            }
+            NCHK(ncclGroupEnd());
+            HCHK(hipEventRecord(ev[1], s->cs));
+            rc = p25fe_shard_pass1_main(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);
+            if (rc) return rc;
+            HCHK(hipStreamWaitEvent(st, ev[1], 0));
+            rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
+            if (rc) return rc;
+        }
+        // ---- 2. one summary per rank to every rank
+        if (s->staged) {
+            HCHK(hipStreamSynchronize(st));
+            HCHK(hipMemcpy(s->shm.summ(s->rank), d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToHost));
+            s->shm.barrier();
+            HCHK(hipMemcpy(s->d_summ, s->shm.summ(0), (size_t)s->world * sizeof(p25fe_result_t), hipMemcpyHostToDevice));
+            s->shm.barrier();
+        } else {
+            HCHK(hipEventRecord(ev[2], st));
+            NCHK(ncclAllGather(d_result, s->d_summ, sizeof(p25fe_result_t), ncclUint8, s->comm, st));
+            HCHK(hipEventRecord(ev[3], st));
+        }
+    } else {
+        rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
+        if (rc) return rc;
+        HCHK(hipMemcpyAsync(s->d_summ, d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToDevice, st));
+    }
+    rc = p25fe_shard_resolve_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, s->d_anc, s->d_off, st);
+    if (rc) return rc;
+    rc = p25fe_shard_pass2(s->h, s->d_anc + s->rank, d_dibits, s->cap, d_result, st);
+    if (rc) return rc;
+    // ---- 3. the reduced dibit stream
+    if (gather != P25FE_GATHER_NONE) {
+        bool have_all = false;
+        if (!multi) {
+            HCHK(hipMemcpyAsync(s->d_gathered, d_dibits, s->cap, hipMemcpyDeviceToDevice, st));
+            have_all = true;
+        } else if (s->staged) {
+            HCHK(hipStreamSynchronize(st));
+            HCHK(hipMemcpy(s->shm.row(s->rank), d_dibits, s->cap, hipMemcpyDeviceToHost));
+            s->shm.barrier();
+            if (s->rank == 0 || gather == P25FE_GATHER_ALL) {
+                HCHK(hipMemcpy(s->d_gathered, s->shm.row(0), (size_t)s->world * s->cap, hipMemcpyHostToDevice));
+                have_all = true;
+            }
+            s->shm.barrier();
+        } else {
+            HCHK(hipEventRecord(ev[4], st));
+            if (gather == P25FE_GATHER_ALL) {
+                NCHK(ncclAllGather(d_dibits, s->d_gathered, s->cap, ncclUint8, s->comm, st));
+                have_all = true;
+            } else {
+                // point-to-point to the root: every rank has its own xGMI link to it, the shards arrive in parallel (an
+                // all-gather would move `world` times the bytes the one consumer needs around a per-link-bound ring)
+                NCHK(ncclGroupStart());
+                if (s->rank == 0) {
+                    for (int r = 1; r < s->world; ++r) NCHK(ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, st));
+                } else {
+                    NCHK(ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, st));
+                }
+                NCHK(ncclGroupEnd());
+                if (s->rank == 0) {
+                    HCHK(hipMemcpyAsync(s->d_gathered, d_dibits, s->cap, hipMemcpyDeviceToDevice, st));
+                    have_all = true;
+                }
+            }
+            HCHK(hipEventRecord(ev[5], st));
+        }
+        if (have_all) {
+            rc = p25fe_shard_compact_dev(s->h, s->d_gathered, s->cap, s->d_off, (size_t)s->world, s->d_stream,
+                                         (size_t)s->world * s->cap, st);
+            if (rc) return rc;
+        }
+    }
+    ++s->steps;
+    return P25FE_OK;
+}
+
+int p25fe_shard_offsets(p25fe_shard_t* s, uint64_t* offsets)
+{
+    if (!s || !offsets) return P25FE_ERR_ARG;
+    HCHK(hipMemcpy(offsets, s->d_off, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost));
+    for (int r = 0; r < s->world; ++r)
+        if (offsets[r + 1] - offsets[r] > s->cap) return P25FE_ERR_CAPACITY;     // the row was filled to the brim; the count is exact
+    return P25FE_OK;
+}
+
+const uint8_t* p25fe_shard_stream_dev(const p25fe_shard_t* s) { return s ? s->d_stream : nullptr; }
+
+int p25fe_shard_comm_ms(p25fe_shard_t* s, double ms[3], uint64_t* n_steps)
+{
+    if (!s || !ms) return P25FE_ERR_ARG;
+    ms[0] = ms[1] = ms[2] = 0.0;
+    uint64_t from = s->read_from, cnt = 0;
+    if (s->steps - from > (uint64_t)RING) from = s->steps - RING;
+    if (s->comm && !s->staged) {
+        for (uint64_t k = from; k < s->steps; ++k) {
+            hipEvent_t* ev = s->ev[k % RING];
+            for (int q = 0; q < 3; ++q) {
+                float t = 0.f;
+                if (hipEventSynchronize(ev[2 * q + 1]) == hipSuccess && hipEventElapsedTime(&t, ev[2 * q], ev[2 * q + 1]) == hipSuccess) ms[q] += t;
+                else (void)hipGetLastError();                        // (a phase this step did not run, e.g. no gather)
+            }
+            ++cnt;
+        }
+    }
+    for (int q = 0; q < 3; ++q) ms[q] = cnt ? ms[q] / (double)cnt : 0.0;
+    if (n_steps) *n_steps = cnt;
+    s->read_from = s->steps;
+    return P25FE_OK;
+}
+
+}  // extern "C"

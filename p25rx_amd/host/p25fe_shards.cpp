@@ -1,0 +1,157 @@
+// p25fe_shards -- one process per GPU over a time-sharded capture (BASELINE.json config 5), the launcher a Rust host would
+// replace: forks RANKS children BEFORE anything touches the GPU; each child owns a contiguous range of a cf32 capture file,
+// drives include/p25fe_rccl.h (halo by ncclSend / ncclRecv behind K1, summaries by ncclAllGather, device resolve, dibit
+// rows to rank 0 + compaction) and rank 0 writes the ORDERED dibit stream -- byte for byte what `p25fe_replay cf32` writes.
+//
+//   p25fe_shards [-n RANKS] [-k STEPS] [--shm] <in.cf32> <dibits.out>
+//
+//   --shm   TEST HOOK: all ranks on GPU 0, exchanges through a shared-memory segment instead of RCCL (a 1-GPU box)
+//   -n 1    runs the same step through a ONE-rank RCCL communicator (self send / recv, all-gather of one)
+// Prints one JSON line (rank 0): dibits, steps, ms per step, ms per step in each exchange.
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "p25fe_rccl.h"
+
+static void die(const char* what, int rc)
+{
+    std::fprintf(stderr, "p25fe_shards: %s (%s, status %d)\n", what, p25fe_strerror(rc), rc);
+    std::_Exit(1);
+}
+
+static int child(int rank, int world, int steps, bool shm, const char* in_path, const char* out_path, const std::string& key)
+{
+    FILE* f = std::fopen(in_path, "rb");
+    if (!f) { std::fprintf(stderr, "unable to open %s\n", in_path); return 1; }
+    struct stat sb;
+    stat(in_path, &sb);
+    const size_t total = (size_t)sb.st_size / 8;
+    const size_t n = total / (size_t)world / 8 * 8;                  // shard cut points stay 16-byte aligned
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::fprintf(stderr, "no HIP device\n"); return 1; }
+    const int dev = shm ? 0 : rank % ndev;
+    p25fe_config_t cfg;
+    p25fe_default_config(&cfg);
+    cfg.device = dev;
+    p25fe_t* h = nullptr;
+    int rc = p25fe_create(&cfg, &h);
+    if (rc) die("unable to create the handle", rc);
+    unsigned char id[P25FE_RCCL_ID_BYTES];
+    const std::string idfile = std::string(out_path) + ".id";
+    if (!shm) {                                                     // bootstrap: rank 0's id travels through a file
+        if (rank == 0) {
+            rc = p25fe_rccl_unique_id(id);
+            if (rc) die("ncclGetUniqueId", rc);
+            FILE* g = std::fopen((idfile + ".tmp").c_str(), "wb");
+            std::fwrite(id, 1, sizeof id, g);
+            std::fclose(g);
+            std::rename((idfile + ".tmp").c_str(), idfile.c_str());
+        } else {
+            FILE* g = nullptr;
+            for (int t = 0; t < 60000 && !(g = std::fopen(idfile.c_str(), "rb")); ++t) usleep(1000);
+            if (!g || std::fread(id, 1, sizeof id, g) != sizeof id) { std::fprintf(stderr, "no communicator id\n"); return 1; }
+            std::fclose(g);
+        }
+    } else {
+        setenv("P25FE_SHARD_SHM", key.c_str(), 1);
+    }
+    p25fe_shard_t* s = nullptr;
+    rc = p25fe_shard_create(h, rank, world, shm ? nullptr : id, n, &s);
+    if (rc) die("unable to create the shard", rc);
+    const size_t halo = p25fe_shard_halo(), cap = p25fe_shard_dibit_cap(s);
+    // resident capture of this rank: [halo | owned]
+    std::vector<float> host(2 * n);
+    std::fseek(f, (long)((size_t)rank * n * 8), SEEK_SET);
+    if (std::fread(host.data(), 8, n, f) != n) { std::fprintf(stderr, "short read\n"); return 1; }
+    std::fclose(f);
+    float* d_buf = nullptr;
+    uint8_t* d_dib = nullptr;
+    p25fe_result_t* d_res = nullptr;
+    hipStream_t st;
+    if (hipMalloc(&d_buf, (halo + n) * 8) != hipSuccess || hipMalloc(&d_dib, cap) != hipSuccess || hipMalloc(&d_res, sizeof *d_res) != hipSuccess ||
+        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+        die("device buffers", P25FE_ERR_NOMEM);
+    (void)hipMemset(d_buf, 0, halo * 8);
+    (void)hipMemcpy(d_buf + 2 * halo, host.data(), n * 8, hipMemcpyHostToDevice);
+    for (int k = 0; k < 2; ++k) {                                     // warm-up (communicator set-up, scratch allocation)
+        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, P25FE_GATHER_ROOT, st);
+        if (rc) die("step", rc);
+    }
+    (void)hipStreamSynchronize(st);
+    double cms[3];
+    uint64_t cn = 0;
+    (void)p25fe_shard_comm_ms(s, cms, &cn);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < steps; ++k) {
+        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, P25FE_GATHER_ROOT, st);
+        if (rc) die("step", rc);
+    }
+    (void)hipStreamSynchronize(st);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
+    (void)p25fe_shard_comm_ms(s, cms, &cn);
+    std::vector<uint64_t> off((size_t)world + 1);
+    rc = p25fe_shard_offsets(s, off.data());
+    if (rc) die("offsets", rc);
+    if (rank == 0) {
+        std::vector<uint8_t> stream((size_t)off[(size_t)world]);
+        (void)hipMemcpy(stream.data(), p25fe_shard_stream_dev(s), stream.size(), hipMemcpyDeviceToHost);
+        FILE* g = std::fopen(out_path, "wb");
+        std::fwrite(stream.data(), 1, stream.size(), g);
+        std::fclose(g);
+        std::printf("{\"ranks\":%d,\"samples_per_rank\":%zu,\"dibits\":%" PRIu64 ",\"steps\":%d,\"ms_per_step\":%.4f,"
+                    "\"comm_ms_per_step\":{\"halo\":%.4f,\"summaries\":%.4f,\"dibit_gather\":%.4f,\"steps_averaged\":%" PRIu64 "},"
+                    "\"exchange\":\"%s\"}\n",
+                    world, n, off[(size_t)world], steps, ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL");
+        std::remove(idfile.c_str());
+    }
+    p25fe_shard_destroy(s);
+    p25fe_destroy(h);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    int ranks = 1, steps = 3, a = 1;
+    bool shm = false;
+    for (; a < argc && argv[a][0] == '-'; ++a) {
+        if (!std::strcmp(argv[a], "-n") && a + 1 < argc) ranks = std::atoi(argv[++a]);
+        else if (!std::strcmp(argv[a], "-k") && a + 1 < argc) steps = std::atoi(argv[++a]);
+        else if (!std::strcmp(argv[a], "--shm")) shm = true;
+        else break;
+    }
+    if (argc - a != 2 || ranks < 1 || steps < 1) {
+        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
+        return 2;
+    }
+    const std::string key = "/p25fe_shards_" + std::to_string((long)getpid());
+    std::remove((std::string(argv[a + 1]) + ".id").c_str());
+    // one process per rank, forked before the GPU is touched (a process that has initialised HIP must not fork workers)
+    std::vector<pid_t> kids;
+    for (int r = 0; r < ranks; ++r) {
+        const pid_t p = fork();
+        if (p == 0) std::_Exit(child(r, ranks, steps, shm, argv[a], argv[a + 1], key));
+        kids.push_back(p);
+    }
+    int bad = 0;
+    for (pid_t p : kids) {
+        int stt = 0;
+        waitpid(p, &stt, 0);
+        if (!WIFEXITED(stt) || WEXITSTATUS(stt) != 0) bad = 1;
+    }
+    if (shm) {
+        const std::string path = "/dev/shm" + key;
+        std::remove(path.c_str());
+    }
+    return bad;
+}

@@ -29,6 +29,22 @@ def test_header_symbols_all_exported(lib):
     assert declared <= exported, declared - exported
 
 
+def test_rccl_library_exports_its_header(lib):
+    """include/p25fe_rccl.h (the N > 1 step behind the C ABI): every declared symbol is exported by libp25fe_rccl.so,
+    which links librccl and libp25fe.so -- checked without loading it (no GPU here)."""
+    hdr = open(os.path.join(ROOT, "include", "p25fe_rccl.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(p25fe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {"p25fe_rccl_unique_id", "p25fe_shard_create", "p25fe_shard_destroy", "p25fe_shard_dibit_cap",
+                        "p25fe_shard_step", "p25fe_shard_offsets", "p25fe_shard_stream_dev", "p25fe_shard_comm_ms"}
+    so = os.path.join(ROOT, "p25rx_amd", "libp25fe_rccl.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    assert declared <= set(re.findall(r" T (p25fe_[a-z0-9_]+)", out))
+    needed = subprocess.check_output(["readelf", "-d", so]).decode()
+    assert "librccl.so" in needed and "libp25fe.so" in needed
+    assert os.path.exists(os.path.join(ROOT, "build", "p25fe_shards"))
+
+
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
     assert cfg.abi_version == lib.ABI_VERSION == 3 and cfg.n_channels == 1 and cfg.symbol_clock == 0

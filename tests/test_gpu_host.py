@@ -372,3 +372,31 @@ def test_timeshard_step_device_rccl_world1():
     p.join(60)
     assert p.exitcode == 0
     assert res == [True, True, True]
+
+
+@pytest.mark.timeout(600)
+def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
+    """include/p25fe_rccl.h through the C++ launcher (no Python, no torch in the ranks): the N > 1 step -- halo exchange
+    beside K1, summary all-gather, device resolve, pass 2, dibit gather to rank 0, compaction -- (a) over RCCL in a
+    one-rank communicator on this GPU, (b) as 2 and 3 PROCESSES that share the GPU with the exchanges staged through shared
+    memory (test hook).  The ordered stream rank 0 writes equals the single-pass dibits byte for byte."""
+    import json
+    from oracle import oracle as O
+    from p25rx_amd import c4fm
+    exe = os.path.join(ROOT, "build", "p25fe_shards")
+    iq, _, _ = c4fm.synth(2.0, seed=91, snr_db=24.0, frame_dibits=700)
+    iq = iq[:480000]
+    ref = O.run_cf32(iq)
+    src = tmp_path / "cap.cf32"
+    iq.tofile(src)
+    for args in (["-n", "1"], ["-n", "2", "--shm"], ["-n", "3", "--shm"]):
+        out = tmp_path / ("dib_" + "_".join(a.strip("-") for a in args))
+        r = subprocess.run([exe] + args + ["-k", "3", str(src), str(out)], capture_output=True, timeout=280)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        rep = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        got = np.fromfile(out, dtype=np.uint8)
+        assert rep["dibits"] == len(got) == len(ref), (args, rep)
+        assert np.array_equal(got, ref), args
+        if "--shm" not in args:
+            assert rep["exchange"] == "RCCL" and rep["comm_ms_per_step"]["steps_averaged"] == 3
+            assert rep["comm_ms_per_step"]["halo"] > 0 and rep["comm_ms_per_step"]["summaries"] > 0
