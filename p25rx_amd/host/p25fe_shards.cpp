@@ -114,6 +114,7 @@ static int child(int rank, int world, int steps, bool shm, const char* in_path, 
                     "\"exchange\":\"%s\"}\n",
                     world, n, off[(size_t)world], steps, ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL");
         std::remove(idfile.c_str());
+        std::fflush(stdout);                                          // the child leaves through _Exit
     }
     p25fe_shard_destroy(s);
     p25fe_destroy(h);
