@@ -160,11 +160,27 @@ def run_extras(torch, dev, args, iq2, truth2):
     dt1 = time.perf_counter() - t0
     got1 = np.concatenate(got1)
     k1_ = min(len(got1), len(truth2) - 24)
+    # the same second as RTL-SDR bytes: the reference's own read size, 32 768 bytes per call (src/consts.rs:6)
+    u8_1 = c4fm.to_u8(host1)
+    fe.reset()
+    chunks8 = [u8_1[o:o + 32768] for o in range(0, len(u8_1), 32768)]
+    for c in chunks8[:3]:
+        fe.run_u8(c)
+    fe.reset()
+    t0 = time.perf_counter()
+    got8 = [fe.run_u8(c) for c in chunks8]
+    dt8 = time.perf_counter() - t0
+    got8 = np.concatenate(got8)
+    k8_ = min(len(got8), len(truth2) - 24)
     out.append({"config": "configs[0]: 1 s cf32 @ 240 ksps in 16 384-sample chunks through the host-buffer streaming API "
-                          "(p25fe_run_cf32: H2D, K1-K4, D2H per chunk)", "ms_per_chunk": round(dt1 / len(chunks) * 1e3, 4),
+                          "(p25fe_run_cf32: pinned zero-copy staging, ONE launch -- K1 + receiver by the last workgroup --, "
+                          "one synchronisation per chunk)", "ms_per_chunk": round(dt1 / len(chunks) * 1e3, 4),
                 "chunks": len(chunks), "Msamples_per_s": round(n1 / dt1 / 1e6, 2), "realtime_factor": round(1.0 / dt1, 1),
                 "parity_gate": bool(k1_ > 0 and np.array_equal(got1[:k1_], truth2[24:24 + k1_])),
-                "note": "latency-bound by construction (one 68 ms chunk per call); the reference needs 1.0x real time"})
+                "u8_32768_byte_chunks": {"ms_per_chunk": round(dt8 / len(chunks8) * 1e3, 4), "Msamples_per_s": round(n1 / dt8 / 1e6, 2),
+                                         "parity_gate": bool(k8_ > 0 and np.count_nonzero(got8[:k8_] != truth2[24:24 + k8_]) == 0)},
+                "note": "latency-bound by construction (one 68 ms chunk per call); the reference needs 1.0x real time; "
+                        "timed through the Python wrapper (ctypes + two small NumPy allocations per call)"})
     del fe
 
     # ---- configs[1] as RTL-SDR u8 pairs: the reference's real input format (src/demod.rs:74-84)
@@ -186,6 +202,20 @@ def run_extras(torch, dev, args, iq2, truth2):
                     "note": "2.02 B per sample leaves HBM idle: this format is priced on the fp32 vector pipe (SPEC section 3's "
                             "arithmetic, an fma = 2 flops); instruction mix in profiles/r03_pmc_u8.txt"})
     del u8, fe
+
+    # ---- configs[1] with the tracking symbol clock (SPEC 3.8b; north_star's "symbol-clock interpolator"): the general receiver
+    fe = FrontEnd(device=dev.index, symbol_clock=1)
+    dib = res = None
+    def step_trk():
+        nonlocal dib, res
+        dib, res = run(fe, iq2, dib, res)
+    k = steps_for(0.35)
+    dt = timed(torch, step_trk, k, 5, finish=fe.join_dev)
+    k1, _, kms = k1_frac(fe, torch, lambda: fe.run_dev(iq2, dibits=dib, result=res), n, BYTES_PER_SAMPLE)
+    entry("configs[1] with symbol_clock = tracking (period from sync word to sync word, 4-tap interpolated instants)", n,
+          dt / k * 1e3, "k_frontend<cf32>", k1, BYTES_PER_SAMPLE, gate(dib, res, truth2), steps=k,
+          receiver_ms={"k_detect<general>": round(kms[1], 4), "k_scan_g": round(kms[2], 4), "k_slice_g": round(kms[3], 4)})
+    del fe
 
     # ---- configs[2]: 2.4 Msps front end, 60 s = 1.44e8 samples -> stage 0 (10:1, 80 taps) -> K1..K4
     n240 = 60 * 240000
@@ -211,7 +241,24 @@ def run_extras(torch, dev, args, iq2, truth2):
     al = c4fm.align_dibits(dib[0, :nd].cpu().numpy(), truth3)
     entry("configs[2]: 2.4 Msps x 60 s -> 10:1 pre-decimator -> FIR + FM + slice, end to end", wide.shape[0], dt / k * 1e3,
           "k_predecim", k0_ms, 8.002, al is not None and al[3] == 0 and al[2] > 287000, steps=k)
-    del wide, nar, fe
+    # ---- polyphase channeliser: the same 60 s wideband capture -> 192 channel streams at 240 ksps
+    chz = None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    chz, no = fe.channelise_dev(wide, out=chz)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        chz, no = fe.channelise_dev(wide, out=chz)
+    e1.record()
+    torch.cuda.synchronize()
+    k6_ms = e0.elapsed_time(e1) / 4
+    k6_bytes = 8.0 + 192 * 8 / 10.0                                 # 8 B read + 192 channels x 8 B per 10 input samples
+    ach6 = k6_bytes * wide.shape[0] / (k6_ms * 1e-3) / 1e9
+    out.append({"config": "polyphase channeliser: 2.4 Msps x 60 s -> 192 x 240 ksps (k_channelise alone)", "kernel_ms": round(k6_ms, 4),
+                "achieved_GBps": round(ach6, 1), "frac": round(ach6 / HBM_PEAK_GBPS, 4), "bytes_per_input_sample": k6_bytes,
+                "parity_gate": bool(torch.allclose(chz[0, :no], nar[0, :no], atol=2e-5)),
+                "note": "store-bound (154 of 161.6 B per input sample are output); gate: channel 0 equals the pre-decimator's stream"})
+    del wide, nar, fe, chz
 
     # ---- configs[3]: 256 independent channels x 60 s, channel-major (29.5 GB)
     C, n4 = 256, 60 * 240000
@@ -379,7 +426,7 @@ def main():
     _, truth = c4fm.synth_torch(n, seed=1000 + rank, device=dev, snr_db=30.0, out=iq)
     torch.cuda.synchronize()
 
-    cap = (n // 50 + 64 + 15) // 16 * 16
+    cap = FrontEnd.dibit_cap(n)
     result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
 
     if world == 1:
@@ -429,6 +476,19 @@ def main():
     fe.profile_enable(2 if (world > 1 or args.steps <= 64) else 3)
     dt = timed(torch, step, args.steps, 0, dist, finish=fe.join_dev)
     kms, ncalls = fe.profile_read()
+    comm_ms = None
+    if world > 1 and not staged:
+        # where a step's time goes between the kernels, from a few extra steps with events around every exchange (outside
+        # the timed region: each event is one more packet on the stream)
+        ts.comm_events = []
+        for _ in range(min(args.steps, 8)):
+            step()
+        torch.cuda.synchronize()
+        acc = {}
+        for ph, e0, e1 in ts.comm_events:
+            acc.setdefault(ph, []).append(e0.elapsed_time(e1))
+        comm_ms = {ph: round(sum(v) / len(v), 4) for ph, v in acc.items()}
+        ts.comm_events = None
     # per-kernel split of the other kernels: a few extra steps OUTSIDE the timed region with events around every kernel
     fe.profile_enable(1)
     n_extra_steps = min(args.steps, 8)
@@ -563,6 +623,10 @@ def main():
                                      "K1 of step i + 1; join + device synchronize inside the timed region")
             if serial_ms is not None:
                 out["config"]["serial_ms_per_step"] = round(serial_ms, 4)
+        if comm_ms is not None:
+            out["config"]["comm_ms_per_step"] = dict(comm_ms, note="rank 0, stream time from just before each exchange is enqueued "
+                                                     "to its completion on the step's stream (halo_wait_after_k1 is what K1's main launch "
+                                                     "did NOT hide); extra steps after the timed region")
         if gather_ok is not None:
             out["config"]["gather_gate"] = ("gathered stream holds every shard at its resolved offset (length, sum and "
                                             "position-weighted sum of every rank's dibits): %s" % gather_ok)

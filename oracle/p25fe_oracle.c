@@ -351,7 +351,7 @@ size_t p25o_demod_u8(p25o_demod *d, const uint8_t *bytes, size_t nbytes, float *
 size_t p25o_demod_cf32(p25o_demod *d, const float *iq, size_t n, float *bb, float *power)
 {
     cf32 *samples = scratch(d, n);
-    memcpy(samples, iq, sizeof(cf32) * n);
+    if (n) memcpy(samples, iq, sizeof(cf32) * n);                /* (an empty chunk has no scratch: memcpy(NULL, ., 0) is undefined) */
     return demod_tail(d, samples, n, bb, power);
 }
 
@@ -360,7 +360,7 @@ size_t p25o_demod_cf32_stages(p25o_demod *d, const float *iq, size_t n, float *c
                               float *bb)
 {
     cf32 *samples = scratch(d, n);
-    memcpy(samples, iq, sizeof(cf32) * n);
+    if (n) memcpy(samples, iq, sizeof(cf32) * n);
     size_t len = decim_in_place(d, samples, n);
     for (size_t i = 0; i < len; i++) {
         fir_push(&d->bandpass, samples[i]);

@@ -163,11 +163,18 @@ class FrontEnd:
             raise TypeError("IQ tensor must be float32 or uint8")
         return fmt, iq.shape[1], (iq.stride(0) // 2 if self.C > 1 else iq.shape[1])
 
+    @staticmethod
+    def dibit_cap(n_iq):
+        """Row size for the dibits of n_iq input samples: n / 50 plus proportional slack (200 ppm) for the transmitter's
+        symbol clock, which a receiver that re-anchors on every sync word follows.  The row's stride is its capacity: the
+        kernels never store past it and p25fe_result_t.n_dibits stays exact."""
+        return (n_iq // 50 + n_iq // 250000 + 64 + 15) // 16 * 16
+
     def run_dev(self, iq, dibits=None, result=None):
         """Fresh-stream IQ -> dibits on device.  Returns (dibits[C, cap] uint8 cuda, result uint8 tensor)."""
         import torch
         fmt, n, stride = self._iq_view(iq)
-        cap = (n // 50 + 64 + 15) // 16 * 16
+        cap = self.dibit_cap(n)
         if dibits is None:
             dibits = torch.empty((self.C, cap), dtype=torch.uint8, device=iq.device)
         if result is None:
@@ -181,7 +188,7 @@ class FrontEnd:
         on a stream of the handle).  Outputs are complete after join_dev() + a synchronisation of the stream."""
         import torch
         fmt, n, stride = self._iq_view(iq)
-        cap = (n // 50 + 64 + 15) // 16 * 16
+        cap = self.dibit_cap(n)
         if dibits is None:
             dibits = torch.empty((self.C, cap), dtype=torch.uint8, device=iq.device)
         if result is None:
@@ -189,11 +196,15 @@ class FrontEnd:
         self._chk(self.L.p25fe_run_dev_pipelined(self.h, C.c_void_p(iq.data_ptr()), fmt, stride, n,
                                                  C.c_void_p(dibits.data_ptr()), dibits.stride(0),
                                                  C.c_void_p(result.data_ptr()), self._stream()))
+        # the receive kernels write these on the handle's own stream, which torch's caching allocator does not see: keep
+        # the outputs of the calls still in flight alive even if the caller drops them (released by join_dev)
+        self._inflight = (getattr(self, "_inflight", ()) + ((dibits, result),))[-2:]
         return dibits, result
 
     def join_dev(self):
         """the current stream waits for every receive kernel run_dev_pipelined has enqueued"""
         self._chk(self.L.p25fe_join_dev(self.h, self._stream()))
+        self._inflight = ()
 
     def demod_dev(self, iq, n_hist=0, abs0=0, bb=None, want_power=False, offset=0):
         """stages 1-5 on a device range; `offset` = index of the first owned sample inside `iq` (>= n_hist)."""

@@ -50,6 +50,7 @@ private:
 };
 
 struct HubEvent { float signal_power_dbm; };                         // HubEvent::UpdateSignalPower, src/hub.rs:455
+struct StatsEvent { uint64_t dibits, syncs; };                       // HubEvent::UpdateStats (src/recv.rs:162-165): what exists of Stats here
 struct Baseband { std::vector<float> samples; };                     // RecvEvent::Baseband, src/recv.rs:25
 
 // demod::DemodTask (src/demod.rs:25-120)
@@ -99,10 +100,30 @@ public:
 
     void resync() { expect(p25fe_resync(h_.get()), "unable to resync"); }     // msg.resync(), src/recv.rs:136, 179
 
+    // Throttler::new(16) of RecvTask::run (src/recv.rs:141, 162-165): a stats report after every 16th event.  The counter
+    // lives in the task (the reference's run() never returns; a driver that calls run() per chunk keeps the cadence).
+    template <class F, class StatsHub> void run(F cb, StatsHub& stats_hub)
+    {
+        Baseband bb;
+        while (events_.recv(bb)) {
+            feed(bb, cb);
+            if (++stats_notifier_ % 16 == 0) stats_hub.send(StatsEvent{n_dibits_, n_sync_});
+        }
+    }
+
     template <class F> void run(F cb)                                 // RecvTask::run<F: FnMut(&[f32])>, :140
     {
         Baseband bb;
         while (events_.recv(bb)) {                                    // :144
+            feed(bb, cb);
+            ++stats_notifier_;
+        }
+    }
+
+private:
+    template <class F> void feed(Baseband& bb, F& cb)
+    {
+        {
             Symbols s;
             const size_t n = bb.samples.size();
             s.dibits.resize(n / 10 + 2);
@@ -115,15 +136,18 @@ public:
             s.dibits.resize(nd);
             s.sync_pos.resize(ns < s.sync_pos.size() ? ns : s.sync_pos.size());
             s.sync_dibit.resize(s.sync_pos.size());
+            n_dibits_ += nd;
+            n_sync_ += ns;
             sink_.send(std::move(s));
             cb(bb.samples);                                           // :152
         }
     }
 
-private:
     Handle& h_;
     Events& events_;
     Sink& sink_;
+    unsigned stats_notifier_ = 0;
+    uint64_t n_dibits_ = 0, n_sync_ = 0;
 };
 
 }  // namespace p25rx

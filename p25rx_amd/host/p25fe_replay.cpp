@@ -13,8 +13,9 @@
 //               `p25fe_replay bb FILE ...` on that file reproduces the dibits of the recording run.
 //     -j FILE   JSON lines in the vocabulary of the reference's hub: {"event":"sigPower"} per power report
 //               (HubEvent::UpdateSignalPower, src/demod.rs:95-101, src/hub.rs:344), {"event":"nid"} per frame sync
-//               (MessageEvent::PacketNID, src/recv.rs:216-222), one final {"event":"updateStats"} with the "bch"
-//               row of serialize_stats (src/hub.rs:401-402, 559, 574-581).
+//               (MessageEvent::PacketNID, src/recv.rs:216-222), {"event":"updateStats","periodic":true} after every 16th
+//               baseband chunk (Throttler::new(16), src/recv.rs:141, 162-165), one final {"event":"updateStats"} with
+//               the "bch" row of serialize_stats (src/hub.rs:401-402, 559, 574-581).
 //     -b N      file chunks per library call (default 64; 1 = the reference's cadence of one 32768-byte buffer per
 //               DemodTask iteration, which also fixes the every-4th-chunk power report of src/demod.rs:67, 95).
 //               The dibits do not depend on N (streaming semantics); only the PCIe transfer size does.
@@ -45,10 +46,16 @@ template <class T> struct Chan {
 struct Hub {
     FILE* js = nullptr;
     size_t n_power = 0;
+    size_t n_stats = 0;
     void send(HubEvent e)
     {
         ++n_power;
         if (js) std::fprintf(js, "{\"event\":\"sigPower\",\"dbm\":%.4f}\n", (double)e.signal_power_dbm);
+    }
+    void send(StatsEvent e)                                           // every 16th receiver event, src/recv.rs:141, 162-165
+    {
+        ++n_stats;
+        if (js) std::fprintf(js, "{\"event\":\"updateStats\",\"periodic\":true,\"dibits\":%" PRIu64 ",\"syncs\":%" PRIu64 "}\n", e.dibits, e.syncs);
     }
 };
 
@@ -119,7 +126,7 @@ int main(int argc, char** argv)
             std::vector<uint8_t> chunk(buf.begin(), buf.begin() + (in.gcount() & ~std::streamsize(1)));
             reader.send(std::move(chunk));
             demod.run();
-            recv.run(dump);
+            recv.run(dump, hub);
         }
     } else if (mode == "cf32") {
         std::vector<float> buf(2 * BUF_SAMPLES * batch), bb(BUF_SAMPLES * batch / 5 + 2);
@@ -133,14 +140,14 @@ int main(int argc, char** argv)
                    "unable to demodulate");
             if (want) hub.send(HubEvent{power});
             chan.send(Baseband{std::vector<float>(bb.begin(), bb.begin() + (long)n_out)});
-            recv.run(dump);
+            recv.run(dump, hub);
         }
     } else if (mode == "bb") {
         std::vector<float> buf(8192 * batch);                         // replay.rs reads 32768-byte blocks (src/replay.rs:27)
         while (in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(buf.size() * 4)) || in.gcount() > 0) {
             const size_t n = (size_t)in.gcount() / 4;                 // only the bytes actually read (replay.rs:36 re-feeds stale tail)
             chan.send(Baseband{std::vector<float>(buf.begin(), buf.begin() + (long)n)});
-            recv.run(dump);
+            recv.run(dump, hub);
         }
     } else {
         return usage(argv[0]);

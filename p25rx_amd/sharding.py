@@ -124,12 +124,16 @@ class TimeShard:
         self.fe, self.rank, self.world, self.n, self.dist = fe, rank, world, n_per_rank, dist
         self.comm = comm if comm is not None else (TorchComm(dist, rank, world) if dist is not None else None)
         self.always_comm = False         # tests: take the collective path at world = 1 too (RCCL on a one-GPU box)
+        self.comm_events = None          # bench: list that receives (phase, start event, end event) per exchange of a step
         self.halo = int(fe.shard_halo())
         self.abs0 = rank * n_per_rank
         from .frontend import n_baseband
         self.bb0 = [n_baseband(0, r * n_per_rank) for r in range(world)]
         self.bbn = [n_baseband(r * n_per_rank, n_per_rank) for r in range(world)]
-        self.dibit_cap = (max(self.bbn) // 10 + 64 + 15) // 16 * 16        # per-shard dibit buffer (gather granule)
+        # per-shard dibit buffer (gather granule): n / 10 plus proportional slack -- a receiver that re-anchors on every sync
+        # word follows the TRANSMITTER's symbol clock (200 ppm here; the kernels stop storing at the row's end and the count
+        # stays exact, so a larger offset is detected, not overrun)
+        self.dibit_cap = (max(self.bbn) // 10 + max(self.bbn) // 50000 + 64 + 15) // 16 * 16
 
     def alloc(self, torch, device, dtype):
         """[halo | owned] buffer; the halo part is filled by the neighbour exchange."""
@@ -175,11 +179,22 @@ class TimeShard:
 
     # ---- device-resolved form (the bench): no host synchronisation anywhere in a step -----------------------------
     def setup_device(self, torch, device):
+        self._torch = torch
         self.d_bb0 = torch.tensor(self.bb0, dtype=torch.int64, device=device)
         self.d_bbn = torch.tensor(self.bbn, dtype=torch.int64, device=device)
         self.d_anchors = self.d_offsets = None
         self.d_gathered = torch.empty((self.world, self.dibit_cap), dtype=torch.uint8, device=device)
         self.d_stream = torch.empty(self.world * self.dibit_cap, dtype=torch.uint8, device=device)
+
+    def _mark(self, phase=None, start=None):
+        """bench only (comm_events is a list): an event on the current stream; with `phase`, files (phase, start, end)."""
+        if self.comm_events is None or not getattr(self, "_torch", None) or not self._torch.cuda.is_available():
+            return None
+        ev = self._torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if phase is not None and start is not None:
+            self.comm_events.append((phase, start, ev))
+        return ev
 
     def step_device(self, buf, result, summ_all, dibits, gather="root"):
         """halo exchange (overlapped with K1) -> pass 1 -> all_gather of summaries -> k_shard_resolve -> pass 2 ->
@@ -190,12 +205,17 @@ class TimeShard:
         h = self.halo if self.rank > 0 else 0
         view = buf[self.halo - h:]
         multi = self.world > 1 or (self.comm is not None and self.always_comm)
+        mark = self._mark
         if multi:
             works = self.comm.halo_start(buf[self.n:], buf[:self.halo])
             self.fe.shard_pass1_main(view, offset=h, n_hist=h, abs0=self.abs0)     # needs no halo
+            e = mark()
             self.comm.halo_wait(works)
+            mark("halo_wait_after_k1", e)
             self.fe.shard_pass1_finish(view, offset=h, n_hist=h, abs0=self.abs0, result=result)
+            e = mark()
             self.comm.all_gather(summ_all, result)
+            mark("summaries_all_gather", e)
         else:
             self.fe.shard_pass1(view, offset=h, n_hist=h, abs0=self.abs0, result=result)
             summ_all.copy_(result)
@@ -204,12 +224,15 @@ class TimeShard:
         self.fe.shard_pass2(self.d_anchors[self.rank:self.rank + 1], self.bbn[self.rank], buf.device, result=result,
                             dibits=dibits)
         if gather:
+            e = mark()
             if not multi:
                 self.d_gathered.copy_(dibits)
             elif gather == "all":
                 self.comm.all_gather(self.d_gathered, dibits)
             else:
                 self.comm.gather_to_root(self.d_gathered, dibits, root=0)
+            if multi:
+                mark("dibit_gather", e)
             if gather == "all" or self.rank == 0:
                 self.fe.shard_compact_dev(self.d_gathered, self.d_offsets, self.d_stream)
         return self.d_offsets

@@ -26,7 +26,8 @@ def test_python_demodtask_recvtask_pipeline(c4fm_1s):
     DemodTask(reader, hub, chan).run()
     chan.put(None)
     got, syncs, dumped = [], [], []
-    RecvTask(chan, lambda d, sp, sd: (got.append(d), syncs.append(sp))).run(cb=lambda s: dumped.append(s))
+    n_events = chan.qsize() - 1
+    RecvTask(chan, lambda d, sp, sd: (got.append(d), syncs.append(sp)), hub=hub).run(cb=lambda s: dumped.append(s))
     od = O.Demod()
     bb = np.concatenate([od.feed_u8(u8[o:o + BUF_BYTES]) for o in range(0, len(u8), BUF_BYTES)])
     dib, spos, _ = O.Recv().feed(bb)
@@ -34,7 +35,11 @@ def test_python_demodtask_recvtask_pipeline(c4fm_1s):
     assert np.array_equal(np.concatenate(syncs), spos)
     assert np.array_equal(np.concatenate(dumped).view(np.uint32), bb.view(np.uint32))    # the -w dump hook (src/recv.rs:152)
     n_chunks = (len(u8) + BUF_BYTES - 1) // BUF_BYTES
-    assert hub.qsize() == n_chunks // 4                                                  # Throttler::new(4), src/demod.rs:67
+    evs = [hub.get() for _ in range(hub.qsize())]
+    assert sum(e.kind == "UpdateSignalPower" for e in evs) == n_chunks // 4              # Throttler::new(4), src/demod.rs:67
+    st = [e.value for e in evs if e.kind == "UpdateStats"]
+    assert len(st) == n_events // 16                                                     # Throttler::new(16), src/recv.rs:141
+    assert st and st[-1]["dibits"] <= len(dib) and st[-1]["syncs"] <= len(spos)
 
 
 @pytest.mark.parametrize("mode", ["u8", "cf32", "bb"])
@@ -97,7 +102,10 @@ def test_cpp_record_replay_roundtrip_and_events(tmp_path):
     assert [(n["nac"], n["duid"], n["errors"], n["valid"]) for n in nids] == \
            [(int(r["nac"]), int(r["duid"]), int(r["n_errors"]), int(r["valid"])) for r in ref]
     assert any(n["valid"] == 1 and n["nac"] == 0x293 and n["duid"] == 0x5 for n in nids)
-    st = [e for e in ev if e["event"] == "updateStats"]
+    per = [e for e in ev if e["event"] == "updateStats" and e.get("periodic")]
+    assert len(per) == n_chunks // 16                             # Throttler::new(16), src/recv.rs:141, 162-165
+    assert all(a["dibits"] <= b["dibits"] for a, b in zip(per, per[1:])) and per[-1]["dibits"] <= len(dib)
+    st = [e for e in ev if e["event"] == "updateStats" and not e.get("periodic")]
     assert len(st) == 1 and st[0]["dibits"] == len(dib) and st[0]["syncs"] == len(spos)
     assert st[0]["bch"]["totalWords"] == sum(int(r["valid"]) >= 0 for r in ref)
 
