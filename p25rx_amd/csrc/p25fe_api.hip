@@ -402,6 +402,10 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     if (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) return P25FE_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_x) & 15u) != 0) return P25FE_ERR_ARG;     // 16-B vector loads
     if (h->C > 1 && (ch_stride % (fmt == P25FE_FMT_CF32 ? 2 : 8)) != 0) return P25FE_ERR_ARG;
+    const bool pro = seg_prologue(fmt);                            // p25fe_kernels.hip: segment prologue (u8) or recomputed halo (cf32)
+    // planar output: the first output K1 produces is the form's (a block boundary of the layout, or 80 outputs in front of
+    // the receiver's 240-sample history) -- the caller's value is ignored
+    if (planar) m_begin = pro ? -(long)PLPAD - h->look : -(long)HIST_BB - h->look;
     const size_t n_out = p25fe_n_baseband(abs0, n);
     const long total = (long)n_out - m_begin;
     if (total <= 0) {
@@ -423,11 +427,13 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     long subs = subs_env > 0 ? subs_env : (fmt == P25FE_FMT_U8 ? 9 : 3);
     if (chunk) subs = 1;                                            // a chunk is latency: every sub-tile its own workgroup
     if (subs > 32768) subs = 32768;
-    const long seg_len = subs * sub;
-    const long nd = HALO_Y + (h->long_taps ? TMAX : T2) - 1;       // decimator outputs the segment prologue computes in front of a segment
+    const long seg_len = pro ? subs * sub : (sub - SEG_HALO) + (subs - 1) * sub;
+    // what a segment needs in front of its first output: the prologue's decimator outputs, or the recomputed halo
+    const long nd = pro ? HALO_Y + (h->long_taps ? TMAX : T2) - 1 : SEG_HALO;
     const long n_seg = (total + seg_len - 1) / seg_len;
     const long pl_shift = PLPAD + h->look;       // the general receiver sees the range h->look samples late (p25fe_recv.hip)
-    if (planar && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % PL_BLK != 0 || seg_len % PL_BLK != 0)) return P25FE_ERR_ARG;
+    if (planar && pro && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % PL_BLK != 0 || seg_len % PL_BLK != 0)) return P25FE_ERR_ARG;
+    if (planar && !pro && (m_begin + pl_shift < SEG_HALO || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
     if (planar && n_out > (size_t)0x7ff00000u * 10u) return P25FE_ERR_ARG;   // symbol indices are 32-bit in the kernels: < 2^31 symbols (124 h of one channel) per call
 
     K1Args a;

@@ -43,11 +43,21 @@ constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[
 constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50 (the build's own tap counts; Geo<PK, 1> has its own)
 constexpr int TMAX = P25FE_MAX_TAPS;         // 64: tap-count ceiling of the ABI (p25fe_config_t), the generic kernels' geometry
 // A segment (the consecutive sub-tiles one workgroup walks) needs, in front of its first output, the HALO_Y + (T2 - 1)
-// decimator outputs its first channel-filter / discriminator / boxcar results depend on.  Rounds 1-2 recomputed 80 whole
-// OUTPUTS there and dropped them (a quarter of a sub-tile of arithmetic and of input per 880 outputs); round 3 computes
-// just those d's, the 10 channel outputs and 9 discriminator values behind them in a short prologue (K1 below), so
-// that every sub-tile yields 320 outputs and -- with ranges that start on a block boundary of the layout below -- IS one
-// 1280-byte block: whole 128-byte rows, one 32-bit sign word per plane.
+// decimator outputs its first channel-filter / discriminator / boxcar results depend on.  Two forms, chosen per input
+// format by measurement (seg_prologue() below):
+//  * halo (rounds 1-2; cf32): the first sub-tile recomputes SEG_HALO = 80 whole OUTPUTS in front of the segment and drops
+//    them -- 80 = one byte of every sign-bit plane (8 symbols x 10 samples), so that with segment lengths that are
+//    multiples of 80 no two workgroups share a byte of the polyphase layout below;
+//  * prologue (round 3; u8): just those d's, the 10 channel outputs and 9 discriminator values behind them are computed in
+//    a short prologue, every sub-tile yields 320 outputs and -- with ranges that start on a block boundary of the layout --
+//    IS one 1280-byte block: whole 128-byte rows, one 32-bit sign word per plane.  4 % fewer instructions and input
+//    bytes per output.  Same box, same capture (tools/bench_ab.sh, tools/k1_ab.sh): the instruction-bound u8 kernel gains
+//    3 % (0.2021 - 0.2029 against 0.2075 - 0.2101 ms); the cf32 kernel, whose time follows neither its instruction count
+//    nor its bytes, LOSES 1.5 - 2 % (0.2570 - 0.2590 against 0.2519 - 0.2550 ms: the prologue's
+//    registers push it from 156 to 168 - 174 VGPRs) and keeps the halo form.
+constexpr int SEG_HALO = 80;
+static_assert(SEG_HALO >= HALO_Y + (TMAX - 1) && SEG_HALO % 80 == 0, "segment halo covers the filter memory (64 taps too) and is byte-aligned per plane");
+__host__ __device__ constexpr bool seg_prologue(int fmt) { return fmt == P25FE_FMT_U8; }
 
 // Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
 // 240 history samples of the receiver at m = -240..-1), sample p belongs to plane r = p % 10 at symbol index i = p / 10.
@@ -515,25 +525,28 @@ struct K1Args {
     int seg_first;          // first segment of this launch (a shard's head segment is launched after its halo has arrived)
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
     float* power_partial;   // nullable: [n_channels][seg_count] partial sums of |y|^2
-    // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Requires m_begin + pl_shift >= 0 and a
-    // multiple of 320: every sub-tile is one block of the layout.
+    // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Prologue form: m_begin + pl_shift >= 0 and a
+    // multiple of 320 (every sub-tile is one block of the layout); halo form: m_begin + pl_shift >= SEG_HALO, a multiple
+    // of 80, and a segment length that is a multiple of 80.
     float* bbp;             // channel 0
     long bbp_ch_stride;     // floats per channel (a whole number of blocks)
     uint8_t* bits;          // channel 0, addressed by byte
     long bits_ch_stride;    // bytes per channel
     int pl_shift;           // output m sits at planar position m + pl_shift: PLPAD, or PLPAD + 2 when the receiver runs with
-                            // the tracking clock's lookahead (p25fe_recv.hip); (m_begin + pl_shift) % 320 == 0
+                            // the tracking clock's lookahead (p25fe_recv.hip)
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
 // registers or LDS reads spent on coefficients.  CT = false: caller-supplied taps, broadcast-read from LDS.
-// Register budget of the planar variants: minimum waves per SIMD the kernel is compiled for.  Round 2 (segment halo of
-// 80 recomputed outputs): bound 3 and bound 2 were both allocated 146 VGPRs, the bound-3 schedule ran 300 us against 272.
-// Round 3 (segment prologue): unbounded the cf32 kernel takes 174 VGPRs = 2 waves per SIMD and runs 0.264 ms; bound to 3
-// it takes 168 with two 8-byte spills OUTSIDE the sub-tile loop (item setup -> after the prologue / after the loop) and
-// runs 0.257 - 0.261 ms against 0.254 - 0.256 of the round-2 kernel on the same box (tools/k1_ab.sh).
+// Register budget of the planar variants: minimum waves per SIMD the kernel is compiled for.  cf32 (halo form): bound 3
+// and bound 2 are both allocated ~150 VGPRs, but the bound-3 schedule ran 300 us against 272 (round 2, same box): 2.  u8
+// (prologue form): 148 VGPRs either way; 3.  (The prologue form of the cf32 kernel takes 174 VGPRs unbounded = 2 waves
+// per SIMD, 168 with two 8-byte spills outside the sub-tile loop when bound to 3: 0.264 / 0.259 ms against 0.253.)
 #ifndef P25FE_K1_PLANAR_WPS
-#define P25FE_K1_PLANAR_WPS 3
+#define P25FE_K1_PLANAR_WPS 2
+#endif
+#ifndef P25FE_K1_PLANAR_WPS_U8
+#define P25FE_K1_PLANAR_WPS_U8 3
 #endif
 // Windows in flight per wave (register-staged loader).  Measured (tools/ab.sh, same box): a second register set costs
 // the cf32 kernel a wave per SIMD (181 VGPRs -> 8 waves per CU instead of 11) and makes it 25 % SLOWER (318 vs 254 us)
@@ -602,7 +615,8 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     auto tap_dec = [&](int k) -> float { return CT ? P25FE_DEFAULT_DECIM_TAPS[k] : TAPS[k]; };
     auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
-    const long seg_len = (long)a.subs_per_seg * SUB;
+    constexpr bool PRO = seg_prologue(FMT);                         // segment prologue (u8) or recomputed halo (cf32), see SEG_HALO
+    const long seg_len = PRO ? (long)a.subs_per_seg * SUB : (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
     // segment prologue: the ND decimator outputs in front of the segment, from a window of PWIN input samples
     constexpr int ND = HALO_Y + (T2 - 1);                           // 50 (73 with 64-tap tables)
     constexpr int PWIN = DEC * (ND - 1) + T1;                       // 276 (424)
@@ -641,9 +655,28 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     using LoaderT = Loader<FMT, PK, TX>;
     using LoaderP = Loader<FMT, PK, TX, NVP>;
     LoaderT ld0, ld1;
-    LoaderP lp;
-    long dlo = m_seg0;                                             // first d index of this sub-tile
+    long dlo = PRO ? m_seg0 : m_seg0 - SEG_HALO;                   // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
+    float pw = 0.f;
+    // context carried across sub-tiles in wave-uniform registers: the last channel output and the
+    // fm values of the last NBACK lanes of the previous sub-tile
+    float2 y_carry = make_float2(0.f, 0.f);
+    float f_carry[NBACK][P];
+    if constexpr (!PRO) {
+        // halo form: zero carries; the first sub-tile's first SEG_HALO outputs absorb the filters' start-up and are dropped
+        for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
+        ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
+        ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+        if constexpr (PF == 2) {
+            ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
+            ld1.load((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
+        }
+#pragma unroll
+        for (int b = 0; b < NBACK; ++b)
+#pragma unroll
+            for (int p = 0; p < P; ++p) f_carry[b][p] = 0.f;
+    } else {
+    LoaderP lp;
     const long pfirst = (long)a.o0 + DEC * (m_seg0 - ND) - (T1 - 1);     // first input sample of the prologue window
     ld0.init(xb, pfirst, a.n_hist, a.n_new, i_last);
     lp.rs = ld0.rs; lp.base_idx = ld0.base_idx;
@@ -655,12 +688,6 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
         ld1.load_first((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
     }
-    float pw = 0.f;
-
-    // context carried across sub-tiles in wave-uniform registers: the last channel output and the
-    // fm values of the last NBACK lanes of the previous sub-tile
-    float2 y_carry = make_float2(0.f, 0.f);
-    float f_carry[NBACK][P];
     {
         // ---- prologue: d[m_seg0 - ND .. m_seg0) on lanes 0 .. ND-1, y[m_seg0 - 10 .. m_seg0) and the discriminator values
         // behind them on lanes 0..9 -- the state a receiver that had run through the previous segment would hand over.
@@ -715,6 +742,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         for (int k = tid; k < D_CARRY; k += WV) D[k] = PD_[ND - D_CARRY + k];
         phase_sync();
     }
+    }   // PRO
 
     // Outputs are kept in registers for one sub-tile and stored at the top of the next one, BEFORE the
     // prefetch loads are issued: vmcnt counts loads and stores in one in-order queue, so stores issued
@@ -731,7 +759,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     const int i_seg = OM == OUT_PLANAR ? (int)((m_seg0 + a.pl_shift) / SPS_) : 0;     // symbol index of the segment's first output (multiple of 32)
     float* const bbp_ch = OM == OUT_PLANAR ? a.bbp + (size_t)ch * a.bbp_ch_stride : nullptr;
     uint8_t* const bits_ch = OM == OUT_PLANAR ? a.bits + (size_t)ch * a.bits_ch_stride : nullptr;
-    unsigned bitsv = 0u;                                            // lanes 0..9: the sign word of plane tid
+    unsigned bitsv = 0u;                                            // prologue form: lanes 0..9 hold the sign word of plane tid; halo form: lanes 0..39 byte (tid & 3) of plane (tid >> 2)
     auto flush_outputs = [&]() {
         if constexpr (OM == OUT_LINEAR) {
 #pragma unroll
@@ -740,9 +768,26 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
                 if (r >= 0 && r < seg_n) bb_seg[r] = outv[q];
             }
         } else {
+            if constexpr (PRO) {
             // a sub-tile is one block of the layout: ten 128-byte rows and ten sign words
             const int blk = (i_seg >> 5) + out_rel / SUB;
             float* const row = bbp_ch + (size_t)blk * PL_BLK + pl_sym + 32 * pl_h5;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
+#if P25FE_K1_NT_STORES
+                if (r >= 0 && r < seg_n) __builtin_nontemporal_store(outv[q], row + 32 * q);
+#else
+                if (r >= 0 && r < seg_n) row[32 * q] = outv[q];
+#endif
+            }
+            // lane j < 10 holds plane j's 32 sign bits of the sub-tile (the range's last word may carry bits past n_out: unread)
+            if (tid < SPS_ && out_rel >= 0 && out_rel < seg_n)
+                reinterpret_cast<unsigned*>(bits_ch)[(size_t)blk * SPS_ + tid] = bitsv;
+            } else {
+            const int i_sub = i_seg + out_rel / SPS_;               // symbol index of the sub-tile (multiple of 8, >= 0)
+            const int i = i_sub + pl_sym;
+            float* const row = bbp_ch + (size_t)(i >> 5) * PL_BLK + (i & 31) + 32 * pl_h5;
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
@@ -756,11 +801,15 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #endif
 #endif
             }
-            // lane j < 10 holds plane j's 32 sign bits of the sub-tile (the range's last word may carry bits past n_out: unread)
+            // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
+            // either wholly inside the segment or wholly halo (the range's last byte may carry bits past n_out: unread)
+            const int r0 = out_rel + 8 * SPS_ * (tid & 3) + (tid >> 2);
+            const int ib = i_sub + 8 * (tid & 3);
 #if !(defined(P25FE_EXP) && (P25FE_EXP & 1))   // (measurement build: no sign planes)
-            if (tid < SPS_ && out_rel >= 0 && out_rel < seg_n)
-                reinterpret_cast<unsigned*>(bits_ch)[(size_t)blk * SPS_ + tid] = bitsv;
+            if (tid < 4 * SPS_ && r0 >= 0 && r0 < seg_n)
+                bits_ch[((size_t)(ib >> 5) * SPS_ + (tid >> 2)) * 4 + ((ib >> 3) & 3)] = (uint8_t)bitsv;
 #endif
+            }
         }
     };
 
@@ -963,7 +1012,12 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #if !(defined(P25FE_EXP) && (P25FE_EXP & 1))
             w = lanes_from_ballots(sg);                              // lane q: word of plane q, lane q + 5: plane q + 5
 #endif
-            bitsv = w;
+            if constexpr (PRO) {
+                bitsv = w;
+            } else {
+                const unsigned pw_ = lane_gather(w, tid >> 2);      // lane j <- word of plane j >> 2
+                bitsv = (pw_ >> (8 * (tid & 3))) & 0xffu;
+            }
         }
         out_rel = (int)(dlo - m_seg0);
         phase_sync();
@@ -1011,7 +1065,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 }
 
 template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
-__global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? P25FE_K1_PLANAR_WPS : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+__global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? (FMT == P25FE_FMT_U8 ? P25FE_K1_PLANAR_WPS_U8 : P25FE_K1_PLANAR_WPS) : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
     frontend_body<FMT, CT, PK, OM, TX>(a, gtaps);
 }
