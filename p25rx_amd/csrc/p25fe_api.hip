@@ -276,7 +276,7 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
         h->rx_cus = rc_ ? atoi(rc_) : 0;
     }
     auto set_lds = [&](const void* f, size_t bytes) {
-        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes + 32768);   // (+ room for P25FE_K1_LDS_PAD)
     };
 #define P25FE_FOR_K1(PK)                                                                                  \
     set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK>), Geo<PK>::LDS_BYTES);    \
@@ -486,7 +486,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const Taps* dt = h->d_taps.as<Taps>();
 #define P25FE_LAUNCH_K1(PK, OM)                                                                                           \
     do {                                                                                                                  \
-        const size_t lds = Geo<PK>::LDS_BYTES - (h->default_taps ? lds_taps_trim : 0);                                   \
+        const size_t lds = Geo<PK>::LDS_BYTES - (h->default_taps ? lds_taps_trim : 0) + lds_pad_env;                     \
         if (fmt == P25FE_FMT_CF32) {                                                                                      \
             if (h->default_taps) launch_ev(k_frontend<P25FE_FMT_CF32, true, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);  \
             else launch_ev(k_frontend<P25FE_FMT_CF32, false, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);                 \
@@ -495,6 +495,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
             else launch_ev(k_frontend<P25FE_FMT_U8, false, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);                   \
         }                                                                                                                 \
     } while (0)
+    // (experiments: extra dynamic LDS per workgroup = fewer resident waves per CU; the occupancy sensitivity of docs/MEASUREMENTS.md)
+    static const size_t lds_pad_env = [] { const char* e = getenv("P25FE_K1_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     // immediate-tap kernels never touch the taps area at the end of the LDS layout: do not allocate it.  (13 376 B per
     // wave is still 11 waves per CU: a 12th would need 13 312; trimming to that in an experiment changed nothing.)
     constexpr size_t lds_taps_trim = sizeof(float) * (T1 + T2 + 3);

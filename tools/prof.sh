@@ -6,10 +6,10 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 40 --warmup 5 --no-cpu --no-extra > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-extra > $OUT/stats.log 2>&1
 grep -o '{"metric.*' $OUT/stats.log > $OUT/bench_under_rocprof.json
 # the same with strictly serial steps: kernel durations without the overlap of the pipelined form
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o stats -- python3 $ROOT/bench.py --steps 40 --warmup 5 --no-cpu --no-extra --no-pipeline > $OUT/stats_serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -o stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-extra --no-pipeline > $OUT/stats_serial.log 2>&1
 i=0
 while read -r grp; do
   [ -z "$grp" ] && continue

@@ -16,7 +16,7 @@ for sub, what in (("stats", "(pipelined steps, the bench's default: the receive 
                                "so their durations here are not their running times)"),
                   ("stats_serial", "--no-pipeline (serial steps: every kernel alone on the chip)")):
   for f in glob.glob(os.path.join(d, sub, "**", "*kernel_stats.csv"), recursive=True):
-    print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu --no-extra", what, ":", os.path.relpath(f, d))
+    print("== rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-extra", what, ":", os.path.relpath(f, d))
     for r in csv.DictReader(open(f)):
         if short(r.get("Name", "")):
             print("  %-12s calls %4s  avg %10.1f ns  min %9s  max %9s  pct %s" % (
