@@ -55,7 +55,10 @@ struct PinBuf {
         if (bytes <= cap) return hipSuccess;
         release();
         const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        // coherent (fine-grained): the chunk kernels' results and completion word must reach the polling host while the
+        // kernel is still running, not at its end
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc(&p, want, hipHostMallocDefault); }
         if (e != hipSuccess) { p = nullptr; return e; }
         e = hipHostGetDevicePointer(&dp, p, 0);
         if (e != hipSuccess) { (void)hipHostFree(p); p = dp = nullptr; return e; }
@@ -130,8 +133,12 @@ struct p25fe {
     bool rx_joined_any[2] = {false, false};
     int lane = 0;
     bool ext_events = true;                // events ride on the kernel dispatches (hipExtLaunchKernelGGL) instead of separate records
+    bool k1_alt_on = false;                // two-stream step: every other call's K1 on a second stream (consecutive K1s are independent)
+    hipStream_t k1_alt = nullptr;
+    hipEvent_t ev_in = nullptr;
     int rx_cus = 0;                        // > 0: the receive stream is confined to this many CUs (hipExtStreamCreateWithCUMask)
     // stream state (per channel, channel-major in the device buffers)
+    unsigned chunk_seq = 0;                // completion sequence number of the one-launch chunk calls
     uint64_t abs_iq = 0;                   // IQ samples consumed
     int fmt_locked = -1;
     std::vector<char> hist_iq;             // [C][SHARD_HALO] raw samples (8 bytes reserved per sample), host side
@@ -274,6 +281,8 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
         h->ext_events = !(ee && atoi(ee) == 0);
         const char* rc_ = getenv("P25FE_RX_CUS");
         h->rx_cus = rc_ ? atoi(rc_) : 0;
+        const char* ka = getenv("P25FE_PIPE_K1ALT");
+        h->k1_alt_on = ka && atoi(ka) != 0;
     }
     auto set_lds = [&](const void* f, size_t bytes) {
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes + 32768);   // (+ room for P25FE_K1_LDS_PAD)
@@ -315,6 +324,8 @@ void p25fe_destroy(p25fe_t* h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     if (h->rx_stream) { (void)hipStreamSynchronize(h->rx_stream); (void)hipStreamDestroy(h->rx_stream); }
+    if (h->k1_alt) { (void)hipStreamSynchronize(h->k1_alt); (void)hipStreamDestroy(h->k1_alt); }
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     for (int l = 0; l < 2; ++l) {
         if (h->ev_k1[l]) (void)hipEventDestroy(h->ev_k1[l]);
         if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
@@ -836,6 +847,17 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     std::swap(h->gsum, h->alt_gsum); std::swap(h->gouts, h->alt_gouts); std::swap(h->evg, h->alt_evg);
     h->lane ^= 1;
     const int lane = h->lane;
+    if (h->k1_alt_on && lane == 1) {
+        // experiment: consecutive calls are independent (different captures, different scratch sets), so this call's K1 may
+        // start while the previous call's K1 drains -- it runs on a second stream that first waits for the caller's
+        if (!h->k1_alt) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->k1_alt, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventRecord(h->ev_in, st));
+        HIPCHK(h, hipStreamWaitEvent(h->k1_alt, h->ev_in, 0));
+        st = h->k1_alt;
+    }
     if (h->rx_pending[lane]) {
         if (!(h->rx_joined_any[lane] && h->rx_joined[lane] == st)) HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[lane], 0));
         h->rx_pending[lane] = false;
@@ -1120,6 +1142,7 @@ struct RecvOut {
     int64_t *spos, *d_spos;
     uint64_t *sdib, *d_sdib;
     float *tail, *d_tail;
+    unsigned *done, *d_done;             // completion words the chunk kernels write last (polled by the host)
     size_t dstride, sstride;
 };
 static int recv_out(p25fe_t* h, size_t n_bb, size_t sync_cap, RecvOut* o)
@@ -1127,7 +1150,7 @@ static int recv_out(p25fe_t* h, size_t n_bb, size_t sync_cap, RecvOut* o)
     const size_t C = (size_t)h->C;
     o->dstride = round_up(n_bb / (W + 1) + 2, 16);                   // hard ceiling: detections, hence re-anchors, are at least W + 1 samples apart
     o->sstride = sync_cap;
-    const size_t bytes = C * (sizeof(p25fe_result_t) + sizeof(p25fe_anchor_t) + o->dstride + 16 * sync_cap + TAILN * sizeof(float)) + 64 * 8;
+    const size_t bytes = C * (sizeof(p25fe_result_t) + sizeof(p25fe_anchor_t) + o->dstride + 16 * sync_cap + TAILN * sizeof(float) + 4) + 64 * 8;
     HIPCHK(h, h->hout.ensure(bytes));
     Arena ar(h->hout);
     o->res = ar.take<p25fe_result_t>(C, &o->d_res);
@@ -1136,6 +1159,7 @@ static int recv_out(p25fe_t* h, size_t n_bb, size_t sync_cap, RecvOut* o)
     o->spos = ar.take<int64_t>(C * sync_cap, &o->d_spos);
     o->sdib = ar.take<uint64_t>(C * sync_cap, &o->d_sdib);
     o->tail = ar.take<float>(C * TAILN, &o->d_tail);
+    o->done = ar.take<unsigned>(C, &o->d_done);
     memcpy(o->anc, h->anchor.data(), sizeof(p25fe_anchor_t) * C);
     return P25FE_OK;
 }
@@ -1170,6 +1194,35 @@ static void chunk_recv_args(p25fe_t* h, const RecvOut& o, size_t n_bb, long view
     c->anchor_in = o.d_anc; c->result = o.d_res; c->dibits = o.d_dib; c->dibit_stride = (long)o.dstride;
     c->sync_pos = want_sync ? o.d_spos : nullptr; c->sync_dibit = want_sync ? o.d_sdib : nullptr; c->sync_stride = (long)o.sstride;
     c->tail = want_tail ? o.d_tail : nullptr; c->look = (int)h->look; c->n_baseband = n_bb;
+    c->done = nullptr; c->seq = 0u;
+}
+
+// One-launch chunk calls finish by POLLING a word the kernel writes last into pinned memory (a system-scope release in front
+// of it) instead of hipStreamSynchronize: the completion signal -> interrupt -> wake-up path costs more than the kernel.
+// P25FE_CHUNK_POLL=0 keeps the synchronisation.  The stream is synchronised anyway if the word does not arrive in time.
+static void chunk_poll_arm(p25fe_t* h, const RecvOut& o, ChunkRecvArgs* c)
+{
+    static const bool poll = [] { const char* e = getenv("P25FE_CHUNK_POLL"); return !(e && atoi(e) == 0); }();
+    if (!poll) return;
+    ++h->chunk_seq;
+    if (h->chunk_seq == 0u) ++h->chunk_seq;
+    for (int ch = 0; ch < h->C; ++ch) o.done[ch] = 0u;
+    c->done = o.d_done; c->seq = h->chunk_seq;
+}
+static int chunk_wait(p25fe_t* h, const RecvOut& o, const ChunkRecvArgs& c)
+{
+    if (c.done) {
+        volatile unsigned* w = o.done;
+        const size_t C = (size_t)h->C;
+        for (long spin = 0; spin < 4000000L; ++spin) {               // ~ tens of milliseconds at worst, then fall back
+            size_t k = 0;
+            while (k < C && w[k] == c.seq) ++k;
+            if (k == C) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return P25FE_OK; }
+            __builtin_ia32_pause();
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return P25FE_OK;
 }
 
 int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits, int64_t* sync_pos,
@@ -1198,11 +1251,15 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
     if (rc) return rc;
     rc = ensure_slice_scratch(h, n);
     if (rc) return rc;
+    ChunkRecvArgs polled;
+    polled.done = nullptr; polled.seq = 0u;
     const size_t hist = h->abs_bb < BBPAD ? (size_t)h->abs_bb : BBPAD;
     const long view0 = (long)h->abs_bb - h->look;
     if (!h->track && n <= (size_t)TS) {
         RecvChunkArgs a;
         chunk_recv_args(h, o, n, view0, sync_cap != 0, false, &a.r);
+        chunk_poll_arm(h, o, &a.r);
+        polled = a.r;
         const PlanarGeo g(n);
         a.bb = db + BBPAD; a.bb_stride = (long)bb_stride; a.n_hist = (long)hist;
         a.f = h->pl_f.as<float>(); a.bits = h->pl_bits.as<uint32_t>(); a.n_blocks = (long)g.n_blocks;
@@ -1218,7 +1275,8 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
                                sync_cap ? o.d_sdib : nullptr, o.sstride, o.d_res, true, h->stream, rcall);
         if (rc) return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    rc = chunk_wait(h, o, polled);
+    if (rc) return rc;
     rc = recv_finish(h, o, n, dibits, cap, n_dibits, sync_pos, sync_dibit, sync_cap, n_sync);
     if (rc) return rc;
     for (size_t c = 0; c < C; ++c)                                   // the tail: last BBPAD samples of [tail | new]
@@ -1262,9 +1320,12 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     const PlanarGeo g(nb);
     ChunkRecvArgs cr;
     chunk_recv_args(h, o, nb, view0, false, true, &cr);
+    bool one_launch = false;
     if (!h->track && nb <= (size_t)TS) {
+        chunk_poll_arm(h, o, &cr);
         rc = launch_chunk(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, cr);
         if (rc) return rc;
+        one_launch = true;
     } else {
         // the baseband stays in HBM; the receiver's history is recomputed from the IQ history, like a shard's from its halo
         const RecvCall rcall = recv_call(h);
@@ -1278,7 +1339,9 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
         hipLaunchKernelGGL(k_tail_extract, dim3((unsigned)C), dim3(WV), 0, h->stream, cr);
         HIPCHK(h, hipGetLastError());
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!one_launch) cr.done = nullptr;
+    rc = chunk_wait(h, o, cr);
+    if (rc) return rc;
     rc = recv_finish(h, o, nb, dibits, cap, n_dibits, nullptr, nullptr, 0, nullptr);
     if (rc) return rc;
     commit_iq(h, fmt, n, sg);

@@ -1244,6 +1244,8 @@ struct ChunkRecvArgs {
                                 // recomputed history are left untouched)
     int look;                   // baseband sample m of the range sits at planar position m + look + PLPAD
     unsigned long long n_baseband;
+    unsigned* done;             // nullable: [ch] in host-visible memory, receives `seq` after everything else of the channel has
+    unsigned seq;               // been written (system-scope release): the host polls it instead of synchronising the stream
 };
 
 // every lane's global stores of the wave are visible to every lane's later loads (one wave: same CU, same L1)
@@ -1305,6 +1307,10 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     so.src = -1; so.event_off = 0u; so.dibit_off = 0ull;
     slice_tile(l, 0, ch, so, u, A.valid, A.s, A.hi, A.mid, A.lo);
     tail_extract(c, ch);
+    if (c.done) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");              // system scope: the host sees dibits, result and tail before the flag
+        if (lane == 0) __hip_atomic_store(&c.done[ch], c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // p25fe_slice for a chunk of at most one tile: planarize (one wave walks the ten planes), then the receiver.
