@@ -505,7 +505,7 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
                 if (track && r->prev_valid) {
                     const int64_t dd = m - r->prev_s, nn = (dd + S / 2) / S;
                     const int64_t err = dd > S * nn ? dd - S * nn : S * nn - dd;
-                    if (nn >= 1 && dd <= ((int64_t)1 << g->clk_dmax_log2) && (err << g->clk_tol_shift) <= S * nn) {
+                    if (nn >= 1 && err != 0 && dd <= ((int64_t)1 << g->clk_dmax_log2) && (err << g->clk_tol_shift) <= S * nn) {
                         r->per_d = dd; r->per_n = nn;
                     }
                 }

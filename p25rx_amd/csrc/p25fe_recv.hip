@@ -102,11 +102,18 @@ __host__ __device__ inline void clock_period(bool track, bool prev_valid, long s
     if (track && prev_valid) {
         const long dd = s_new - s_prev, nn = (dd + SPS / 2) / SPS;
         const long err = dd > SPS * nn ? dd - SPS * nn : SPS * nn - dd;
-        if (nn >= 1 && dd <= (1L << P25FE_CLK_DMAX_LOG2) && (err << P25FE_CLK_TOL_SHIFT) <= SPS * nn) { D = (int)dd; N = (int)nn; }
+        // (an interval of exactly 10 N samples IS the nominal clock: kept as 10 / 1, the same instants, so that the
+        // division-free paths below apply)
+        if (nn >= 1 && err != 0 && dd <= (1L << P25FE_CLK_DMAX_LOG2) && (err << P25FE_CLK_TOL_SHIFT) <= SPS * nn) { D = (int)dd; N = (int)nn; }
     }
 }
 // number of instants j >= 1 of a clock (D, N) with floor(j D / N) < x
-__host__ __device__ inline long clock_J(long x, int D, int N) { return x > 0 ? (x * (long)N - 1) / (long)D : 0; }
+__host__ __device__ inline long clock_J(long x, int D, int N)
+{
+    if (x <= 0) return 0;
+    if (N == 1 && D == SPS) return (x - 1) / SPS;                  // nominal clock: a division by a constant
+    return (x * (long)N - 1) / (long)D;
+}
 // instants of the detection (s, D, N) with index in [lo, hi) that it governs (index > s + W)
 __host__ __device__ inline long clock_count(long s, int D, int N, long lo, long hi)
 {
@@ -920,6 +927,7 @@ struct ScanArgsG {
     int track;
 };
 
+constexpr int KG_CHUNK = 1024;          // tiles whose summaries k_scan_g stages in LDS at a time (48 KB)
 struct Top2 { int a, b; };              // latest and second-latest event tile, -1: none
 __device__ __forceinline__ Top2 top2_merge(Top2 l, Top2 r)      // r is later than l
 {
@@ -940,7 +948,12 @@ struct CState { int valid; long s; int D, N; int src; };
 
 __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
 {
-    __shared__ unsigned CNT[K3_CHUNK], PRE[K3_CHUNK];
+    // a chunk of summaries (and of the tiles' last detection positions) is staged in LDS: the per-tile work below is a chain
+    // of dependent reads (summary -> latest event tile's summary -> the one before) that cost a memory round trip each
+    // when they went to global memory (k_scan_g 45 us for config 2; 3 750 tiles)
+    __shared__ TileSumG GS[KG_CHUNK];
+    __shared__ long LS[KG_CHUNK];
+    __shared__ unsigned CNT[KG_CHUNK], PRE[KG_CHUNK];
     __shared__ Top2 sh2[NT3 / 64];
     __shared__ unsigned long long shu[NT3 / 64];
     __shared__ Top2 c_top;                                         // latest two event tiles before the chunk (global indices)
@@ -963,17 +976,20 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     }
     __syncthreads();
 
+    int cc0 = 0, ccn = 0;                                           // the chunk staged in LDS: tiles [cc0, cc0 + ccn)
+    auto sum_of = [&](int t) -> TileSumG { return (t >= cc0 && t < cc0 + ccn) ? GS[t - cc0] : gsum[t]; };
+    auto last_s_of = [&](int t) -> long { return (t >= cc0 && t < cc0 + ccn) ? LS[t - cc0] : recs[t].last_s; };
     // state after event tile t1 (t2: the event tile before it, -1: the range's carry-in)
     auto state_after = [&](int t1, int t2) -> CState {
         CState st;
         if (t1 < 0) { st.valid = Ain.valid; st.s = Ain.s; st.D = Ain.period_d; st.N = Ain.period_n; st.src = Ain.valid ? -1 : -2; return st; }
-        const TileSumG g = gsum[t1];
+        const TileSumG g = sum_of(t1);
         const unsigned fl = g.n_det_flags >> 16;
         if (!(fl & G_OUT_VALID)) { st.valid = 0; st.s = 0; st.D = SPS; st.N = 1; st.src = -2; return st; }
-        st.valid = 1; st.src = t1; st.s = recs[t1].last_s;
+        st.valid = 1; st.src = t1; st.s = last_s_of(t1);
         if (fl & G_OUT_PERIOD_KNOWN) { st.D = g.out_D; st.N = g.out_N; return st; }
         bool pv; long ps;
-        if (t2 >= 0) { pv = ((gsum[t2].n_det_flags >> 16) & G_OUT_VALID) != 0; ps = pv ? recs[t2].last_s : 0; }
+        if (t2 >= 0) { pv = ((sum_of(t2).n_det_flags >> 16) & G_OUT_VALID) != 0; ps = pv ? last_s_of(t2) : 0; }
         else { pv = Ain.valid != 0; ps = Ain.s; }
         clock_period(track, pv, ps, st.s, st.D, st.N);
         return st;
@@ -983,14 +999,18 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         return rem < TS ? (int)rem : TS;
     };
 
-    for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
-        const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
+    for (int c0 = 0; c0 < a.n_tiles; c0 += KG_CHUNK) {
+        const int cn = (a.n_tiles - c0 < KG_CHUNK) ? a.n_tiles - c0 : KG_CHUNK;
+        __syncthreads();                                            // the previous chunk's readers are done with GS / LS
+        for (int k = tid; k < cn; k += NT3) { GS[k] = gsum[c0 + k]; LS[k] = recs[c0 + k].last_s; }
+        cc0 = c0; ccn = cn;
+        __syncthreads();
         const int per = (cn + NT3 - 1) / NT3;
         const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
         // ---- latest two event tiles of my run -> exclusive scan
         Top2 mine; mine.a = mine.b = -1;
         for (int k = k0; k < k1; ++k)
-            if (gsum[c0 + k].pre_end1) { mine.b = mine.a; mine.a = c0 + k; }
+            if (GS[k].pre_end1) { mine.b = mine.a; mine.a = c0 + k; }
         Top2 inc = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1014,7 +1034,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
             Top2 t2 = exc;
             CState st = state_after(t2.a, t2.b);
             for (int k = k0; k < k1; ++k) {
-                const TileSumG g = gsum[c0 + k];
+                const TileSumG g = GS[k];
                 const long T0 = a.abs0 + (long)(c0 + k) * TS, TE = T0 + tile_len(c0 + k);
                 const long pre_hi = g.pre_end1 ? T0 + (long)g.pre_end1 - 1 : TE;
                 const unsigned pre = st.valid ? (unsigned)clock_count(st.s, st.D, st.N, T0, pre_hi) : 0u;
@@ -1038,7 +1058,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
             Top2 t2 = exc;
             CState st = state_after(t2.a, t2.b);
             for (int k = k0; k < k1; ++k) {
-                const TileSumG g = gsum[c0 + k];
+                const TileSumG g = GS[k];
                 ScanOutG o;
                 o.s = st.s; o.dibit_off = dc; o.src = st.src; o.event_off = (unsigned)ec; o.D = st.D; o.N = st.N;
                 outs[c0 + k] = o;
@@ -1071,6 +1091,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         }
         __syncthreads();
     }
+    ccn = 0;                                                        // (nothing staged any more: read the final tiles from global memory)
     if (tid == 0) {
         const CState st = state_after(c_top.a, c_top.b);
         p25fe_result_t r;

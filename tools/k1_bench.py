@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the kernels on random IQ (within-process A/B across env settings is done by the caller).
-usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|chz|run|split] [channels=1] [fmt=cf32|u8]
+usage: k1_bench.py [seconds=600] [iters=20] [mode=k1|k0|chz|run|split] [channels=1] [fmt=cf32|u8] [symbol_clock=0|1]
 mode split = run, plus the per-kernel split from the library's own HIP events."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mode = sys.argv[3] if len(sys.argv) > 3 else "k1"
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 fmt = sys.argv[5] if len(sys.argv) > 5 else "cf32"
+clock = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 n = int(secs * 240000) // 8 * 8
 dev = torch.device("cuda", 0)
 if fmt == "cf32" and mode in ("run", "split"):      # the symbol receiver's cost depends on the signal: real C4FM
@@ -23,7 +24,7 @@ elif fmt == "cf32":
     iq = torch.randn((C, n, 2), dtype=torch.float32, device=dev) * 0.3
 else:
     iq = torch.randint(0, 256, (C, n, 2), dtype=torch.uint8, device=dev)
-fe = FrontEnd(n_channels=C)
+fe = FrontEnd(n_channels=C, symbol_clock=clock)
 bb = None
 def step():
     global bb
