@@ -151,7 +151,8 @@ int p25fe_resync(p25fe_t *h);
 /* The same for device-resident ranges, where "the current position" lies INSIDE the range (RecvTask handles
  * RecvEvent::SetControlFreq between two baseband chunks, src/recv.rs:127-137; a resident capture spans many): the NEXT
  * call on this handle that runs the receiver (p25fe_slice_dev, p25fe_run_dev, p25fe_run_dev_pipelined,
- * p25fe_shard_pass1 / _finish + the p25fe_shard_pass2 that follows) drops lock before each listed sample -- exactly as
+ * p25fe_shard_pass1 / _finish + the p25fe_shard_pass2 that follows; also the host-buffer calls p25fe_slice,
+ * p25fe_run_u8 / _cf32, whose range is the chunk) drops lock before each listed sample -- exactly as
  * if resync() had been called between feeding samples q - 1 and q.  d_idx: device array, n_idx ascending ABSOLUTE
  * baseband indices per channel, channel c at d_idx + c * idx_stride (pad a shorter list with INT64_MAX); it must stay
  * valid and unchanged until that call's kernels have run.  n_idx = 0 cancels.  The list is consumed by that call. */

@@ -231,10 +231,14 @@ int p25fe_reset(p25fe_t* h)
     h->abs_iq = 0;
     h->fmt_locked = -1;
     h->abs_bb = 0;
-    h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0, SPS, 1});
-    h->total_dibits.assign((size_t)h->C, 0);
-    h->hist_iq.assign((size_t)h->C * SHARD_HALO * 8, 0);
-    h->tail_bb.assign((size_t)h->C * BBPAD, 0.f);
+    try {                                                           // no exception crosses the C boundary
+        h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0, SPS, 1});
+        h->total_dibits.assign((size_t)h->C, 0);
+        h->hist_iq.assign((size_t)h->C * SHARD_HALO * 8, 0);
+        h->tail_bb.assign((size_t)h->C * BBPAD, 0.f);
+    } catch (...) {
+        return P25FE_ERR_NOMEM;
+    }
     return P25FE_OK;
 }
 
@@ -336,7 +340,7 @@ void p25fe_destroy(p25fe_t* h)
     DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps};
     for (DevBuf* b : bufs) b->release();
     h->hin.release(); h->hbb.release(); h->hout.release();
-    for (auto& e : h->prof_ev) (void)hipEventDestroy(e);
+    for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -834,10 +838,10 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
                 HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));     // any non-blocking stream will do
             }
         }
-        for (int l = 0; l < 2; ++l) {
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
-        }
+    }
+    for (int l = 0; l < 2; ++l) {                                    // (per event: a failed creation is retried by the next call)
+        if (!h->ev_k1[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
+        if (!h->ev_rx[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
     }
     // the other scratch set becomes the current one; it was last read by the receive kernels of the call before the
     // previous one, which this call's K1 (it overwrites the planes) has to wait for
@@ -1026,7 +1030,7 @@ int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_
 int p25fe_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
                         size_t n_shards, int symbol_clock, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {
-    if (!summaries || !shard_bb0 || !shard_bb_n || !anchor_in || !dibit_offset) return P25FE_ERR_ARG;
+    if (!summaries || !shard_bb0 || !shard_bb_n || !anchor_in || !dibit_offset || n_shards > 0x7fffffffu) return P25FE_ERR_ARG;
     shard_resolve_impl(summaries, shard_bb0, shard_bb_n, (int)n_shards, symbol_clock, anchor_in, dibit_offset);
     return P25FE_OK;
 }
@@ -1035,7 +1039,7 @@ int p25fe_shard_resolve_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const
                             const uint64_t* d_shard_bb_n, size_t n_shards, p25fe_anchor_t* d_anchor_in,
                             uint64_t* d_dibit_offset, void* stream)
 {
-    if (!h || !d_summaries || !d_shard_bb0 || !d_shard_bb_n || !d_anchor_in || !d_dibit_offset) return P25FE_ERR_ARG;
+    if (!h || !d_summaries || !d_shard_bb0 || !d_shard_bb_n || !d_anchor_in || !d_dibit_offset || n_shards > 0x7fffffffu) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_summaries, d_shard_bb0, d_shard_bb_n,
                        (int)n_shards, h->track, d_anchor_in, d_dibit_offset);
@@ -1255,7 +1259,7 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
     polled.done = nullptr; polled.seq = 0u;
     const size_t hist = h->abs_bb < BBPAD ? (size_t)h->abs_bb : BBPAD;
     const long view0 = (long)h->abs_bb - h->look;
-    if (!h->track && n <= (size_t)TS) {
+    if (!h->track && !h->rs_n && n <= (size_t)TS) {
         RecvChunkArgs a;
         chunk_recv_args(h, o, n, view0, sync_cap != 0, false, &a.r);
         chunk_poll_arm(h, o, &a.r);
@@ -1267,6 +1271,7 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
         HIPCHK(h, hipGetLastError());
     } else {
         const RecvCall rcall = recv_call(h);
+        h->rs_n = 0;                                                 // a pending p25fe_resync_at_dev list belongs to this call
         rc = launch_planarize(h, db + BBPAD, bb_stride, hist, n, h->stream);
         if (rc) return rc;
         rc = launch_detect(h, n, view0, h->stream, rcall);
@@ -1321,7 +1326,7 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     ChunkRecvArgs cr;
     chunk_recv_args(h, o, nb, view0, false, true, &cr);
     bool one_launch = false;
-    if (!h->track && nb <= (size_t)TS) {
+    if (!h->track && !h->rs_n && nb <= (size_t)TS) {
         chunk_poll_arm(h, o, &cr);
         rc = launch_chunk(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, cr);
         if (rc) return rc;
@@ -1329,6 +1334,7 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     } else {
         // the baseband stays in HBM; the receiver's history is recomputed from the IQ history, like a shard's from its halo
         const RecvCall rcall = recv_call(h);
+        h->rs_n = 0;
         rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)PLPAD - h->look, nullptr, 0,
                              nullptr, h->stream, &g);
         if (rc) return rc;
@@ -1443,9 +1449,22 @@ int p25fe_profile_enable(p25fe_t* h, int on)
     if (!h) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (on && h->prof_ev.empty()) {
-        h->prof_ev.resize((size_t)PROF_RING * 5);
-        h->prof_mask.assign((size_t)PROF_RING, 0);
-        for (auto& e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
+        try {
+            h->prof_ev.assign((size_t)PROF_RING * 5, nullptr);
+            h->prof_mask.assign((size_t)PROF_RING, 0);
+        } catch (...) {
+            h->prof_ev.clear();
+            return P25FE_ERR_NOMEM;
+        }
+        for (auto& e : h->prof_ev) {
+            const hipError_t er = hipEventCreate(&e);
+            if (er != hipSuccess) {                                 // all or nothing: a half-made ring is never indexed
+                for (auto& d : h->prof_ev) if (d) (void)hipEventDestroy(d);
+                h->prof_ev.clear();
+                h->last_hip = (int)er;
+                return P25FE_ERR_HIP;
+            }
+        }
     }
     h->prof_on = on != 0;
     h->prof_level = on == 2 ? 2 : (on == 3 ? 3 : 1);
@@ -1542,7 +1561,16 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
     StateHeader hd;
     memcpy(&hd, p, sizeof hd); p += sizeof hd;
     if (hd.magic != STATE_MAGIC || hd.abi != P25FE_ABI_VERSION || hd.n_channels != h->C) return P25FE_ERR_ARG;
+    if (hd.fmt_locked != -1 && hd.fmt_locked != P25FE_FMT_U8 && hd.fmt_locked != P25FE_FMT_CF32) return P25FE_ERR_ARG;
     const size_t C = (size_t)h->C;
+    {   // a blob is data from outside: every anchor's clock must be a usable period before anything is taken over
+        const char* pa = p + C * SHARD_HALO * 8 + C * BBPAD * sizeof(float);
+        for (size_t c = 0; c < C; ++c) {
+            p25fe_anchor_t a;
+            memcpy(&a, pa + c * sizeof a, sizeof a);
+            if (a.period_d <= 0 || a.period_n <= 0) return P25FE_ERR_ARG;
+        }
+    }
     memcpy(h->hist_iq.data(), p, C * SHARD_HALO * 8); p += C * SHARD_HALO * 8;
     memcpy(h->tail_bb.data(), p, C * BBPAD * sizeof(float)); p += C * BBPAD * sizeof(float);
     memcpy(h->anchor.data(), p, C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);

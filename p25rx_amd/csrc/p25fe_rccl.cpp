@@ -113,10 +113,15 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     for (auto& row : s->ev) for (hipEvent_t& e : row) e = nullptr;
     s->h = h; s->rank = rank; s->world = world; s->n = n_per_rank; s->halo = p25fe_shard_halo();
     size_t bbmax = 0;
-    for (int r = 0; r < world; ++r) {
-        s->bb0.push_back(p25fe_n_baseband(0, (size_t)r * n_per_rank));
-        s->bbn.push_back(p25fe_n_baseband((uint64_t)r * n_per_rank, n_per_rank));
-        if (s->bbn.back() > bbmax) bbmax = (size_t)s->bbn.back();
+    try {                                                           // no exception crosses the C boundary
+        for (int r = 0; r < world; ++r) {
+            s->bb0.push_back(p25fe_n_baseband(0, (size_t)r * n_per_rank));
+            s->bbn.push_back(p25fe_n_baseband((uint64_t)r * n_per_rank, n_per_rank));
+            if (s->bbn.back() > bbmax) bbmax = (size_t)s->bbn.back();
+        }
+    } catch (...) {
+        delete s;
+        return P25FE_ERR_NOMEM;
     }
     // a receiver that re-anchors on every sync word follows the TRANSMITTER's symbol clock: proportional slack (200 ppm)
     s->cap = ((bbmax / 10 + bbmax / 50000 + 64) + 15) / 16 * 16;

@@ -219,6 +219,19 @@ def test_state_export_import(O, FE, c4fm_1s):
     fe2.state_import(blob)
     b = fe2.run_cf32(iq[100001:])
     assert np.array_equal(np.concatenate([a, b]), ref)
+    # a blob is outside data: a damaged one is refused and leaves the handle as it was
+    from p25rx_amd._lib import P25feError
+    fe3 = FE()
+    c = fe3.run_cf32(iq[:100001])
+    for off, val in ((0, 0), (12, 9)):                               # magic; fmt_locked
+        bad = np.array(blob, dtype=np.uint8, copy=True)
+        bad[off] = val
+        with pytest.raises(P25feError):
+            fe3.state_import(bad)
+    with pytest.raises(P25feError):
+        fe3.state_import(blob[:-1])
+    d = fe3.run_cf32(iq[100001:])
+    assert np.array_equal(np.concatenate([c, d]), ref)
 
 
 def test_time_shards_equal_single_pass(O, FE):

@@ -164,6 +164,45 @@ def test_resync_inside_device_ranges(O, FE, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
+def test_lock_drops_through_the_streaming_calls(O, FE, mode):
+    """p25fe_resync_at_dev before a host-buffer call (p25fe_slice, p25fe_run_cf32): the chunk is the range, the indices stay
+    ABSOLUTE, the list is consumed by that call -- also when the chunk would otherwise take the one-launch path."""
+    import torch
+    from p25rx_amd import c4fm
+    iq, _, _ = c4fm.synth(1.5, seed=9, snr_db=28.0)
+    iq = iq[:len(iq) // 16384 * 16384]
+    bb = O.Demod().feed_cf32(iq)
+    L = 2 * mode
+    free = oracle_recv(O, bb, mode)
+    sp = [int(x) + 5 + L for x in free[1]]
+    drops = [sp[1], sp[3] + 1, sp[3] + 700, sp[5] - 1]
+    ref = oracle_recv(O, bb, mode, drops)
+    assert len(ref[0]) < len(free[0])
+
+    def feed(fe, call, sizes, n_total, units):
+        """chunks of the given sizes; before each chunk the drops that fall inside it go to the handle"""
+        parts, o = [], 0
+        while o < n_total:
+            n = min(sizes[len(parts) % len(sizes)], n_total - o)
+            lo, hi = units(o), units(o + n)
+            mine = [q for q in drops if lo <= q < hi]
+            if mine:
+                fe.resync_at_dev(torch.tensor(mine, dtype=torch.int64, device="cuda"))
+            parts.append(call(o, n))
+            o += n
+        return parts
+
+    fe = FE(symbol_clock=mode)
+    parts = feed(fe, lambda o, n: fe.slice(bb[o:o + n]), [3277, 3276, 9000, 1, 2500], len(bb), lambda o: o)
+    same([np.concatenate([p[k] for p in parts]) for k in range(3)], ref, "p25fe_slice")
+    fe = FE(symbol_clock=mode)
+    n_bb = lambda o: (o - 5) // 5 + 1 if o > 4 else 0                  # baseband samples produced by the first o IQ samples (p25fe_n_baseband)
+    parts = feed(fe, lambda o, n: fe.run_cf32(iq[o:o + n]), [16384, 16384, 49152], len(iq), n_bb)
+    got = np.concatenate(parts)
+    assert len(got) == len(ref[0]) and np.array_equal(got, ref[0])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
 def test_time_shards_with_tracking_clock_and_lock_drops(O, FE, mode):
     """Config 5's shard / resolve / pass 2 with the general receiver: carry-in clocks across shards, a shard whose only
     event is a lock drop, a shard with one detection that takes its period from the previous shard."""
