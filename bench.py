@@ -371,7 +371,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=None,
                     help="capture length: per GPU at N = 1 / --scaling weak (default 600 = configs[1]), TOTAL at N > 1 strong "
                          "(default 3600 = configs[4])")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1 only")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
+                    help="N > 1 only.  weak (default): every GPU holds configs[1]'s 600 s, the capture is N x 600 s cut into N time "
+                         "shards -- per-GPU work is that of the N = 1 line, so the per-N values form one curve; strong: configs[4] "
+                         "as BASELINE.json words it, ONE 3 600 s capture cut N ways")
     ap.add_argument("--workload", choices=["time", "channels"], default="time",
                     help="N > 1: 'time' = configs[4], one capture cut into time shards (default); 'channels' = configs[3], "
                          "a 256-channel batch cut into channel blocks (no communication on the data path)")
@@ -587,8 +590,12 @@ def main():
                 halo, {"root": "point-to-point gather to rank 0", "all": "all_gather", "none": "nothing"}[args.gather],
                 "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
         else:
-            workload = ("configs[4] weak-scaled: %.0f s per GPU (%d samples per rank)" % (total_s, n))
-            sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries by all_gather, dibits gathered (RCCL)" % halo
+            workload = ("configs[4]'s partitioning at configs[1]'s per-GPU size: ONE %.0f s capture (%d samples, %.3f GB) cut into %d "
+                        "contiguous time shards of %.0f s, decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather (%s)"
+                        % (total_s * world, n * world, n * world * 8 / 1e9, world, total_s, args.gather))
+            sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries by all_gather, dibits by %s (%s)" % (
+                halo, {"root": "point-to-point gather to rank 0", "all": "all_gather", "none": "nothing"}[args.gather],
+                "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
         out = {
             "metric": "IQ Msamples/s through FM-demod+C4FM slice",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

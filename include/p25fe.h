@@ -119,6 +119,7 @@ int p25fe_create(const p25fe_config_t *cfg, p25fe_t **out);
 void p25fe_destroy(p25fe_t *h);
 const char *p25fe_strerror(int status);
 int p25fe_last_hip_error(const p25fe_t *h);      /* raw hipError_t of the last P25FE_ERR_HIP */
+int p25fe_device(const p25fe_t *h);              /* HIP device ordinal the handle lives on (p25fe_config_t.device); < 0: null handle */
 
 /* ---- streaming, host buffers: the bodies of DemodTask::run and RecvTask::run ----------------
  * Multi-channel handles take channel-major buffers: channel c starts at c * (elements per

@@ -51,7 +51,7 @@ assert ANCHOR_DTYPE.itemsize == C.sizeof(Anchor) and RESULT_DTYPE.itemsize == C.
 
 # every symbol include/p25fe.h declares (tests check the library exports exactly these)
 SYMBOLS = [
-    "p25fe_default_config", "p25fe_create", "p25fe_destroy", "p25fe_strerror", "p25fe_last_hip_error",
+    "p25fe_default_config", "p25fe_create", "p25fe_destroy", "p25fe_strerror", "p25fe_last_hip_error", "p25fe_device",
     "p25fe_demod_u8", "p25fe_demod_cf32", "p25fe_slice", "p25fe_run_u8", "p25fe_run_cf32", "p25fe_resync",
     "p25fe_reset", "p25fe_state_size", "p25fe_state_export", "p25fe_state_import", "p25fe_demod_dev",
     "p25fe_slice_dev", "p25fe_run_dev", "p25fe_run_dev_pipelined", "p25fe_join_dev", "p25fe_shard_halo", "p25fe_shard_pass1", "p25fe_shard_pass2",
@@ -98,6 +98,7 @@ def load():
     L.p25fe_strerror.argtypes = [C.c_int]
     L.p25fe_strerror.restype = C.c_char_p
     L.p25fe_last_hip_error.argtypes = [vp]
+    L.p25fe_device.argtypes = [vp]
     L.p25fe_demod_u8.argtypes = [vp, vp, sz, vp, sz, psz, vp]
     L.p25fe_demod_cf32.argtypes = [vp, vp, sz, vp, sz, psz, vp]
     L.p25fe_slice.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp]

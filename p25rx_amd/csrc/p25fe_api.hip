@@ -216,6 +216,7 @@ const char* p25fe_strerror(int status)
 }
 
 int p25fe_last_hip_error(const p25fe_t* h) { return h ? h->last_hip : 0; }
+int p25fe_device(const p25fe_t* h) { return h ? h->cfg.device : -1; }
 
 size_t p25fe_n_baseband(uint64_t abs0, size_t n)
 {

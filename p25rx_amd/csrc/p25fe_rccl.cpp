@@ -93,6 +93,7 @@ size_t p25fe_shard_dibit_cap(const p25fe_shard_t* s) { return s ? s->cap : 0; }
 void p25fe_shard_destroy(p25fe_shard_t* s)
 {
     if (!s) return;
+    if (s->h) (void)hipSetDevice(p25fe_device(s->h));
     if (s->cs) { (void)hipStreamSynchronize(s->cs); (void)hipStreamDestroy(s->cs); }
     if (s->comm) (void)ncclCommDestroy(s->comm);
     if (s->e_fork) (void)hipEventDestroy(s->e_fork);
@@ -108,6 +109,8 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
 {
     if (!h || !out || world < 1 || rank < 0 || rank >= world || n_per_rank == 0 || (n_per_rank % 8) != 0) return P25FE_ERR_ARG;
     *out = nullptr;
+    // streams, events, buffers and the communicator belong to the handle's device, whatever the caller's current one is
+    if (hipSetDevice(p25fe_device(h)) != hipSuccess) return P25FE_ERR_HIP;
     p25fe_shard_t* s = new (std::nothrow) p25fe_shard;
     if (!s) return P25FE_ERR_NOMEM;
     for (auto& row : s->ev) for (hipEvent_t& e : row) e = nullptr;
@@ -125,7 +128,6 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     }
     // a receiver that re-anchors on every sync word follows the TRANSMITTER's symbol clock: proportional slack (200 ppm)
     s->cap = ((bbmax / 10 + bbmax / 50000 + 64) + 15) / 16 * 16;
-    int rc = P25FE_OK;
     auto fail = [&](int code) { p25fe_shard_destroy(s); return code; };
     if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess) return fail(P25FE_ERR_HIP);
     if (hipEventCreateWithFlags(&s->e_fork, hipEventDisableTiming) != hipSuccess ||
@@ -162,7 +164,6 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
             s->shm.hd->row_bytes = s->cap;
         }
     }
-    (void)rc;
     *out = s;
     return P25FE_OK;
 }
@@ -171,6 +172,7 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
 {
     if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8)) return P25FE_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    HCHK(hipSetDevice(p25fe_device(s->h)));
     const size_t eb = fmt == P25FE_FMT_CF32 ? 8 : 2;
     char* buf = static_cast<char*>(d_buf);
     char* owned = buf + s->halo * eb;
@@ -279,6 +281,7 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
 int p25fe_shard_offsets(p25fe_shard_t* s, uint64_t* offsets)
 {
     if (!s || !offsets) return P25FE_ERR_ARG;
+    HCHK(hipSetDevice(p25fe_device(s->h)));
     HCHK(hipMemcpy(offsets, s->d_off, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost));
     for (int r = 0; r < s->world; ++r)
         if (offsets[r + 1] - offsets[r] > s->cap) return P25FE_ERR_CAPACITY;     // the row was filled to the brim; the count is exact
@@ -291,6 +294,7 @@ int p25fe_shard_comm_ms(p25fe_shard_t* s, double ms[3], uint64_t* n_steps)
 {
     if (!s || !ms) return P25FE_ERR_ARG;
     ms[0] = ms[1] = ms[2] = 0.0;
+    HCHK(hipSetDevice(p25fe_device(s->h)));
     uint64_t from = s->read_from, cnt = 0;
     if (s->steps - from > (uint64_t)RING) from = s->steps - RING;
     if (s->comm && !s->staged) {

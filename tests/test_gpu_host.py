@@ -222,8 +222,9 @@ def test_timeshard_step_device_two_ranks_one_gpu():
 
 
 @pytest.mark.timeout(300)
-def test_bench_two_ranks_strong_split_host_staged():
-    """bench.py's N > 1 step (strong split of one capture, halo behind K1, device resolve, dibit gather) launched exactly
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_time_shards_host_staged(scaling):
+    """bench.py's N > 1 step (one capture cut into time shards, halo behind K1, device resolve, dibit gather) launched exactly
     as the driver launches it, with the collectives staged through gloo (P25FE_BENCH_HOST_STAGED: two ranks cannot share
     one GPU under RCCL).  Both gates must hold and the line must say what it measured."""
     import json
@@ -236,15 +237,17 @@ def test_bench_two_ranks_strong_split_host_staged():
     env = dict(os.environ, P25FE_BENCH_HOST_STAGED="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "60"],
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "60"]
+                         + (["--scaling", "strong"] if scaling == "strong" else []),     # weak is the default (the driver's command)
                          env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 3
     assert d["config"]["parity_gate"].endswith("True") and d["config"]["gather_gate"].endswith("True")
-    assert "ONE 60 s capture" in d["config"]["workload"] and d["value"] > 0
+    # weak: 60 s per rank = one 120 s capture; strong: the 60 s are the whole capture
+    assert ("ONE 120 s capture" if scaling == "weak" else "ONE 60 s capture") in d["config"]["workload"] and d["value"] > 0
 
 
 @pytest.mark.timeout(300)
