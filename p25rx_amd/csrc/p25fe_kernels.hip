@@ -1083,7 +1083,10 @@ __global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? (FMT == P25FE_FMT_U8 ? P25F
 // ------------------------------------------------------------------------------------------
 constexpr int PD = P25FE_PRE_DECIM;          // 10
 constexpr int T0 = P25FE_T0;                 // 80
-constexpr int K0_P = 3;                      // outputs per lane (odd)
+#ifndef P25FE_K0_P
+#define P25FE_K0_P 3
+#endif
+constexpr int K0_P = P25FE_K0_P;             // outputs per lane (odd)
 constexpr int K0_SUB = WV * K0_P;            // 192 outputs per sub-tile
 #ifndef P25FE_K0_SUBS
 #define P25FE_K0_SUBS 2
@@ -1094,7 +1097,8 @@ constexpr int K0_SUB = WV * K0_P;            // 192 outputs per sub-tile
 constexpr int K0_SUBS = P25FE_K0_SUBS;       // sub-tiles per workgroup (prefetch pipeline depth)
 constexpr int K0_HALO = T0 - PD;             // 70 input samples of left context
 constexpr int K0_NIN = PD * K0_SUB + K0_HALO;       // 1990 window positions
-constexpr int K0_JP = 205;                   // entries per phase row (>= K0_NIN / PD + 2); = 13 mod 16: staging position t lands on
+constexpr int k0_row_pitch(int need) { return need + ((13 - need % 16) + 16) % 16; }
+constexpr int K0_JP = k0_row_pitch(K0_NIN / PD + 2);   // entries per phase row (205 for 192 outputs); = 13 mod 16: staging position t lands on
                                              // bank pair 13 t + c (mod 16) whether or not the phase wraps -> conflict-free ds_write_b64
 static_assert(K0_JP >= K0_NIN / PD + 2 && K0_JP % 16 == 13, "polyphase row pitch");
 constexpr int K0_NV = (K0_NIN + 2 + 2 * WV - 1) / (2 * WV);   // 16-B vectors per lane: 16
