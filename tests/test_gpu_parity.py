@@ -476,6 +476,41 @@ def test_tiny_and_empty_inputs(O, FE):
         assert all(np.array_equal(p, q) for p, q in zip(a1, a2))
 
 
+def test_non_finite_and_extreme_samples(O, FE, c4fm_1s):
+    """A damaged capture: NaN, +-Inf, 1e30, denormals and -0.0 sprinkled into the IQ stream.  Every baseband sample that is a
+    number must equal the oracle's bit for bit, every NaN must be a NaN on both sides (the payload and sign of a generated
+    NaN are the hardware's), and the receiver's output on the parts of the stream the damage does not reach must agree."""
+    import torch
+    iq = np.array(c4fm_1s[0][:120000], copy=True)
+    f = iq.view(np.float32)
+    rng = np.random.default_rng(5)
+    vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-42, -1e-42, -0.0, 3.0e38], dtype=np.float32)
+    hits = np.sort(rng.choice(np.arange(20000, 60000), size=40, replace=False))
+    for k, i in enumerate(hits):
+        f[2 * i + (k & 1)] = vals[k % len(vals)]
+    ref = O.Demod().feed_cf32(iq)
+    fe = FE()
+    got = fe.demod_cf32(iq)
+    assert len(got) == len(ref)
+    nan_r, nan_g = np.isnan(ref), np.isnan(got)
+    assert np.array_equal(nan_r, nan_g) and nan_r.any()
+    assert np.array_equal(bits(got[~nan_g]), bits(ref[~nan_r]))
+    # the device-resident form (polyphase planes) and the streaming form see the same floats
+    t = torch.from_numpy(f.reshape(-1, 2)).cuda()
+    bb, nb = fe.demod_dev(t)
+    g2 = bb[0, :nb].cpu().numpy()
+    assert np.array_equal(np.isnan(g2), nan_r) and np.array_equal(bits(g2[~nan_r]), bits(ref[~nan_r]))
+    # the receiver on it: a NaN fails every comparison on both sides alike, so the streams agree THROUGH the damage, under
+    # both clocks, from the oracle's baseband, from the GPU's (its NaNs carry the other sign bit) and fused
+    for mode in (0, 1):
+        ro = O.Recv(O.make_config(symbol_clock=mode)).feed(ref)
+        assert len(ro[1]) >= 2
+        for src in (ref, got):
+            d, sp, sd = FE(symbol_clock=mode).slice(src)
+            assert np.array_equal(d, ro[0]) and np.array_equal(sp, ro[1]) and np.array_equal(sd, ro[2].astype(np.uint64))
+        assert np.array_equal(FE(symbol_clock=mode).run_cf32(iq), ro[0])
+
+
 def test_nid_after_sync_matches_oracle(O, FE):
     """Next row: NID after every frame sync, GPU exhaustive BCH(63,16,23) search == oracle, record
     for record, on clean frames, on frames with injected bit errors (<= 11 corrected, more rejected) and at the
