@@ -177,6 +177,10 @@ struct PlanarGeo {
     size_t words() const { return n_blocks * SPS; }
 };
 
+// Symbol indices are 32-bit in the receive kernels: a range holds < 2^31 symbols (124 h of one channel).  Checked by every
+// entry point BEFORE it sizes scratch for the range, so that an absurd length is an argument error, not an allocation failure.
+constexpr size_t MAX_RANGE_BB = (size_t)0x7ff00000u * 10u;
+
 constexpr int PROF_RING = 64;
 constexpr int PROF_SAMPLE = 8;
 
@@ -450,7 +454,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const long pl_shift = PLPAD + h->look;       // the general receiver sees the range h->look samples late (p25fe_recv.hip)
     if (planar && pro && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % PL_BLK != 0 || seg_len % PL_BLK != 0)) return P25FE_ERR_ARG;
     if (planar && !pro && (m_begin + pl_shift < SEG_HALO || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
-    if (planar && n_out > (size_t)0x7ff00000u * 10u) return P25FE_ERR_ARG;   // symbol indices are 32-bit in the kernels: < 2^31 symbols (124 h of one channel) per call
+    if (planar && n_out > MAX_RANGE_BB) return P25FE_ERR_ARG;
 
     K1Args a;
     a.x = d_x;
@@ -700,6 +704,7 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
                      size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit, size_t sync_stride,
                      p25fe_result_t* d_result, hipStream_t st)
 {
+    if (n_bb > MAX_RANGE_BB) return P25FE_ERR_ARG;
     shard_invalidate(h);
     if (int jrc = pipe_join(h, st)) return jrc;
     const long view0 = (long)abs_bb0 - h->look;          // first processed index: the tracking clock runs h->look samples late
@@ -811,7 +816,7 @@ int p25fe_join_dev(p25fe_t* h, void* stream)
 int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
                             size_t dibit_stride, p25fe_result_t* d_result, void* stream)
 {
-    if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
+    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband(0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     shard_invalidate(h);
@@ -910,7 +915,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
 int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
                   size_t dibit_stride, p25fe_result_t* d_result, void* stream)
 {
-    if (!h || !d_iq || !d_dibits || !d_result) return P25FE_ERR_ARG;
+    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband(0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     shard_invalidate(h);
@@ -946,7 +951,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
 static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
                             p25fe_result_t* d_result, hipStream_t st, bool do_main, bool do_finish)
 {
-    if (!h || !d_iq || (do_finish && !d_result)) return P25FE_ERR_ARG;
+    if (!h || !d_iq || (do_finish && !d_result) || p25fe_n_baseband(abs0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     if (do_main) shard_invalidate(h);
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));

@@ -458,6 +458,28 @@ def test_fuzz_ranges_and_alignment(O, FE, c4fm_1s):
         fe3.demod_dev(bad)
 
 
+def test_range_longer_than_the_kernels_index_is_an_argument_error(FE):
+    """A range of 2^31 symbols or more (124 h of one channel) is refused as an argument error before anything is sized
+    for it -- the sample pointer is never followed."""
+    import ctypes as C
+    import torch
+    from p25rx_amd._lib import ERR_ARG, RESULT_DTYPE
+    fe = FE()
+    x = torch.zeros((64, 2), dtype=torch.float32, device="cuda")
+    dib = torch.zeros((1, 64), dtype=torch.uint8, device="cuda")
+    res = torch.zeros((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    n = 5 * (0x7ff00000 * 10 + 5)
+    args = (fe.h, C.c_void_p(x.data_ptr()), 0, 0, n, C.c_void_p(dib.data_ptr()), 64, C.c_void_p(res.data_ptr()), fe._stream())
+    assert fe.L.p25fe_run_dev(*args) == ERR_ARG
+    assert fe.L.p25fe_run_dev_pipelined(*args) == ERR_ARG
+    assert fe.L.p25fe_shard_pass1(fe.h, C.c_void_p(x.data_ptr()), 0, 0, 0, n, 0, C.c_void_p(res.data_ptr()), fe._stream()) == ERR_ARG
+    assert fe.L.p25fe_slice_dev(fe.h, C.c_void_p(x.data_ptr()), 0, 0, n // 5, 0, None, C.c_void_p(dib.data_ptr()), 64, None, None, 0,
+                                C.c_void_p(res.data_ptr()), fe._stream()) == ERR_ARG
+    # the handle is as good as before
+    d2, r2 = fe.run_dev(x)
+    torch.cuda.synchronize()
+
+
 def test_tiny_and_empty_inputs(O, FE):
     """Empty, 1-sample and sub-filter-length inputs through every host entry point."""
     fe = FE()
