@@ -106,7 +106,7 @@ typedef struct p25fe_result {
     /* what p25fe_shard_resolve needs beyond that when the clock tracks or lock is dropped inside ranges: */
     int64_t carry_end;                   /* index from which the carry-in anchor no longer governs (first_event + 1, or the first lock
                                             drop if that comes first); -1: it governs the whole range */
-    int64_t first_seg_end;               /* end (exclusive) of the interval the first own detection governs */
+    int64_t first_seg_end;               /* end (exclusive) of the interval the first own detection governs: the next event of the range (detection or lock drop) or the range's end */
     uint32_t flags;                      /* P25FE_RES_* */
     uint32_t reserved;
 } p25fe_result_t;
@@ -139,11 +139,15 @@ int p25fe_demod_cf32(p25fe_t *h, const float *iq, size_t n_samples, float *bb, s
  * dibits (channel c at dibits + c * cap), counts to n_dibits[c].  sync_pos / sync_dibit
  * (nullable) receive, per detection, the absolute baseband index of the sync word's last
  * symbol and the index (in the channel's dibit stream) of the first dibit it governs;
- * n_sync[c] gets the number of detections (may exceed sync_cap; extra ones are not stored). */
+ * n_sync[c] gets the number of detections (may exceed sync_cap; extra ones are not stored).
+ * Capacity: cap >= n / 10 + 1 is required (an undisturbed lock), cap = n / 6 + 2 is always enough (every re-anchor starts
+ * a new symbol grid and two of them are at least 6 samples apart); a chunk that needs more than `cap` returns
+ * P25FE_ERR_CAPACITY with the stream state untouched -- repeat the call with more room. */
 int p25fe_slice(p25fe_t *h, const float *bb, size_t n, uint8_t *dibits, size_t cap, size_t *n_dibits,
                 int64_t *sync_pos, uint64_t *sync_dibit, size_t sync_cap, size_t *n_sync);
 
-/* Both halves with the baseband kept in HBM (DemodTask -> RecvTask without the channel hop). */
+/* Both halves with the baseband kept in HBM (DemodTask -> RecvTask without the channel hop).  Capacity as for
+ * p25fe_slice with n = the chunk's baseband samples (p25fe_n_baseband): n_samples / 30 + 4 is always enough. */
 int p25fe_run_u8(p25fe_t *h, const uint8_t *iq, size_t n_bytes, uint8_t *dibits, size_t cap, size_t *n_dibits);
 int p25fe_run_cf32(p25fe_t *h, const float *iq, size_t n_samples, uint8_t *dibits, size_t cap, size_t *n_dibits);
 

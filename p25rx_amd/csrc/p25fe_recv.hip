@@ -958,7 +958,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     __shared__ unsigned long long shu[NT3 / 64];
     __shared__ Top2 c_top;                                         // latest two event tiles before the chunk (global indices)
     __shared__ unsigned long long c_cnt, c_ev, c_base_first;
-    __shared__ long c_first_event, c_carry_end, c_first_seg_end;
+    __shared__ long c_first_event, c_carry_end, c_first_seg_end, c_first_seg_next;
     __shared__ unsigned c_flags;
 
     const int tid = threadIdx.x, ch = blockIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     const bool track = a.track != 0;
     if (tid == 0) {
         c_top.a = c_top.b = -1;
-        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_flags = 0u;
+        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_first_seg_next = -1; c_flags = 0u;
     }
     __syncthreads();
 
@@ -1072,12 +1072,19 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
                     if (ec == 0) {
                         const long T0 = a.abs0 + (long)(c0 + k) * TS;
                         c_first_event = T0 + (long)g.first1 - 1;
-                        c_first_seg_end = T0 + g.end0;
-                        c_base_first = dc + PRE[k];
+                        c_first_seg_end = T0 + g.end0;              // inside its tile; an interval that is still open at the tile's end
+                        c_base_first = dc + PRE[k];                 // runs on to the next event tile (c_first_seg_next) or the range's end
                         unsigned fl = 0u;
                         if (((g.n_det_flags >> 16) & G_FIRST_TRACKS) && t2.a < 0) fl |= 1u;      // no lock drop between the range's start and it
                         c_flags = fl;
                     }
+                }
+                if (g.pre_end1 && t2.a >= 0) {
+                    // the event tile that follows the tile of the range's first detection (exactly one thread): the carry
+                    // into it -- that detection's clock, if it was its tile's last event -- ends here
+                    const TileSumG gp = sum_of(t2.a);
+                    if (gp.first1 && ec == (unsigned long long)(gp.n_det_flags & 0xffffu))
+                        c_first_seg_next = a.abs0 + (long)(c0 + k) * TS + (long)g.pre_end1 - 1;
                 }
                 dc += CNT[k]; ec += g.n_det_flags & 0xffffu;
                 if (g.pre_end1) { t2.b = t2.a; t2.a = c0 + k; st = state_after(t2.a, t2.b); }
@@ -1109,7 +1116,16 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         r.first_event = c_first_event;
         r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
         r.carry_end = c_carry_end;
-        r.first_seg_end = c_first_seg_end;
+        // where the first detection's governed interval ends IN THE RANGE: inside its tile, or -- still open at the tile's end
+        // -- at the next event tile's first event, or at the range's end (p25fe_shard_resolve recounts that interval
+        // under the detection's real clock)
+        long fse = c_first_seg_end;
+        if (c_first_event >= 0) {
+            const long ft = (c_first_event - a.abs0) / TS;           // its tile
+            const long te = a.abs0 + ((ft + 1) * TS < a.n ? (ft + 1) * TS : a.n);
+            if (fse >= te) fse = c_first_seg_next >= 0 ? c_first_seg_next : a.abs0 + a.n;
+        }
+        r.first_seg_end = fse;
         unsigned fl = c_flags;
         // the clock the range ends on was taken from the carry-in: its only event is one tracking detection
         if (st.src >= 0 && c_top.b < 0 && !((gsum[c_top.a].n_det_flags >> 16) & G_OUT_PERIOD_KNOWN)) fl |= 2u;

@@ -76,7 +76,7 @@ class FrontEnd:
         """RecvTask sample loop on baseband; returns (dibits, sync_pos, sync_dibit) (lists per channel if C > 1)."""
         bb = np.ascontiguousarray(bb, dtype=np.float32).reshape(self.C, -1)
         n = bb.shape[1]
-        cap = n // 10 + 2
+        cap = n // 6 + 2                                         # hard ceiling: re-anchors are at least 6 samples apart (n // 10 + 1 is the undisturbed lock)
         scap = sync_cap if sync_cap is not None else n // 6 + 2
         dib = np.empty((self.C, cap), dtype=np.uint8)
         spos = np.empty((self.C, scap), dtype=np.int64)
@@ -89,7 +89,7 @@ class FrontEnd:
         return outs[0] if self.C == 1 else outs
 
     def _run(self, fn, arr, n_units, n_samples):
-        cap = n_samples // 50 + 4
+        cap = n_samples // 30 + 4                                # hard ceiling of the baseband (n // 5) under back-to-back re-anchors
         dib = np.empty((self.C, cap), dtype=np.uint8)
         nd = (C.c_size_t * self.C)()
         self._chk(fn(self.h, _p(arr), n_units, _p(dib), cap, nd))

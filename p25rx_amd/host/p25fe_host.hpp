@@ -126,7 +126,7 @@ private:
         {
             Symbols s;
             const size_t n = bb.samples.size();
-            s.dibits.resize(n / 10 + 2);
+            s.dibits.resize(n / 6 + 2);                              // hard ceiling: re-anchors are at least 6 samples apart
             s.sync_pos.resize(n / 6 + 2);
             s.sync_dibit.resize(n / 6 + 2);
             size_t nd = 0, ns = 0;
