@@ -63,8 +63,9 @@ typedef enum p25fe_format {
 
 /* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54) and the
  * type-level tap tables of p25_filts (DecimFir / BandpassFir, src/demod.rs:27-29).  Up to
- * P25FE_MAX_TAPS = 64 taps per filter; tables are zero-padded at the old end, which is bit-neutral
- * (docs/SPEC.md 3.3).  The build's own tables (p25fe_default_config) run as immediate-coefficient
+ * P25FE_MAX_TAPS = 64 taps per filter; a table of n taps is evaluated as 31 / 41 taps (64 / 64 as soon as either table is
+ * longer) with zero coefficients at the old end: the same filter on finite samples; a NaN / Inf sample reaches that many
+ * taps' worth of outputs (docs/SPEC.md 3.3).  The build's own tables (p25fe_default_config) run as immediate-coefficient
  * kernels; anything else up to 31 / 41 taps, and anything longer, as generic-tap kernels. */
 typedef struct p25fe_config {
     int32_t abi_version;                 /* P25FE_ABI_VERSION */
@@ -105,7 +106,7 @@ typedef struct p25fe_result {
     uint64_t n_dibits_after_first;       /* dibits governed by the range's own detections */
     /* what p25fe_shard_resolve needs beyond that when the clock tracks or lock is dropped inside ranges: */
     int64_t carry_end;                   /* index from which the carry-in anchor no longer governs (first_event + 1, or the first lock
-                                            drop if that comes first); -1: it governs the whole range */
+                                            drop if that comes first; never negative); -1: it governs the whole range */
     int64_t first_seg_end;               /* end (exclusive) of the interval the first own detection governs: the next event of the range (detection or lock drop) or the range's end */
     uint32_t flags;                      /* P25FE_RES_* */
     uint32_t reserved;

@@ -49,6 +49,11 @@ def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0):
     c.decim, c.sps, c.boxcar, c.peak_w = s["decim"], s["sps"], s["boxcar_len"], s["sync_peak_w"]
     dt = list(s["decim_taps"] if decim_taps is None else decim_taps)
     ct = list(s["chan_taps"] if chan_taps is None else chan_taps)
+    # docs/SPEC.md 3.3: a configured table IS the table of the evaluation length -- the build's 31 / 41, or 64 / 64 as soon as
+    # either is longer -- with zero coefficients at the old end (the same filter; a non-finite sample then reaches that many taps)
+    long_ = len(dt) > len(s["decim_taps"]) or len(ct) > len(s["chan_taps"])
+    dt += [0.0] * ((64 if long_ else len(s["decim_taps"])) - len(dt))
+    ct += [0.0] * ((64 if long_ else len(s["chan_taps"])) - len(ct))
     c.t1, c.t2 = len(dt), len(ct)
     for i, v in enumerate(dt):
         c.decim_taps[i] = v

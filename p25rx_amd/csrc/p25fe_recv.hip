@@ -960,6 +960,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     __shared__ unsigned long long c_cnt, c_ev, c_base_first;
     __shared__ long c_first_event, c_carry_end, c_first_seg_end, c_first_seg_next;
     __shared__ unsigned c_flags;
+    __shared__ int c_has_event;
 
     const int tid = threadIdx.x, ch = blockIdx.x, lane = tid & 63, wv = tid >> 6;
     const TileSumG* gsum = a.gsum + (size_t)ch * a.n_tiles;
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     const bool track = a.track != 0;
     if (tid == 0) {
         c_top.a = c_top.b = -1;
-        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_first_seg_next = -1; c_flags = 0u;
+        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_first_seg_next = -1; c_flags = 0u; c_has_event = 0;
     }
     __syncthreads();
 
@@ -1065,6 +1066,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
                 if (g.pre_end1 && t2.a < 0) {                      // the range's first event tile (one thread finds it)
                     const long T0 = a.abs0 + (long)(c0 + k) * TS;
                     c_carry_end = T0 + (long)g.pre_end1 - 1;
+                    c_has_event = 1;
                 }
                 if (g.first1 && c_first_event < 0) {
                     // the range's first detection: the one tile with detections and none before it (every earlier event
@@ -1115,7 +1117,9 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         r.anchor_out = A;
         r.first_event = c_first_event;
         r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
-        r.carry_end = c_carry_end;
+        // -1 means "no event": an event IN FRONT of index 0 (a lock drop at sample 0 or 1 of a fresh stream, which the tracking
+        // clock's lookahead puts at -2 / -1; nothing can be locked there) is reported at 0
+        r.carry_end = c_has_event ? (c_carry_end > 0 ? c_carry_end : 0) : -1;
         // where the first detection's governed interval ends IN THE RANGE: inside its tile, or -- still open at the tile's end
         // -- at the next event tile's first event, or at the range's end (p25fe_shard_resolve recounts that interval
         // under the detection's real clock)

@@ -4,12 +4,14 @@ infrastructure, like everything that imports `oracle`.
 
     python tests/fuzz_parity.py [--minutes M | --cases N] [--seed S]
 
-A scene draws: capture length, SNR (down to where false and missed sync words happen), frame length (down to back-to-back
-sync words), carrier offset, sample-clock error, amplitude, input format (cf32 / u8), tap tables (the build's, or random
-ones of random length up to the ABI's 64), symbol clock (fixed / tracking), lock drops at random indices, and a random
-chunking for the streaming entry points.  Compared bit for bit: baseband (linear, device and host forms), dibits, sync
-positions, sync dibit indices -- for the device-resident forms (demod_dev, slice_dev, run_dev, run_dev_pipelined), the
-streaming forms (demod_*, slice, run_*) under that chunking, and time shards at random cut points.  Any difference
+A scene draws: 1 - 3 channels, capture length, SNR (down to where false and missed sync words happen), frame length (down to
+back-to-back sync words), carrier offset, sample-clock error, amplitude, input format (cf32 / u8), NaN / Inf / huge samples,
+tap tables (the build's, or random ones of random length up to the ABI's 64), symbol clock (fixed / tracking), lock drops at
+random indices (device lists per channel, and MessageReceiver::resync between chunks), a random chunking for the streaming
+entry points with the handle's state exported and imported at a random boundary.  Compared bit for bit: baseband (linear,
+device and host forms; power within 1e-3 dB), dibits, sync positions, sync dibit indices -- for the device-resident forms
+(demod_dev, slice_dev, run_dev, run_dev_pipelined), the streaming forms (demod_*, slice, run_*) under that chunking, and
+time shards at random cut points (one- and two-launch pass 1, lock drops, host and device resolve).  Any difference
 prints the scene's seed and stops with exit code 1; `tests/test_gpu_fuzz.py` runs a few fixed seeds under pytest."""
 import argparse
 import os
@@ -50,6 +52,8 @@ def scene(seed):
     s["taps"] = int(rng.choice([0, 0, 0, 1, 2]))             # 0: the build's, 1: random <= 31 / 41, 2: random up to 64 / 64
     s["n_drops"] = int(rng.choice([0, 0, 1, 3, 20]))
     s["timing"] = int(rng.integers(0, 50))
+    s["channels"] = int(rng.choice([1, 1, 1, 2, 3]))
+    s["damage"] = int(rng.choice([0, 0, 0, 0, 1]))           # cf32 only: NaN / Inf / huge / denormal samples sprinkled in
     return s, rng
 
 
@@ -57,22 +61,30 @@ def run_scene(seed, O, FE, torch, verbose=False):
     from p25rx_amd import c4fm
     from p25rx_amd.frontend import parse_results, n_baseband
     s, rng = scene(seed)
+    Cn = s["channels"]
     n_iq = int(round(s["seconds"] * 240000)) // 8 * 8
     lead = 4
     nsym = n_iq // 50 - 2 * lead
-    d = c4fm.make_dibits(nsym, seed, s["frame"])
-    iq, _ = c4fm.modulate(d, snr_db=s["snr_db"], seed=seed, freq_offset_hz=s["freq"], amplitude=s["amp"], timing_offset=s["timing"],
-                          lead_symbols=lead, clock_ppm=s["ppm"])
-    iq = np.ascontiguousarray(iq[:n_iq])
-    n_iq = len(iq) // 8 * 8
-    iq = iq[:n_iq]
+    iqs = []
+    for c in range(Cn):
+        d = c4fm.make_dibits(nsym, seed + 7919 * c, s["frame"])
+        x, _ = c4fm.modulate(d, snr_db=s["snr_db"], seed=seed + 7919 * c, freq_offset_hz=s["freq"], amplitude=s["amp"],
+                             timing_offset=(s["timing"] + 13 * c) % 50, lead_symbols=lead, clock_ppm=s["ppm"])
+        iqs.append(np.ascontiguousarray(x[:n_iq]))
+    n_iq = min(len(x) for x in iqs) // 8 * 8
+    iq = np.stack([x[:n_iq] for x in iqs])                            # [C, n] complex64
+    if s["damage"] and s["fmt"] == "cf32" and n_iq > 4000:
+        f = iq.view(np.float32)
+        vals = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-42, -0.0, 3.0e38], dtype=np.float32)
+        for k in range(12):
+            f[int(rng.integers(0, Cn)), int(rng.integers(0, 2 * n_iq))] = vals[k % len(vals)]
     dt = ct = None
     if s["taps"] == 1:
         dt, ct = random_taps(rng, int(rng.integers(1, 32))), random_taps(rng, int(rng.integers(1, 42)))
     elif s["taps"] == 2:
         dt, ct = random_taps(rng, int(rng.integers(32, 65))), random_taps(rng, int(rng.integers(42, 65)))
     cfg = O.make_config(decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"])
-    mk = lambda **kw: FE(decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"], **kw)
+    mk = lambda C_=Cn: FE(n_channels=C_, decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"])
     what = []
 
     def check(name, ok):
@@ -80,117 +92,170 @@ def run_scene(seed, O, FE, torch, verbose=False):
         if not ok:
             raise AssertionError("seed %d: %s differs; scene %r" % (seed, name, s))
 
-    # ---- oracle
-    if s["fmt"] == "u8":
-        raw = c4fm.to_u8(iq)
-        ref_bb = O.Demod(cfg).feed_u8(raw)
-    else:
-        raw = iq
-        ref_bb = O.Demod(cfg).feed_cf32(iq)
-    nb = len(ref_bb)
-    drops = sorted(int(x) for x in rng.integers(0, nb + 5, size=s["n_drops"])) if s["n_drops"] else []
-    r = O.Recv(cfg)
-    outs, o = [], 0
-    for q in drops:
-        q = min(max(q, 0), nb)
-        outs.append(r.feed(ref_bb[o:q]))
-        r.resync()
-        o = q
-    outs.append(r.feed(ref_bb[o:]))
-    ref = (np.concatenate([x[0] for x in outs]), np.concatenate([x[1] for x in outs]), np.concatenate([x[2] for x in outs]).astype(np.uint64))
+    def same_f(a, b):          # floats: bit for bit where the oracle has a number, NaN where it has a NaN
+        a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+        na, nb_ = np.isnan(a), np.isnan(b)
+        return a.shape == b.shape and np.array_equal(na, nb_) and np.array_equal(bits(a[~na]), bits(b[~nb_]))
 
-    def set_drops(fe, lo=None, hi=None):
-        mine = [q for q in drops if (lo is None or lo <= q < hi)]
-        if mine:
-            fe.resync_at_dev(torch.tensor(mine, dtype=torch.int64, device="cuda"))
+    rows = lambda x: [x] if Cn == 1 else list(x)                    # the wrappers return a bare array for one channel
+
+    # ---- oracle, per channel
+    raw = np.stack([c4fm.to_u8(iq[c]) for c in range(Cn)]) if s["fmt"] == "u8" else iq
+    ref_bb, ref_pw = [], []
+    for c in range(Cn):
+        dm = O.Demod(cfg)
+        b, pw = (dm.feed_u8(raw[c], want_power=True) if s["fmt"] == "u8" else dm.feed_cf32(raw[c], want_power=True))
+        ref_bb.append(b); ref_pw.append(pw)
+    nb = len(ref_bb[0])
+    # lock drops: random indices (every channel its own list) + some boundaries of the slice pass's chunking (host resync())
+    plan, po = [], 0
+    while po < nb:
+        n = min(int(rng.choice([1, 3, 239, 241, 3276, 3277, 9000, int(rng.integers(1, 30000))])), nb - po)
+        plan.append((po, n)); po += n
+    host_rs = sorted(set(int(plan[int(k)][0]) for k in rng.integers(0, len(plan), size=int(rng.choice([0, 0, 1, 3]))))) if plan else []
+    drops = [sorted(set([int(x) for x in rng.integers(0, nb + 5, size=s["n_drops"])] + host_rs)) for c in range(Cn)]
+    n_list = max(len(x) for x in drops)
+
+    def oracle_recv(c):
+        r = O.Recv(cfg)
+        outs, o = [], 0
+        for q in drops[c]:
+            q = min(max(q, 0), nb)
+            outs.append(r.feed(ref_bb[c][o:q]))
+            r.resync()
+            o = q
+        outs.append(r.feed(ref_bb[c][o:]))
+        return (np.concatenate([x[0] for x in outs]), np.concatenate([x[1] for x in outs]),
+                np.concatenate([x[2] for x in outs]).astype(np.uint64))
+    ref = [oracle_recv(c) for c in range(Cn)]
+
+    def set_drops(fe, lo=None, hi=None, skip=()):
+        """the drops inside [lo, hi) (all of them: None) as a device list [C, n], short rows padded with INT64_MAX"""
+        mine = [[q for q in drops[c] if (lo is None or lo <= q < hi) and q not in skip] for c in range(Cn)]
+        k = max(len(x) for x in mine)
+        if k:
+            arr = np.full((Cn, k), np.iinfo(np.int64).max, dtype=np.int64)
+            for c in range(Cn):
+                arr[c, :len(mine[c])] = mine[c]
+            fe.resync_at_dev(torch.from_numpy(arr).cuda())
 
     # ---- device-resident forms
     if s["fmt"] == "u8":
-        t = torch.from_numpy(raw.reshape(-1, 2)).cuda()
+        t = torch.from_numpy(raw.reshape(Cn, -1, 2)).cuda()
     else:
-        t = torch.from_numpy(raw.view(np.float32).reshape(-1, 2)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(raw).view(np.float32).reshape(Cn, -1, 2)).cuda()
     fe = mk()
-    bb, nb_g = fe.demod_dev(t)
+    bb, nb_g, pw = fe.demod_dev(t, want_power=True)
     check("demod_dev length", nb_g == nb)
-    g = bb[0, :nb].cpu().numpy()
-    check("demod_dev baseband", np.array_equal(bits(g), bits(ref_bb)))
+    for c in range(Cn):
+        check("demod_dev baseband", same_f(bb[c, :nb].cpu().numpy(), ref_bb[c]))
+        p_, q_ = float(pw[c].item()), float(ref_pw[c])
+        check("demod_dev power", (np.isnan(p_) and np.isnan(q_)) or p_ == q_ or abs(p_ - q_) <= 1e-3 or not np.isfinite(q_))
     set_drops(fe)
-    dib, res, sp, sd = fe.slice_dev(bb[:, :nb].contiguous(), nb, sync_cap=nb // 6 + 2)
-    rr = parse_results(res)[0]
-    nd, ns = int(rr["n_dibits"]), int(rr["n_sync"])
-    check("slice_dev counts", nd == len(ref[0]) and ns == len(ref[1]))
-    check("slice_dev dibits", np.array_equal(dib[0, :nd].cpu().numpy(), ref[0]))
-    check("slice_dev sync_pos", np.array_equal(sp[0, :ns].cpu().numpy(), ref[1]))
-    check("slice_dev sync_dibit", np.array_equal(sd[0, :ns].cpu().numpy().astype(np.uint64), ref[2]))
-    for name in ("run_dev", "run_dev_pipelined"):
+    scap = nb // 6 + 2
+    dib, res, sp, sd = fe.slice_dev(bb[:, :nb].contiguous(), nb, sync_cap=scap)
+    rr = parse_results(res)
+    for c in range(Cn):
+        nd, ns = int(rr[c]["n_dibits"]), int(rr[c]["n_sync"])
+        check("slice_dev counts", nd == len(ref[c][0]) and ns == len(ref[c][1]))
+        k = min(nd, dib.shape[1])
+        check("slice_dev dibits", np.array_equal(dib[c, :k].cpu().numpy(), ref[c][0][:k]))
+        check("slice_dev sync_pos", np.array_equal(sp[c, :ns].cpu().numpy(), ref[c][1]))
+        check("slice_dev sync_dibit", np.array_equal(sd[c, :ns].cpu().numpy().astype(np.uint64), ref[c][2]))
+    for name in ("run_dev", "run_dev_pipelined", "run_dev_pipelined"):
         set_drops(fe)
         dib2, res2 = getattr(fe, name)(t)
         if name == "run_dev_pipelined":
             fe.join_dev()
         torch.cuda.synchronize()
-        nd2 = int(parse_results(res2)[0]["n_dibits"])
-        check(name, nd2 == len(ref[0]) and np.array_equal(dib2[0, :nd2].cpu().numpy(), ref[0]))
+        r2 = parse_results(res2)
+        for c in range(Cn):
+            nd2 = int(r2[c]["n_dibits"])
+            k = min(nd2, dib2.shape[1])
+            check(name, nd2 == len(ref[c][0]) and np.array_equal(dib2[c, :k].cpu().numpy(), ref[c][0][:k]))
 
-    # ---- streaming forms under a random chunking (IQ samples per call; u8: two bytes per sample)
-    def chunks(total):
-        o, out = 0, []
-        while o < total:
-            n = int(rng.choice([1, 2, 7, 333, 16384, 16384, 40000, int(rng.integers(1, 100000))]))
-            n = min(n, total - o)
-            out.append((o, n))
-            o += n
-        return out
-
-    ch = chunks(n_iq)
+    # ---- streaming forms under a random chunking (IQ samples per call; u8: two bytes per sample); the handle's state goes
+    # through export / import at one random boundary
+    ch, o = [], 0
+    while o < n_iq:
+        n = min(int(rng.choice([1, 2, 7, 333, 16384, 16384, 40000, int(rng.integers(1, 100000))])), n_iq - o)
+        ch.append((o, n)); o += n
+    swap_at = int(rng.integers(0, len(ch))) if ch else -1
     fe_d, fe_r = mk(), mk()
-    parts_bb, parts_d = [], []
-    for o, n in ch:
+    parts_bb, parts_d = [[] for _ in range(Cn)], [[] for _ in range(Cn)]
+    for k, (o, n) in enumerate(ch):
+        if k == swap_at:
+            blob = fe_r.state_export()
+            fe_r = mk()
+            fe_r.state_import(blob)
         if s["fmt"] == "u8":
-            parts_bb.append(fe_d.demod_u8(raw[2 * o:2 * (o + n)]))
+            pb = fe_d.demod_u8(raw[:, 2 * o:2 * (o + n)])
         else:
-            parts_bb.append(fe_d.demod_cf32(raw[o:o + n]))
+            pb = fe_d.demod_cf32(raw[:, o:o + n])
         set_drops(fe_r, n_baseband(0, o), n_baseband(0, o + n))
-        parts_d.append(fe_r.run_u8(raw[2 * o:2 * (o + n)]) if s["fmt"] == "u8" else fe_r.run_cf32(raw[o:o + n]))
-    gbb = np.concatenate(parts_bb) if parts_bb else np.zeros(0, np.float32)
-    check("streaming baseband", len(gbb) == nb and np.array_equal(bits(gbb), bits(ref_bb)))
-    gd = np.concatenate(parts_d) if parts_d else np.zeros(0, np.uint8)
-    check("streaming run", len(gd) == len(ref[0]) and np.array_equal(gd, ref[0]))
+        pd = fe_r.run_u8(raw[:, 2 * o:2 * (o + n)]) if s["fmt"] == "u8" else fe_r.run_cf32(raw[:, o:o + n])
+        for c in range(Cn):
+            parts_bb[c].append(rows(pb)[c]); parts_d[c].append(rows(pd)[c])
+    for c in range(Cn):
+        check("streaming baseband", same_f(np.concatenate(parts_bb[c]), ref_bb[c]))
+        gd = np.concatenate(parts_d[c])
+        check("streaming run", len(gd) == len(ref[c][0]) and np.array_equal(gd, ref[c][0]))
     fe_s = mk()
-    po, parts = 0, []
-    while po < nb:
-        n = min(int(rng.choice([1, 3, 239, 241, 3276, 3277, 9000, int(rng.integers(1, 30000))])), nb - po)
-        set_drops(fe_s, po, po + n)
-        parts.append(fe_s.slice(ref_bb[po:po + n]))
-        po += n
-    if parts:
-        cat = [np.concatenate([p[k] for p in parts]) for k in range(3)]
-        check("streaming slice", all(len(cat[k]) == len(ref[k]) and np.array_equal(cat[k], ref[k].astype(cat[k].dtype)) for k in range(3)))
+    parts = [[] for _ in range(Cn)]
+    for po, n in plan:
+        if po in host_rs:
+            fe_s.resync()                                            # MessageReceiver::resync between two chunks (src/recv.rs:136)
+        set_drops(fe_s, po, po + n, skip=[po] if po in host_rs else ())
+        out = fe_s.slice(np.stack([ref_bb[c][po:po + n] for c in range(Cn)]))
+        for c in range(Cn):
+            parts[c].append(out if Cn == 1 else out[c])
+    for c in range(Cn):
+        if parts[c]:
+            cat = [np.concatenate([p_[k] for p_ in parts[c]]) for k in range(3)]
+            check("streaming slice", all(len(cat[k]) == len(ref[c][k]) and np.array_equal(cat[k], ref[c][k].astype(cat[k].dtype)) for k in range(3)))
 
-    # ---- time shards at random (8-aligned) cut points, cf32 and u8 alike
-    if n_iq >= 64 and not drops:
-        k = int(rng.integers(2, 5))
+    # ---- time shards at random (8-aligned) cut points: one channel, every shard handed the whole drop list, the two-launch
+    # form on odd shards, host and device resolve
+    if n_iq >= 64 and Cn == 1:
+        k = int(rng.integers(2, 6))
         cuts = sorted(set([0, n_iq] + [int(x) // 8 * 8 for x in rng.integers(8, n_iq, size=k - 1)]))
-        halo = fe.shard_halo()
+        t1 = t[0]
+        fe1 = mk(1)
+        halo = fe1.shard_halo()
+        d_rs = torch.tensor(drops[0], dtype=torch.int64, device="cuda") if drops[0] else None
         fes, summ, bb0, bbn = [], [], [], []
-        for a, b in zip(cuts[:-1], cuts[1:]):
+        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
             h = min(a, halo)
-            f = mk()
-            rs = f.shard_pass1(t[a - h:b], offset=h, n_hist=h, abs0=a)
+            f = mk(1)
+            f.resync_at_dev(d_rs)
+            if i % 2:
+                f.shard_pass1_main(t1[a - h:b], offset=h, n_hist=h, abs0=a)
+                rs = f.shard_pass1_finish(t1[a - h:b], offset=h, n_hist=h, abs0=a)
+            else:
+                rs = f.shard_pass1(t1[a - h:b], offset=h, n_hist=h, abs0=a)
             summ.append(parse_results(rs)[0])
             bb0.append(n_baseband(0, a)); bbn.append(n_baseband(a, b - a)); fes.append(f)
+        anc_h, off_h = fe1.shard_resolve(np.array(summ), bb0, bbn)
         summ_t = torch.from_numpy(np.frombuffer(np.array(summ).tobytes(), dtype=np.uint8).copy()).view(len(fes), -1).cuda()
-        anc, off = fe.shard_resolve_dev(summ_t, torch.tensor(bb0, dtype=torch.int64, device="cuda"),
-                                        torch.tensor(bbn, dtype=torch.int64, device="cuda"))
+        anc, off = fe1.shard_resolve_dev(summ_t, torch.tensor(bb0, dtype=torch.int64, device="cuda"),
+                                         torch.tensor(bbn, dtype=torch.int64, device="cuda"))
         offs = off.cpu().numpy()
-        rows = []
+        check("shard resolve host == device", np.array_equal(offs.astype(np.uint64), off_h) and anc.cpu().numpy().tobytes() == anc_h.tobytes())
+        got_rows = []
         for i, f in enumerate(fes):
             dd, rs2 = f.shard_pass2(anc[i:i + 1], bbn[i], t.device)
             kk = int(parse_results(rs2)[0]["n_dibits"])
             check("shard %d count" % i, kk == int(offs[i + 1] - offs[i]))
-            rows.append(dd[0, :kk].cpu().numpy())
-        check("time shards", np.array_equal(np.concatenate(rows) if rows else np.zeros(0, np.uint8), ref[0]))
+            got_rows.append(dd[0, :kk].cpu().numpy())
+        got_all = np.concatenate(got_rows) if got_rows else np.zeros(0, np.uint8)
+        if not np.array_equal(got_all, ref[0][0]):
+            m = min(len(got_all), len(ref[0][0]))
+            s["detail"] = {"cuts": cuts, "bb0": bb0, "offsets": [int(x) for x in offs], "len": (len(got_all), len(ref[0][0])),
+                           "first_diff": [int(x) for x in np.nonzero(got_all[:m] != ref[0][0][:m])[0][:4]], "drops": drops[0],
+                           "syncs": [int(x) for x in ref[0][1][:12]], "sync_dibit": [int(x) for x in ref[0][2][:12]]}
+        check("time shards", np.array_equal(got_all, ref[0][0]))
     if verbose:
-        print("seed %d ok: %r -> %d baseband, %d dibits, %d syncs, %d chunks" % (seed, s, nb, len(ref[0]), len(ref[1]), len(ch)))
+        print("seed %d ok: %r -> %d baseband, %s dibits, %s syncs, %d chunks" % (seed, s, nb, [len(r_[0]) for r_ in ref], [len(r_[1]) for r_ in ref], len(ch)))
     return len(what)
 
 

@@ -70,6 +70,9 @@ def test_tracking_clock_device_matches_oracle(O, FE, ppm, frame):
     for k in range(1, len(ref[2]) - 1):                              # locked frames are error free
         assert np.array_equal(ref[0][int(ref[2][k]):int(ref[2][k + 1])], truth[frame * k + 24:frame * (k + 1) + 24])
     r = got[3]
+    # the summary a time shard hands to p25fe_shard_resolve: the first detection's governed interval ends at the NEXT event of
+    # the range, not at the end of its 7 680-sample tile (sync words are further apart than a tile here)
+    assert int(r["first_event"]) == int(ref[1][0]) + 5 and int(r["first_seg_end"]) == int(ref[1][1]) + 6
     a = r["anchor_out"]
     if ppm:
         assert int(a["period_n"]) == frame and abs(int(a["period_d"]) - frame * 10 * (1 + ppm * 1e-6)) <= 1.5
@@ -216,7 +219,9 @@ def test_time_shards_with_tracking_clock_and_lock_drops(O, FE, mode):
     sp = [int(x) for x in free[1]]
     drops = [sp[3] + 5 + 2 * mode, 100000 // 5 + 4000, 310006 // 5 + 50, 310006 // 5 + 60]
     t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
-    for rs in ([], drops):
+    # ([0, 1]: lock drops in front of the stream's first samples -- under the tracking clock's lookahead they sit at -2 / -1,
+    # and the summary's carry_end must still say "this shard has an event")
+    for rs in ([], drops, [0, 1] + drops, [0]):
         ref = oracle_recv(O, bb, mode, rs)
         fe = FE(symbol_clock=mode)
         halo = fe.shard_halo()
