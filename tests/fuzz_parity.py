@@ -259,6 +259,94 @@ def run_scene(seed, O, FE, torch, verbose=False):
     return len(what)
 
 
+def run_aux_scene(seed, O, FE, torch, verbose=False):
+    """The forms around the fresh-stream ones: an owned range INSIDE a longer device buffer (random start, random amount of
+    history, absolute decimation grid), the wideband stages K0 (bit-exact) and K6 (fp64 oracle, 2e-6 tolerance) on random
+    lengths / offsets, multi-channel K0, and network identifiers with random bit errors."""
+    from p25rx_amd import c4fm
+    from p25rx_amd._lib import NID_DTYPE
+    from p25rx_amd.frontend import n_baseband
+    rng = np.random.default_rng(seed ^ 0x5a5a5a)
+    what = []
+
+    def check(name, ok, **info):
+        what.append(name)
+        if not ok:
+            raise AssertionError("aux seed %d: %s differs; %r" % (seed, name, info))
+
+    # ---- (a) range inside a buffer: demod_dev(offset, n_hist, abs0), cf32 and u8
+    n_iq = int(rng.choice([4000, 24000, 120000])) // 8 * 8
+    iq, _, _ = c4fm.synth(n_iq / 240000.0 + 0.01, seed=seed, snr_db=float(rng.choice([30.0, 8.0])), frame_dibits=int(rng.choice([100, 864])))
+    iq = np.ascontiguousarray(iq[:n_iq])
+    fmt = str(rng.choice(["cf32", "u8"]))
+    raw = c4fm.to_u8(iq) if fmt == "u8" else iq
+    t = torch.from_numpy(raw.reshape(-1, 2) if fmt == "u8" else raw.view(np.float32).reshape(-1, 2)).cuda()
+    fe = FE()
+    for _ in range(4):
+        a = int(rng.integers(0, n_iq // 8)) * 8                      # owned range [a, b): 16-byte aligned start for both formats
+        b = int(rng.integers(a, n_iq + 1))
+        h = int(min(a, rng.choice([0, 8, 40, 280, 284, 288, 1000, 2048])))
+        if fmt == "u8":
+            # (zeros in front of a short history cannot be written as bytes -- 127.5 is no byte: the u8 form is compared where the
+            # history is complete or reaches the start of the stream)
+            ref_all = O.Demod().feed_u8(raw) if (a - h == 0 or h >= 284) else None
+        else:
+            z = np.array(raw, copy=True)
+            z[:a - h] = 0                                            # what lies in front of the history does not exist: zeros, as at
+            ref_all = O.Demod().feed_cf32(z)                         # the start of a stream
+        if ref_all is None:
+            continue
+        p0, p1 = n_baseband(0, a), n_baseband(0, b)
+        bb, nb = fe.demod_dev(t[:b], n_hist=h, abs0=a, offset=a)
+        check("demod_dev range length", nb == p1 - p0, a=a, b=b, h=h, fmt=fmt)
+        check("demod_dev range", np.array_equal(bits(bb[0, :nb].cpu().numpy()), bits(ref_all[p0:p1])), a=a, b=b, h=h, fmt=fmt)
+
+    # ---- (b) K0 on 1 - 3 channels of random wideband samples, whole and as a range with history; K6 on the first channel
+    Cw = int(rng.choice([1, 1, 2, 3]))
+    nw = int(rng.choice([1000, 20000, 100000])) // 2 * 2 + int(rng.choice([0, 2, 6]))
+    wide = (rng.normal(0, 0.3, (Cw, nw)) + 1j * rng.normal(0, 0.3, (Cw, nw))).astype(np.complex64)
+    tw = torch.from_numpy(wide.view(np.float32).reshape(Cw, nw, 2)).cuda()
+    few = FE(n_channels=Cw)
+    refs = [O.PreDecim().feed(wide[c]) for c in range(Cw)]
+    y, no = few.predecim_dev(tw)
+    check("predecim length", no == len(refs[0]), nw=nw)
+    for c in range(Cw):
+        check("predecim", np.array_equal(bits(y[c, :no].cpu().numpy().reshape(-1)), bits(refs[c].view(np.float32))), nw=nw, c=c)
+    if Cw == 1 and nw > 400:
+        off = int(rng.integers(1, nw // 2)) * 2
+        hh = int(min(off, rng.choice([79, 80, 96, 500])))
+        y2, no2 = few.predecim_dev(tw[0], n_hist=hh, abs0=off, offset=off)
+        first = off // 10                                            # outputs whose instant 10 m + 9 lies in front of the range
+        check("predecim range", np.array_equal(bits(y2[0, :no2].cpu().numpy().reshape(-1)),
+                                               bits(refs[0][first:first + no2].view(np.float32))), nw=nw, off=off, hh=hh)
+        if nw <= 20000:
+            spec = O.load_spec()
+            refc = O.channelise(wide[0])
+            yc, nc = few.channelise_dev(tw[0])
+            tol = 2e-6 * float(np.sum(np.abs(np.array(spec["pre_taps"], dtype=np.float64)))) * float(np.abs(wide[0]).max())
+            got = yc[:, :nc].cpu().numpy().view(np.complex64)[:, :, 0]
+            check("channelise", nc == refc.shape[1] and float(np.abs(got - refc).max()) <= tol, nw=nw)
+
+    # ---- (c) network identifiers: frames with a valid NID, random bit errors in the dibit stream
+    nf = int(rng.integers(3, 12))
+    nidf = lambda f: (int((seed * 31 + f * 7) & 0xfff), int((f * 5 + seed) & 0xf))
+    d = c4fm.make_dibits(nf * 150 + 60, seed, 150, nid=nidf)
+    flips = rng.integers(0, len(d), size=int(rng.choice([0, 5, 40, 200])))
+    d = np.array(d, copy=True)
+    d[flips] ^= rng.integers(1, 4, size=len(flips)).astype(np.uint8)
+    sdib = np.array([24 + 150 * f for f in range(nf)], dtype=np.uint64)
+    spos = np.array([2400 + 1500 * f for f in range(nf)], dtype=np.int64)
+    refn = O.nid_decode(d, sdib, spos)
+    out = np.zeros(nf, dtype=NID_DTYPE)
+    import ctypes as C_
+    fe._chk(fe.L.p25fe_nid(fe.h, d.ctypes.data_as(C_.c_void_p), len(d), sdib.ctypes.data_as(C_.c_void_p), spos.ctypes.data_as(C_.c_void_p),
+                           nf, out.ctypes.data_as(C_.c_void_p)))
+    check("nid", out.tobytes() == refn.tobytes(), nf=nf, flips=len(flips))
+    if verbose:
+        print("aux seed %d ok: %d comparisons" % (seed, len(what)))
+    return len(what)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=None)
@@ -279,6 +367,8 @@ def main():
             break
         try:
             checks += run_scene(a.seed + n, O, FE, torch, a.v)
+            if n % 4 == 0:
+                checks += run_aux_scene(a.seed + n, O, FE, torch, a.v)
         except AssertionError as e:
             print("FAIL", e)
             sys.exit(1)
