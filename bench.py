@@ -513,6 +513,33 @@ def main():
             fe.run_dev(iq, dibits=dibits, result=result)
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t0) / ks * 1e3
+    copy_gbps = sum_gbps = None
+    if world == 1:
+        # context for the roofline: what a plain device-to-device copy of the same capture moves on THIS box, right now
+        # (read + write bytes / time over 30 back-to-back copies, torch's copy kernel) -- the practical ceiling of a
+        # streaming kernel, against which K1's measured traffic is set below; not part of any timed region above
+        try:
+            dst = torch.empty_like(iq)
+            for _ in range(3):
+                dst.copy_(iq)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                dst.copy_(iq)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 2.0 * iq.numel() * 4 * 30 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del dst
+            for _ in range(3):
+                iq.sum()
+            e0.record()
+            for _ in range(30):
+                iq.sum()
+            e1.record()
+            torch.cuda.synchronize()
+            sum_gbps = iq.numel() * 4 * 30 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception:
+            copy_gbps = sum_gbps = None
     cdev = torch.device("cpu") if staged else dev
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -614,6 +641,13 @@ def main():
                                       "frac": round(achieved_k1_alone / HBM_PEAK_GBPS, 4),
                                       "note": "K1 priced on what it reads AND writes (8 B in + 0.8 B polyphase baseband out); "
                                               "the baseband is an intermediate of this design, so `frac` above uses SURVEY 8(d)'s 8.02 B"},
+                         "vs_library_streams": ({"torch_copy_GBps": round(copy_gbps, 1), "torch_sum_read_only_GBps": round(sum_gbps, 1),
+                                      "k1_traffic_GBps": (round(traffic / (k1_ms * 1e-3) / 1e9, 1) if (traffic and k1_ms > 0) else None),
+                                      "k1_traffic_over_copy": (round(traffic / (k1_ms * 1e-3) / 1e9 / copy_gbps, 4) if (traffic and k1_ms > 0) else None),
+                                      "note": "reference points measured by this process on the same capture, after the timed region: "
+                                              "torch's device-to-device copy (read + write bytes / time) and torch's sum (read-only); "
+                                              "k1_traffic_GBps = the PMC traffic above / this run's K1 time -- the HBM stream K1 sustains "
+                                              "WHILE doing the arithmetic of SPEC section 3"} if copy_gbps else None),
                          "whole_step": {"algorithmic_bytes_per_sample": 8.02,
                                         "achieved": round(8.02 * n * world * args.steps / dt / 1e9, 1),
                                         "frac_of_peak_x_gpus": round(8.02 * n * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)},
