@@ -5,9 +5,9 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" i
 TimeShard -- one long capture cut into contiguous time ranges, rank r owns [r*n, (r+1)*n).  Exchange steps:
 
   1. filter-state overlap: the last `halo` IQ samples of rank r go to rank r+1 (point-to-point; on MI355X one xGMI
-     link, ~12.5 KB).  The receive is hidden behind K1: everything that does not touch the halo is launched first
+     link, 2 048 samples = 16 KB of cf32).  The receive is hidden behind K1: everything that does not touch the halo is launched first
      (p25fe_shard_pass1_main), the shard's head after the halo has arrived (p25fe_shard_pass1_finish);
-  2. symbol-timing carry: every rank's 56-byte shard summary is all-gathered; a one-thread kernel resolves every
+  2. symbol-timing carry: every rank's 96-byte shard summary (p25fe_result_t) is all-gathered; a one-thread kernel resolves every
      shard's carry-in anchor and dibit offset (p25fe_shard_resolve_dev) -- no host synchronisation;
   3. the reduced dibit stream: after pass 2 the shards' dibit buffers (n/50 bytes each) are GATHERED TO THE ROOT rank
      (point-to-point, every rank has a direct xGMI link to it) and compacted there into ONE ordered stream
