@@ -1,4 +1,4 @@
-"""debug: compare run_dev / slice paths with the oracle receiver, channel by channel (GPU box)."""
+"""debug (test infrastructure: imports the oracle): run_dev / slice paths against the oracle receiver, channel by channel (GPU box)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

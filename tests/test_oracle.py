@@ -175,7 +175,7 @@ def test_recv_with_offsets_and_noise():
 
 
 def test_golden_fixture_matches():
-    """Self-generated golden (tools/gen_golden.py): pins the oracle across rounds."""
+    """Self-generated golden (tests/golden/gen_golden.py): pins the oracle across rounds."""
     g = np.load(os.path.join(GOLDEN, "c4fm_seed7_u8.npz"))
     d = O.Demod()
     bb = np.concatenate([d.feed_u8(g["iq_u8"][o:o + 32768]) for o in range(0, len(g["iq_u8"]), 32768)])

@@ -2,9 +2,7 @@ import time, numpy as np, sys
 sys.path.insert(0, '.')
 from p25rx_amd import c4fm
 from p25rx_amd.frontend import FrontEnd
-from oracle import oracle as O
 iq, truth, _ = c4fm.synth(2.0, seed=1, snr_db=30.0)
-ref = O.run_cf32(iq)
 for fmt in ("cf32", "u8"):
     data = iq if fmt == "cf32" else c4fm.to_u8(iq)
     step = 16384 if fmt == "cf32" else 32768
@@ -15,7 +13,8 @@ for fmt in ("cf32", "u8"):
     fe.reset()
     t0 = time.perf_counter(); got = [run(c) for c in chunks]; dt = time.perf_counter() - t0
     got = np.concatenate(got)
-    ok = np.array_equal(got, ref) if fmt == "cf32" else None
+    k = min(len(got), len(truth) - 24)
+    ok = bool(k > 0 and np.array_equal(got[:k], truth[24:24 + k]))          # the modulator's symbols (parity vs the oracle: tests/)
     print(fmt, "ms/chunk %.4f" % (dt / len(chunks) * 1e3), "chunks", len(chunks), "parity", ok)
     # raw C call timing without the Python wrapper's allocations
     import ctypes as C
