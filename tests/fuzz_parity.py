@@ -54,6 +54,9 @@ def scene(seed):
     s["timing"] = int(rng.integers(0, 50))
     s["channels"] = int(rng.choice([1, 1, 1, 2, 3]))
     s["damage"] = int(rng.choice([0, 0, 0, 0, 1]))           # cf32 only: NaN / Inf / huge / denormal samples sprinkled in
+    # ragged lengths: around multiples of a receiver tile (7 680 baseband = 38 400 IQ samples), of a K1 sub-tile (1 600) and anything
+    s["extra"] = int(rng.choice([0, 8, 1600, 1608, 38400 - 8, 38400, 38400 + 8, 2 * 38400, int(rng.integers(0, 50000)) // 8 * 8]))
+    s["cut"] = int(rng.choice([0, 0, 1]))                    # 1: the capture is cut down to (a multiple of 38 400) + extra
     return s, rng
 
 
@@ -63,6 +66,9 @@ def run_scene(seed, O, FE, torch, verbose=False):
     s, rng = scene(seed)
     Cn = s["channels"]
     n_iq = int(round(s["seconds"] * 240000)) // 8 * 8
+    if s["cut"]:
+        n_iq = max(n_iq // 38400, 0) * 38400
+    n_iq = max(n_iq + s["extra"], 4000)
     lead = 4
     nsym = n_iq // 50 - 2 * lead
     iqs = []
