@@ -180,6 +180,29 @@ def run_scene(seed, O, FE, torch, verbose=False):
             k = min(nd2, dib2.shape[1])
             check(name, nd2 == len(ref[c][0]) and np.array_equal(dib2[c, :k].cpu().numpy(), ref[c][0][:k]))
 
+    # ---- mixed sequence on ONE handle without joining in between: two pipelined calls (their receive kernels run on the handle's
+    # stream), then a call that overwrites the same scratch -- the library has to order them itself
+    set_drops(fe)
+    dA, rA = fe.run_dev_pipelined(t)
+    dB, rB = fe.run_dev_pipelined(t)
+    set_drops(fe)
+    dib3, res3, sp3, sd3 = fe.slice_dev(bb[:, :nb].contiguous(), nb, sync_cap=scap)
+    dC, rC = fe.run_dev(t)
+    fe.join_dev()
+    torch.cuda.synchronize()
+    rA_, rB_, r3_, rC_ = parse_results(rA), parse_results(rB), parse_results(res3), parse_results(rC)
+    free = None
+    for c in range(Cn):
+        ndA, ndB, nd3, ndC = int(rA_[c]["n_dibits"]), int(rB_[c]["n_dibits"]), int(r3_[c]["n_dibits"]), int(rC_[c]["n_dibits"])
+        check("mixed: pipelined A", ndA == len(ref[c][0]) and np.array_equal(dA[c, :min(ndA, dA.shape[1])].cpu().numpy(), ref[c][0][:dA.shape[1]]))
+        check("mixed: slice_dev", nd3 == len(ref[c][0]) and np.array_equal(dib3[c, :min(nd3, dib3.shape[1])].cpu().numpy(), ref[c][0][:dib3.shape[1]]))
+        # B and C ran without a drop list (the list is consumed by the call it was set for): the free-running receiver
+        if not any(drops[c_] for c_ in range(Cn)):
+            check("mixed: pipelined B", ndB == len(ref[c][0]) and np.array_equal(dB[c, :min(ndB, dB.shape[1])].cpu().numpy(), ref[c][0][:dB.shape[1]]))
+            check("mixed: run_dev C", ndC == len(ref[c][0]) and np.array_equal(dC[c, :min(ndC, dC.shape[1])].cpu().numpy(), ref[c][0][:dC.shape[1]]))
+        else:
+            check("mixed: B == C", ndB == ndC and np.array_equal(dB[c, :min(ndB, dB.shape[1])].cpu().numpy(), dC[c, :min(ndC, dC.shape[1])].cpu().numpy()))
+
     # ---- streaming forms under a random chunking (IQ samples per call; u8: two bytes per sample); the handle's state goes
     # through export / import at one random boundary
     ch, o = [], 0
