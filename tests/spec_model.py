@@ -1,0 +1,185 @@
+"""An INDEPENDENT restatement of docs/SPEC.md 3.7 + 3.8 (frame-sync correlation, peak test, thresholds, fixed-stride symbol
+clock, 4-level slicer, resync) written from the SPEC's text as a BATCH computation over a whole baseband array in numpy
+float32 -- no per-sample state machine, no chunking, nothing shared with oracle/p25fe_oracle.c, which is a streaming
+`feed()` object like the reference's.  tests/test_oracle.py checks that the two agree dibit for dibit: a second pair of
+eyes on the oracle's receiver, which is the parity target of the HIP path (test infrastructure).
+
+Arithmetic: every SPEC operation on float32 arrays in the SPEC's order; the one fused multiply-add of the section
+(e[n] = fma(v, v, acc)) is evaluated in float64 and rounded once (v * v is exact in float64; the sum then rounds twice,
+which can differ from a true fma in the last bit -- the energy only enters two threshold comparisons, and
+`margins()` reports how close any candidate came to them so that a test can tell a razor's-edge case from a defect)."""
+import numpy as np
+
+F = np.float32
+
+
+def _shifted(b, k):
+    """b[n - k] for every n, zero where n - k < 0"""
+    if k == 0:
+        return b
+    out = np.zeros_like(b)
+    out[k:] = b[:-k] if k < len(b) else 0
+    return out
+
+
+class Model:
+    def __init__(self, spec):
+        self.mask = int(spec["sync_sign_mask"])
+        self.sps = int(spec["sps"])
+        self.W = int(spec["sync_peak_w"])
+        self.rho2_n = F(spec["sync_rho2_n"])
+        self.e_min = F(spec["sync_e_min"])
+        self.inv_p, self.inv_n = F(spec["sync_inv_npos"]), F(spec["sync_inv_nneg"])
+        self.frac = F(spec["slice_frac"])
+        self.signs = [(self.mask >> j) & 1 for j in range(24)]        # j = 0: oldest symbol of the sync word
+
+    def correlate(self, b):
+        """c[n], e[n] of SPEC 3.7 for every n (b[n] = 0 for n < 0)"""
+        b = np.ascontiguousarray(b, dtype=F)
+        c = np.zeros(len(b), dtype=F)
+        e = np.zeros(len(b), dtype=F)
+        for j in range(24):
+            v = _shifted(b, self.sps * (23 - j))
+            c = (c + v) if self.signs[j] else (c - v)
+            e = (v.astype(np.float64) * v.astype(np.float64) + e.astype(np.float64)).astype(F)
+        return c, e
+
+    def detections(self, b):
+        """sync positions s (ascending) with their thresholds (hi, mid, lo); a detection needs sample s + W to exist"""
+        b = np.ascontiguousarray(b, dtype=F)
+        n = len(b)
+        c, e = self.correlate(b)
+        cand = (c > 0) & (e >= self.e_min) & (c * c >= self.rho2_n * e)
+        det = cand.copy()
+        for i in range(1, self.W + 1):
+            left = _shifted(c, i)                                     # c[s - i] (zero in front of the stream: the correlation of zeros)
+            right = np.full(n, np.inf, dtype=F)                       # c[s + i]: not there yet -> no decision
+            right[:n - i] = c[i:] if i < n else 0
+            det &= (c > left) & (c >= right)
+        pos = np.nonzero(det)[0]
+        out = []
+        for s in pos:
+            P = F(0.0)
+            N = F(0.0)
+            for j in range(24):
+                idx = s - self.sps * (23 - j)
+                v = b[idx] if idx >= 0 else F(0.0)
+                if self.signs[j]:
+                    P = F(P + v)
+                else:
+                    N = F(N + v)
+            P = F(P * self.inv_p)
+            N = F(N * self.inv_n)
+            mid = F(F(P + N) * F(0.5))
+            span = F(F(P - N) * F(0.5))
+            d = F(span * self.frac)
+            out.append((int(s), F(mid + d), mid, F(mid - d)))
+        self._c, self._e, self._cand = c, e, cand
+        return out
+
+    def margins(self):
+        """smallest relative distance of any position with c > 0 to the two energy thresholds of the last detections() call"""
+        c, e = self._c.astype(np.float64), self._e.astype(np.float64)
+        m = c > 0
+        if not m.any():
+            return np.inf
+        a = np.abs(e[m] - float(self.e_min)) / float(self.e_min)
+        r = np.abs(c[m] * c[m] - float(self.rho2_n) * e[m]) / np.maximum(c[m] * c[m], 1e-30)
+        return float(min(a.min(), r.min()))
+
+    def receive(self, b, resync=()):
+        """(dibits, sync_pos, sync_dibit) of SPEC 3.8 over the whole array; resync = sample indices q (lock dropped between
+        samples q - 1 and q)."""
+        b = np.ascontiguousarray(b, dtype=F)
+        n = len(b)
+        dets = self.detections(b)
+        # events in the order they take effect: a detection governs instants > s + W, a drop removes instants >= q;
+        # at the same instant the detection comes first (decided at q - 1) and is dropped with the rest
+        ev = [(s + self.W + 1, 0, k) for k, (s, _, _, _) in enumerate(dets)] + [(min(max(int(q), 0), n), 1, -1) for q in resync]
+        ev.sort()
+        dib, spos, sdib = [], [], []
+        anchor, start = None, 0
+        bounds = ev + [(n, 2, -1)]
+        for t, kind, k in bounds:
+            if anchor is not None and t > start:
+                s, hi, mid, lo = anchor
+                m0 = max(1, -(-(start - s) // self.sps))              # first m with s + 10 m >= start
+                idx = np.arange(s + self.sps * m0, min(t, n), self.sps)
+                v = b[idx]
+                d = np.where(v >= hi, 1, np.where(v >= mid, 0, np.where(v >= lo, 2, 3))).astype(np.uint8)
+                dib.append(d)
+            start = t
+            if kind == 0:
+                anchor = dets[k]
+                spos.append(dets[k][0])
+                sdib.append(sum(len(x) for x in dib))
+            elif kind == 1:
+                anchor = None
+        return (np.concatenate(dib) if dib else np.zeros(0, np.uint8), np.array(spos, dtype=np.int64), np.array(sdib, dtype=np.uint64))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SPEC 3.1 - 3.5 as batch array operations (the oracle: streaming feed() objects with ring buffers, chunk by chunk).
+# fma(a, b, c) is evaluated as float32(float64(a) * float64(b) + float64(c)): the product is exact in float64, the sum
+# rounds to 53 bits and then to 24 -- a double rounding that differs from a fused operation only when the 53-bit result
+# lands exactly on a float32 tie, about once in 2^29 operations; demod() is therefore expected to equal the oracle bit for
+# bit on captures of test size, and the test that uses it says what it tolerates.
+# ---------------------------------------------------------------------------------------------------------------------
+def fma(a, b, c):
+    return (np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64) + np.asarray(c, dtype=np.float64)).astype(F)
+
+
+def _fir(x, taps, step, first):
+    """acc = +0; for k: acc = fma(h[k], x[first + step m - k], acc) for every m with first + step m < len(x); x[n < 0] = 0"""
+    n_out = (len(x) - first + step - 1) // step if len(x) > first else 0
+    idx = first + step * np.arange(n_out)
+    xp = np.concatenate([np.zeros(len(taps), dtype=F), x])          # index i of x sits at i + len(taps)
+    acc = np.zeros(n_out, dtype=F)
+    for k, h in enumerate(taps):
+        acc = fma(F(h), xp[idx - k + len(taps)], acc)
+    return acc
+
+
+def atan2s(spec, y, x):
+    c = [F(v) for v in spec["atan_coeffs"]]
+    ax, ay = np.abs(x), np.abs(y)
+    mx = np.where(ax > ay, ax, ay)
+    mn = np.where(ax > ay, ay, ax)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = (mn / mx).astype(F)
+    s = (t * t).astype(F)
+    p = np.full(len(t), c[-1], dtype=F)
+    for i in range(len(c) - 2, -1, -1):
+        p = fma(p, s, c[i])
+    r = (p * t).astype(F)
+    r = np.where(ay > ax, (F(spec["half_pi"]) - r).astype(F), r)
+    r = np.where(x < 0, (F(spec["pi"]) - r).astype(F), r)
+    r = np.where(y < 0, -r, r)
+    return np.where(mx == 0, F(0.0), r).astype(F)
+
+
+def demod(spec, iq=None, u8=None):
+    """48 kHz baseband of a whole capture (SPEC 3.1 - 3.5, the build's own tap tables)"""
+    if u8 is not None:
+        b = np.asarray(u8, dtype=np.uint8).astype(F)
+        v = fma(b, F(spec["u8_scale"]), F(-1.0))
+        xr, xi = v[0::2], v[1::2]
+    else:
+        z = np.ascontiguousarray(iq, dtype=np.complex64)
+        xr, xi = z.real.astype(F), z.imag.astype(F)
+    h1, h2 = spec["decim_taps"], spec["chan_taps"]
+    dec = int(spec["decim"])
+    dr, di = _fir(xr, h1, dec, dec - 1), _fir(xi, h1, dec, dec - 1)
+    yr, yi = _fir(dr, h2, 1, 0), _fir(di, h2, 1, 0)
+    pr, pi_ = np.concatenate([[F(0)], yr[:-1]]), np.concatenate([[F(0)], yi[:-1]])        # y[m - 1], y[-1] = 0
+    t = (yi * pi_).astype(F)
+    re = fma(yr, pr, t)
+    u = (yr * pi_).astype(F)
+    im = fma(yi, pr, -u)
+    fmv = (atan2s(spec, im, re) * F(spec["fm_gain"])).astype(F)
+    n = len(fmv)
+    fp = np.concatenate([np.zeros(int(spec["boxcar_len"]), dtype=F), fmv])
+    acc = fmv.copy()
+    for j in range(1, int(spec["boxcar_len"])):
+        acc = (acc + fp[int(spec["boxcar_len"]) - j:int(spec["boxcar_len"]) - j + n]).astype(F)
+    return (acc * F(spec["boxcar_scale"])).astype(F)

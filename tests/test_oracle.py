@@ -314,3 +314,62 @@ def test_tracking_clock_follows_a_sample_clock_error(ppm, frame):
         off += n
     for q in range(3):
         assert np.array_equal(np.concatenate([o[q] for o in outs]), trk[q])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_receiver_against_an_independent_batch_model(spec, seed):
+    """The oracle's streaming receiver (per-sample feed objects, state across chunks, resync between chunks) against
+    tests/spec_model.py -- SPEC 3.7 / 3.8 restated from the text as a batch computation in numpy float32: dibits, sync
+    positions and sync dibit indices must be identical over random SNRs (down to false and missed sync words), frame
+    lengths (down to back-to-back sync words), offsets, chunkings and lock drops."""
+    import spec_model
+    from p25rx_amd import c4fm
+    rng = np.random.default_rng(1000 + seed)
+    snr = float(rng.choice([30.0, 12.0, 6.0, 3.0, 0.0]))
+    frame = int(rng.choice([24, 30, 48, 100, 864]))
+    iq, _, _ = c4fm.synth(float(rng.choice([0.1, 0.3, 0.6])), seed=seed, snr_db=snr, frame_dibits=frame,
+                          freq_offset_hz=float(rng.choice([0.0, 300.0, -800.0])), timing_offset=int(rng.integers(0, 50)),
+                          amplitude=float(rng.choice([0.5, 0.05])))
+    bb = O.Demod().feed_cf32(iq)
+    drops = sorted(set(int(x) for x in rng.integers(0, len(bb) + 3, size=int(rng.choice([0, 0, 2, 15])))))
+    r = O.Recv()
+    outs, o = [], 0
+    cuts = sorted(set(drops + [int(x) for x in rng.integers(0, len(bb), size=6)] + [len(bb)]))
+    for q in cuts:                                               # random chunking; resync() exactly at the drop indices
+        q = min(q, len(bb))
+        outs.append(r.feed(bb[o:q]))
+        if q in drops:
+            r.resync()
+        o = q
+    got = [np.concatenate([x[k] for x in outs]) for k in range(3)]
+    m = spec_model.Model(spec)
+    ref = m.receive(bb, drops)
+    same = all(len(got[k]) == len(ref[k]) and np.array_equal(got[k], ref[k].astype(got[k].dtype)) for k in range(3))
+    # (the model's energy is a double-rounded fma: a candidate within 1e-6 of a threshold may legitimately fall either way)
+    assert same or m.margins() < 1e-6, (seed, snr, frame, len(got[0]), len(ref[0]), len(got[1]), len(ref[1]))
+    if snr >= 12.0 and frame >= 48:
+        assert len(ref[1]) >= 2 and len(ref[0]) > 50
+
+
+@pytest.mark.parametrize("fmt", ["cf32", "u8"])
+def test_demod_against_an_independent_batch_model(spec, c4fm_1s, fmt):
+    """Stages 3.1 - 3.5 of the oracle (streaming objects, ragged chunks) against tests/spec_model.demod -- the same SPEC
+    text as whole-array numpy float32 operations with the fused multiply-adds evaluated through float64: equal BIT FOR BIT
+    (a double rounding could move a last bit about once in 2^29 operations; none does on these captures)."""
+    import spec_model
+    from p25rx_amd import c4fm
+    iq = c4fm_1s[0][:60000]
+    d = O.Demod()
+    if fmt == "u8":
+        raw = c4fm.to_u8(iq)
+        got = np.concatenate([d.feed_u8(raw[o:o + 2 * 7001]) for o in range(0, len(raw), 2 * 7001)])
+        ref = spec_model.demod(spec, u8=raw)
+    else:
+        got = np.concatenate([d.feed_cf32(iq[o:o + 7001]) for o in range(0, len(iq), 7001)])
+        ref = spec_model.demod(spec, iq=iq)
+    assert len(got) == len(ref) == 12000
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # and the receiver on top: the two independent restatements give the same symbols end to end
+    m = spec_model.Model(spec)
+    a, b = O.Recv().feed(got), m.receive(ref)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[0]) > 1000
