@@ -87,6 +87,59 @@ class Model:
         r = np.abs(c[m] * c[m] - float(self.rho2_n) * e[m]) / np.maximum(c[m] * c[m], 1e-30)
         return float(min(a.min(), r.min()))
 
+    def receive_tracking(self, b, spec, resync=()):
+        """SPEC 3.8b (symbol_clock = 1): every detection carries a clock D / N measured from the previous sync word, instants
+        s + (j D) div N are read by the 4-tap interpolation of their phase; the receiver runs L samples behind the
+        baseband (it processes index u when sample u + L exists), a drop before sample q removes instants >= q - L."""
+        b = np.ascontiguousarray(b, dtype=F)
+        n = len(b)
+        L = int(spec["clk_lookahead"])
+        tol, dmax, phases = 1 << int(spec["clk_tol_shift"]), 1 << int(spec["clk_dmax_log2"]), int(spec["clk_phases"])
+        Ci = np.array(spec["clk_interp"], dtype=F).reshape(phases, 4)
+        dets = [d for d in self.detections(b) if d[0] + self.W < n - L]
+        ev = [(s + self.W + 1, 0, k) for k, (s, _, _, _) in enumerate(dets)] + [(min(max(int(q) - L, -L), n), 1, -1) for q in resync]
+        ev.sort()
+        bp = np.concatenate([np.zeros(2, dtype=F), b, np.zeros(4, dtype=F)])       # b[i] sits at bp[i + 2]
+        dib, spos, sdib = [], [], []
+        anchor, start = None, -L
+        for t, kind, k in ev + [(n - L, 2, -1)]:
+            t = min(t, n - L)
+            if anchor is not None and t > start:
+                s, hi, mid, lo, D, N = anchor
+                # j with start <= s + (j D) div N < t, j >= 1
+                j = max(1, ((start - s) * N + D - 1) // D)
+                while s + (j * D) // N < start:
+                    j += 1
+                js = []
+                while s + (j * D) // N < t:
+                    js.append(j); j += 1
+                if js:
+                    js = np.array(js, dtype=np.int64)
+                    num = js * D
+                    i = s + num // N
+                    q = ((num % N) * phases) // N
+                    w = Ci[q]
+                    acc = (w[:, 0] * bp[i - 1 + 2]).astype(F)
+                    acc = fma(w[:, 1], bp[i + 2], acc)
+                    acc = fma(w[:, 2], bp[i + 1 + 2], acc)
+                    acc = fma(w[:, 3], bp[i + 2 + 2], acc)
+                    dib.append(np.where(acc >= hi, 1, np.where(acc >= mid, 0, np.where(acc >= lo, 2, 3))).astype(np.uint8))
+            start = max(start, t)
+            if kind == 0:
+                s, hi, mid, lo = dets[k]
+                D, N = self.sps, 1
+                if anchor is not None:                               # lock was held from the previous sync word to this one
+                    delta = s - anchor[0]
+                    Nn = (delta + 5) // 10
+                    if Nn >= 1 and delta <= dmax and abs(delta - 10 * Nn) * tol <= 10 * Nn and delta != 10 * Nn:
+                        D, N = delta, Nn
+                anchor = (s, hi, mid, lo, D, N)
+                spos.append(s)
+                sdib.append(sum(len(x) for x in dib))
+            elif kind == 1:
+                anchor = None
+        return (np.concatenate(dib) if dib else np.zeros(0, np.uint8), np.array(spos, dtype=np.int64), np.array(sdib, dtype=np.uint64))
+
     def receive(self, b, resync=()):
         """(dibits, sync_pos, sync_dibit) of SPEC 3.8 over the whole array; resync = sample indices q (lock dropped between
         samples q - 1 and q)."""

@@ -373,3 +373,33 @@ def test_demod_against_an_independent_batch_model(spec, c4fm_1s, fmt):
     m = spec_model.Model(spec)
     a, b = O.Recv().feed(got), m.receive(ref)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[0]) > 1000
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_tracking_receiver_against_an_independent_batch_model(spec, seed):
+    """SPEC 3.8b (the tracking symbol clock: period from sync word to sync word, interpolated instants, lookahead 2) the
+    same way: the oracle's streaming receiver in mode 1, fed in random chunks with lock drops, against
+    spec_model.Model.receive_tracking over the whole array -- sample-clock errors up to 250 ppm, frames from back-to-back
+    sync words to 3 000 dibits."""
+    import spec_model
+    from p25rx_amd import c4fm
+    rng = np.random.default_rng(7000 + seed)
+    snr = float(rng.choice([30.0, 12.0, 6.0, 3.0]))
+    frame = int(rng.choice([24, 30, 48, 100, 864, 3000]))
+    ppm = float(rng.choice([0.0, 40.0, -100.0, 250.0]))
+    iq, _, _ = c4fm.synth(float(rng.choice([0.1, 0.3, 0.7, 1.5])), seed=seed, snr_db=snr, frame_dibits=frame,
+                          timing_offset=int(rng.integers(0, 50)), clock_ppm=ppm)
+    bb = O.Demod().feed_cf32(iq)
+    drops = sorted(set(int(x) for x in rng.integers(0, len(bb) + 3, size=int(rng.choice([0, 0, 2, 15])))))
+    r = O.Recv(O.make_config(symbol_clock=1))
+    outs, o = [], 0
+    for q in sorted(set(drops + [int(x) for x in rng.integers(0, len(bb), size=6)] + [len(bb)])):
+        q = min(q, len(bb))
+        outs.append(r.feed(bb[o:q]))
+        if q in drops:
+            r.resync()
+        o = q
+    got = [np.concatenate([x[k] for x in outs]) for k in range(3)]
+    ref = spec_model.Model(spec).receive_tracking(bb, spec, drops)
+    for k in range(3):
+        assert len(got[k]) == len(ref[k]) and np.array_equal(got[k], ref[k].astype(got[k].dtype)), (seed, snr, frame, ppm, k)
