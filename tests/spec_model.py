@@ -236,3 +236,36 @@ def demod(spec, iq=None, u8=None):
     for j in range(1, int(spec["boxcar_len"])):
         acc = (acc + fp[int(spec["boxcar_len"]) - j:int(spec["boxcar_len"]) - j + n]).astype(F)
     return (acc * F(spec["boxcar_scale"])).astype(F)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SPEC 3.9: the 65 536 code words of BCH(63,16,23) straight from the published generator polynomial (TIA-102.BAAA,
+# 6331141367235453 octal) by polynomial division -- not from the generator-matrix rows tools/gen_spec.py writes.
+# ---------------------------------------------------------------------------------------------------------------------
+NID_GEN_OCTAL = "6331141367235453"
+
+
+def nid_codewords():
+    g = int(NID_GEN_OCTAL, 8)
+    assert g.bit_length() == 48                                    # degree 47
+    words = np.zeros(65536, dtype=np.uint64)
+    for d in range(65536):
+        r = d << 47
+        for bit in range(62, 46, -1):                              # remainder of d x^47 modulo g
+            if (r >> bit) & 1:
+                r ^= g << (bit - 47)
+        words[d] = (d << 47) | r
+    return words
+
+
+def nid_decode(codewords, word63):
+    """(data, distance) of the nearest code word, smallest data word on ties"""
+    x = codewords ^ np.uint64(word63)
+    dist = np.zeros(len(x), dtype=np.int32)
+    for sh in range(0, 64, 16):
+        dist += _POP16[((x >> np.uint64(sh)) & np.uint64(0xffff)).astype(np.int64)]
+    k = int(np.argmin(dist))                                        # argmin returns the first (smallest data word)
+    return k, int(dist[k])
+
+
+_POP16 = np.array([bin(i).count("1") for i in range(65536)], dtype=np.int32)

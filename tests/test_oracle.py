@@ -403,3 +403,34 @@ def test_tracking_receiver_against_an_independent_batch_model(spec, seed):
     ref = spec_model.Model(spec).receive_tracking(bb, spec, drops)
     for k in range(3):
         assert len(got[k]) == len(ref[k]) and np.array_equal(got[k], ref[k].astype(got[k].dtype)), (seed, snr, frame, ppm, k)
+
+
+def test_nid_against_the_published_generator_polynomial(spec):
+    """SPEC 3.9 independently: all 65 536 code words by polynomial division with the published octal generator (not the
+    matrix rows of spec.json): minimum weight 23, the spec's systematic rows are among them, and the oracle's decoder agrees
+    with a brute-force nearest-code-word search on words with 0 - 14 random bit errors (inside and outside the radius)."""
+    import spec_model
+    cw = spec_model.nid_codewords()
+    w = spec_model._POP16[(cw & np.uint64(0xffff)).astype(np.int64)] + spec_model._POP16[((cw >> np.uint64(16)) & np.uint64(0xffff)).astype(np.int64)] \
+        + spec_model._POP16[((cw >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)] + spec_model._POP16[((cw >> np.uint64(48)) & np.uint64(0xffff)).astype(np.int64)]
+    assert int(w[1:].min()) == 23 and int(spec["nid_gen_poly"]) == int(spec_model.NID_GEN_OCTAL, 8)
+    rows = [int(r) for r in spec["nid_rows"]]
+    assert sorted(rows) == sorted(int(cw[1 << k]) for k in range(16))                       # one row per data bit
+    rng = np.random.default_rng(9)
+    for trial in range(60):
+        data = int(rng.integers(0, 65536))
+        nerr = int(rng.choice([0, 1, 5, 11, 11, 12, 14]))
+        word = int(cw[data])
+        for b in rng.choice(63, size=nerr, replace=False):
+            word ^= 1 << int(b)
+        extra = int(rng.integers(0, 2))                              # the 64th bit is not part of the code word
+        raw = (word << 1) | extra
+        # as dibits: 32 NID dibits MSB first with the status symbol interleaved after the 11th
+        nid_d = [(raw >> (62 - 2 * k)) & 3 for k in range(32)]
+        stream = [0] * 5 + nid_d[:11] + [int(rng.integers(0, 4))] + nid_d[11:] + [0] * 3
+        r = O.nid_decode(np.array(stream, dtype=np.uint8), np.array([5], dtype=np.uint64))[0]
+        k, dist = spec_model.nid_decode(cw, word)
+        assert int(r["raw"]) == raw and int(r["n_errors"]) == dist and int(r["valid"]) == (1 if dist <= 11 else 0)
+        assert (int(r["nac"]), int(r["duid"])) == (k >> 4, k & 15)
+        if nerr <= 11:
+            assert k == data and dist == nerr
