@@ -434,3 +434,18 @@ def test_nid_against_the_published_generator_polynomial(spec):
         assert (int(r["nac"]), int(r["duid"])) == (k >> 4, k & 15)
         if nerr <= 11:
             assert k == data and dist == nerr
+
+
+def test_predecimator_against_the_batch_model(spec):
+    """SPEC 3.0 (the 2.4 Msps -> 240 ksps stage of config 3): the oracle's streaming object in ragged chunks against the
+    whole-array restatement, bit for bit."""
+    import spec_model
+    rng = np.random.default_rng(4)
+    x = (rng.normal(0, 0.3, 50003) + 1j * rng.normal(0, 0.3, 50003)).astype(np.complex64)
+    p = O.PreDecim()
+    got = np.concatenate([p.feed(x[o:o + 7777]) for o in range(0, len(x), 7777)])
+    h0 = spec["pre_taps"]
+    ref_r = spec_model._fir(x.real.astype(np.float32), h0, int(spec["pre_decim"]), int(spec["pre_decim"]) - 1)
+    ref_i = spec_model._fir(x.imag.astype(np.float32), h0, int(spec["pre_decim"]), int(spec["pre_decim"]) - 1)
+    assert len(got) == len(ref_r) == 5000
+    assert np.array_equal(got.real.view(np.uint32), ref_r.view(np.uint32)) and np.array_equal(got.imag.view(np.uint32), ref_i.view(np.uint32))
