@@ -533,6 +533,51 @@ def test_non_finite_and_extreme_samples(O, FE, c4fm_1s):
         assert np.array_equal(FE(symbol_clock=mode).run_cf32(iq), ro[0])
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gpu_against_the_independent_batch_model(spec, FE, mode):
+    """The HIP path against tests/spec_model.py directly (the whole-array numpy restatement of SPEC 3.1 - 3.8b that the CPU
+    suite pins the oracle with): baseband bit for bit from cf32 and from u8, dibits / sync positions / sync dibit indices
+    with lock drops, fused and through the streaming calls -- no oracle in between."""
+    import torch
+    import spec_model
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    iq, _, _ = c4fm.synth(0.8, seed=77, snr_db=14.0, frame_dibits=300, clock_ppm=120.0 if mode else 0.0, timing_offset=17)
+    iq = iq[:len(iq) // 8 * 8]
+    m = spec_model.Model(spec)
+    fe = FE(symbol_clock=mode)
+    ref_bb = spec_model.demod(spec, iq=iq)
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    bb, nb = fe.demod_dev(t)
+    assert nb == len(ref_bb) and np.array_equal(bits(bb[0, :nb].cpu().numpy()), bits(ref_bb))
+    u8 = c4fm.to_u8(iq)
+    ref_u8 = spec_model.demod(spec, u8=u8)
+    got_u8 = np.concatenate([fe.demod_u8(u8[o:o + 32768]) for o in range(0, len(u8), 32768)])
+    assert np.array_equal(bits(got_u8), bits(ref_u8))
+    drops = [5000, 5001, 20011, 30000]
+    recv = (lambda b, d: m.receive_tracking(b, spec, d)) if mode else m.receive
+    for rs in ([], drops):
+        ref = recv(ref_bb, rs)
+        assert len(ref[1]) >= 8
+        if rs:
+            fe.resync_at_dev(torch.tensor(rs, dtype=torch.int64, device="cuda"))
+        dib, res, sp, sd = fe.slice_dev(bb[:, :nb].contiguous(), nb, sync_cap=256)
+        r = parse_results(res)[0]
+        nd, ns = int(r["n_dibits"]), int(r["n_sync"])
+        assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
+        assert ns == len(ref[1]) and np.array_equal(sp[0, :ns].cpu().numpy(), ref[1])
+        assert np.array_equal(sd[0, :ns].cpu().numpy().astype(np.uint64), ref[2])
+        if rs:
+            fe.resync_at_dev(torch.tensor(rs, dtype=torch.int64, device="cuda"))
+        d2, r2 = fe.run_dev(t)
+        n2 = int(parse_results(r2)[0]["n_dibits"])
+        assert n2 == len(ref[0]) and np.array_equal(d2[0, :n2].cpu().numpy(), ref[0])
+    fe2 = FE(symbol_clock=mode)
+    free = recv(ref_bb, [])
+    got = np.concatenate([fe2.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)])
+    assert np.array_equal(got, free[0])
+
+
 def test_nid_after_sync_matches_oracle(O, FE):
     """Next row: NID after every frame sync, GPU exhaustive BCH(63,16,23) search == oracle, record
     for record, on clean frames, on frames with injected bit errors (<= 11 corrected, more rejected) and at the
