@@ -3,8 +3,9 @@
 // drives include/p25fe_rccl.h (halo by ncclSend / ncclRecv behind K1, summaries by ncclAllGather, device resolve, dibit
 // rows to rank 0 + compaction) and rank 0 writes the ORDERED dibit stream -- byte for byte what `p25fe_replay cf32` writes.
 //
-//   p25fe_shards [-n RANKS] [-k STEPS] [--shm] <in.cf32> <dibits.out>
+//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [--shm] <in.cf32> <dibits.out>
 //
+//   -c 1    the tracking symbol clock (docs/SPEC.md 3.8b; p25fe_config_t.symbol_clock)
 //   --shm   TEST HOOK: all ranks on GPU 0, exchanges through a shared-memory segment instead of RCCL (a 1-GPU box)
 //   -n 1    runs the same step through a ONE-rank RCCL communicator (self send / recv, all-gather of one)
 // Prints one JSON line (rank 0): dibits, steps, ms per step, ms per step in each exchange.
@@ -30,7 +31,7 @@ static void die(const char* what, int rc)
     std::_Exit(1);
 }
 
-static int child(int rank, int world, int steps, bool shm, const char* in_path, const char* out_path, const std::string& key)
+static int child(int rank, int world, int steps, bool shm, int clock, const char* in_path, const char* out_path, const std::string& key)
 {
     FILE* f = std::fopen(in_path, "rb");
     if (!f) { std::fprintf(stderr, "unable to open %s\n", in_path); return 1; }
@@ -44,6 +45,7 @@ static int child(int rank, int world, int steps, bool shm, const char* in_path, 
     p25fe_config_t cfg;
     p25fe_default_config(&cfg);
     cfg.device = dev;
+    cfg.symbol_clock = clock;
     p25fe_t* h = nullptr;
     int rc = p25fe_create(&cfg, &h);
     if (rc) die("unable to create the handle", rc);
@@ -123,16 +125,17 @@ static int child(int rank, int world, int steps, bool shm, const char* in_path, 
 
 int main(int argc, char** argv)
 {
-    int ranks = 1, steps = 3, a = 1;
+    int ranks = 1, steps = 3, clock = 0, a = 1;
     bool shm = false;
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!std::strcmp(argv[a], "-n") && a + 1 < argc) ranks = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "-k") && a + 1 < argc) steps = std::atoi(argv[++a]);
+        else if (!std::strcmp(argv[a], "-c") && a + 1 < argc) clock = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "--shm")) shm = true;
         else break;
     }
-    if (argc - a != 2 || ranks < 1 || steps < 1) {
-        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
+    if (argc - a != 2 || ranks < 1 || steps < 1 || (clock != 0 && clock != 1)) {
+        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
         return 2;
     }
     const std::string key = "/p25fe_shards_" + std::to_string((long)getpid());
@@ -141,7 +144,7 @@ int main(int argc, char** argv)
     std::vector<pid_t> kids;
     for (int r = 0; r < ranks; ++r) {
         const pid_t p = fork();
-        if (p == 0) std::_Exit(child(r, ranks, steps, shm, argv[a], argv[a + 1], key));
+        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, argv[a], argv[a + 1], key));
         kids.push_back(p);
     }
     int bad = 0;

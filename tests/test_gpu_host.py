@@ -411,3 +411,17 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
         if "--shm" not in args:
             assert rep["exchange"] == "RCCL" and rep["comm_ms_per_step"]["steps_averaged"] == 3
             assert rep["comm_ms_per_step"]["halo"] > 0 and rep["comm_ms_per_step"]["summaries"] > 0
+    # the same with the tracking symbol clock on a capture whose sample clock is 150 ppm off: every shard's first detection
+    # takes its period from the previous shard's anchor (the carry resolution with clocks, p25fe_shard_resolve_dev)
+    iq2, _, _ = c4fm.synth(2.0, seed=92, snr_db=24.0, frame_dibits=700, clock_ppm=150.0)
+    iq2 = iq2[:480000]
+    bb2 = O.Demod().feed_cf32(iq2)
+    ref2 = O.Recv(O.make_config(symbol_clock=1)).feed(bb2)[0]
+    src2 = tmp_path / "cap_ppm.cf32"
+    iq2.tofile(src2)
+    for args in (["-n", "1", "-c", "1"], ["-n", "3", "-c", "1", "--shm"]):
+        out = tmp_path / ("dibt_" + "_".join(a.strip("-") for a in args))
+        r = subprocess.run([exe] + args + ["-k", "2", str(src2), str(out)], capture_output=True, timeout=280)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got = np.fromfile(out, dtype=np.uint8)
+        assert len(got) == len(ref2) and np.array_equal(got, ref2), args
