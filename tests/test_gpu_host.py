@@ -389,7 +389,7 @@ def test_timeshard_step_device_rccl_world1():
 def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
     """include/p25fe_rccl.h through the C++ launcher (no Python, no torch in the ranks): the N > 1 step -- halo exchange
     beside K1, summary all-gather, device resolve, pass 2, dibit gather to rank 0, compaction -- (a) over RCCL in a
-    one-rank communicator on this GPU, (b) as 2 and 3 PROCESSES that share the GPU with the exchanges staged through shared
+    one-rank communicator on this GPU, (b) as 2, 3 and 8 PROCESSES that share the GPU with the exchanges staged through shared
     memory (test hook).  The ordered stream rank 0 writes equals the single-pass dibits byte for byte."""
     import json
     from oracle import oracle as O
@@ -400,7 +400,7 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
     ref = O.run_cf32(iq)
     src = tmp_path / "cap.cf32"
     iq.tofile(src)
-    for args in (["-n", "1"], ["-n", "2", "--shm"], ["-n", "3", "--shm"]):
+    for args in (["-n", "1"], ["-n", "2", "--shm"], ["-n", "3", "--shm"], ["-n", "8", "--shm"]):
         out = tmp_path / ("dib_" + "_".join(a.strip("-") for a in args))
         r = subprocess.run([exe] + args + ["-k", "3", str(src), str(out)], capture_output=True, timeout=280)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
