@@ -53,6 +53,8 @@ def scene(seed):
     s["n_drops"] = int(rng.choice([0, 0, 1, 3, 20]))
     s["timing"] = int(rng.integers(0, 50))
     s["channels"] = int(rng.choice([1, 1, 1, 2, 3]))
+    if s["seconds"] <= 0.2 and rng.integers(0, 8) == 0:
+        s["channels"] = int(rng.choice([17, 64]))            # a real batch now and then (short captures): channel indexing at scale
     s["damage"] = int(rng.choice([0, 0, 0, 0, 1]))           # cf32 only: NaN / Inf / huge / denormal samples sprinkled in
     # ragged lengths: around multiples of a receiver tile (7 680 baseband = 38 400 IQ samples), of a K1 sub-tile (1 600) and anything
     s["extra"] = int(rng.choice([0, 8, 1600, 1608, 38400 - 8, 38400, 38400 + 8, 2 * 38400, int(rng.integers(0, 50000)) // 8 * 8]))
