@@ -869,9 +869,13 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
         st = h->k1_alt;
     }
     if (h->rx_pending[lane]) {
-        // (P25FE_PIPE_NOWAIT=1, measurement only: what this wait packet costs -- without it the planes can be overwritten under a
-        // receive kernel that is still reading them)
+#ifdef P25FE_MEASURE_UNSAFE
+        // measurement builds only (-DP25FE_MEASURE_UNSAFE + P25FE_PIPE_NOWAIT=1): what this wait packet costs -- without it the
+        // planes can be overwritten under a receive kernel that is still reading them
         static const bool nowait = [] { const char* e = getenv("P25FE_PIPE_NOWAIT"); return e && atoi(e) != 0; }();
+#else
+        constexpr bool nowait = false;
+#endif
         if (!nowait && !(h->rx_joined_any[lane] && h->rx_joined[lane] == st)) HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[lane], 0));
         h->rx_pending[lane] = false;
     }
