@@ -204,18 +204,48 @@ def run_extras(torch, dev, args, iq2, truth2):
     del u8, fe
 
     # ---- configs[1] with the tracking symbol clock (SPEC 3.8b; north_star's "symbol-clock interpolator"): the general receiver
+    # The capture gets a sample-clock error first -- one IQ sample in 6 667 is dropped (150 ppm), so that sync-to-sync intervals
+    # are 8 638 / 8 639 baseband samples, the receiver runs its general D / N arithmetic with non-zero interpolation phases
+    # (on the exact capture every interval is 10 N and the clock degenerates to the fixed stride's fast path), and the fixed
+    # stride walks 1.3 samples off the eye per frame.  The modulator's symbols are the truth for BOTH clocks: the line reports
+    # their symbol errors side by side (the tracking clock is the right tool from ~100 ppm up; below that its +-1-sample
+    # period estimate is noisier than re-anchoring alone -- docs/SPEC.md 3.8b).
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    keep[6666::6667] = False
+    iq_ppm = iq2[keep]
+    n_ppm = iq_ppm.shape[0] // 8 * 8
+    iq_ppm = iq_ppm[:n_ppm].contiguous()
+    del keep
+
+    def sym_errors(dib_, res_):
+        nd_ = int(parse_results(res_)[0]["n_dibits"])
+        got_ = dib_[0, :nd_].cpu().numpy()
+        k_ = min(nd_, len(truth2) - 24)
+        return int(np.count_nonzero(got_[:k_] != truth2[24:24 + k_])), k_
+
+    fe0 = FrontEnd(device=dev.index)
+    d0, r0 = fe0.run_dev(iq_ppm)
+    torch.cuda.synchronize()
+    err_fixed, k_fixed = sym_errors(d0, r0)
+    del fe0, d0, r0
     fe = FrontEnd(device=dev.index, symbol_clock=1)
     dib = res = None
     def step_trk():
         nonlocal dib, res
-        dib, res = run(fe, iq2, dib, res)
+        dib, res = run(fe, iq_ppm, dib, res)
     k = steps_for(0.35)
     dt = timed(torch, step_trk, k, 5, finish=fe.join_dev)
-    k1, _, kms = k1_frac(fe, torch, lambda: fe.run_dev(iq2, dibits=dib, result=res), n, BYTES_PER_SAMPLE)
-    entry("configs[1] with symbol_clock = tracking (period from sync word to sync word, 4-tap interpolated instants)", n,
-          dt / k * 1e3, "k_frontend<cf32>", k1, BYTES_PER_SAMPLE, gate(dib, res, truth2), steps=k,
-          receiver_ms={"k_detect<general>": round(kms[1], 4), "k_scan_g": round(kms[2], 4), "k_slice_g": round(kms[3], 4)})
-    del fe
+    k1, _, kms = k1_frac(fe, torch, lambda: fe.run_dev(iq_ppm, dibits=dib, result=res), n_ppm, BYTES_PER_SAMPLE)
+    a_out = parse_results(res)[0]["anchor_out"]
+    err_trk, k_trk = sym_errors(dib, res)
+    entry("configs[1] with a 150 ppm sample clock and symbol_clock = tracking (period from sync word to sync word, 4-tap interpolated "
+          "instants)", n_ppm, dt / k * 1e3, "k_frontend<cf32>", k1, BYTES_PER_SAMPLE,
+          k_trk > 2800000 and err_trk <= k_trk // 1000 and err_trk < err_fixed, steps=k,
+          receiver_ms={"k_detect<general>": round(kms[1], 4), "k_scan_g": round(kms[2], 4), "k_slice_g": round(kms[3], 4)},
+          last_period="%d / %d" % (int(a_out["period_d"]), int(a_out["period_n"])),
+          symbol_errors={"tracking_clock": err_trk, "fixed_stride_same_capture": err_fixed, "of": k_trk},
+          gate="symbol errors vs the modulator: tracking <= 0.1 % and fewer than the fixed stride's on the same capture")
+    del fe, iq_ppm
 
     # ---- configs[2]: 2.4 Msps front end, 60 s = 1.44e8 samples -> stage 0 (10:1, 80 taps) -> K1..K4
     n240 = 60 * 240000
