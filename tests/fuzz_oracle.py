@@ -34,12 +34,17 @@ def main():
         iq, _, _ = c4fm.synth(float(rng.choice([0.1, 0.3, 0.7])), seed=seed, snr_db=snr, frame_dibits=frame,
                               freq_offset_hz=float(rng.choice([0.0, 300.0, -800.0])), timing_offset=int(rng.integers(0, 50)),
                               amplitude=float(rng.choice([0.5, 0.05])), clock_ppm=ppm)
-        d = O.Demod()
+        dt = ct = None
+        if rng.integers(0, 5) == 0:                                  # caller-supplied tables of random length (SPEC 3.3's padding rule)
+            big = bool(rng.integers(0, 2))
+            dt = [float(np.float32(v)) for v in rng.normal(0, 0.2, int(rng.integers(32, 65) if big else rng.integers(1, 32)))]
+            ct = [float(np.float32(v)) for v in rng.normal(0, 0.2, int(rng.integers(1, 65) if big else rng.integers(1, 42)))]
+        d = O.Demod(O.make_config(decim_taps=dt, chan_taps=ct))
         if rng.integers(0, 2):
             raw = c4fm.to_u8(iq)
-            bb, ref_bb = d.feed_u8(raw), spec_model.demod(spec, u8=raw)
+            bb, ref_bb = d.feed_u8(raw), spec_model.demod(spec, u8=raw, decim_taps=dt, chan_taps=ct)
         else:
-            bb, ref_bb = d.feed_cf32(iq), spec_model.demod(spec, iq=iq)
+            bb, ref_bb = d.feed_cf32(iq), spec_model.demod(spec, iq=iq, decim_taps=dt, chan_taps=ct)
         if not np.array_equal(bb.view(np.uint32), ref_bb.view(np.uint32)):
             bad += 1
             print("baseband differs: seed", seed)

@@ -217,8 +217,19 @@ def atan2s(spec, y, x):
     return np.where(mx == 0, F(0.0), r).astype(F)
 
 
-def demod(spec, iq=None, u8=None):
-    """48 kHz baseband of a whole capture (SPEC 3.1 - 3.5, the build's own tap tables)"""
+def padded_tables(spec, decim_taps=None, chan_taps=None):
+    """SPEC 3.3: a configured table IS the table of the evaluation length -- 31 / 41, or 64 / 64 as soon as either is longer --
+    with zero coefficients at the old end"""
+    h1 = list(spec["decim_taps"] if decim_taps is None else decim_taps)
+    h2 = list(spec["chan_taps"] if chan_taps is None else chan_taps)
+    long_ = len(h1) > len(spec["decim_taps"]) or len(h2) > len(spec["chan_taps"])
+    h1 += [0.0] * ((64 if long_ else len(spec["decim_taps"])) - len(h1))
+    h2 += [0.0] * ((64 if long_ else len(spec["chan_taps"])) - len(h2))
+    return h1, h2
+
+
+def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None):
+    """48 kHz baseband of a whole capture (SPEC 3.1 - 3.5; the build's own tap tables unless others are given)"""
     if u8 is not None:
         b = np.asarray(u8, dtype=np.uint8).astype(F)
         v = fma(b, F(spec["u8_scale"]), F(-1.0))
@@ -226,7 +237,7 @@ def demod(spec, iq=None, u8=None):
     else:
         z = np.ascontiguousarray(iq, dtype=np.complex64)
         xr, xi = z.real.astype(F), z.imag.astype(F)
-    h1, h2 = spec["decim_taps"], spec["chan_taps"]
+    h1, h2 = padded_tables(spec, decim_taps, chan_taps)
     dec = int(spec["decim"])
     dr, di = _fir(xr, h1, dec, dec - 1), _fir(xi, h1, dec, dec - 1)
     yr, yi = _fir(dr, h2, 1, 0), _fir(di, h2, 1, 0)
