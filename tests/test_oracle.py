@@ -449,3 +449,21 @@ def test_predecimator_against_the_batch_model(spec):
     ref_i = spec_model._fir(x.imag.astype(np.float32), h0, int(spec["pre_decim"]), int(spec["pre_decim"]) - 1)
     assert len(got) == len(ref_r) == 5000
     assert np.array_equal(got.real.view(np.uint32), ref_r.view(np.uint32)) and np.array_equal(got.imag.view(np.uint32), ref_i.view(np.uint32))
+
+
+def test_tracking_clock_range_of_usefulness():
+    """docs/SPEC.md 3.8b's table, two of its rows: at 150 ppm with P25's 0.18 s between sync words the tracking clock makes a
+    handful of symbol errors where the fixed stride makes hundreds; at 20 ppm re-anchoring alone is error free and the
+    tracking clock's whole-sample period estimate costs a few symbols (the limit the SPEC states, and what the refined
+    period of tests/exp_frac_period.py is for)."""
+    def errors(ppm, mode):
+        iq, truth, _ = c4fm.synth(4.0, seed=5, snr_db=30.0, clock_ppm=ppm)
+        d = O.Recv(O.make_config(symbol_clock=mode)).feed(O.Demod().feed_cf32(iq))[0]
+        k = min(len(d), len(truth) - 24)
+        return int(np.count_nonzero(d[:k] != truth[24:24 + k])), k
+    f150, k = errors(150.0, 0)
+    t150, _ = errors(150.0, 1)
+    f20, _ = errors(20.0, 0)
+    t20, _ = errors(20.0, 1)
+    assert k > 19000 and f150 > 50 and t150 < f150 // 8
+    assert f20 == 0 and t20 < k // 500
