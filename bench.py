@@ -208,8 +208,7 @@ def run_extras(torch, dev, args, iq2, truth2):
     # are 8 638 / 8 639 baseband samples, the receiver runs its general D / N arithmetic with non-zero interpolation phases
     # (on the exact capture every interval is 10 N and the clock degenerates to the fixed stride's fast path), and the fixed
     # stride walks 1.3 samples off the eye per frame.  The modulator's symbols are the truth for BOTH clocks: the line reports
-    # their symbol errors side by side (the tracking clock is the right tool from ~100 ppm up; below that its +-1-sample
-    # period estimate is noisier than re-anchoring alone -- docs/SPEC.md 3.8b).
+    # their symbol errors side by side (docs/SPEC.md 3.8b has the table over clock offsets).
     keep = torch.ones(n, dtype=torch.bool, device=dev)
     keep[6666::6667] = False
     iq_ppm = iq2[keep]

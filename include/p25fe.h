@@ -92,8 +92,11 @@ typedef struct p25fe p25fe_t;
 typedef struct p25fe_anchor {
     int64_t s;                           /* absolute baseband index of the sync word's last symbol */
     float hi, mid, lo;                   /* slicer thresholds derived from that sync word */
-    int32_t valid;
-    int32_t period_d, period_n;          /* symbol period period_d / period_n samples (10 / 1 unless the clock tracks; 0 / 0 reads as 10 / 1) */
+    int32_t valid;                       /* 0: no lock.  Non-zero: locked -- bit 0 set; with the tracking clock bits 8..10 carry the sync
+                                            position's fraction in quarter samples (3-bit two's complement, docs/SPEC.md 3.8b: it
+                                            enters the NEXT detection's period; 0 from the fixed-stride receiver).  Test `valid != 0`. */
+    int32_t period_d, period_n;          /* symbol period period_d / period_n samples (10 / 1 unless the clock tracks -- then quarter
+                                            samples over four times the interval's symbol count; 0 / 0 reads as 10 / 1) */
 } p25fe_anchor_t;
 
 /* Per-channel summary of one processed range (device or host memory, see each call). */
@@ -109,7 +112,7 @@ typedef struct p25fe_result {
                                             drop if that comes first; never negative); -1: it governs the whole range */
     int64_t first_seg_end;               /* end (exclusive) of the interval the first own detection governs: the next event of the range (detection or lock drop) or the range's end */
     uint32_t flags;                      /* P25FE_RES_* */
-    uint32_t reserved;
+    uint32_t reserved;                   /* tracking clock: quarter-sample fraction (3-bit two's complement) of the first own detection's sync position; else 0 */
 } p25fe_result_t;
 #define P25FE_RES_FIRST_TRACKS_CARRY 1u  /* no lock drop between the range's start and its first detection: with a tracking clock that
                                             detection takes its period from the carry-in (n_dibits_after_first assumed 10 / 1) */

@@ -407,6 +407,7 @@ typedef struct {
     int next_q;
     int prev_valid;             /* a detection since the last lock drop: the next sync-to-sync interval is a period estimate */
     int64_t prev_s;
+    int prev_f;                 /* ... and its position's fraction in quarter samples (SPEC 3.8b) */
     uint64_t n_dibits;
 } p25o_recv;
 
@@ -500,16 +501,31 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
                 float dlt = span * g->slice_frac;
                 r->mid = mid; r->hi = mid + dlt; r->lo = mid - dlt;
                 /* SPEC 3.8b: the interval from the previous sync word, if lock was held throughout and it is a
-                 * plausible whole number of symbols, is the period estimate D / N; otherwise the nominal 10 / 1 */
+                 * plausible whole number of symbols, is the period estimate D / N; otherwise the nominal 10 / 1.  The two
+                 * positions enter with their fractions f (quarter samples: vertex of the parabola through the correlation
+                 * peak and its neighbours) -- the period only; the anchor stays on the whole sample m */
+                int fq = 0;
+                {
+                    const float cl = cget(r, m - 1), cr = cget(r, m + 1);
+                    const float num = cl - cr, den = (cl - (cm + cm)) + cr;
+                    if (den < 0.0f) {
+                        const float q = (num * 0.5f) / den;
+                        if (q == q) {
+                            const float v = floorf(q * 4.0f + 0.5f);
+                            fq = v < -2.0f ? -2 : v > 2.0f ? 2 : (int)v;
+                        }
+                    }
+                }
                 r->per_d = S; r->per_n = 1;
                 if (track && r->prev_valid) {
                     const int64_t dd = m - r->prev_s, nn = (dd + S / 2) / S;
                     const int64_t err = dd > S * nn ? dd - S * nn : S * nn - dd;
-                    if (nn >= 1 && err != 0 && dd <= ((int64_t)1 << g->clk_dmax_log2) && (err << g->clk_tol_shift) <= S * nn) {
-                        r->per_d = dd; r->per_n = nn;
+                    if (nn >= 1 && dd <= ((int64_t)1 << g->clk_dmax_log2) && (err << g->clk_tol_shift) <= S * nn) {
+                        const int64_t d4 = 4 * dd + (fq - r->prev_f);
+                        if (d4 != 4 * S * nn) { r->per_d = d4; r->per_n = 4 * nn; }     /* (exactly nominal: written 10 / 1, the same instants) */
                     }
                 }
-                r->prev_s = m; r->prev_valid = 1;
+                r->prev_s = m; r->prev_f = fq; r->prev_valid = 1;
                 r->anchor_s = m;
                 r->anchor_valid = 1;
                 r->next_j = 1;

@@ -580,7 +580,7 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
     if (h->track || h->rs_n) {                                       // the general receiver's summaries and carry-ins
         HIPCHK(h, h->gsum.ensure(C * g.n_tiles * sizeof(TileSumG)));
         HIPCHK(h, h->gouts.ensure(C * g.n_tiles * sizeof(ScanOutG)));
-        HIPCHK(h, h->evg.ensure(C * g.n_tiles * EVCAP * sizeof(uint16_t)));
+        HIPCHK(h, h->evg.ensure(C * g.n_tiles * EVCAP * sizeof(uint32_t)));
     }
     return P25FE_OK;
 }
@@ -631,7 +631,7 @@ static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, 
     DetArgs d;
     d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = abs_bb0; d.n_tiles = (int)g.n_tiles;
     d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>(); d.evthr = h->evthr.as<float>();
-    d.opt = rc.opt; d.gsum = h->gsum.as<TileSumG>(); d.evg = h->evg.as<uint16_t>();
+    d.opt = rc.opt; d.gsum = h->gsum.as<TileSumG>(); d.evg = h->evg.as<uint32_t>();
     if (rc.gen) hipLaunchKernelGGL(k_detect<true>, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
     else hipLaunchKernelGGL(k_detect<false>, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
     HIPCHK(h, hipGetLastError());
@@ -660,7 +660,7 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         SliceArgsG l;
         l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = abs_bb0; l.n_tiles = n_tiles;
         l.outs = h->gouts.as<ScanOutG>(); l.gsum = h->gsum.as<TileSumG>(); l.recs = h->recs.as<TileRec>();
-        l.evl = h->evl.as<uint16_t>(); l.evg = h->evg.as<uint16_t>(); l.evthr = h->evthr.as<float>(); l.anchor_in = d_anchor_in;
+        l.evl = h->evl.as<uint16_t>(); l.evg = h->evg.as<uint32_t>(); l.evthr = h->evthr.as<float>(); l.anchor_in = d_anchor_in;
         l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
         l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
         l.sync_stride = (long)sync_stride; l.track = h->track;

@@ -1652,7 +1652,7 @@ __host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summari
         if (R.first_event >= 0 && tracks) {
             const long s0 = (long)R.first_event - W;
             int D0, N0;
-            clock_period(true, true, cur.s, s0, D0, N0);
+            clock_period(true, true, cur.s, frac3((unsigned)cur.valid >> 8), s0, frac3(R.reserved), D0, N0);
             own = own - (uint64_t)clock_count(s0, SPS, 1, s0 + W + 1, (long)R.first_seg_end) +
                   (uint64_t)clock_count(s0, D0, N0, s0 + W + 1, (long)R.first_seg_end);
         }
@@ -1661,7 +1661,8 @@ __host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summari
             if (R.anchor_out.valid) {
                 p25fe_anchor_t nxt = R.anchor_out;
                 if (nxt.period_n <= 0 || nxt.period_d <= 0) { nxt.period_d = SPS; nxt.period_n = 1; }
-                if (R.flags & P25FE_RES_OUT_PERIOD_FROM_CARRY) clock_period(track, tracks, cur.s, nxt.s, nxt.period_d, nxt.period_n);
+                if (R.flags & P25FE_RES_OUT_PERIOD_FROM_CARRY)
+                    clock_period(track, tracks, cur.s, frac3((unsigned)cur.valid >> 8), nxt.s, frac3((unsigned)nxt.valid >> 8), nxt.period_d, nxt.period_n);
                 cur = nxt;
             } else {
                 cur.valid = 0;

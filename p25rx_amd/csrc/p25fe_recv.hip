@@ -51,6 +51,8 @@ struct TileRec {            // per (channel, tile) summary written by K2
     float hi, mid, lo;      // thresholds of the last event
     int n_events;
     long post_count;        // instants in (first_event, tile_end) under the tile's own events
+    int last_f;             // quarter-sample fraction of the last event's sync position (SPEC 3.8b; 0 outside the general receiver)
+    int pad_;
 };
 
 // Packed per-tile summary for the scan (one coalesced 8-byte word per tile):
@@ -96,15 +98,36 @@ __host__ __device__ inline long count_instants(long s, long lo, long hi)
 // ------------------------------------------------------------------------------------------
 constexpr int CLK_L = P25FE_CLK_LOOKAHEAD;
 
-__host__ __device__ inline void clock_period(bool track, bool prev_valid, long s_prev, long s_new, int& D, int& N)
+// Fraction of a sync position in quarter samples (SPEC 3.8b): vertex of the parabola through the correlation peak c0 = c[s] and
+// its neighbours cl = c[s - 1], cr = c[s + 1]; -2 .. 2.  Only the PERIOD uses it; the anchor stays on the whole sample.
+__host__ __device__ inline int sync_frac(float cl, float c0, float cr)
+{
+    const float num = cl - cr, den = (cl - (c0 + c0)) + cr;
+    int f = 0;
+    if (den < 0.0f) {
+        const float q = (num * 0.5f) / den;
+        if (q == q) {
+            const float v = __builtin_floorf(q * 4.0f + 0.5f);
+            f = v < -2.0f ? -2 : v > 2.0f ? 2 : (int)v;
+        }
+    }
+    return f;
+}
+// the fraction travels in three bits (two's complement) of records that have them to spare
+__host__ __device__ inline int frac3(unsigned v) { return (int)((v & 7u) ^ 4u) - 4; }
+
+__host__ __device__ inline void clock_period(bool track, bool prev_valid, long s_prev, int f_prev, long s_new, int f_new, int& D, int& N)
 {
     D = SPS; N = 1;
     if (track && prev_valid) {
         const long dd = s_new - s_prev, nn = (dd + SPS / 2) / SPS;
         const long err = dd > SPS * nn ? dd - SPS * nn : SPS * nn - dd;
-        // (an interval of exactly 10 N samples IS the nominal clock: kept as 10 / 1, the same instants, so that the
-        // division-free paths below apply)
-        if (nn >= 1 && err != 0 && dd <= (1L << P25FE_CLK_DMAX_LOG2) && (err << P25FE_CLK_TOL_SHIFT) <= SPS * nn) { D = (int)dd; N = (int)nn; }
+        if (nn >= 1 && dd <= (1L << P25FE_CLK_DMAX_LOG2) && (err << P25FE_CLK_TOL_SHIFT) <= SPS * nn) {
+            const long d4 = 4 * dd + (f_new - f_prev);
+            // (an interval of exactly 10 N samples IS the nominal clock: kept as 10 / 1, the same instants, so that the
+            // division-free paths below apply)
+            if (d4 != 4 * SPS * nn) { D = (int)d4; N = (int)(4 * nn); }
+        }
     }
 }
 // number of instants j >= 1 of a clock (D, N) with floor(j D / N) < x
@@ -145,7 +168,7 @@ __device__ __forceinline__ long first_kill(const RecvOpt& o, int ch, long x)
 // Per-tile summary of the general receiver (K2 -> K3 / K4), 32 bytes
 struct TileSumG {
     unsigned pre_end1;          // (tile offset from which the carry-in anchor no longer governs) + 1; 0: the tile has no event of any kind
-    unsigned first1;            // first own detection's decision offset + 1; 0: none
+    unsigned first1;            // first own detection's decision offset + 1 (bits 0..15; 0: none) | its sync position's fraction (3 bits) << 16
     unsigned end0;              // tile offset (exclusive) at which the first detection's governed interval ends
     unsigned last1;             // last own detection's decision offset + 1
     unsigned n_det_flags;       // detections (low 16 bits) | flags << 16
@@ -251,7 +274,7 @@ struct DetArgs {
     // general receiver only (k_detect<true>)
     RecvOpt opt;
     TileSumG* gsum;         // [ch][n_tiles]
-    uint16_t* evg;          // [ch][n_tiles][EVCAP] per detection: end offset of its governed interval | (tracks its predecessor) << 15
+    uint32_t* evg;          // [ch][n_tiles][EVCAP] per detection: end offset of its governed interval | (tracks its predecessor) << 15 | fraction of its sync position (3 bits) << 16
 };
 
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
@@ -272,6 +295,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
     __shared__ uint16_t DETE[K2_DCAP];                           // per detection: decision offset ...
     __shared__ float DETT[K2_DCAP][3];                           // ... and thresholds
     __shared__ unsigned DETN;
+    __shared__ uint8_t FRO[GEN ? TS : 4];                         // GEN: per decision offset, the detection's position fraction (3 bits)
 
     const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
@@ -362,6 +386,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
 #pragma unroll
                     for (int i = 1; i <= W; ++i) det = det && (c0 > CN[q][W - i]) && (c0 >= CN[q][W + i]);
                     if (det) {
+                        if constexpr (GEN) FRO[ec] = (uint8_t)(sync_frac(CN[q][W - 1], c0, CN[q][W + 1]) & 7);
                         atomicOr(&EVB[ec >> 5], 1u << (ec & 31));
                         const unsigned di = atomicAdd(&DETN, 1u);
                         if (di < (unsigned)K2_DCAP) {
@@ -412,7 +437,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
     if (n_ev == 0) {
         if (lane == 0) {
             TileRec rc;
-            rc.first_event = -1; rc.last_s = -1; rc.hi = rc.mid = rc.lo = 0.f; rc.n_events = 0; rc.post_count = 0;
+            rc.first_event = -1; rc.last_s = -1; rc.hi = rc.mid = rc.lo = 0.f; rc.n_events = 0; rc.post_count = 0; rc.last_f = 0; rc.pad_ = 0;
             a.recs[(size_t)ch * a.n_tiles + tile] = rc;
             a.tsum[(size_t)ch * a.n_tiles + tile] = 0ull;
             if constexpr (GEN) {
@@ -462,14 +487,14 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         }
         if (lane == 0) TRK[0] = kill0 > T0 + first_off ? 1 : 0;
         phase_sync();
-        uint16_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+        uint32_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
         long rest = 0;
         for (int k = lane; k < n_ev; k += WV) {
-            evg[k] = (uint16_t)(ENDO[k] | (TRK[k] << 15));
+            evg[k] = (uint32_t)ENDO[k] | ((uint32_t)TRK[k] << 15) | ((uint32_t)FRO[EVS[k]] << 16);
             if (k >= 1) {
                 const long sk = T0 + EVS[k] - W, sp = T0 + EVS[k - 1] - W;
                 int D, N;
-                clock_period(a.opt.track != 0, TRK[k] != 0, sp, sk, D, N);
+                clock_period(a.opt.track != 0, TRK[k] != 0, sp, frac3(FRO[EVS[k - 1]]), sk, frac3(FRO[EVS[k]]), D, N);
                 rest += clock_count(sk, D, N, sk + W + 1, T0 + ENDO[k]);
             }
         }
@@ -478,7 +503,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
             TileSumG g;
             const long pe = kill0 < T0 + first_off + 1 ? kill0 : T0 + first_off + 1;
             g.pre_end1 = (unsigned)(pe - T0) + 1u;
-            g.first1 = (unsigned)first_off + 1u;
+            g.first1 = ((unsigned)first_off + 1u) | ((unsigned)FRO[first_off] << 16);
             g.end0 = ENDO[0];
             g.last1 = (unsigned)last_off + 1u;
             unsigned fl = TRK[0] ? G_FIRST_TRACKS : 0u;
@@ -486,7 +511,8 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
             g.out_D = SPS; g.out_N = 1;
             if (n_ev >= 2) {
                 fl |= G_OUT_PERIOD_KNOWN;
-                clock_period(a.opt.track != 0, TRK[n_ev - 1] != 0, T0 + EVS[n_ev - 2] - W, T0 + last_off - W, g.out_D, g.out_N);
+                clock_period(a.opt.track != 0, TRK[n_ev - 1] != 0, T0 + EVS[n_ev - 2] - W, frac3(FRO[EVS[n_ev - 2]]), T0 + last_off - W,
+                             frac3(FRO[last_off]), g.out_D, g.out_N);
             } else if (!a.opt.track || !TRK[0]) {
                 fl |= G_OUT_PERIOD_KNOWN;                          // nominal period: nothing to take it from
             }
@@ -524,6 +550,8 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         rc.hi = hi; rc.mid = mid; rc.lo = lo;
         rc.n_events = n_ev;
         rc.post_count = post;
+        rc.last_f = 0; rc.pad_ = 0;
+        if constexpr (GEN) rc.last_f = frac3(FRO[last_off]);
         a.recs[(size_t)ch * a.n_tiles + tile] = rc;
         a.tsum[(size_t)ch * a.n_tiles + tile] = pack_tsum(first_off, last_off, n_ev, post);
     }
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
     };
 
     TileRec last_rec;
-    last_rec.first_event = -1; last_rec.last_s = 0; last_rec.hi = last_rec.mid = last_rec.lo = 0.f; last_rec.n_events = 0; last_rec.post_count = 0;
+    last_rec.first_event = -1; last_rec.last_s = 0; last_rec.hi = last_rec.mid = last_rec.lo = 0.f; last_rec.n_events = 0; last_rec.post_count = 0; last_rec.last_f = 0; last_rec.pad_ = 0;
     bool have_last_rec = false;
     for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
         const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
@@ -912,6 +940,8 @@ struct ScanOutG {               // per (channel, tile) carry-in written by k_sca
     int src;                    // tile whose record holds that detection's thresholds; -1: the range's anchor_in; -2: not locked
     unsigned event_off;
     int D, N;                   // its clock
+    int f;                      // quarter-sample fraction of its sync position (enters the NEXT detection's period only)
+    int pad_;
 };
 
 struct ScanArgsG {
@@ -944,7 +974,7 @@ __device__ __forceinline__ Top2 top2_shfl_up(Top2 v, int d)
     return o;
 }
 
-struct CState { int valid; long s; int D, N; int src; };
+struct CState { int valid; long s; int D, N; int src; int f; };
 
 __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
 {
@@ -953,6 +983,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     // when they went to global memory (k_scan_g 45 us for config 2; 3 750 tiles)
     __shared__ TileSumG GS[KG_CHUNK];
     __shared__ long LS[KG_CHUNK];
+    __shared__ int LF[KG_CHUNK];
     __shared__ unsigned CNT[KG_CHUNK], PRE[KG_CHUNK];
     __shared__ Top2 sh2[NT3 / 64];
     __shared__ unsigned long long shu[NT3 / 64];
@@ -960,7 +991,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     __shared__ unsigned long long c_cnt, c_ev, c_base_first;
     __shared__ long c_first_event, c_carry_end, c_first_seg_end, c_first_seg_next;
     __shared__ unsigned c_flags;
-    __shared__ int c_has_event;
+    __shared__ int c_has_event, c_first_f;
 
     const int tid = threadIdx.x, ch = blockIdx.x, lane = tid & 63, wv = tid >> 6;
     const TileSumG* gsum = a.gsum + (size_t)ch * a.n_tiles;
@@ -973,26 +1004,28 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     const bool track = a.track != 0;
     if (tid == 0) {
         c_top.a = c_top.b = -1;
-        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_first_seg_next = -1; c_flags = 0u; c_has_event = 0;
+        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_first_seg_next = -1; c_flags = 0u; c_has_event = 0; c_first_f = 0;
     }
     __syncthreads();
 
     int cc0 = 0, ccn = 0;                                           // the chunk staged in LDS: tiles [cc0, cc0 + ccn)
     auto sum_of = [&](int t) -> TileSumG { return (t >= cc0 && t < cc0 + ccn) ? GS[t - cc0] : gsum[t]; };
     auto last_s_of = [&](int t) -> long { return (t >= cc0 && t < cc0 + ccn) ? LS[t - cc0] : recs[t].last_s; };
+    auto last_f_of = [&](int t) -> int { return (t >= cc0 && t < cc0 + ccn) ? LF[t - cc0] : recs[t].last_f; };
+    const int Ain_f = frac3((unsigned)Ain.valid >> 8);               // the carry-in's fraction rides in bits 8..10 of `valid`
     // state after event tile t1 (t2: the event tile before it, -1: the range's carry-in)
     auto state_after = [&](int t1, int t2) -> CState {
         CState st;
-        if (t1 < 0) { st.valid = Ain.valid; st.s = Ain.s; st.D = Ain.period_d; st.N = Ain.period_n; st.src = Ain.valid ? -1 : -2; return st; }
+        if (t1 < 0) { st.valid = Ain.valid != 0; st.s = Ain.s; st.D = Ain.period_d; st.N = Ain.period_n; st.src = Ain.valid ? -1 : -2; st.f = Ain_f; return st; }
         const TileSumG g = sum_of(t1);
         const unsigned fl = g.n_det_flags >> 16;
-        if (!(fl & G_OUT_VALID)) { st.valid = 0; st.s = 0; st.D = SPS; st.N = 1; st.src = -2; return st; }
-        st.valid = 1; st.src = t1; st.s = last_s_of(t1);
+        if (!(fl & G_OUT_VALID)) { st.valid = 0; st.s = 0; st.D = SPS; st.N = 1; st.src = -2; st.f = 0; return st; }
+        st.valid = 1; st.src = t1; st.s = last_s_of(t1); st.f = last_f_of(t1);
         if (fl & G_OUT_PERIOD_KNOWN) { st.D = g.out_D; st.N = g.out_N; return st; }
-        bool pv; long ps;
-        if (t2 >= 0) { pv = ((sum_of(t2).n_det_flags >> 16) & G_OUT_VALID) != 0; ps = pv ? last_s_of(t2) : 0; }
-        else { pv = Ain.valid != 0; ps = Ain.s; }
-        clock_period(track, pv, ps, st.s, st.D, st.N);
+        bool pv; long ps; int pf;
+        if (t2 >= 0) { pv = ((sum_of(t2).n_det_flags >> 16) & G_OUT_VALID) != 0; ps = pv ? last_s_of(t2) : 0; pf = pv ? last_f_of(t2) : 0; }
+        else { pv = Ain.valid != 0; ps = Ain.s; pf = Ain_f; }
+        clock_period(track, pv, ps, pf, st.s, st.f, st.D, st.N);
         return st;
     };
     auto tile_len = [&](int k) -> int {
@@ -1003,7 +1036,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     for (int c0 = 0; c0 < a.n_tiles; c0 += KG_CHUNK) {
         const int cn = (a.n_tiles - c0 < KG_CHUNK) ? a.n_tiles - c0 : KG_CHUNK;
         __syncthreads();                                            // the previous chunk's readers are done with GS / LS
-        for (int k = tid; k < cn; k += NT3) { GS[k] = gsum[c0 + k]; LS[k] = recs[c0 + k].last_s; }
+        for (int k = tid; k < cn; k += NT3) { GS[k] = gsum[c0 + k]; LS[k] = recs[c0 + k].last_s; LF[k] = recs[c0 + k].last_f; }
         cc0 = c0; ccn = cn;
         __syncthreads();
         const int per = (cn + NT3 - 1) / NT3;
@@ -1041,9 +1074,9 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
                 const unsigned pre = st.valid ? (unsigned)clock_count(st.s, st.D, st.N, T0, pre_hi) : 0u;
                 unsigned tot_k = pre;
                 if (g.first1) {
-                    const long s0 = T0 + (long)g.first1 - 1 - W;
+                    const long s0 = T0 + (long)(g.first1 & 0xffffu) - 1 - W;
                     int D0, N0;
-                    clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && st.valid, st.s, s0, D0, N0);
+                    clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && st.valid, st.s, st.f, s0, frac3(g.first1 >> 16), D0, N0);
                     tot_k += (unsigned)clock_count(s0, D0, N0, s0 + W + 1, T0 + g.end0) + g.post_rest;
                 }
                 PRE[k] = pre; CNT[k] = tot_k;
@@ -1061,7 +1094,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
             for (int k = k0; k < k1; ++k) {
                 const TileSumG g = GS[k];
                 ScanOutG o;
-                o.s = st.s; o.dibit_off = dc; o.src = st.src; o.event_off = (unsigned)ec; o.D = st.D; o.N = st.N;
+                o.s = st.s; o.dibit_off = dc; o.src = st.src; o.event_off = (unsigned)ec; o.D = st.D; o.N = st.N; o.f = st.f; o.pad_ = 0;
                 outs[c0 + k] = o;
                 if (g.pre_end1 && t2.a < 0) {                      // the range's first event tile (one thread finds it)
                     const long T0 = a.abs0 + (long)(c0 + k) * TS;
@@ -1073,7 +1106,8 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
                     // tile holds lock drops only) -- exactly one thread gets here with ec == 0
                     if (ec == 0) {
                         const long T0 = a.abs0 + (long)(c0 + k) * TS;
-                        c_first_event = T0 + (long)g.first1 - 1;
+                        c_first_event = T0 + (long)(g.first1 & 0xffffu) - 1;
+                        c_first_f = frac3(g.first1 >> 16);
                         c_first_seg_end = T0 + g.end0;              // inside its tile; an interval that is still open at the tile's end
                         c_base_first = dc + PRE[k];                 // runs on to the next event tile (c_first_seg_next) or the range's end
                         unsigned fl = 0u;
@@ -1110,7 +1144,8 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         p25fe_anchor_t A = Ain;
         if (st.src >= 0) {
             const TileRec t = recs[st.src];
-            A.valid = 1; A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo; A.period_d = st.D; A.period_n = st.N;
+            A.valid = 1 | ((st.f & 7) << 8);                         // bit 0: locked; bits 8..10: the sync position's fraction (SPEC 3.8b)
+            A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo; A.period_d = st.D; A.period_n = st.N;
         } else if (st.src == -2) {
             A.valid = 0;
         }
@@ -1133,7 +1168,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         unsigned fl = c_flags;
         // the clock the range ends on was taken from the carry-in: its only event is one tracking detection
         if (st.src >= 0 && c_top.b < 0 && !((gsum[c_top.a].n_det_flags >> 16) & G_OUT_PERIOD_KNOWN)) fl |= 2u;
-        r.flags = fl; r.reserved = 0u;
+        r.flags = fl; r.reserved = c_first_event >= 0 ? (unsigned)(c_first_f & 7) : 0u;     // the first own detection's fraction
         a.result[ch] = r;
     }
 }
@@ -1147,7 +1182,7 @@ struct SliceArgsG {
     const TileSumG* gsum;
     const TileRec* recs;
     const uint16_t* evl;
-    const uint16_t* evg;
+    const uint32_t* evg;
     const float* evthr;
     const p25fe_anchor_t* anchor_in;
     uint8_t* dibits;
@@ -1160,7 +1195,8 @@ struct SliceArgsG {
 
 __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
 {
-    __shared__ uint16_t EV[EVCAP], EG[EVCAP];
+    __shared__ uint16_t EV[EVCAP];
+    __shared__ uint32_t EG[EVCAP];
     __shared__ float ETH[EVTHR_N * 3];
     __shared__ float CI[P25FE_CLK_PHASES * 4];
     const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
@@ -1185,7 +1221,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
     if (track) for (int k = lane; k < P25FE_CLK_PHASES * 4; k += WV) CI[k] = P25FE_CLK_INTERP[k];
     if (n_ev) {
         const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
-        const uint16_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+        const uint32_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
         for (int k = lane; k < n_ev; k += WV) { EV[k] = evl[k]; EG[k] = evg[k]; }
         if (lane < EVTHR_N * 3) ETH[lane] = a.evthr[((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3) + lane];
     }
@@ -1239,8 +1275,8 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
         const long ek = T0 + EV[k], sk = ek - W;
         const unsigned eg = EG[k];
         int D, N;
-        if (k == 0) clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && valid, so.s, sk, D, N);
-        else clock_period(track, (eg >> 15) != 0, T0 + EV[k - 1] - W, sk, D, N);
+        if (k == 0) clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && valid, so.s, so.f, sk, frac3(eg >> 16), D, N);
+        else clock_period(track, ((eg >> 15) & 1u) != 0, T0 + EV[k - 1] - W, frac3(EG[k - 1] >> 16), sk, frac3(eg >> 16), D, N);
         float h, m, l;
         if (k < EVTHR_N) {
             h = ETH[3 * k]; m = ETH[3 * k + 1]; l = ETH[3 * k + 2];

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Experiment (numpy, CPU; not part of the product or the suite): the tracking clock of SPEC 3.8b with the PERIOD taken from
-sync positions refined to 1/8 sample (vertex of the parabola through the correlation peak and its two neighbours), the
-anchor itself staying on the whole sample.  Question: does it remove the small-ppm penalty of the whole-sample estimate?
-Prints symbol errors against the modulator for the fixed stride, SPEC 3.8b as built, and the refined period."""
+"""Experiment (numpy, CPU; not part of the product or the suite): the prototype sweep behind SPEC 3.8b's period rule -- the
+PERIOD taken from sync positions refined to 1 / `sub` sample (vertex of the parabola through the correlation peak and its two
+neighbours), the anchor itself staying on the whole sample.  It showed that this removes the small-ppm penalty of the
+whole-sample estimate and that quarter samples are enough; the rule is now built (oracle, tests/spec_model.py, kernels), so
+the middle column below (SPEC 3.8b as built) equals the `sub = 4` one.  Prints symbol errors against the modulator."""
 import os
 import sys
 

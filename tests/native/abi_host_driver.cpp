@@ -48,7 +48,7 @@ int main()
         summ[2].flags = P25FE_RES_FIRST_TRACKS_CARRY | P25FE_RES_OUT_PERIOD_FROM_CARRY;
         summ[2].anchor_out = p25fe_anchor_t{2503, 0.3f, 0.1f, -0.1f, 1, 0, 0};
         EXPECT(p25fe_shard_resolve(summ.data(), bb0, bbn, 4, 0, anc, off) == P25FE_OK && off[4] > off[3] && anc[3].s == 2503);
-        EXPECT(p25fe_shard_resolve(summ.data(), bb0, bbn, 4, 1, anc, off) == P25FE_OK && anc[3].period_d == 2201 && anc[3].period_n == 220);
+        EXPECT(p25fe_shard_resolve(summ.data(), bb0, bbn, 4, 1, anc, off) == P25FE_OK && anc[3].period_d == 4 * 2201 && anc[3].period_n == 4 * 220);
         EXPECT(p25fe_shard_resolve(nullptr, bb0, bbn, 4, 0, anc, off) == P25FE_ERR_ARG);
         EXPECT(p25fe_shard_resolve(summ.data(), bb0, bbn, 0, 0, anc, off) == P25FE_OK && off[0] == 0);
     }

@@ -97,6 +97,18 @@ class Model:
         tol, dmax, phases = 1 << int(spec["clk_tol_shift"]), 1 << int(spec["clk_dmax_log2"]), int(spec["clk_phases"])
         Ci = np.array(spec["clk_interp"], dtype=F).reshape(phases, 4)
         dets = [d for d in self.detections(b) if d[0] + self.W < n - L]
+        # fraction of every sync position in quarter samples: vertex of the parabola through c[s - 1], c[s], c[s + 1]
+        c = self._c
+        fr = []
+        for (s, _, _, _) in dets:
+            cl, c0, cr = (c[s - 1] if s > 0 else F(0.0)), c[s], c[s + 1]
+            num, den = F(cl - cr), F(F(cl - F(c0 + c0)) + cr)
+            f = 0
+            if den < 0:
+                q = F(F(num * F(0.5)) / den)
+                if q == q:
+                    f = int(min(max(np.floor(F(F(q * F(4.0)) + F(0.5))), -2), 2))
+            fr.append(f)
         ev = [(s + self.W + 1, 0, k) for k, (s, _, _, _) in enumerate(dets)] + [(min(max(int(q) - L, -L), n), 1, -1) for q in resync]
         ev.sort()
         bp = np.concatenate([np.zeros(2, dtype=F), b, np.zeros(4, dtype=F)])       # b[i] sits at bp[i + 2]
@@ -105,7 +117,7 @@ class Model:
         for t, kind, k in ev + [(n - L, 2, -1)]:
             t = min(t, n - L)
             if anchor is not None and t > start:
-                s, hi, mid, lo, D, N = anchor
+                s, hi, mid, lo, D, N, _ = anchor
                 # j with start <= s + (j D) div N < t, j >= 1
                 j = max(1, ((start - s) * N + D - 1) // D)
                 while s + (j * D) // N < start:
@@ -131,9 +143,11 @@ class Model:
                 if anchor is not None:                               # lock was held from the previous sync word to this one
                     delta = s - anchor[0]
                     Nn = (delta + 5) // 10
-                    if Nn >= 1 and delta <= dmax and abs(delta - 10 * Nn) * tol <= 10 * Nn and delta != 10 * Nn:
-                        D, N = delta, Nn
-                anchor = (s, hi, mid, lo, D, N)
+                    if Nn >= 1 and delta <= dmax and abs(delta - 10 * Nn) * tol <= 10 * Nn:
+                        d4 = 4 * delta + (fr[k] - anchor[6])
+                        if d4 != 40 * Nn:
+                            D, N = d4, 4 * Nn
+                anchor = (s, hi, mid, lo, D, N, fr[k])
                 spos.append(s)
                 sdib.append(sum(len(x) for x in dib))
             elif kind == 1:

@@ -113,18 +113,23 @@ def test_shard_resolve_host_logic(lib):
     assert anc["valid"].tolist() == [0, 1, 0, 1]
     e2 = exp1 + inst(302, 1000, 1500)
     assert off.tolist() == [0, exp1, e2, e2 + 49, e2 + 49 + inst(2503, 3000, 4000)]
-    # tracking clock: shard 2's one detection takes its period from the carry-in (2503 - 302 = 2201 -> 220 symbols, a
-    # period of 2201 / 220), which replaces the 10 / 1 that pass 1 assumed for its 49 dibits
+    # tracking clock: shard 2's one detection takes its period from the carry-in (2503 - 302 = 2201 -> 220 symbols; with the
+    # positions' quarter-sample fractions -- +1 for the carry, -2 for the detection -- a period of (4 * 2201 - 3) / (4 * 220)),
+    # which replaces the 10 / 1 that pass 1 assumed for its 49 dibits
     summ[1]["carry_end"] = -1
     summ[2]["first_seg_end"] = 3000 - 2
     summ[2]["flags"] = 3                                      # FIRST_TRACKS_CARRY | OUT_PERIOD_FROM_CARRY
+    summ[0]["anchor_out"]["valid"] = 1 | (1 << 8)             # fraction +1 in bits 8..10 of `valid`
+    summ[2]["anchor_out"]["valid"] = 1 | ((-2 & 7) << 8)      # fraction -2 (the shard's one detection is its anchor_out) ...
+    summ[2]["reserved"] = -2 & 7                              # ... and its first own detection
     assert L.p25fe_shard_resolve(p(summ), p(bb0), p(bbn), 4, 1, p(anc), p(off)) == 0
-    assert (int(anc["period_d"][3]), int(anc["period_n"][3])) == (2201, 220)
+    assert (int(anc["period_d"][3]), int(anc["period_n"][3])) == (4 * 2201 - 3, 4 * 220)
+    assert int(anc["valid"][3]) == 1 | ((-2 & 7) << 8)
     instq = lambda s, d, n, lo, hi: len([j for j in range(1, 2000) if lo <= s + (j * d) // n < hi and s + (j * d) // n > s + 5])
     t1 = 69                                                   # shard 0 ends 2 samples early: it owns [-2, 998)
     t2 = t1 + instq(302, 10, 1, 998, 1998)
-    t3 = t2 + instq(302, 10, 1, 1998, 2509) + 49 - instq(2503, 10, 1, 2509, 2998) + instq(2503, 2201, 220, 2509, 2998)
-    assert off.tolist() == [0, t1, t2, t3, t3 + instq(2503, 2201, 220, 2998, 3998)]
+    t3 = t2 + instq(302, 10, 1, 1998, 2509) + 49 - instq(2503, 10, 1, 2509, 2998) + instq(2503, 4 * 2201 - 3, 4 * 220, 2509, 2998)
+    assert off.tolist() == [0, t1, t2, t3, t3 + instq(2503, 4 * 2201 - 3, 4 * 220, 2998, 3998)]
 
 
 def test_cpp_host_driver_built_and_fails_loudly_without_gpu(lib, tmp_path):

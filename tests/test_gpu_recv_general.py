@@ -74,10 +74,12 @@ def test_tracking_clock_device_matches_oracle(O, FE, ppm, frame):
     # the range, not at the end of its 7 680-sample tile (sync words are further apart than a tile here)
     assert int(r["first_event"]) == int(ref[1][0]) + 5 and int(r["first_seg_end"]) == int(ref[1][1]) + 6
     a = r["anchor_out"]
+    # (the period is kept in quarter samples over four times the symbol count: docs/SPEC.md 3.8b)
     if ppm:
-        assert int(a["period_n"]) == frame and abs(int(a["period_d"]) - frame * 10 * (1 + ppm * 1e-6)) <= 1.5
+        assert int(a["period_n"]) == 4 * frame and abs(int(a["period_d"]) - 4 * frame * 10 * (1 + ppm * 1e-6)) <= 6
     else:
-        assert (int(a["period_d"]), int(a["period_n"])) in ((10, 1), (frame * 10, frame))
+        assert int(a["period_n"]) in (1, 4 * frame) and abs(int(a["period_d"]) / int(a["period_n"]) - 10.0) < 0.01
+    assert (int(a["valid"]) & 1) == 1 and -2 <= ((int(a["valid"]) >> 8) ^ 4) - 4 <= 2
     # fused: IQ -> dibits in one pass
     t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
     dib, res = fe.run_dev(t)
