@@ -557,7 +557,8 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
     }
 }
 
-template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 3 : 4) void k_detect(DetArgs a)
+// (GEN: 21 KB of LDS per one-wave workgroup -- the per-offset fraction table -- bounds it at 7 workgroups per CU)
+template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 2 : 4) void k_detect(DetArgs a)
 {
     detect_tile<GEN>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
