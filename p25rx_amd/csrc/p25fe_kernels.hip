@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const p25fe_result_t* result
     if (tid == 0) {
         p25fe_chan_stats_t o;
         o.sig_power_dbm = power_dbm ? power_dbm[ch] : __int_as_float(0x7fc00000);
-        o.locked = r.anchor_out.valid;
+        o.locked = r.anchor_out.valid != 0 ? 1 : 0;                 // (the tracking clock keeps a fraction in valid's upper bits)
         o.n_dibits = r.n_dibits;
         o.n_sync = r.n_sync;
         o.last_sync_pos = (r.n_sync > 0 && r.anchor_out.valid) ? r.anchor_out.s : -1;
