@@ -35,16 +35,21 @@
 #ifndef P25FE_H
 #define P25FE_H
 
+#ifndef __HIPCC_RTC__      /* (the library's own kernel source includes this header under hipRTC, which has no system headers) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 #define P25FE_MAX_TAPS 64
-#define P25FE_ABI_VERSION 3        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
-                                      flags in p25fe_result_t, p25fe_resync_at_dev, symbol_clock argument of p25fe_shard_resolve */
+#define P25FE_ABI_VERSION 4        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
+                                      flags in p25fe_result_t, p25fe_resync_at_dev, symbol_clock argument of p25fe_shard_resolve
+                                      4: the run-time arguments of the reference's constructors in the config (FM deviation / rate,
+                                      the u8 -> float LUT), `specialize`, p25fe_specialize / p25fe_kernel_variant,
+                                      p25fe_run_host_windows */
 
 typedef enum p25fe_status {
     P25FE_OK = 0,
@@ -53,7 +58,8 @@ typedef enum p25fe_status {
     P25FE_ERR_HIP = -3,        /* a HIP runtime call failed (see p25fe_last_hip_error) */
     P25FE_ERR_CAPACITY = -4,   /* output buffer too small; nothing consumed */
     P25FE_ERR_FORMAT = -5,     /* u8 / cf32 mixed within one stream */
-    P25FE_ERR_NOMEM = -6
+    P25FE_ERR_NOMEM = -6,
+    P25FE_ERR_JIT = -7         /* specialising the kernels failed (p25fe_specialize_log has the compiler's words) */
 } p25fe_status;
 
 typedef enum p25fe_format {
@@ -61,12 +67,17 @@ typedef enum p25fe_format {
     P25FE_FMT_U8 = 1           /* interleaved uint8 I,Q (RTL-SDR; src/demod.rs:74-76) */
 } p25fe_format;
 
-/* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54) and the
- * type-level tap tables of p25_filts (DecimFir / BandpassFir, src/demod.rs:27-29).  Up to
- * P25FE_MAX_TAPS = 64 taps per filter; a table of n taps is evaluated as 31 / 41 taps (64 / 64 as soon as either table is
- * longer) with zero coefficients at the old end: the same filter on finite samples; a NaN / Inf sample reaches that many
- * taps' worth of outputs (docs/SPEC.md 3.3).  The build's own tables (p25fe_default_config) run as immediate-coefficient
- * kernels; anything else up to 31 / 41 taps, and anything longer, as generic-tap kernels. */
+/* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54), the type-level tap tables of p25_filts
+ * (DecimFir / BandpassFir, src/demod.rs:27-29), the arguments of FmDemod::new (src/demod.rs:54) and the rtlsdr_iq::IQ lookup
+ * table (src/demod.rs:83).  Up to P25FE_MAX_TAPS = 64 taps per filter; a table of n taps is evaluated as 31 / 41 taps (64 / 64
+ * as soon as either table is longer) with zero coefficients at the old end: the same filter on finite samples; a NaN / Inf
+ * sample reaches that many taps' worth of outputs (docs/SPEC.md 3.3).
+ *
+ * Which kernels run (p25fe_kernel_variant): the build's own numbers (p25fe_default_config) run as the immediate-coefficient
+ * kernels compiled into the library.  ANY other table / constant set is compiled the same way -- the reference fixes its
+ * tables at compile time too (type-level FIRs, src/demod.rs:27-29) -- by hipRTC at p25fe_create (or ahead of time by
+ * p25fe_specialize) from the kernel source embedded in the library, cached on disk under a hash of the numbers; the
+ * generic kernels (taps broadcast-read from LDS, the LUT in LDS) are the fallback when that is switched off or fails. */
 typedef struct p25fe_config {
     int32_t abi_version;                 /* P25FE_ABI_VERSION */
     int32_t device;                      /* HIP device ordinal */
@@ -80,11 +91,31 @@ typedef struct p25fe_config {
                                             3.8b -- the stride is the measured interval between the last two sync words over its
                                             symbol count, instants are read by 4-tap interpolation, the receiver runs 2 samples
                                             behind the baseband */
-    int32_t reserved;
+    int32_t specialize;                  /* P25FE_SPECIALIZE_AUTO (0): non-default numbers get immediate-coefficient kernels (cache, then
+                                            hipRTC), the generic kernels if that fails; _OFF (-1): always the generic kernels for
+                                            non-default numbers; _REQUIRE (1): p25fe_create fails with P25FE_ERR_JIT instead of
+                                            falling back; _FORCE (2): as _REQUIRE, and the build's own numbers are specialised too
+                                            (measurement: the hipRTC product beside the library's own code object) */
+    /* ---- ABI 4 ---- */
+    uint32_t fm_deviation_hz;            /* FmDemod::new(5000, BASEBAND_SAMPLE_RATE), src/demod.rs:54: first argument */
+    uint32_t fm_sample_rate_hz;          /* ... second argument: the rate of the discriminator's input (src/consts.rs:13: 48 000) */
+    float fm_gain;                       /* 0 (default): the discriminator's output scale is (float)(fm_sample_rate_hz / (2 pi
+                                            fm_deviation_hz)), evaluated in double and rounded once (docs/SPEC.md 3.4); any other
+                                            finite value is used verbatim (a dump of demod_fm's own constant, tools/pin/) */
+    float u8_scale, u8_offset;           /* rtlsdr_iq::IQ (src/demod.rs:83) as arithmetic: byte b -> fma((float)b, u8_scale, u8_offset)
+                                            (docs/SPEC.md 3.1; defaults 2 / 255, -1) */
+    int32_t u8_lut_valid;                /* non-zero: u8_lut[b] IS the value of byte b (I and Q alike) and u8_scale / u8_offset are
+                                            ignored.  A table that equals fma(b, s, o) bit for bit for some (s, o) the library
+                                            finds runs as arithmetic; any other table is looked up in LDS. */
+    float u8_lut[256];
 } p25fe_config_t;
 
 #define P25FE_CLOCK_FIXED 0
 #define P25FE_CLOCK_TRACKING 1
+#define P25FE_SPECIALIZE_AUTO 0
+#define P25FE_SPECIALIZE_OFF (-1)
+#define P25FE_SPECIALIZE_REQUIRE 1
+#define P25FE_SPECIALIZE_FORCE 2
 
 typedef struct p25fe p25fe_t;
 
@@ -124,6 +155,21 @@ void p25fe_destroy(p25fe_t *h);
 const char *p25fe_strerror(int status);
 int p25fe_last_hip_error(const p25fe_t *h);      /* raw hipError_t of the last P25FE_ERR_HIP */
 int p25fe_device(const p25fe_t *h);              /* HIP device ordinal the handle lives on (p25fe_config_t.device); < 0: null handle */
+
+/* Which front-end kernels the handle launches: the library's own immediate-coefficient kernels (the config's numbers are
+ * the build's), kernels specialised for the config's numbers (cache / hipRTC), or the generic LDS-tap kernels. */
+#define P25FE_VARIANT_BUILTIN 0
+#define P25FE_VARIANT_SPECIALIZED 1
+#define P25FE_VARIANT_GENERIC 2
+int p25fe_kernel_variant(const p25fe_t *h);      /* < 0: null handle */
+/* Ahead-of-time form of what p25fe_create does for non-default numbers (the `make SPEC=` step; needs no GPU): compile the
+ * front-end kernels for cfg's tables and constants and store the code object as <dir>/p25fe-<hash>.hsaco (dir NULL: the
+ * cache directory -- $P25FE_CACHE_DIR, else $XDG_CACHE_HOME/p25fe, else $HOME/.cache/p25fe, else /tmp/p25fe-cache-<uid>;
+ * p25fe_create looks in $P25FE_SPEC_DIR first, then there).  path_out (nullable) receives the file name.  Returns P25FE_OK
+ * (also when cfg holds the build's own numbers: nothing to do, path_out = ""), P25FE_ERR_JIT or P25FE_ERR_ARG. */
+int p25fe_specialize(const p25fe_config_t *cfg, const char *dir, char *path_out, size_t path_cap);
+/* compiler log of the calling thread's last p25fe_specialize / p25fe_create; returns the length copied (NUL-terminated) */
+size_t p25fe_specialize_log(char *buf, size_t cap);
 
 /* ---- streaming, host buffers: the bodies of DemodTask::run and RecvTask::run ----------------
  * Multi-channel handles take channel-major buffers: channel c starts at c * (elements per

@@ -30,6 +30,7 @@ class Config(C.Structure):
         ("e_min", C.c_float), ("slice_frac", C.c_float),
         ("symbol_clock", C.c_int32), ("clk_lookahead", C.c_int32), ("clk_tol_shift", C.c_int32), ("clk_dmax_log2", C.c_int32),
         ("clk_interp", C.c_float * 256),
+        ("u8_offset", C.c_float), ("u8_lut_valid", C.c_int32), ("u8_lut", C.c_float * 256),
     ]
 
 
@@ -38,7 +39,15 @@ def load_spec(path=SPEC_JSON):
         return json.load(f)
 
 
-def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0):
+def fm_gain_from(deviation_hz, sample_rate_hz):
+    """FmDemod::new(deviation, sample_rate), src/demod.rs:54 -> output scale (docs/SPEC.md 3.4): evaluated in double, rounded once"""
+    return float(np.float32(float(sample_rate_hz) / (2.0 * np.pi * float(deviation_hz))))
+
+
+def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0, fm_deviation_hz=None, fm_sample_rate_hz=None,
+                fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None):
+    """The oracle's numbers: the build's (tests/golden/spec.json) unless overridden -- same keyword names and meaning as
+    the p25fe_config_t fields (p25rx_amd/_lib.make_config)."""
     s = spec or load_spec()
     c = Config()
     c.symbol_clock = symbol_clock
@@ -63,6 +72,19 @@ def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0):
         c.atan_c[i] = v
     c.sync_sign_mask = s["sync_sign_mask"]
     c.fm_gain, c.u8_scale, c.boxcar_scale = s["fm_gain"], s["u8_scale"], s["boxcar_scale"]
+    c.u8_offset = s["u8_offset"]
+    if fm_gain is not None and fm_gain != 0.0:
+        c.fm_gain = fm_gain
+    elif fm_deviation_hz is not None or fm_sample_rate_hz is not None:
+        c.fm_gain = fm_gain_from(fm_deviation_hz or s["fm_deviation_hz"], fm_sample_rate_hz or s["fm_sample_rate_hz"])
+    if u8_scale is not None:
+        c.u8_scale = u8_scale
+    if u8_offset is not None:
+        c.u8_offset = u8_offset
+    if u8_lut is not None:
+        c.u8_lut_valid = 1
+        for i, v in enumerate(np.asarray(u8_lut, dtype=np.float32)):
+            c.u8_lut[i] = v
     c.pi, c.half_pi = s["pi"], s["half_pi"]
     c.inv_npos, c.inv_nneg = s["sync_inv_npos"], s["sync_inv_nneg"]
     c.rho2_n, c.e_min, c.slice_frac = s["sync_rho2_n"], s["sync_e_min"], s["slice_frac"]

@@ -53,18 +53,27 @@ typedef struct {
     int32_t clk_lookahead;               /* samples the receiver runs behind the baseband in mode 1 (2) */
     int32_t clk_tol_shift, clk_dmax_log2;
     float clk_interp[64 * 4];            /* cubic-Lagrange weights of the samples at -1, 0, +1, +2, row q: mu = q / 64 */
+    /* rtlsdr_iq::IQ as a caller-supplied table (src/demod.rs:83): byte b -> u8_lut[b] when u8_lut_valid, else
+     * fma(b, u8_scale, u8_offset) */
+    float u8_offset;
+    int32_t u8_lut_valid;
+    float u8_lut[256];
 } p25o_config;
 
 /* ------------------------------------------------------------------------------------------
  * stage 1: rtlsdr_iq::IQ -- 65536-entry LUT indexed by the native-endian u16 made of two
  * consecutive bytes (src/demod.rs:74-76, 82-84).  Little endian: low byte = first byte = I.
- * Value (build-defined): fma((float)b, 2/255, -1).
+ * Value (build-defined): fma((float)b, 2/255, -1); scale / offset or the whole 256-entry table can be configured (the
+ * p25fe_config_t fields of the same names).
  * ---------------------------------------------------------------------------------------- */
-static void build_iq_lut(cf32 *lut, float scale)
+static void build_iq_lut(cf32 *lut, const p25o_config *c)
 {
+    float v[256];
+    for (uint32_t b = 0; b < 256u; b++)
+        v[b] = c->u8_lut_valid ? c->u8_lut[b] : fmaf((float)b, c->u8_scale, c->u8_offset);
     for (uint32_t s = 0; s < 65536u; s++) {
-        lut[s].re = fmaf((float)(s & 0xffu), scale, -1.0f);
-        lut[s].im = fmaf((float)(s >> 8), scale, -1.0f);
+        lut[s].re = v[s & 0xffu];
+        lut[s].im = v[s >> 8];
     }
 }
 
@@ -185,7 +194,7 @@ p25o_demod *p25o_demod_create(const p25o_config *cfg)
     p25o_demod *d = calloc(1, sizeof *d);
     d->cfg = *cfg;
     d->lut = malloc(sizeof(cf32) * 65536);
-    build_iq_lut(d->lut, cfg->u8_scale);
+    build_iq_lut(d->lut, cfg);
     fir_init(&d->decim, cfg->decim_taps, cfg->t1);       /* Decimator::new(5)  :50 */
     fir_init(&d->bandpass, cfg->chan_taps, cfg->t2);     /* FirFilter::new()   :51 */
     d->avg.len = cfg->boxcar;                            /* MovingAverage::new(10) :52 */

@@ -11,17 +11,21 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libp25fe.so")
 MAX_TAPS = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 FMT_CF32, FMT_U8 = 0, 1
 
-OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM, ERR_JIT = 0, -1, -2, -3, -4, -5, -6, -7
+SPECIALIZE_AUTO, SPECIALIZE_OFF, SPECIALIZE_REQUIRE, SPECIALIZE_FORCE = 0, -1, 1, 2
+VARIANT_BUILTIN, VARIANT_SPECIALIZED, VARIANT_GENERIC = 0, 1, 2
 
 
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_channels", C.c_int32),
                 ("n_decim_taps", C.c_int32), ("n_chan_taps", C.c_int32),
                 ("decim_taps", C.c_float * MAX_TAPS), ("chan_taps", C.c_float * MAX_TAPS),
-                ("symbol_clock", C.c_int32), ("reserved", C.c_int32)]
+                ("symbol_clock", C.c_int32), ("specialize", C.c_int32),
+                ("fm_deviation_hz", C.c_uint32), ("fm_sample_rate_hz", C.c_uint32), ("fm_gain", C.c_float),
+                ("u8_scale", C.c_float), ("u8_offset", C.c_float), ("u8_lut_valid", C.c_int32), ("u8_lut", C.c_float * 256)]
 
 
 class Anchor(C.Structure):
@@ -59,6 +63,7 @@ SYMBOLS = [
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
     "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
+    "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log",
 ]
 
 
@@ -99,6 +104,10 @@ def load():
     L.p25fe_strerror.restype = C.c_char_p
     L.p25fe_last_hip_error.argtypes = [vp]
     L.p25fe_device.argtypes = [vp]
+    L.p25fe_kernel_variant.argtypes = [vp]
+    L.p25fe_specialize.argtypes = [C.POINTER(Config), C.c_char_p, C.c_char_p, sz]
+    L.p25fe_specialize_log.argtypes = [C.c_char_p, sz]
+    L.p25fe_specialize_log.restype = sz
     L.p25fe_demod_u8.argtypes = [vp, vp, sz, vp, sz, psz, vp]
     L.p25fe_demod_cf32.argtypes = [vp, vp, sz, vp, sz, psz, vp]
     L.p25fe_slice.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp]
@@ -144,6 +153,55 @@ def default_config():
     cfg = Config()
     load().p25fe_default_config(C.byref(cfg))
     return cfg
+
+
+def specialize_log():
+    buf = C.create_string_buffer(1 << 16)
+    load().p25fe_specialize_log(buf, len(buf))
+    return buf.value.decode(errors="replace")
+
+
+def make_config(n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_clock=0, specialize=SPECIALIZE_AUTO,
+                fm_deviation_hz=None, fm_sample_rate_hz=None, fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None):
+    """p25fe_config_t from keyword arguments (None = the build's default)."""
+    cfg = default_config()
+    cfg.device, cfg.n_channels, cfg.symbol_clock, cfg.specialize = device, n_channels, symbol_clock, specialize
+    if decim_taps is not None:
+        cfg.n_decim_taps = len(decim_taps)                       # the library rejects counts above P25FE_MAX_TAPS
+        for i, v in enumerate(decim_taps[:MAX_TAPS]):
+            cfg.decim_taps[i] = v
+    if chan_taps is not None:
+        cfg.n_chan_taps = len(chan_taps)
+        for i, v in enumerate(chan_taps[:MAX_TAPS]):
+            cfg.chan_taps[i] = v
+    if fm_deviation_hz is not None:
+        cfg.fm_deviation_hz = int(fm_deviation_hz)
+    if fm_sample_rate_hz is not None:
+        cfg.fm_sample_rate_hz = int(fm_sample_rate_hz)
+    if fm_gain is not None:
+        cfg.fm_gain = float(fm_gain)
+    if u8_scale is not None:
+        cfg.u8_scale = float(u8_scale)
+    if u8_offset is not None:
+        cfg.u8_offset = float(u8_offset)
+    if u8_lut is not None:
+        lut = np.asarray(u8_lut, dtype=np.float32)
+        assert lut.shape == (256,)
+        cfg.u8_lut_valid = 1
+        for i in range(256):
+            cfg.u8_lut[i] = lut[i]
+    return cfg
+
+
+def specialize(cfg, directory=None):
+    """p25fe_specialize: compile (no GPU needed) and store the kernels for cfg's numbers; returns the file name ('' for the
+    build's own numbers)."""
+    L = load()
+    out = C.create_string_buffer(4096)
+    rc = L.p25fe_specialize(C.byref(cfg), directory.encode() if directory else None, out, len(out))
+    if rc != OK:
+        raise P25feError(rc, L.p25fe_strerror(rc).decode() + ": " + specialize_log()[-2000:])
+    return out.value.decode()
 
 
 def check(L, h, rc):

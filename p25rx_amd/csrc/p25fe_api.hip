@@ -6,6 +6,7 @@
 #include "p25fe_kernels.hip"
 
 #include <hip/hip_ext.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,7 +15,10 @@
 #include <mutex>
 #include <new>
 #include <utility>
+#include <string>
 #include <vector>
+
+#include "p25fe_jit.h"
 
 using namespace p25k;
 
@@ -106,11 +110,14 @@ struct p25fe {
     int C = 1;
     int last_hip = 0;
     int n_cu = 256;
-    Taps taps;
+    Taps taps;                             // resolved numbers: padded tables, the u8 table, the discriminator's scale
     int k1_p = 5;                          // FIR outputs per thread
-    bool default_taps = true;              // taps == p25fe_spec.h tables bit for bit -> immediate-coefficient kernels
+    int variant = P25FE_VARIANT_BUILTIN;   // which front-end kernels run (p25fe_kernel_variant)
     bool long_taps = false;                // more than P25FE_T1 / P25FE_T2 taps -> the 64 / 64 geometry (Geo<5, 1>)
-    DevBuf d_taps;                         // device copy for the generic kernels
+    bool u8_lut_mode = false;              // the u8 table is not affine: the specialised kernels look it up in LDS (the generic ones always do)
+    DevBuf d_taps;                         // device copy (generic kernels: everything; specialised ones: the u8 table, if not affine)
+    hipModule_t jit_mod = nullptr;         // specialised kernels (p25fe_jit.cpp): [format][linear, planar, chunk]
+    hipFunction_t jit_fn[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
     int track = 0;                         // p25fe_config_t.symbol_clock (docs/SPEC.md 3.8b)
@@ -133,9 +140,6 @@ struct p25fe {
     bool rx_joined_any[2] = {false, false};
     int lane = 0;
     bool ext_events = true;                // events ride on the kernel dispatches (hipExtLaunchKernelGGL) instead of separate records
-    bool k1_alt_on = false;                // two-stream step: every other call's K1 on a second stream (consecutive K1s are independent)
-    hipStream_t k1_alt = nullptr;
-    hipEvent_t ev_in = nullptr;
     int rx_cus = 0;                        // > 0: the receive stream is confined to this many CUs (hipExtStreamCreateWithCUMask)
     // stream state (per channel, channel-major in the device buffers)
     unsigned chunk_seq = 0;                // completion sequence number of the one-launch chunk calls
@@ -184,6 +188,100 @@ constexpr size_t MAX_RANGE_BB = (size_t)0x7ff00000u * 10u;
 constexpr int PROF_RING = 64;
 constexpr int PROF_SAMPLE = 8;
 
+// --------------------------------------------------------------------------------------------
+// p25fe_config_t -> the numbers the kernels run with.  No device needed (p25fe_specialize runs on a build host).
+// --------------------------------------------------------------------------------------------
+struct Resolved {
+    Taps taps;              // tables zero-padded to the evaluation length, the u8 table, the discriminator's scale
+    bool long_taps;         // 64 / 64 evaluation
+    bool lut_affine;        // the u8 table is fma(b, u8_scale, u8_offset) for every byte
+    float u8_scale, u8_offset;
+    bool dflt;              // every number is the build's own (p25fe_spec.h): the built-in immediate-coefficient kernels apply
+};
+
+static inline bool finite_f(float v) { return v - v == 0.0f; }
+static inline bool same_bits(float a, float b) { return memcmp(&a, &b, sizeof a) == 0; }
+
+static bool lut_is_affine(const float* lut, float sc, float of)
+{
+    for (int b = 0; b < 256; ++b)
+        if (!same_bits(lut[b], fmaf((float)b, sc, of))) return false;
+    return true;
+}
+
+static int resolve_config(const p25fe_config_t* cfg, Resolved* r)
+{
+    if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_decim_taps < 1 || cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 ||
+        cfg->n_chan_taps > P25FE_MAX_TAPS || (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING) ||
+        cfg->specialize < P25FE_SPECIALIZE_OFF || cfg->specialize > P25FE_SPECIALIZE_FORCE)
+        return P25FE_ERR_ARG;
+    memset(&r->taps, 0, sizeof r->taps);                             // zero padding at the old end is bit-neutral on finite samples
+    for (int k = 0; k < cfg->n_decim_taps; ++k) { if (!finite_f(cfg->decim_taps[k])) return P25FE_ERR_ARG; r->taps.dec[k] = cfg->decim_taps[k]; }
+    for (int k = 0; k < cfg->n_chan_taps; ++k) { if (!finite_f(cfg->chan_taps[k])) return P25FE_ERR_ARG; r->taps.ch[k] = cfg->chan_taps[k]; }
+    r->long_taps = cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps > P25FE_T2;
+    // FmDemod::new(deviation, sample_rate), src/demod.rs:54 -> output scale (docs/SPEC.md 3.4)
+    if (cfg->fm_gain != 0.0f) {
+        if (!finite_f(cfg->fm_gain)) return P25FE_ERR_ARG;
+        r->taps.fm_gain = cfg->fm_gain;
+    } else {
+        if (cfg->fm_deviation_hz == 0 || cfg->fm_sample_rate_hz == 0) return P25FE_ERR_ARG;
+        r->taps.fm_gain = (float)((double)cfg->fm_sample_rate_hz / (2.0 * M_PI * (double)cfg->fm_deviation_hz));
+    }
+    // rtlsdr_iq::IQ, src/demod.rs:83 (docs/SPEC.md 3.1)
+    if (cfg->u8_lut_valid) {
+        for (int b = 0; b < 256; ++b) { if (!finite_f(cfg->u8_lut[b])) return P25FE_ERR_ARG; r->taps.lut[b] = cfg->u8_lut[b]; }
+        // a table that IS an fma of the byte runs as arithmetic: the caller's own pair first, then the two obvious fits
+        const float* L = r->taps.lut;
+        const float cand[3][2] = {{cfg->u8_scale, cfg->u8_offset}, {L[1] - L[0], L[0]},
+                                  {(float)(((double)L[255] - (double)L[0]) / 255.0), L[0]}};
+        r->lut_affine = false;
+        for (int c = 0; c < 3 && !r->lut_affine; ++c)
+            if (finite_f(cand[c][0]) && finite_f(cand[c][1]) && lut_is_affine(L, cand[c][0], cand[c][1])) {
+                r->lut_affine = true; r->u8_scale = cand[c][0]; r->u8_offset = cand[c][1];
+            }
+        if (!r->lut_affine) r->u8_scale = r->u8_offset = 0.0f;
+    } else {
+        if (!finite_f(cfg->u8_scale) || !finite_f(cfg->u8_offset)) return P25FE_ERR_ARG;
+        r->lut_affine = true; r->u8_scale = cfg->u8_scale; r->u8_offset = cfg->u8_offset;
+        for (int b = 0; b < 256; ++b) r->taps.lut[b] = fmaf((float)b, cfg->u8_scale, cfg->u8_offset);
+    }
+    Taps def;
+    memset(&def, 0, sizeof def);
+    memcpy(def.dec, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
+    memcpy(def.ch, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
+    r->dflt = !r->long_taps && memcmp(def.dec, r->taps.dec, sizeof def.dec) == 0 && memcmp(def.ch, r->taps.ch, sizeof def.ch) == 0 &&
+              same_bits(r->taps.fm_gain, P25FE_FM_GAIN) && r->lut_affine && same_bits(r->u8_scale, P25FE_U8_SCALE) &&
+              same_bits(r->u8_offset, P25FE_U8_OFFSET);
+    return P25FE_OK;
+}
+
+static p25jit::Spec jit_spec(const Resolved& r)
+{
+    p25jit::Spec s;
+    memset(&s, 0, sizeof s);
+    s.tx = r.long_taps ? 1 : 0;
+    s.t1 = r.long_taps ? TMAX : T1;
+    s.t2 = r.long_taps ? TMAX : T2;
+    memcpy(s.dec, r.taps.dec, sizeof s.dec);
+    memcpy(s.ch, r.taps.ch, sizeof s.ch);
+    s.fm_gain = r.taps.fm_gain;
+    s.u8_lut = r.lut_affine ? 0 : 1;
+    s.u8_scale = r.u8_scale; s.u8_offset = r.u8_offset;
+    return s;
+}
+
+static thread_local std::string t_jit_log;          // compiler log of this thread's last p25fe_create / p25fe_specialize
+
+// Where specialised code objects are looked for: $P25FE_SPEC_DIR (a deployment's ahead-of-time directory), then the cache.
+static std::vector<std::string> jit_dirs()
+{
+    std::vector<std::string> d;
+    const char* e = getenv("P25FE_SPEC_DIR");
+    if (e && *e) d.push_back(e);
+    d.push_back(p25jit::default_cache_dir());
+    return d;
+}
+
 #define HIPCHK(h, expr)                                                        \
     do {                                                                       \
         hipError_t e__ = (expr);                                               \
@@ -203,6 +301,13 @@ void p25fe_default_config(p25fe_config_t* cfg)
     cfg->n_chan_taps = P25FE_T2;
     memcpy(cfg->decim_taps, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
     memcpy(cfg->chan_taps, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
+    cfg->specialize = P25FE_SPECIALIZE_AUTO;
+    cfg->fm_deviation_hz = P25FE_FM_DEVIATION_HZ;                    // FmDemod::new(5000, BASEBAND_SAMPLE_RATE), src/demod.rs:54
+    cfg->fm_sample_rate_hz = P25FE_FM_SAMPLE_RATE_HZ;
+    cfg->fm_gain = 0.0f;                                             // derived from the two
+    cfg->u8_scale = P25FE_U8_SCALE;
+    cfg->u8_offset = P25FE_U8_OFFSET;
+    cfg->u8_lut_valid = 0;
 }
 
 const char* p25fe_strerror(int status)
@@ -215,12 +320,44 @@ const char* p25fe_strerror(int status)
     case P25FE_ERR_CAPACITY: return "output buffer too small";
     case P25FE_ERR_FORMAT: return "sample format changed within a stream";
     case P25FE_ERR_NOMEM: return "out of memory";
+    case P25FE_ERR_JIT: return "kernel specialisation failed (p25fe_specialize_log)";
     default: return "unknown status";
     }
 }
 
 int p25fe_last_hip_error(const p25fe_t* h) { return h ? h->last_hip : 0; }
 int p25fe_device(const p25fe_t* h) { return h ? h->cfg.device : -1; }
+int p25fe_kernel_variant(const p25fe_t* h) { return h ? h->variant : -1; }
+
+size_t p25fe_specialize_log(char* buf, size_t cap)
+{
+    if (!buf || cap == 0) return 0;
+    const size_t n = t_jit_log.size() < cap - 1 ? t_jit_log.size() : cap - 1;
+    memcpy(buf, t_jit_log.data(), n);
+    buf[n] = '\0';
+    return n;
+}
+
+int p25fe_specialize(const p25fe_config_t* cfg, const char* dir, char* path_out, size_t path_cap)
+{
+    if (!cfg) return P25FE_ERR_ARG;
+    if (path_out && path_cap) path_out[0] = '\0';
+    Resolved r;
+    const int rc = resolve_config(cfg, &r);
+    if (rc) return rc;
+    if (r.dflt && cfg->specialize != P25FE_SPECIALIZE_FORCE) return P25FE_OK;   // the library's own kernels carry these numbers
+    try {
+        t_jit_log.clear();
+        const std::string d = (dir && *dir) ? std::string(dir) : p25jit::default_cache_dir();
+        std::vector<char> code;
+        std::string path;
+        if (!p25jit::get_code(jit_spec(r), {d}, true, d, code, path, t_jit_log) || path.empty()) return P25FE_ERR_JIT;
+        if (path_out && path_cap) snprintf(path_out, path_cap, "%s", path.c_str());
+    } catch (...) {
+        return P25FE_ERR_NOMEM;
+    }
+    return P25FE_OK;
+}
 
 size_t p25fe_n_baseband(uint64_t abs0, size_t n)
 {
@@ -251,10 +388,9 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
 {
     if (!cfg || !out) return P25FE_ERR_ARG;
     *out = nullptr;
-    if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_channels > 65535 /* grid.y */ || cfg->n_decim_taps < 1 ||
-        cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 || cfg->n_chan_taps > P25FE_MAX_TAPS ||
-        (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING))
-        return P25FE_ERR_ARG;
+    if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_channels < 1 || cfg->n_channels > 65535 /* grid.y */) return P25FE_ERR_ARG;
+    Resolved rs;
+    if (int rrc = resolve_config(cfg, &rs)) return rrc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return P25FE_ERR_NO_DEVICE;
@@ -270,16 +406,11 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     h->track = cfg->symbol_clock;
     h->look = cfg->symbol_clock ? CLK_L : 0;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    memset(&h->taps, 0, sizeof h->taps);                 // zero padding at the old end is bit-neutral
-    memcpy(h->taps.dec, cfg->decim_taps, sizeof(float) * (size_t)cfg->n_decim_taps);
-    memcpy(h->taps.ch, cfg->chan_taps, sizeof(float) * (size_t)cfg->n_chan_taps);
+    h->taps = rs.taps;
+    h->long_taps = rs.long_taps;
+    h->u8_lut_mode = !rs.lut_affine;
+    h->variant = rs.dflt ? P25FE_VARIANT_BUILTIN : P25FE_VARIANT_GENERIC;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return P25FE_ERR_HIP; }
-    Taps def;
-    memset(&def, 0, sizeof def);
-    memcpy(def.dec, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
-    memcpy(def.ch, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
-    h->default_taps = memcmp(&def, &h->taps, sizeof def) == 0;
-    h->long_taps = cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps > P25FE_T2;
     hipError_t e = hipSuccess;
     {
         const char* pv = getenv("P25FE_K1_P");            // tuning knob: FIR outputs per lane (5 default, 3)
@@ -290,37 +421,50 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
         h->ext_events = !(ee && atoi(ee) == 0);
         const char* rc_ = getenv("P25FE_RX_CUS");
         h->rx_cus = rc_ ? atoi(rc_) : 0;
-        const char* ka = getenv("P25FE_PIPE_K1ALT");
-        h->k1_alt_on = ka && atoi(ka) != 0;
     }
-    auto set_lds = [&](const void* f, size_t bytes) {
-        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes + 32768);   // (+ room for P25FE_K1_LDS_PAD)
-    };
-#define P25FE_FOR_K1(PK)                                                                                  \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK>), Geo<PK>::LDS_BYTES);    \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK>), Geo<PK>::LDS_BYTES);   \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK>), Geo<PK>::LDS_BYTES);      \
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK>), Geo<PK>::LDS_BYTES);
-    P25FE_FOR_K1(5)
-    P25FE_FOR_K1(3)
-#undef P25FE_FOR_K1
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_LINEAR, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_LINEAR, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OUT_PLANAR>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_CF32, true, 0>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_CF32, false, 0>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_U8, true, 0>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_U8, false, 0>), Geo<5>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_CF32, false, 1>), Geo<5, 1>::LDS_BYTES);
-    set_lds(reinterpret_cast<const void*>(&k_chunk<P25FE_FMT_U8, false, 1>), Geo<5, 1>::LDS_BYTES);
     if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); h->d_taps.release(); delete h; return P25FE_ERR_HIP; }
+    // Numbers other than the build's own: the same kernels with THOSE numbers as immediates (cached code object, else
+    // hipRTC -- seconds, once per set of numbers and library build); the generic LDS-tap kernels if that is off or fails.
+    // P25FE_JIT=0 in the environment switches the AUTO mode off for a whole process.
+    static const bool jit_env_off = [] { const char* v = getenv("P25FE_JIT"); return v && atoi(v) == 0; }();
+    const bool must = cfg->specialize >= P25FE_SPECIALIZE_REQUIRE;
+    const bool want_jit = (!rs.dflt || cfg->specialize == P25FE_SPECIALIZE_FORCE) && cfg->specialize != P25FE_SPECIALIZE_OFF && !(jit_env_off && !must);
+    if (want_jit) {
+        bool ok = false;
+        try {
+            t_jit_log.clear();
+            std::vector<char> code;
+            std::string path;
+            const std::string store = p25jit::default_cache_dir();
+            if (p25jit::get_code(jit_spec(rs), jit_dirs(), true, store, code, path, t_jit_log)) {
+                hipError_t me = hipModuleLoadData(&h->jit_mod, code.data());
+                if (me != hipSuccess && !path.empty()) {
+                    // a stale or damaged cache entry: compile afresh, replace it
+                    (void)hipGetLastError();
+                    t_jit_log += "cached code object " + path + " did not load: recompiling\n";
+                    (void)remove(path.c_str());
+                    h->jit_mod = nullptr;
+                    if (p25jit::get_code(jit_spec(rs), {}, true, store, code, path, t_jit_log)) me = hipModuleLoadData(&h->jit_mod, code.data());
+                }
+                ok = me == hipSuccess;
+                for (int f = 0; f < 2 && ok; ++f)
+                    for (int k = 0; k < 3 && ok; ++k)
+                        ok = hipModuleGetFunction(&h->jit_fn[f][k], h->jit_mod, p25jit::KERNEL_NAMES[f][k]) == hipSuccess;
+                if (!ok) { (void)hipGetLastError(); t_jit_log += "loading the specialised code object failed\n"; }
+            }
+        } catch (...) {
+            ok = false;
+        }
+        if (ok) {
+            h->variant = P25FE_VARIANT_SPECIALIZED;
+        } else {
+            if (h->jit_mod) { (void)hipModuleUnload(h->jit_mod); h->jit_mod = nullptr; }
+            if (must) { p25fe_destroy(h); return P25FE_ERR_JIT; }
+            h->variant = rs.dflt ? P25FE_VARIANT_BUILTIN : P25FE_VARIANT_GENERIC;
+        }
+    }
     int rc = p25fe_reset(h);
     if (rc != P25FE_OK) { p25fe_destroy(h); return rc; }
     *out = h;
@@ -333,8 +477,7 @@ void p25fe_destroy(p25fe_t* h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     if (h->rx_stream) { (void)hipStreamSynchronize(h->rx_stream); (void)hipStreamDestroy(h->rx_stream); }
-    if (h->k1_alt) { (void)hipStreamSynchronize(h->k1_alt); (void)hipStreamDestroy(h->k1_alt); }
-    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->jit_mod) (void)hipModuleUnload(h->jit_mod);
     for (int l = 0; l < 2; ++l) {
         if (h->ev_k1[l]) (void)hipEventDestroy(h->ev_k1[l]);
         if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
@@ -384,25 +527,6 @@ static void prof_k1_events(p25fe_t* h, hipEvent_t* e0, hipEvent_t* e1)
 // --------------------------------------------------------------------------------------------
 // internal launchers
 // --------------------------------------------------------------------------------------------
-// Resident one-wave workgroups per CU of a K1 instantiation (occupancy query, cached per kernel and LDS size).
-static int k1_slots_per_cu(const void* kern, size_t lds)
-{
-    static std::mutex mu;
-    static std::map<std::pair<const void*, size_t>, int> cache;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find({kern, lds});
-    if (it != cache.end()) return it->second;
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, WV, lds) != hipSuccess || nb <= 0) nb = 8;
-    // the query is advisory (observed: 12 for a 13.4-KB workgroup, of which only 11 fit 160 KB): bound it by the LDS
-    const size_t lds_alloc = (lds + 511) / 512 * 512;
-    if (lds_alloc > 0 && (size_t)nb > 163840 / lds_alloc) nb = (int)(163840 / lds_alloc);
-    static const int slots_env = [] { const char* e = getenv("P25FE_K1_SLOTS"); return e ? atoi(e) : 0; }();
-    if (slots_env > 0) nb = slots_env;
-    cache[{kern, lds}] = nb;
-    return nb;
-}
-
 static int ensure_chunk_scratch(p25fe_t* h)
 {
     if (h->chunk_cnt.p) return P25FE_OK;
@@ -438,7 +562,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     // 0.23-0.27 ms depending on the box -- neighbouring workgroups then stream neighbouring DRAM pages and the
     // dispatcher balances the CUs, which outweighs recomputing the 50-sample filter halo once per segment (5.5 % at
     // 3 sub-tiles; A/B on one box, three rounds: 2 -> 0.275, 3 -> 0.264, 4 -> 0.269 ms).  P25FE_SUBS overrides.
-    const int pk = (planar || h->long_taps) ? 5 : h->k1_p;
+    const int pk = (planar || h->long_taps || h->variant == P25FE_VARIANT_SPECIALIZED) ? 5 : h->k1_p;
     const int t1 = h->long_taps ? TMAX : T1;
     const long sub = (long)WV * pk;
     static const long subs_env = [] { const char* e = getenv("P25FE_SUBS"); return e ? atol(e) : 0L; }();
@@ -491,72 +615,61 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
         HIPCHK(h, h->power_partial.ensure(sizeof(float) * (size_t)h->C * (size_t)n_seg));
         a.power_partial = h->power_partial.as<float>();
     }
-    // One workgroup (= one wave) per resident wave slot; the kernel walks the (segment, channel) items in a grid-stride loop.
-    // P25FE_K1_PERSIST=0 (experiments): one workgroup per item, the round-1 / round-2 launch shape.
-    static const int persist_env = [] { const char* e = getenv("P25FE_K1_PERSIST"); return e ? atoi(e) : 0; }();
     const long n_items = seg_count * (long)h->C;
     if (n_items > 0x7fffffffL) return P25FE_ERR_ARG;
-    auto k1_grid = [&](const void* kern, size_t lds) -> dim3 {
-        if (persist_env > 0) {
-            const long slots = (long)k1_slots_per_cu(kern, lds) * h->n_cu * persist_env;
-            if (slots > 0 && slots < n_items && slots != seg_count) return dim3((unsigned)slots);
-        }
-        return dim3((unsigned)seg_count, (unsigned)h->C);             // one workgroup per item
-    };
     const Taps* dt = h->d_taps.as<Taps>();
-#define P25FE_LAUNCH_K1(PK, OM)                                                                                           \
-    do {                                                                                                                  \
-        const size_t lds = Geo<PK>::LDS_BYTES - (h->default_taps ? lds_taps_trim : 0) + lds_pad_env;                     \
-        if (fmt == P25FE_FMT_CF32) {                                                                                      \
-            if (h->default_taps) launch_ev(k_frontend<P25FE_FMT_CF32, true, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, true, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);  \
-            else launch_ev(k_frontend<P25FE_FMT_CF32, false, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);                 \
-        } else {                                                                                                          \
-            if (h->default_taps) launch_ev(k_frontend<P25FE_FMT_U8, true, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, true, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);    \
-            else launch_ev(k_frontend<P25FE_FMT_U8, false, PK, OM>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, PK, OM>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);                   \
-        }                                                                                                                 \
-    } while (0)
+    const bool u8 = fmt == P25FE_FMT_U8;
+    const dim3 grid((unsigned)seg_count, (unsigned)h->C);            // one one-wave workgroup per (segment, channel)
+    // LDS per workgroup: [d carry | window] (+ taps: generic kernels) (+ the u8 table: generic u8 kernels, and specialised ones
+    // whose table is not affine).  Immediate-coefficient kernels never touch the taps area at the end of the layout: not
+    // allocated.  (13 376 B per wave is 11 waves per CU; a 12th would need 13 312 -- trimming to that changed nothing.)
+    const bool ct = h->variant != P25FE_VARIANT_GENERIC;
+    const bool lut = u8 && (!ct || h->u8_lut_mode);
+    size_t lds = h->long_taps ? Geo<5, 1>::LDS_BYTES : (pk == 3 ? Geo<3>::LDS_BYTES : Geo<5>::LDS_BYTES);
+    if (lut) lds += sizeof(float) * 256;
+    else if (ct) lds -= sizeof(float) * (size_t)((h->long_taps ? 2 * TMAX : T1 + T2) + 3);
     // (experiments: extra dynamic LDS per workgroup = fewer resident waves per CU; the occupancy sensitivity of docs/MEASUREMENTS.md)
     static const size_t lds_pad_env = [] { const char* e = getenv("P25FE_K1_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    // immediate-tap kernels never touch the taps area at the end of the LDS layout: do not allocate it.  (13 376 B per
-    // wave is still 11 waves per CU: a 12th would need 13 312; trimming to that in an experiment changed nothing.)
-    constexpr size_t lds_taps_trim = sizeof(float) * (T1 + T2 + 3);
-#define P25FE_LAUNCH_K1_LONG(OM)                                                                                          \
-    do {                                                                                                                  \
-        const size_t lds = Geo<5, 1>::LDS_BYTES;                                                                          \
-        if (fmt == P25FE_FMT_CF32) launch_ev(k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_CF32, false, 5, OM, 1>), lds), dim3(WV), lds, st, ev0, ev1, a, dt); \
-        else launch_ev(k_frontend<P25FE_FMT_U8, false, 5, OM, 1>, k1_grid(reinterpret_cast<const void*>(&k_frontend<P25FE_FMT_U8, false, 5, OM, 1>), lds), dim3(WV), lds, st, ev0, ev1, a, dt);    \
-    } while (0)
+    lds += lds_pad_env;
+    ChunkTail tail;
     if (chunk) {
         if (!planar || part) return P25FE_ERR_ARG;
         int rc = ensure_chunk_scratch(h);
         if (rc) return rc;
-        ChunkTail t;
-        t.r = *chunk; t.counter = h->chunk_cnt.as<unsigned>(); t.wg_per_ch = (int)seg_count;
-        const dim3 grid((unsigned)seg_count, (unsigned)h->C);
-        if (h->long_taps) {
-            const size_t lds = Geo<5, 1>::LDS_BYTES;
-            if (fmt == P25FE_FMT_CF32) hipLaunchKernelGGL((k_chunk<P25FE_FMT_CF32, false, 1>), grid, dim3(WV), lds, st, a, dt, t);
-            else hipLaunchKernelGGL((k_chunk<P25FE_FMT_U8, false, 1>), grid, dim3(WV), lds, st, a, dt, t);
-        } else {
-            const size_t lds = Geo<5>::LDS_BYTES;
-            if (fmt == P25FE_FMT_CF32) {
-                if (h->default_taps) hipLaunchKernelGGL((k_chunk<P25FE_FMT_CF32, true, 0>), grid, dim3(WV), lds, st, a, dt, t);
-                else hipLaunchKernelGGL((k_chunk<P25FE_FMT_CF32, false, 0>), grid, dim3(WV), lds, st, a, dt, t);
-            } else {
-                if (h->default_taps) hipLaunchKernelGGL((k_chunk<P25FE_FMT_U8, true, 0>), grid, dim3(WV), lds, st, a, dt, t);
-                else hipLaunchKernelGGL((k_chunk<P25FE_FMT_U8, false, 0>), grid, dim3(WV), lds, st, a, dt, t);
-            }
-        }
-        HIPCHK(h, hipGetLastError());
-        return P25FE_OK;
+        tail.r = *chunk; tail.counter = h->chunk_cnt.as<unsigned>(); tail.wg_per_ch = (int)seg_count;
     }
-    if (h->long_taps && planar) P25FE_LAUNCH_K1_LONG(OUT_PLANAR);
-    else if (h->long_taps) P25FE_LAUNCH_K1_LONG(OUT_LINEAR);
-    else if (planar) P25FE_LAUNCH_K1(5, OUT_PLANAR);
-    else if (pk == 3) P25FE_LAUNCH_K1(3, OUT_LINEAR);
-    else P25FE_LAUNCH_K1(5, OUT_LINEAR);
-#undef P25FE_LAUNCH_K1_LONG
-#undef P25FE_LAUNCH_K1
+    if (h->variant == P25FE_VARIANT_SPECIALIZED) {
+        // kernels compiled for this handle's numbers (p25fe_jit.cpp): same source, same launch shape, C entry points
+        hipFunction_t f = h->jit_fn[u8 ? 1 : 0][chunk ? 2 : (planar ? 1 : 0)];
+        void* params[3] = {&a, &dt, &tail};
+        if (ev0 || ev1)
+            HIPCHK(h, hipExtModuleLaunchKernel(f, grid.x * WV, grid.y, 1, WV, 1, 1, lds, st, params, nullptr, ev0, ev1, 0));
+        else
+            HIPCHK(h, hipModuleLaunchKernel(f, grid.x, grid.y, 1, WV, 1, 1, (unsigned)lds, st, params, nullptr));
+    } else {
+#define P25FE_K1_CASE(FMT, CT, PK, OM, TX) launch_ev(k_frontend<FMT, CT, PK, OM, TX>, grid, dim3(WV), lds, st, ev0, ev1, a, dt)
+#define P25FE_CHUNK_CASE(FMT, CT, TX) hipLaunchKernelGGL((k_chunk<FMT, CT, TX>), grid, dim3(WV), lds, st, a, dt, tail)
+        if (chunk) {
+            if (h->long_taps) { if (u8) P25FE_CHUNK_CASE(P25FE_FMT_U8, false, 1); else P25FE_CHUNK_CASE(P25FE_FMT_CF32, false, 1); }
+            else if (ct) { if (u8) P25FE_CHUNK_CASE(P25FE_FMT_U8, true, 0); else P25FE_CHUNK_CASE(P25FE_FMT_CF32, true, 0); }
+            else { if (u8) P25FE_CHUNK_CASE(P25FE_FMT_U8, false, 0); else P25FE_CHUNK_CASE(P25FE_FMT_CF32, false, 0); }
+        } else if (h->long_taps) {
+            if (planar) { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, false, 5, OUT_PLANAR, 1); else P25FE_K1_CASE(P25FE_FMT_CF32, false, 5, OUT_PLANAR, 1); }
+            else { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, false, 5, OUT_LINEAR, 1); else P25FE_K1_CASE(P25FE_FMT_CF32, false, 5, OUT_LINEAR, 1); }
+        } else if (planar) {
+            if (ct) { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, true, 5, OUT_PLANAR, 0); else P25FE_K1_CASE(P25FE_FMT_CF32, true, 5, OUT_PLANAR, 0); }
+            else { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, false, 5, OUT_PLANAR, 0); else P25FE_K1_CASE(P25FE_FMT_CF32, false, 5, OUT_PLANAR, 0); }
+        } else if (pk == 3) {
+            if (ct) { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, true, 3, OUT_LINEAR, 0); else P25FE_K1_CASE(P25FE_FMT_CF32, true, 3, OUT_LINEAR, 0); }
+            else { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, false, 3, OUT_LINEAR, 0); else P25FE_K1_CASE(P25FE_FMT_CF32, false, 3, OUT_LINEAR, 0); }
+        } else {
+            if (ct) { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, true, 5, OUT_LINEAR, 0); else P25FE_K1_CASE(P25FE_FMT_CF32, true, 5, OUT_LINEAR, 0); }
+            else { if (u8) P25FE_K1_CASE(P25FE_FMT_U8, false, 5, OUT_LINEAR, 0); else P25FE_K1_CASE(P25FE_FMT_CF32, false, 5, OUT_LINEAR, 0); }
+        }
+#undef P25FE_K1_CASE
+#undef P25FE_CHUNK_CASE
+    }
+    if (chunk) { HIPCHK(h, hipGetLastError()); return P25FE_OK; }
     HIPCHK(h, hipGetLastError());
     if (d_power_dbm) {
         hipLaunchKernelGGL(k_power_finish, dim3((unsigned)h->C), dim3(256), 0, st, a.power_partial, (int)n_seg,
@@ -857,17 +970,6 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     std::swap(h->gsum, h->alt_gsum); std::swap(h->gouts, h->alt_gouts); std::swap(h->evg, h->alt_evg);
     h->lane ^= 1;
     const int lane = h->lane;
-    if (h->k1_alt_on && lane == 1) {
-        // experiment: consecutive calls are independent (different captures, different scratch sets), so this call's K1 may
-        // start while the previous call's K1 drains -- it runs on a second stream that first waits for the caller's
-        if (!h->k1_alt) {
-            HIPCHK(h, hipStreamCreateWithFlags(&h->k1_alt, hipStreamNonBlocking));
-            HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-        }
-        HIPCHK(h, hipEventRecord(h->ev_in, st));
-        HIPCHK(h, hipStreamWaitEvent(h->k1_alt, h->ev_in, 0));
-        st = h->k1_alt;
-    }
     if (h->rx_pending[lane]) {
 #ifdef P25FE_MEASURE_UNSAFE
         // measurement builds only (-DP25FE_MEASURE_UNSAFE + P25FE_PIPE_NOWAIT=1): what this wait packet costs -- without it the

@@ -1,0 +1,237 @@
+// p25fe_jit.cpp -- front-end kernels specialised for a caller's numbers: hipRTC + an on-disk cache.
+//
+// Host-only C++ (no device code here).  The kernel source is the library's own: p25fe_kernels.hip, p25fe_recv.hip,
+// p25fe.h and p25fe_spec.h are embedded as strings at build time (p25fe_embed.inc, written by tools/embed_src.py), so a
+// deployed libp25fe.so needs no source tree -- only libhiprtc, which every ROCm installation carries.  The reference
+// fixes the same numbers at ITS compile time (type-level FIR tables, src/demod.rs:27-29; FmDemod::new(5000, 48000),
+// src/demod.rs:54; the rtlsdr_iq table, src/demod.rs:83).
+#include "p25fe_jit.h"
+
+#include <errno.h>
+#include <hip/hiprtc.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include "p25fe_embed.inc"      // P25FE_SRC_KERNELS, P25FE_SRC_RECV, P25FE_SRC_P25FE_H, P25FE_SRC_SPEC_H
+
+namespace p25jit {
+
+const char* const KERNEL_NAMES[2][3] = {
+    {"p25jit_k1_cf32_lin", "p25jit_k1_cf32_pl", "p25jit_chunk_cf32"},
+    {"p25jit_k1_u8_lin", "p25jit_k1_u8_pl", "p25jit_chunk_u8"},
+};
+
+// the same code-generation options as the library's own build (p25rx_amd/csrc/Makefile): fma only where the source says
+// fma, correctly rounded division -- the specialised kernels must produce the bits of the built-in ones
+static const char* const OPTIONS[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                                      "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-function"};
+static const int N_OPTIONS = (int)(sizeof OPTIONS / sizeof OPTIONS[0]);
+
+// the translation unit: generated numbers, the kernel source, six entry points with C names
+static const char WRAPPER[] =
+    "#include \"p25fe_jit_spec.h\"\n"
+    "#include \"p25fe_kernels.hip\"\n"
+    "using namespace p25k;\n"
+    "#define P25JIT_K1(NAME, FMT, OM, WPS) extern \"C\" __global__ __launch_bounds__(WV, WPS) void NAME(K1Args a, const Taps* __restrict__ t) "
+    "{ frontend_body<FMT, true, 5, OM, P25FE_JIT_TX>(a, t); }\n"
+    "P25JIT_K1(p25jit_k1_cf32_lin, P25FE_FMT_CF32, OUT_LINEAR, Geo<5>::WAVES_PER_SIMD)\n"
+    "P25JIT_K1(p25jit_k1_u8_lin, P25FE_FMT_U8, OUT_LINEAR, Geo<5>::WAVES_PER_SIMD)\n"
+    "P25JIT_K1(p25jit_k1_cf32_pl, P25FE_FMT_CF32, OUT_PLANAR, P25FE_K1_PLANAR_WPS)\n"
+    "P25JIT_K1(p25jit_k1_u8_pl, P25FE_FMT_U8, OUT_PLANAR, P25FE_K1_PLANAR_WPS_U8)\n"
+    "extern \"C\" __global__ __launch_bounds__(WV, 2) void p25jit_chunk_cf32(K1Args a, const Taps* __restrict__ t, ChunkTail c) "
+    "{ chunk_body<P25FE_FMT_CF32, true, P25FE_JIT_TX>(a, t, c); }\n"
+    "extern \"C\" __global__ __launch_bounds__(WV, 2) void p25jit_chunk_u8(K1Args a, const Taps* __restrict__ t, ChunkTail c) "
+    "{ chunk_body<P25FE_FMT_U8, true, P25FE_JIT_TX>(a, t, c); }\n";
+
+static uint64_t fnv(uint64_t h, const void* p, size_t n)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+uint64_t spec_hash(const Spec& s)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    // everything the code object depends on: the source, the options, the compiler, the numbers
+    h = fnv(h, "p25fe-jit-1", 11);
+    h = fnv(h, P25FE_SRC_KERNELS, sizeof P25FE_SRC_KERNELS);
+    h = fnv(h, P25FE_SRC_RECV, sizeof P25FE_SRC_RECV);
+    h = fnv(h, P25FE_SRC_P25FE_H, sizeof P25FE_SRC_P25FE_H);
+    h = fnv(h, P25FE_SRC_SPEC_H, sizeof P25FE_SRC_SPEC_H);
+    h = fnv(h, WRAPPER, sizeof WRAPPER);
+    for (int i = 0; i < N_OPTIONS; ++i) h = fnv(h, OPTIONS[i], strlen(OPTIONS[i]) + 1);
+    int vmaj = 0, vmin = 0;
+    if (hiprtcVersion(&vmaj, &vmin) == HIPRTC_SUCCESS) { h = fnv(h, &vmaj, sizeof vmaj); h = fnv(h, &vmin, sizeof vmin); }
+    h = fnv(h, &s.tx, sizeof s.tx);
+    h = fnv(h, &s.t1, sizeof s.t1);
+    h = fnv(h, &s.t2, sizeof s.t2);
+    h = fnv(h, s.dec, sizeof(float) * (size_t)s.t1);
+    h = fnv(h, s.ch, sizeof(float) * (size_t)s.t2);
+    h = fnv(h, &s.fm_gain, sizeof s.fm_gain);
+    h = fnv(h, &s.u8_lut, sizeof s.u8_lut);
+    if (s.u8_lut) {
+        // (the table's VALUES are read from the handle's device copy: the code is the same for every non-affine table)
+    } else {
+        h = fnv(h, &s.u8_scale, sizeof s.u8_scale);
+        h = fnv(h, &s.u8_offset, sizeof s.u8_offset);
+    }
+    return h;
+}
+
+std::string file_name(uint64_t hash)
+{
+    char b[64];
+    snprintf(b, sizeof b, "p25fe-%016llx.hsaco", (unsigned long long)hash);
+    return b;
+}
+
+std::string default_cache_dir()
+{
+    const char* e = getenv("P25FE_CACHE_DIR");
+    if (e && *e) return e;
+    e = getenv("XDG_CACHE_HOME");
+    if (e && *e) return std::string(e) + "/p25fe";
+    e = getenv("HOME");
+    if (e && *e && access(e, W_OK) == 0) return std::string(e) + "/.cache/p25fe";
+    char b[64];
+    snprintf(b, sizeof b, "/tmp/p25fe-cache-%u", (unsigned)getuid());
+    return b;
+}
+
+static bool mkdir_p(const std::string& dir)
+{
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); ++i) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!cur.empty() && mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST) return false;
+        }
+        if (i < dir.size()) cur.push_back(dir[i]);
+    }
+    struct stat st;
+    return stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+static bool read_file(const std::string& path, std::vector<char>& out)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long n = ftell(f);
+        if (n > 64 && n < (64L << 20) && fseek(f, 0, SEEK_SET) == 0) {
+            out.resize((size_t)n);
+            ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n && memcmp(out.data(), "\x7f" "ELF", 4) == 0;
+        }
+    }
+    fclose(f);
+    if (!ok) out.clear();
+    return ok;
+}
+
+// write to a temporary name, then rename: concurrent creators (one process per GPU, all with the same numbers) never
+// see a half-written file
+static bool write_file_atomic(const std::string& dir, const std::string& name, const std::vector<char>& data)
+{
+    if (!mkdir_p(dir)) return false;
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, "/.tmp-%ld-%p", (long)getpid(), (const void*)&data);
+    const std::string t = dir + tmp, final_ = dir + "/" + name;
+    FILE* f = fopen(t.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    if (fclose(f) != 0 || !ok || rename(t.c_str(), final_.c_str()) != 0) { unlink(t.c_str()); return false; }
+    return true;
+}
+
+static void put_float(std::string& o, float v)
+{
+    char b[48];
+    if (v != v || v - v != 0.0f) snprintf(b, sizeof b, "__builtin_nanf(\"\")");     // (callers reject non-finite numbers; never emitted)
+    else snprintf(b, sizeof b, "%af", (double)v);
+    o += b;
+}
+
+static std::string gen_header(const Spec& s)
+{
+    std::string o;
+    o.reserve(8192);
+    // hipRTC brings no system headers: the fixed-width types p25fe.h and the kernels use
+    o += "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+         "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
+         "typedef unsigned long size_t; typedef unsigned long uintptr_t;\n"
+         "#define P25FE_JIT 1\n";
+    char b[128];
+    snprintf(b, sizeof b, "#define P25FE_JIT_TX %d\n", s.tx);
+    o += b;
+    snprintf(b, sizeof b, "static constexpr float P25FE_JIT_DECIM_TAPS[%d] = {", s.t1);
+    o += b;
+    for (int k = 0; k < s.t1; ++k) { if (k) o += ", "; put_float(o, s.dec[k]); }
+    snprintf(b, sizeof b, "};\nstatic constexpr float P25FE_JIT_CHAN_TAPS[%d] = {", s.t2);
+    o += b;
+    for (int k = 0; k < s.t2; ++k) { if (k) o += ", "; put_float(o, s.ch[k]); }
+    o += "};\n#define P25FE_JIT_FM_GAIN ";
+    put_float(o, s.fm_gain);
+    snprintf(b, sizeof b, "\n#define P25FE_JIT_U8_LUT %d\n#define P25FE_JIT_U8_SCALE ", s.u8_lut ? 1 : 0);
+    o += b;
+    put_float(o, s.u8_lut ? 0.0f : s.u8_scale);
+    o += "\n#define P25FE_JIT_U8_OFFSET ";
+    put_float(o, s.u8_lut ? 0.0f : s.u8_offset);
+    o += "\n";
+    return o;
+}
+
+static bool compile(const Spec& s, std::vector<char>& code, std::string& log)
+{
+    const std::string spec_h = gen_header(s);
+    const char* headers[] = {spec_h.c_str(), P25FE_SRC_KERNELS, P25FE_SRC_RECV, P25FE_SRC_P25FE_H, P25FE_SRC_SPEC_H};
+    const char* names[] = {"p25fe_jit_spec.h", "p25fe_kernels.hip", "p25fe_recv.hip", "p25fe.h", "p25fe_spec.h"};
+    hiprtcProgram prog = nullptr;
+    hiprtcResult r = hiprtcCreateProgram(&prog, WRAPPER, "p25fe_jit.hip", 5, headers, names);
+    if (r != HIPRTC_SUCCESS) { log += std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r) + "\n"; return false; }
+    r = hiprtcCompileProgram(prog, N_OPTIONS, const_cast<const char**>(OPTIONS));
+    size_t ls = 0;
+    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        std::string l(ls, '\0');
+        if (hiprtcGetProgramLog(prog, &l[0]) == HIPRTC_SUCCESS) log += l.c_str();
+    }
+    bool ok = false;
+    if (r == HIPRTC_SUCCESS) {
+        size_t cs = 0;
+        if (hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0) {
+            code.resize(cs);
+            ok = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+        }
+    } else {
+        log += std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n";
+    }
+    hiprtcDestroyProgram(&prog);
+    if (!ok) code.clear();
+    return ok;
+}
+
+bool get_code(const Spec& s, const std::vector<std::string>& dirs, bool do_compile, const std::string& store_dir,
+              std::vector<char>& code, std::string& path, std::string& log)
+{
+    const std::string name = file_name(spec_hash(s));
+    for (const std::string& d : dirs) {
+        if (d.empty()) continue;
+        const std::string p = d + "/" + name;
+        if (read_file(p, code)) { path = p; return true; }
+    }
+    if (!do_compile) { log += "no cached code object " + name + " and compilation is switched off\n"; return false; }
+    if (!compile(s, code, log)) return false;
+    path.clear();
+    if (!store_dir.empty()) {
+        if (write_file_atomic(store_dir, name, code)) path = store_dir + "/" + name;
+        else log += "could not store " + store_dir + "/" + name + " (the code object is used from memory)\n";
+    }
+    return true;
+}
+
+}  // namespace p25jit

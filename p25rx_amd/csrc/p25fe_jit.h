@@ -1,0 +1,41 @@
+// p25fe_jit.h -- internal: kernels specialised for a caller's numbers (p25fe_jit.cpp), shared with p25fe_api.hip.
+//
+// The reference fixes its FIR tables at compile time (type-level filters, src/demod.rs:27-29) and its discriminator /
+// LUT constants at construction (src/demod.rs:54, 83).  The library's built-in immediate-coefficient kernels carry the
+// build's own numbers; for any other set the same kernel source -- embedded in the library -- is compiled by hipRTC with
+// the caller's numbers as immediates, and the code object is cached on disk under a hash of the numbers.
+#ifndef P25FE_JIT_H
+#define P25FE_JIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace p25jit {
+
+struct Spec {
+    int tx;                 // 0: evaluation lengths 31 / 41, 1: 64 / 64 (docs/SPEC.md 3.3)
+    int t1, t2;             // evaluation lengths (tables zero-padded to them)
+    float dec[64], ch[64];
+    float fm_gain;
+    int u8_lut;             // 1: the u8 table is not affine -> LDS lookup; the VALUES come from the handle's device table, so
+                            // one code object serves every such table
+    float u8_scale, u8_offset;      // the affine table: byte b -> fma(b, scale, offset) (ignored when u8_lut)
+};
+
+// names of the extern "C" kernels of a specialised module: [fmt 0 = cf32, 1 = u8][0 = linear, 1 = planar, 2 = chunk]
+extern const char* const KERNEL_NAMES[2][3];
+
+uint64_t spec_hash(const Spec& s);
+std::string default_cache_dir();                       // $P25FE_CACHE_DIR, $XDG_CACHE_HOME/p25fe, $HOME/.cache/p25fe, /tmp/p25fe-cache-<uid>
+std::string file_name(uint64_t hash);                  // "p25fe-<16 hex>.hsaco"
+
+// Code object for `s`: looked up in `dirs` (first hit wins); if absent and `compile`, built with hipRTC and stored in
+// `store_dir` (empty: not stored).  Returns true on success; `log` receives the compiler's words / what was tried.
+bool get_code(const Spec& s, const std::vector<std::string>& dirs, bool compile, const std::string& store_dir,
+              std::vector<char>& code, std::string& path, std::string& log);
+
+}  // namespace p25jit
+#endif

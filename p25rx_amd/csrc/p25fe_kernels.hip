@@ -20,14 +20,40 @@
 // Arithmetic contract (docs/SPEC.md section 3): fp32, fma only where the spec says fma, single
 // accumulator per output in tap order 0..T-1.  Compiled with -ffp-contract=off.
 // Stencil / element-wise work: no MFMA.  HBM-bound by design: 8 B in + 0.8 B out per IQ sample.
+// The same file is the source of the SPECIALISED kernels: p25fe_jit.cpp hands it to hipRTC (which brings its own runtime
+// declarations and no system headers) behind a generated header that defines P25FE_JIT and the caller's numbers.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
+#endif
 
 #include "p25fe.h"
 #include "p25fe_spec.h"
 
 namespace p25k {
+
+// (own two-line versions: hipRTC has no <type_traits>)
+template <int V> struct icst { static constexpr int value = V; };
+template <bool B, class A, class C> struct cond { using type = A; };
+template <class A, class C> struct cond<false, A, C> { using type = C; };
+
+// Numbers of the immediate-coefficient ("CT") kernels: the build's own tables (p25fe_spec.h), or -- in a hipRTC build --
+// the caller's, from the generated header (p25fe_jit.cpp: tables already padded to the evaluation length).
+#ifdef P25FE_JIT
+#define K1_CT_DECIM_TAPS P25FE_JIT_DECIM_TAPS
+#define K1_CT_CHAN_TAPS P25FE_JIT_CHAN_TAPS
+#define K1_CT_FM_GAIN P25FE_JIT_FM_GAIN
+#define K1_CT_U8_SCALE P25FE_JIT_U8_SCALE
+#define K1_CT_U8_OFFSET P25FE_JIT_U8_OFFSET
+#define K1_CT_U8_LUT P25FE_JIT_U8_LUT             /* 1: the u8 table is not affine -> looked up in LDS */
+#else
+#define K1_CT_DECIM_TAPS P25FE_DEFAULT_DECIM_TAPS
+#define K1_CT_CHAN_TAPS P25FE_DEFAULT_CHAN_TAPS
+#define K1_CT_FM_GAIN P25FE_FM_GAIN
+#define K1_CT_U8_SCALE P25FE_U8_SCALE
+#define K1_CT_U8_OFFSET P25FE_U8_OFFSET
+#define K1_CT_U8_LUT 0
+#endif
 
 // ------------------------------------------------------------------------------------------
 // geometry of K1.  A workgroup is ONE wave (64 lanes): no s_barrier anywhere, and the CU's resident
@@ -92,14 +118,20 @@ template <int PK, int TX = 0> struct Geo {
     // front of the window region once the decimator has consumed it (one wave: program order), so that 11 one-wave
     // workgroups fit a CU's 160 KB instead of 9 (occupancy is what bounds the overlap of HBM, LDS and VALU work).
     static constexpr size_t LDS_BYTES = sizeof(float2) * (D_CARRY + XIN_N) + sizeof(float) * (T1 + T2 + 3);
+    static constexpr size_t LDS_BYTES_LUT = LDS_BYTES + sizeof(float) * 256;     // + the u8 table (generic u8 kernels, non-affine specialised ones)
     static_assert(sizeof(float2) * XIN_N >= sizeof(float2) * SUB + sizeof(float) * SUB, "d and the transpose fit the window region");
     static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
     static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
 
+// What the generic kernels read their numbers from (device memory; the immediate-coefficient kernels read only `lut`, and
+// only when the handle's u8 table is not affine)
 struct Taps {
     float dec[TMAX];
     float ch[TMAX];
+    float lut[256];         // rtlsdr_iq::IQ as one byte -> float table (src/demod.rs:83); I and Q alike
+    float fm_gain;          // FmDemod's output scale (src/demod.rs:54)
+    float pad_[3];
 };
 
 // SPEC 3.4: polynomial atan2, identical operation sequence to the oracle's restatement.
@@ -125,13 +157,13 @@ __device__ __forceinline__ float spec_atan2f(float y, float x)
 }
 
 // SPEC 3.4: FM discriminator, angle of s * conj(prev) times fs / (2 pi dev)   (src/demod.rs:54, 110)
-__device__ __forceinline__ float fm_discriminate(float2 s, float2 prev)
+__device__ __forceinline__ float fm_discriminate(float2 s, float2 prev, float gain)
 {
     const float t = s.y * prev.y;
     const float re = __builtin_fmaf(s.x, prev.x, t);
     const float u = s.x * prev.y;
     const float im = __builtin_fmaf(s.y, prev.x, -u);
-    return spec_atan2f(im, re) * P25FE_FM_GAIN;
+    return spec_atan2f(im, re) * gain;
 }
 
 // Complex sample as a native 2-vector: fma on it is ONE v_pk_fma_f32 (re and im lanes, each a fused multiply-add, SPEC
@@ -192,7 +224,7 @@ template <int N> __device__ __forceinline__ void lds_landed(v2f& v)
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f)
 {
     if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
+        f(icst<I>{});
         static_for<I + 1, N>(f);
     }
 }
@@ -214,7 +246,7 @@ template <int N, int DEPTH, class Body> __device__ __forceinline__ void lds_walk
         constexpr int i = decltype(ic)::value;
         constexpr int after = (N - 1 - i) < (DEPTH - 1) ? (N - 1 - i) : (DEPTH - 1);      // reads issued after read i by now
         lds_landed<after>(ring[i % DEPTH]);
-        body(std::integral_constant<int, N - 1 - i>{}, ring[i % DEPTH]);
+        body(icst<N - 1 - i>{}, ring[i % DEPTH]);
         if constexpr (i + DEPTH < N) ring[i % DEPTH] = lds_issue_b64<8 * (N - 1 - (i + DEPTH))>(base);
     });
 }
@@ -254,17 +286,17 @@ template <int N, int G, class Body> __device__ __forceinline__ void lds_walk_dow
         lds_landed_group<G, next>(r);
         static_for<0, G>([&](auto kc) {
             constexpr int k = decltype(kc)::value, i = g * G + k;
-            if constexpr (i < N) body(std::integral_constant<int, N - 1 - i>{}, r[k]);
+            if constexpr (i < N) body(icst<N - 1 - i>{}, r[k]);
         });
     };
-    issue(std::integral_constant<int, 0>{}, ra);
+    issue(icst<0>{}, ra);
     static_for<0, NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         if constexpr (g % 2 == 0) {
-            if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{}, rb);
+            if constexpr (g + 1 < NG) issue(icst<g + 1>{}, rb);
             consume(gc, ra);
         } else {
-            if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{}, ra);
+            if constexpr (g + 1 < NG) issue(icst<g + 1>{}, ra);
             consume(gc, rb);
         }
     });
@@ -294,7 +326,7 @@ template <int N, bool GROUPED, class Body> __device__ __forceinline__ void lds_w
 #else
     static_for<0, N>([&](auto ic) {
         constexpr int j = N - 1 - decltype(ic)::value;
-        body(std::integral_constant<int, j>{}, lds_read_v2(w + j));       // compiler-scheduled (volatile) reads
+        body(icst<j>{}, lds_read_v2(w + j));       // compiler-scheduled (volatile) reads
     });
 #endif
 }
@@ -345,8 +377,9 @@ __device__ __forceinline__ void phase_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// SPEC 3.1: rtlsdr_iq LUT value as arithmetic (src/demod.rs:82-84)
-__device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((float)b, P25FE_U8_SCALE, -1.0f); }
+// SPEC 3.1: rtlsdr_iq LUT value as arithmetic (src/demod.rs:82-84) -- the immediate-coefficient kernels; the generic
+// kernels (and a specialised build whose table is not affine) look the byte up in a 256-entry table in LDS
+__device__ __forceinline__ float u8_to_f32(unsigned b) { return __builtin_fmaf((float)b, K1_CT_U8_SCALE, K1_CT_U8_OFFSET); }
 
 // ------------------------------------------------------------------------------------------
 // window loader: global -> registers, one 16-B vector per lane per load.
@@ -369,7 +402,7 @@ template <int FMT, int PK, int TX = 0, int NVX = 0> struct Loader {
     static constexpr int LOG_SPV = 1;
     static constexpr int SPV = 1 << LOG_SPV;
     static constexpr int NV = NVX ? NVX : (G::XWIN + SPV + SPV * WV - 1) / (SPV * WV);   // vectors per lane: 13 for PK = 5 (NVX: the segment prologue's short window)
-    using V = typename std::conditional<FMT == P25FE_FMT_CF32, uint4, unsigned>::type;
+    using V = typename cond<FMT == P25FE_FMT_CF32, uint4, unsigned>::type;
     V v[NV];
 
     // Window loads are BUFFER loads through one descriptor per segment: the hardware bounds check returns zeros for
@@ -460,7 +493,8 @@ template <int FMT, int PK, int TX = 0, int NVX = 0> struct Loader {
     // if-converted that into selects that every window executed -- 26 x (64-bit add, two 64-bit compares, two
     // v_cndmask) = ~150 of the 900 VALU instructions per sub-tile.  Conditional LDS stores cannot be speculated, so
     // the branch around fixup() survives.)
-    __device__ __forceinline__ void store(float2* XIN, long first, long n_hist, long n_new, int tid) const
+    template <bool LUTM = false>
+    __device__ __forceinline__ void store(float2* XIN, long first, long n_hist, long n_new, int tid, const float* lut = nullptr) const
     {
         float4* XV = reinterpret_cast<float4*>(__builtin_assume_aligned(XIN, 16));
 #pragma unroll
@@ -473,7 +507,8 @@ template <int FMT, int PK, int TX = 0, int NVX = 0> struct Loader {
                     s[e] = make_float2(__uint_as_float(w[2 * e]), __uint_as_float(w[2 * e + 1]));
                 } else {
                     const unsigned pair = (v[j] >> (16 * e)) & 0xffffu;
-                    s[e] = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
+                    if constexpr (LUTM) s[e] = make_float2(lut[pair & 0xffu], lut[pair >> 8]);
+                    else s[e] = make_float2(u8_to_f32(pair & 0xffu), u8_to_f32(pair >> 8));   // low byte = I (SPEC 3.1)
                 }
             }
             // only the last round of vectors can run past the window: everything else is stored unconditionally
@@ -591,7 +626,9 @@ template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
 __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __restrict__ gtaps)
 {
     constexpr int PF = (PK != 5 || TX != 0) ? 1 : (FMT == P25FE_FMT_U8 ? P25FE_K1_PF_U8 : P25FE_K1_PF_CF32);
+#ifndef P25FE_JIT
     static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
+#endif
     static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
 #ifdef P25FE_K1_STAMP
     unsigned long long st_t0, st_r0;                                // entry: shader clock / constant 100 MHz clock
@@ -606,14 +643,22 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region (register loader)
     float2* XIN = D + D_CARRY;                                      // 16-B aligned: staged with ds_write_b128
     float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose: inside the window region
-    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2], only when !CT
+    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2 | 3 | u8 table 256]: taps only when !CT, table only when LUTM
+    float* const LUT = TAPS + (T1 + T2 + 3);
+    // u8 -> float: arithmetic with immediate constants (CT, affine table) or a table in LDS (the generic kernels always:
+    // one code path for every table; a specialised build only when its table is not affine)
+    constexpr bool LUTM = FMT == P25FE_FMT_U8 && (!CT || K1_CT_U8_LUT != 0);
     const int tid = threadIdx.x;
     if (!CT) {
         for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
         for (int k = tid; k < T2; k += WV) TAPS[T1 + k] = gtaps->ch[k];
     }
-    auto tap_dec = [&](int k) -> float { return CT ? P25FE_DEFAULT_DECIM_TAPS[k] : TAPS[k]; };
-    auto tap_ch = [&](int k) -> float { return CT ? P25FE_DEFAULT_CHAN_TAPS[k] : TAPS[T1 + k]; };
+    if constexpr (LUTM)
+        for (int k = tid; k < 256; k += WV) LUT[k] = gtaps->lut[k];
+    float fm_gain = K1_CT_FM_GAIN;
+    if constexpr (!CT) fm_gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gtaps->fm_gain)));
+    auto tap_dec = [&](int k) -> float { return CT ? K1_CT_DECIM_TAPS[k] : TAPS[k]; };
+    auto tap_ch = [&](int k) -> float { return CT ? K1_CT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
     constexpr bool PRO = seg_prologue(FMT);                         // segment prologue (u8) or recomputed halo (cf32), see SEG_HALO
     const long seg_len = PRO ? (long)a.subs_per_seg * SUB : (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
@@ -693,7 +738,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         // behind them on lanes 0..9 -- the state a receiver that had run through the previous segment would hand over.
         // Same tap order and single accumulators as the sub-tiles (SPEC 3.2 - 3.4): the same bits.
         float2* const PD_ = XIN + PBASE;
-        lp.store(XIN, pfirst, a.n_hist, a.n_new, tid);
+        lp.template store<LUTM>(XIN, pfirst, a.n_hist, a.n_new, tid, LUT);
         lp.fixup(XIN, pfirst, a.n_hist, a.n_new, tid);
         phase_sync();
         const int pxsh = (int)(pfirst & 1);
@@ -727,7 +772,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         float2 yp;
         yp.x = wave_shr1(yv.x, 0.f);
         yp.y = wave_shr1(yv.y, 0.f);
-        const float fmv = fm_discriminate(make_float2(yv.x, yv.y), yp);     // lane l: fm[m_seg0 - 10 + l], l = 1..9 (lane 0: unused)
+        const float fmv = fm_discriminate(make_float2(yv.x, yv.y), yp, fm_gain);     // lane l: fm[m_seg0 - 10 + l], l = 1..9 (lane 0: unused)
         y_carry.x = lane_bcast<HALO_Y - 1>(yv.x);
         y_carry.y = lane_bcast<HALO_Y - 1>(yv.y);
         static_for<0, NBACK>([&](auto bc) {
@@ -826,7 +871,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #if P25FE_K1_TURNAROUND_PRIO
         __builtin_amdgcn_s_setprio(P25FE_K1_TURNAROUND_PRIO);       // see below
 #endif
-        ld.store(XIN, first, a.n_hist, a.n_new, tid);
+        ld.template store<LUTM>(XIN, first, a.n_hist, a.n_new, tid, LUT);
         ld.fixup(XIN, first, a.n_hist, a.n_new, tid);
         phase_sync();
         K1_STAMP(0);                                                // window landed + staged
@@ -937,9 +982,9 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             float2 yprev;
             yprev.x = wave_shr1(y[P - 1].x, y_carry.x);
             yprev.y = wave_shr1(y[P - 1].y, y_carry.y);
-            f[0] = fm_discriminate(y[0], yprev);
+            f[0] = fm_discriminate(y[0], yprev, fm_gain);
 #pragma unroll
-            for (int p = 1; p < P; ++p) f[p] = fm_discriminate(y[p], y[p - 1]);
+            for (int p = 1; p < P; ++p) f[p] = fm_discriminate(y[p], y[p - 1], fm_gain);
             y_carry.x = lane_bcast<WV - 1>(y[P - 1].x);
             y_carry.y = lane_bcast<WV - 1>(y[P - 1].y);
         }
@@ -1064,8 +1109,15 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #endif
 }
 
+// (register budget of the generic u8 kernels: one wave per SIMD less than the immediate-coefficient ones -- the taps' LDS
+// addresses and the table look-ups cost registers, and a spilled FIR loop costs far more than the occupancy)
+constexpr int k1_wps(int fmt, bool ct, int pk, int om)
+{
+    if (om == OUT_PLANAR) return fmt == P25FE_FMT_U8 ? (ct ? P25FE_K1_PLANAR_WPS_U8 : 2) : P25FE_K1_PLANAR_WPS;
+    return (fmt == P25FE_FMT_U8 && !ct && pk <= 3) ? 3 : (pk <= 3 ? 4 : 2);
+}
 template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
-__global__ __launch_bounds__(WV, (OM == OUT_PLANAR ? (FMT == P25FE_FMT_U8 ? P25FE_K1_PLANAR_WPS_U8 : P25FE_K1_PLANAR_WPS) : Geo<PK>::WAVES_PER_SIMD)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
+__global__ __launch_bounds__(WV, k1_wps(FMT, CT, PK, OM)) void k_frontend(K1Args a, const Taps* __restrict__ gtaps)
 {
     frontend_body<FMT, CT, PK, OM, TX>(a, gtaps);
 }
@@ -1114,6 +1166,7 @@ struct K0Args {
     long n_out;
 };
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV, P25FE_K0_WPS) void k_predecim(K0Args a)
 {
     __shared__ float2 X[PD * K0_JP];
@@ -1220,6 +1273,7 @@ __global__ __launch_bounds__(WV, P25FE_K0_WPS) void k_predecim(K0Args a)
     }
     flush();
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K6: polyphase channeliser (SPEC 3.11; SURVEY.md section 8f rank 4, no reference counterpart -- the reference tunes
@@ -1288,7 +1342,9 @@ constexpr CzTw cz_make_tw()
     }
     return t;
 }
+#ifndef P25FE_JIT
 __constant__ CzTw CZ_TW = cz_make_tw();
+#endif
 __device__ __forceinline__ float2 cz_mac(float2 acc, float2 v, CzC w)              // acc + v * w
 {
     acc.x = __builtin_fmaf(v.x, w.x, acc.x); acc.y = __builtin_fmaf(v.y, w.x, acc.y);
@@ -1310,6 +1366,7 @@ __device__ __forceinline__ void cz_bf4(float2& x0, float2& x1, float2& x2, float
     x3 = make_float2(t1.x + t3.y, t1.y - t3.x);                 // t1 - j t3
 }
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
 {
     __shared__ float2 X[PD * CZ_JP];
@@ -1460,8 +1517,10 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
         }
     }
 }
+#endif
 
 // finish power_dbm (src/demod.rs:123-134): 30 + 10 log10( (sum / N) / R ), R = 1
+#ifndef P25FE_JIT
 __global__ void k_power_finish(const float* partial, int n_partial, long n, float* out_dbm)
 {
     const int ch = blockIdx.x;
@@ -1479,6 +1538,7 @@ __global__ void k_power_finish(const float* partial, int n_partial, long n, floa
         out_dbm[ch] = 30.0f + 10.0f * log10f(avg / 1.0f);       // n = 0: 0 / 0 -> NaN, as the reference's fold over an empty chunk
     }
 }
+#endif
 
 }  // namespace p25k
 
@@ -1493,6 +1553,7 @@ namespace p25k {
 // equivalent to a bounded-distance decoder when at most t = 11 bits are wrong, and embarrassingly parallel.
 // ------------------------------------------------------------------------------------------
 // Batch form: blockIdx.y = channel, per-channel strides, event / dibit counts read from the channel's p25fe_result_t.
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(256) void k_nid(const uint8_t* dibits, unsigned long long n_dibits, const unsigned long long* sync_dibit,
                                              const long* sync_pos, p25fe_nid_t* out, const p25fe_result_t* results,
                                              unsigned long long dibit_stride, unsigned long long sync_stride)
@@ -1555,9 +1616,11 @@ __global__ __launch_bounds__(256) void k_nid(const uint8_t* dibits, unsigned lon
         out[k] = r;
     }
 }
+#endif
 
 // Per-channel observability record (src/hub.rs:344, 401-402, 557-581): one workgroup per
 // channel folds the channel's NID records into the "bch" CodeStats row and copies the lock state.
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(256) void k_chan_stats(const p25fe_result_t* results, const p25fe_nid_t* nid,
                                                     unsigned long long sync_stride, const float* power_dbm,
                                                     p25fe_chan_stats_t* stats)
@@ -1595,6 +1658,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const p25fe_result_t* result
         stats[ch] = o;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // One launch per streaming chunk (the body of DemodTask::run + the sample loop of RecvTask::run for one buffer of the
@@ -1609,7 +1673,7 @@ struct ChunkTail {
 };
 
 template <int FMT, bool CT, int TX>
-__global__ __launch_bounds__(WV, 2) void k_chunk(K1Args a, const Taps* __restrict__ gtaps, ChunkTail t)
+__device__ __forceinline__ void chunk_body(const K1Args& a, const Taps* __restrict__ gtaps, const ChunkTail& t)
 {
     frontend_body<FMT, CT, 5, OUT_PLANAR, TX>(a, gtaps);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1622,6 +1686,12 @@ __global__ __launch_bounds__(WV, 2) void k_chunk(K1Args a, const Taps* __restric
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (threadIdx.x == 0) t.counter[blockIdx.y] = 0u;               // the next launch (a kernel boundary later) starts from zero
     recv_one_tile(t.r, (int)blockIdx.y);
+}
+
+template <int FMT, bool CT, int TX>
+__global__ __launch_bounds__(WV, 2) void k_chunk(K1Args a, const Taps* __restrict__ gtaps, ChunkTail t)
+{
+    chunk_body<FMT, CT, TX>(a, gtaps, t);
 }
 
 // Carry resolution across time shards (BASELINE.json config 5): the same "latest anchor wins" rule as K3, one level
@@ -1674,6 +1744,7 @@ __host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summari
 
 // Dibit gather, second half: the all-gathered, padded per-shard streams -> one contiguous stream.  Shard r's dibits
 // are gathered[r * cap .. + offset[r + 1] - offset[r]) and belong at out[offset[r] ..).
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, unsigned long long cap, const uint64_t* offset,
                                                         int n_shards, uint8_t* out, unsigned long long out_cap)
 {
@@ -1684,12 +1755,15 @@ __global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, 
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n && i < cap; i += (unsigned long long)gridDim.x * 256)
         if (o0 + i < out_cap) out[o0 + i] = src[i];
 }
+#endif
 
+#ifndef P25FE_JIT
 __global__ void k_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
                                 int n_shards, int symbol_clock, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0)
         shard_resolve_impl(summaries, shard_bb0, shard_bb_n, n_shards, symbol_clock, anchor_in, dibit_offset);
 }
+#endif
 
 }  // namespace p25k

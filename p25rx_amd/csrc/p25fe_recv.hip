@@ -19,8 +19,10 @@
 // has g_j w_j <= -a, so w_j^2 >= a^2: at most 4 of them fit.  The fp32 evaluation of c and e moves the ratio by
 // < 1e-5 relative, nowhere near the 18 % that separates 4.24 from 5.  The screen counts a mismatch only where the
 // SIGN BIT disagrees (a +0 under a '+' symbol is not counted), which can only under-count: still a superset.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace p25k {
 
@@ -630,6 +632,7 @@ __device__ __forceinline__ unsigned long long block_incl_sum(unsigned long long 
     return inc + carry;
 }
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
 {
     __shared__ unsigned long long TSL[K3_CHUNK];
@@ -800,6 +803,7 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
         a.result[ch] = r;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K4: slicer.  One wave per tile.  A tile is a short list of segments -- [tile start, first own detection] under the
@@ -905,6 +909,7 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
     }
 }
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
 {
     const int tile = blockIdx.x, ch = blockIdx.y;
@@ -923,6 +928,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
     }
     slice_tile(a, tile, ch, so, u, valid, s_abs, hi, mid, lo);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K3 / K4 of the general receiver (tracking clock and / or lock drops inside the range).
@@ -977,6 +983,7 @@ __device__ __forceinline__ Top2 top2_shfl_up(Top2 v, int d)
 
 struct CState { int valid; long s; int D, N; int src; int f; };
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
 {
     // a chunk of summaries (and of the tiles' last detection positions) is staged in LDS: the per-tile work below is a chain
@@ -1173,6 +1180,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         a.result[ch] = r;
     }
 }
+#endif
 
 struct SliceArgsG {
     Planar pl;
@@ -1194,6 +1202,7 @@ struct SliceArgsG {
     int track;
 };
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
 {
     __shared__ uint16_t EV[EVCAP];
@@ -1293,6 +1302,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
         rank += emit(sk, D, N, ek + 1, T0 + (long)(eg & 0x7fffu), h, m, l, rank);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Streaming chunks (the reference's unit of work: one 32 768-byte read of the dongle = 3 276 / 3 277 baseband samples,
@@ -1344,7 +1354,9 @@ __device__ __forceinline__ void tail_extract(const ChunkRecvArgs& c, const int c
         }
     }
 }
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV) void k_tail_extract(ChunkRecvArgs c) { tail_extract(c, (int)blockIdx.x); }
+#endif
 
 __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int ch)
 {
@@ -1402,6 +1414,7 @@ struct RecvChunkArgs {
     long n_blocks;
 };
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV, 4) void k_recv_chunk(RecvChunkArgs a)
 {
     const int lane = threadIdx.x, ch = blockIdx.x;
@@ -1426,6 +1439,7 @@ __global__ __launch_bounds__(WV, 4) void k_recv_chunk(RecvChunkArgs a)
     wave_global_sync();
     recv_one_tile(a.r, ch);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // linear baseband -> planes + sign bits (entry points that receive a 48 kHz float stream).  Workgroup = 10 waves,
@@ -1445,6 +1459,7 @@ struct PlanarizeArgs {
     int shift;              // sample m goes to planar position m + shift + PLPAD (the general receiver's lookahead)
 };
 
+#ifndef P25FE_JIT
 __global__ __launch_bounds__(WV * SPS) void k_planarize(PlanarizeArgs a)
 {
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6, ch = blockIdx.y;
@@ -1457,5 +1472,6 @@ __global__ __launch_bounds__(WV * SPS) void k_planarize(PlanarizeArgs a)
     const unsigned long long sg = __ballot(__float_as_int(v) < 0);
     if ((lane & 31) == 0 && in) a.bits[(size_t)ch * a.bits_ch + (i >> 5) * SPS + r] = (unsigned)(sg >> (lane & 32));
 }
+#endif
 
 }  // namespace p25k

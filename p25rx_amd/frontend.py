@@ -19,26 +19,27 @@ def _p(a):
 
 
 class FrontEnd:
-    def __init__(self, n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_clock=0):
+    def __init__(self, n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_clock=0, **spec):
+        """spec: the other p25fe_config_t fields by name (specialize, fm_deviation_hz, fm_sample_rate_hz, fm_gain, u8_scale,
+        u8_offset, u8_lut) -- the run-time arguments of the reference's constructors (src/demod.rs:54, 83)."""
         self.L = _lib.load()
-        cfg = _lib.default_config()
-        cfg.device = device
-        cfg.n_channels = n_channels
-        cfg.symbol_clock = symbol_clock                          # 0: fixed stride (the reference's receiver), 1: SPEC 3.8b
+        # symbol_clock 0: fixed stride (the reference's receiver), 1: SPEC 3.8b
+        cfg = _lib.make_config(n_channels=n_channels, device=device, decim_taps=decim_taps, chan_taps=chan_taps,
+                               symbol_clock=symbol_clock, **spec)
         self.symbol_clock = symbol_clock
-        if decim_taps is not None:
-            cfg.n_decim_taps = len(decim_taps)                   # the library rejects counts above P25FE_MAX_TAPS
-            for i, v in enumerate(decim_taps[:_lib.MAX_TAPS]):
-                cfg.decim_taps[i] = v
-        if chan_taps is not None:
-            cfg.n_chan_taps = len(chan_taps)
-            for i, v in enumerate(chan_taps[:_lib.MAX_TAPS]):
-                cfg.chan_taps[i] = v
         self.cfg = cfg
         self.C = n_channels
         self.device = device
         self.h = C.c_void_p()
-        _lib.check(self.L, None, self.L.p25fe_create(C.byref(cfg), C.byref(self.h)))
+        rc = self.L.p25fe_create(C.byref(cfg), C.byref(self.h))
+        if rc == _lib.ERR_JIT:
+            raise _lib.P25feError(rc, self.L.p25fe_strerror(rc).decode() + ": " + _lib.specialize_log()[-2000:])
+        _lib.check(self.L, None, rc)
+
+    @property
+    def kernel_variant(self):
+        """0: the library's own immediate-coefficient kernels, 1: kernels specialised for this handle's numbers, 2: generic"""
+        return int(self.L.p25fe_kernel_variant(self.h))
 
     def close(self):
         if getattr(self, "h", None):

@@ -16,7 +16,7 @@ int main(void)
     memcpy(c.decim_taps, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
     memcpy(c.chan_taps, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
     memcpy(c.atan_c, P25FE_ATAN_COEFFS, sizeof(float) * P25FE_ATAN_NCOEF);
-    c.fm_gain = P25FE_FM_GAIN; c.u8_scale = P25FE_U8_SCALE; c.boxcar_scale = P25FE_BOXCAR_SCALE; c.pi = P25FE_PI; c.half_pi = P25FE_HALF_PI;
+    c.fm_gain = P25FE_FM_GAIN; c.u8_scale = P25FE_U8_SCALE; c.u8_offset = P25FE_U8_OFFSET; c.boxcar_scale = P25FE_BOXCAR_SCALE; c.pi = P25FE_PI; c.half_pi = P25FE_HALF_PI;
     c.inv_npos = P25FE_SYNC_INV_NPOS; c.inv_nneg = P25FE_SYNC_INV_NNEG; c.rho2_n = P25FE_SYNC_RHO2_N; c.e_min = P25FE_SYNC_E_MIN;
     c.slice_frac = P25FE_SLICE_FRAC;
     c.clk_lookahead = P25FE_CLK_LOOKAHEAD; c.clk_tol_shift = P25FE_CLK_TOL_SHIFT; c.clk_dmax_log2 = P25FE_CLK_DMAX_LOG2;

@@ -242,11 +242,15 @@ def padded_tables(spec, decim_taps=None, chan_taps=None):
     return h1, h2
 
 
-def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None):
-    """48 kHz baseband of a whole capture (SPEC 3.1 - 3.5; the build's own tap tables unless others are given)"""
+def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None, fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None):
+    """48 kHz baseband of a whole capture (SPEC 3.1 - 3.5; the build's own numbers unless others are given: the same
+    keywords as p25fe_config_t -- fm_gain is the resolved output scale)"""
     if u8 is not None:
-        b = np.asarray(u8, dtype=np.uint8).astype(F)
-        v = fma(b, F(spec["u8_scale"]), F(-1.0))
+        if u8_lut is not None:
+            v = np.asarray(u8_lut, dtype=F)[np.asarray(u8, dtype=np.uint8)]
+        else:
+            b = np.asarray(u8, dtype=np.uint8).astype(F)
+            v = fma(b, F(spec["u8_scale"] if u8_scale is None else u8_scale), F(spec["u8_offset"] if u8_offset is None else u8_offset))
         xr, xi = v[0::2], v[1::2]
     else:
         z = np.ascontiguousarray(iq, dtype=np.complex64)
@@ -260,7 +264,7 @@ def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None):
     re = fma(yr, pr, t)
     u = (yr * pi_).astype(F)
     im = fma(yi, pr, -u)
-    fmv = (atan2s(spec, im, re) * F(spec["fm_gain"])).astype(F)
+    fmv = (atan2s(spec, im, re) * F(spec["fm_gain"] if fm_gain is None else fm_gain)).astype(F)
     n = len(fmv)
     fp = np.concatenate([np.zeros(int(spec["boxcar_len"]), dtype=F), fmv])
     acc = fmv.copy()

@@ -47,10 +47,90 @@ def test_rccl_library_exports_its_header(lib):
 
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
-    assert cfg.abi_version == lib.ABI_VERSION == 3 and cfg.n_channels == 1 and cfg.symbol_clock == 0
+    assert cfg.abi_version == lib.ABI_VERSION == 4 and cfg.n_channels == 1 and cfg.symbol_clock == 0
+    # ABI 4: the run-time arguments of the reference's constructors (src/demod.rs:54, 83) default to the build's numbers
+    assert cfg.fm_deviation_hz == spec["fm_deviation_hz"] == 5000 and cfg.fm_sample_rate_hz == spec["fm_sample_rate_hz"] == 48000
+    assert cfg.fm_gain == 0.0 and cfg.specialize == lib.SPECIALIZE_AUTO and cfg.u8_lut_valid == 0
+    assert np.float32(cfg.u8_scale) == np.float32(spec["u8_scale"]) and np.float32(cfg.u8_offset) == np.float32(spec["u8_offset"])
+    from oracle import oracle as O
+    assert np.float32(O.fm_gain_from(cfg.fm_deviation_hz, cfg.fm_sample_rate_hz)) == np.float32(spec["fm_gain"])
     assert cfg.n_decim_taps == spec["t1"] and cfg.n_chan_taps == spec["t2"]
     assert np.array_equal(np.array(cfg.decim_taps[:spec["t1"]], dtype=np.float32), np.array(spec["decim_taps"], dtype=np.float32))
     assert np.array_equal(np.array(cfg.chan_taps[:spec["t2"]], dtype=np.float32), np.array(spec["chan_taps"], dtype=np.float32))
+
+
+def _hsaco_kernels(path):
+    """{kernel name: (vgprs, scratch bytes per lane)} from a code object's metadata"""
+    out = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path]).decode()
+    names = re.findall(r"\.name:\s+(\S+)", out)
+    scr = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", out)]
+    vg = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", out)]
+    assert len(names) == len(scr) == len(vg)
+    return {n: (v, s_) for n, v, s_ in zip(names, vg, scr)}
+
+
+def test_specialize_compiles_without_a_gpu_and_caches(lib, tmp_path):
+    """p25fe_specialize (the `make SPEC=` step of p25fe_create's hipRTC path): a caller's tables / constants become the
+    immediates of the same kernels; the code object lands under a hash of the numbers; the six entry points exist, none
+    of them spills; the build's own numbers need nothing; bad numbers are argument errors."""
+    rng = np.random.default_rng(5)
+    d = str(tmp_path / "spec")
+    assert lib.specialize(lib.default_config(), d) == ""              # the library's own kernels carry these
+    dt, ct = (rng.standard_normal(31) * 0.1).astype(np.float32), (rng.standard_normal(41) * 0.1).astype(np.float32)
+    cfg = lib.make_config(decim_taps=list(dt), chan_taps=list(ct))
+    f1 = lib.specialize(cfg, d)
+    assert os.path.dirname(f1) == d and re.fullmatch(r"p25fe-[0-9a-f]{16}\.hsaco", os.path.basename(f1))
+    t1 = os.path.getmtime(f1)
+    assert lib.specialize(cfg, d) == f1 and os.path.getmtime(f1) == t1  # second call: found, not rebuilt
+    k = _hsaco_kernels(f1)
+    want = {"p25jit_k1_cf32_lin", "p25jit_k1_u8_lin", "p25jit_k1_cf32_pl", "p25jit_k1_u8_pl", "p25jit_chunk_cf32", "p25jit_chunk_u8"}
+    assert set(k) == want, set(k) ^ want
+    assert all(s_ == 0 for _, s_ in k.values()), k                     # ScratchSize 0 everywhere
+    # any number that differs gives another code object: one tap bit, the deviation, the u8 offset, a non-affine table
+    dt2 = dt.copy()
+    dt2[3] = np.nextafter(dt2[3], np.float32(1))
+    names = {os.path.basename(f1)}
+    for kw in (dict(decim_taps=list(dt2), chan_taps=list(ct)), dict(decim_taps=list(dt), chan_taps=list(ct), fm_deviation_hz=4000),
+               dict(u8_offset=-0.996), dict(u8_lut=np.tanh((np.arange(256) - 127.5) / 90.0))):
+        names.add(os.path.basename(lib.specialize(lib.make_config(**kw), d)))
+    assert len(names) == 5
+    # 64 / 64 tables: the long geometry, still no scratch
+    f64 = lib.specialize(lib.make_config(decim_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
+                                         chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32))), d)
+    assert all(s_ == 0 for _, s_ in _hsaco_kernels(f64).values())
+    # a table that IS fma(b, s, o) runs as arithmetic: the same code object as naming (s, o) directly
+    sc, of = np.float32(1.0 / 128.0), np.float32(-127.0 / 128.0)
+    lut = (np.arange(256, dtype=np.float32) * sc + of).astype(np.float32)       # exact in fp32: products of small integers by 2^-7
+    assert lib.specialize(lib.make_config(u8_lut=lut), d) == lib.specialize(lib.make_config(u8_scale=sc, u8_offset=of), d)
+    # argument errors: a NaN tap, a zero deviation, an unknown specialize mode, the old ABI
+    for bad in (dict(decim_taps=[float("nan")] * 31), dict(fm_deviation_hz=0), dict(specialize=7), dict(fm_gain=float("inf"))):
+        with pytest.raises(lib.P25feError) as e:
+            lib.specialize(lib.make_config(**bad), d)
+        assert e.value.status == lib.ERR_ARG
+    old = lib.default_config()
+    old.abi_version = 3
+    with pytest.raises(lib.P25feError):
+        lib.specialize(old, d)
+
+
+def test_generic_kernels_do_not_spill(lib):
+    """No k_frontend / k_chunk instantiation of the library may use scratch memory (a spilled FIR loop is ~2x the time)."""
+    k = _hsaco_kernels_of_library(lib.LIB_PATH)
+    k1 = {n: v for n, v in k.items() if "k_frontend" in n or "k_chunk" in n}
+    assert len(k1) >= 20, sorted(k)
+    assert all(s_ == 0 for _, s_ in k1.values()), {n: v for n, v in k1.items() if v[1]}
+
+
+def _hsaco_kernels_of_library(so):
+    """metadata of the gfx950 code object bundled in a HIP shared library"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, fat])
+        subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + os.path.join(d, "k.hsaco")],
+                              stderr=subprocess.DEVNULL)
+        return _hsaco_kernels(os.path.join(d, "k.hsaco"))
 
 
 def test_spec_files_regenerate_bit_for_bit():

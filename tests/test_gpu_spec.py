@@ -1,0 +1,172 @@
+"""GPU parity of the reference's REAL configuration surface: caller-supplied tap tables (p25_filts' DecimFir / BandpassFir,
+src/demod.rs:27-29), the arguments of FmDemod::new (src/demod.rs:54) and the rtlsdr_iq table (src/demod.rs:83) -- through
+all three kernel variants of the library: the built-in immediate-coefficient kernels (the build's own numbers), kernels
+specialised for the caller's numbers (hipRTC at p25fe_create + on-disk cache) and the generic LDS-tap fallback.
+Every comparison is bit for bit against the oracle configured with the same numbers.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from p25rx_amd import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def FE():
+    from p25rx_amd.frontend import FrontEnd
+    return FrontEnd
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rand_taps(rng, n):
+    return (rng.standard_normal(n) * np.hanning(n + 2)[1:-1] / 6).astype(np.float32).tolist()
+
+
+def all_paths(O, FE, lib, iq, ocfg_kw, fe_kw, want_variant, u8=None):
+    """One handle configuration through every front-end kernel shape: linear K1 (demod_*: the RecvEvent::Baseband hand-off),
+    planar K1 (run_dev), the one-launch chunk kernel (run_* on 16 384-sample chunks), cf32 and u8."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    spec = O.load_spec()
+    ocfg = O.make_config(spec, **ocfg_kw)
+    u8 = c4fm.to_u8(iq) if u8 is None else u8
+    ref = O.Demod(ocfg).feed_cf32(iq)
+    ref8 = O.Demod(ocfg).feed_u8(u8)
+    fe = FE(**fe_kw)
+    assert fe.kernel_variant == want_variant, (fe.kernel_variant, want_variant, lib.specialize_log()[-500:])
+    cuts = [0, 5, 16384, 16385, 60001, len(iq)]
+    got = np.concatenate([fe.demod_cf32(iq[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(bits(got), bits(ref))
+    fe.reset()
+    got8 = np.concatenate([fe.demod_u8(u8[2 * a:2 * b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(bits(got8), bits(ref8))
+    # planar K1 + receiver on a resident capture, both formats
+    dib_ref = O.Recv(ocfg).feed(ref)[0]
+    dib_ref8 = O.Recv(ocfg).feed(ref8)[0]
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    dib, res = fe.run_dev(t)
+    n = int(parse_results(res)[0]["n_dibits"])
+    assert n == len(dib_ref) and np.array_equal(dib[0, :n].cpu().numpy(), dib_ref)
+    t8 = torch.from_numpy(u8.reshape(-1, 2)).cuda()
+    dib, res = fe.run_dev(t8)
+    n = int(parse_results(res)[0]["n_dibits"])
+    assert n == len(dib_ref8) and np.array_equal(dib[0, :n].cpu().numpy(), dib_ref8)
+    # the reference's own chunking through the streaming call: one launch per chunk (k_chunk)
+    fe.reset()
+    got = np.concatenate([fe.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)])
+    assert np.array_equal(got, dib_ref)
+    fe.reset()
+    got = np.concatenate([fe.run_u8(u8[o:o + 32768]) for o in range(0, len(u8), 32768)])
+    assert np.array_equal(got, dib_ref8)
+    return fe
+
+
+@pytest.mark.parametrize("nt", [(31, 41), (19, 33), (64, 64), (40, 41)])
+def test_custom_tables_specialised_and_generic(O, FE, lib, c4fm_1s, nt):
+    """Random asymmetric tables: the specialised kernels (immediates) and the generic ones (LDS) give the oracle's bits"""
+    rng = np.random.default_rng(500 + nt[0])
+    dt, ct = rand_taps(rng, nt[0]), rand_taps(rng, nt[1])
+    iq = c4fm_1s[0][:140000]
+    ok = dict(decim_taps=dt, chan_taps=ct)
+    all_paths(O, FE, lib, iq, ok, dict(ok, specialize=lib.SPECIALIZE_REQUIRE), lib.VARIANT_SPECIALIZED)
+    all_paths(O, FE, lib, iq, ok, dict(ok, specialize=lib.SPECIALIZE_OFF), lib.VARIANT_GENERIC)
+
+
+def test_default_numbers_builtin_and_forced_specialisation(O, FE, lib, c4fm_1s):
+    """The build's own numbers: the library's code object, and the hipRTC product of the same source (the two must agree
+    with the oracle, hence with each other)"""
+    iq = c4fm_1s[0][:140000]
+    all_paths(O, FE, lib, iq, {}, {}, lib.VARIANT_BUILTIN)
+    all_paths(O, FE, lib, iq, {}, dict(specialize=lib.SPECIALIZE_FORCE), lib.VARIANT_SPECIALIZED)
+    # naming the defaults explicitly is still "the build's own numbers"
+    spec = O.load_spec()
+    # (fma(b, s, -1) exactly: b * s and the sum are exact in double, rounded once)
+    lut = np.array([np.float32(np.float64(b) * np.float64(np.float32(spec["u8_scale"])) - 1.0) for b in range(256)], dtype=np.float32)
+    fe = FE(fm_deviation_hz=5000, fm_sample_rate_hz=48000, u8_scale=spec["u8_scale"], u8_offset=-1.0, fm_gain=spec["fm_gain"], u8_lut=lut)
+    assert fe.kernel_variant == lib.VARIANT_BUILTIN
+
+
+@pytest.mark.parametrize("mode", ["specialised", "generic"])
+def test_runtime_fm_deviation_and_u8_constants(O, FE, lib, c4fm_1s, mode):
+    """FmDemod::new(deviation, rate) and the u8 conversion as run-time arguments (ABI 4)"""
+    sp = lib.SPECIALIZE_REQUIRE if mode == "specialised" else lib.SPECIALIZE_OFF
+    var = lib.VARIANT_SPECIALIZED if mode == "specialised" else lib.VARIANT_GENERIC
+    iq = c4fm_1s[0][:100000]
+    # another deviation (the C4FM levels then read +-0.45 / +-0.15: the slicer's thresholds follow the sync word)
+    kw = dict(fm_deviation_hz=4000)
+    all_paths(O, FE, lib, iq, kw, dict(kw, specialize=sp), var)
+    # an explicit scale (demod_fm's own constant, once someone dumps it) wins over deviation / rate
+    g = float(np.nextafter(np.float32(O.load_spec()["fm_gain"]), np.float32(2)))
+    all_paths(O, FE, lib, iq, dict(fm_gain=g), dict(fm_gain=g, fm_deviation_hz=1234, specialize=sp), var)
+    # (b - 127.5) / 127.5 style and (b - 127) / 128 style tables as scale / offset
+    kw = dict(u8_scale=float(np.float32(1 / 128.0)), u8_offset=float(np.float32(-127 / 128.0)))
+    all_paths(O, FE, lib, iq, kw, dict(kw, specialize=sp), var)
+
+
+@pytest.mark.parametrize("mode", ["specialised", "generic"])
+def test_u8_lookup_table(O, FE, lib, c4fm_1s, mode):
+    """rtlsdr_iq::IQ as a TABLE (src/demod.rs:83): an affine table runs as arithmetic, any other one is looked up in LDS"""
+    from p25rx_amd import c4fm
+    sp = lib.SPECIALIZE_REQUIRE if mode == "specialised" else lib.SPECIALIZE_OFF
+    var = lib.VARIANT_SPECIALIZED if mode == "specialised" else lib.VARIANT_GENERIC
+    iq = c4fm_1s[0][:100000]
+    # correctly rounded (b - 127.5) / 127.5: NOT an fma of the byte for every b -> the LDS table
+    lut = ((np.arange(256, dtype=np.float64) - 127.5) / 127.5).astype(np.float32)
+    kw = dict(u8_lut=lut)
+    all_paths(O, FE, lib, iq, kw, dict(kw, specialize=sp), var)
+    # a companded table (nothing like a line), on bytes that cover the whole range
+    lut2 = np.tanh((np.arange(256) - 127.5) / 70.0).astype(np.float32)
+    rng = np.random.default_rng(9)
+    u8 = c4fm.to_u8(iq)
+    u8[::7] = rng.integers(0, 256, size=len(u8[::7]), dtype=np.uint8)
+    all_paths(O, FE, lib, iq, dict(u8_lut=lut2), dict(u8_lut=lut2, specialize=sp), var, u8=u8)
+
+
+def test_cache_is_used_and_survives_damage(FE, lib, tmp_path, monkeypatch):
+    """The code object of a set of numbers is compiled once, found again, and rebuilt if the cached file is damaged"""
+    import time
+    d = tmp_path / "cache"
+    monkeypatch.setenv("P25FE_CACHE_DIR", str(d))
+    monkeypatch.delenv("P25FE_SPEC_DIR", raising=False)
+    rng = np.random.default_rng(77)
+    kw = dict(decim_taps=rand_taps(rng, 31), chan_taps=rand_taps(rng, 41), specialize=lib.SPECIALIZE_REQUIRE)
+    t0 = time.perf_counter()
+    fe = FE(**kw)
+    t_cold = time.perf_counter() - t0
+    files = sorted(os.listdir(d))
+    assert fe.kernel_variant == lib.VARIANT_SPECIALIZED and len(files) == 1 and files[0].endswith(".hsaco")
+    t0 = time.perf_counter()
+    fe2 = FE(**kw)
+    t_warm = time.perf_counter() - t0
+    assert fe2.kernel_variant == lib.VARIANT_SPECIALIZED and t_warm < t_cold / 3, (t_cold, t_warm)
+    # an ahead-of-time directory ($P25FE_SPEC_DIR, the `make SPEC=` deployment) is looked in first
+    aot = tmp_path / "aot"
+    name = lib.specialize(lib.make_config(**kw), str(aot))
+    os.unlink(d / files[0])
+    monkeypatch.setenv("P25FE_SPEC_DIR", str(aot))
+    assert FE(**kw).kernel_variant == lib.VARIANT_SPECIALIZED and os.listdir(d) == [] and os.path.exists(name)
+    monkeypatch.delenv("P25FE_SPEC_DIR")
+    # damage: a truncated ELF -> recompiled and replaced
+    with open(d / files[0], "wb") as f:
+        f.write(open(name, "rb").read()[:4096])
+    fe3 = FE(**kw)
+    assert fe3.kernel_variant == lib.VARIANT_SPECIALIZED and os.path.getsize(d / files[0]) > 4096
+    x = np.zeros(16384, dtype=np.complex64)
+    assert len(fe3.demod_cf32(x)) == 3276

@@ -152,7 +152,8 @@ def main():
         "pre_decim": PRE_DECIM, "t0": T0, "pre_taps": [float(x) for x in pre],
         "atan_coeffs": [float(x) for x in atc],
         "fm_gain": float(fm_gain),
-        "u8_scale": float(np.float32(2.0 / 255.0)),
+        "u8_scale": float(np.float32(2.0 / 255.0)), "u8_offset": -1.0,
+        "fm_deviation_hz": 5000, "fm_sample_rate_hz": int(FS_BB),
         "boxcar_len": 10, "boxcar_scale": float(np.float32(0.1)),
         "sync_symbols": syms, "sync_sign_mask": sync_sign_mask,
         "sync_npos": npos, "sync_nneg": nneg,
@@ -207,6 +208,9 @@ def main():
     h.append("#define P25FE_SLICE_FRAC %s    /* 2/3 */\n" % hexf(spec["slice_frac"]))
     h.append("#define P25FE_FM_GAIN %s       /* 48000 / (2 pi 5000); src/demod.rs:54 */\n" % hexf(fm_gain))
     h.append("#define P25FE_U8_SCALE %s      /* 2/255 */\n" % hexf(spec["u8_scale"]))
+    h.append("#define P25FE_U8_OFFSET %s\n" % hexf(spec["u8_offset"]))
+    h.append("#define P25FE_FM_DEVIATION_HZ %d       /* src/demod.rs:54 */\n#define P25FE_FM_SAMPLE_RATE_HZ %d   /* src/consts.rs:13 */\n"
+             % (spec["fm_deviation_hz"], spec["fm_sample_rate_hz"]))
     h.append("#define P25FE_BOXCAR_SCALE %s  /* 1/10 */\n" % hexf(spec["boxcar_scale"]))
     h.append("#define P25FE_PI %s\n#define P25FE_HALF_PI %s\n" % (hexf(spec["pi"]), hexf(spec["half_pi"])))
     h.append("#define P25FE_NID_GEN_POLY 0x%xULL   /* octal 6331141367235453: BCH(63,16,23), TIA-102.BAAA */\n" % NID_GEN_POLY)
