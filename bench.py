@@ -203,6 +203,66 @@ def run_extras(torch, dev, args, iq2, truth2):
                             "arithmetic, an fma = 2 flops); instruction mix in profiles/r03_pmc_u8.txt"})
     del u8, fe
 
+    # ---- configs[1] with tables and constants that are NOT the build's own -- what a pinned build runs: the reference fixes
+    # p25_filts' tables at compile time (src/demod.rs:27-29), the library compiles the same kernels for the caller's numbers
+    # (hipRTC at p25fe_create, cached).  Other Kaiser designs of the two filters (the signal still decodes: the truth gate
+    # applies), 31 / 41 and 64 / 64 taps, cf32 and u8; beside them the generic LDS-tap fallback and the hipRTC product of the
+    # build's OWN numbers (same source, same options: the time must be the built-in kernels').
+    from scipy import signal as sps
+    from p25rx_amd import _lib
+
+    def design(n1, n2):
+        h1 = sps.firwin(n1, 11000.0, window=("kaiser", 6.0), fs=240000.0).astype(np.float32)
+        h2 = sps.firwin(n2, 6500.0, window=("kaiser", 4.5), fs=48000.0).astype(np.float32)
+        return h1.tolist(), h2.tolist()
+
+    def flops_per_sample(t1, t2, is_u8):
+        return (2 * 2 * t1 + 2 * 2 * t2 + 30 + 10) / 5.0 + (4.0 if is_u8 else 0.0)
+
+    def oracle_prefix_gate(fe_, x_, kw_, is_u8, n_pre=480000):
+        """GPU baseband of the first 2 s == the oracle configured with the same numbers, bit for bit"""
+        from oracle import oracle as O
+        bb_, nb_ = fe_.demod_dev(x_[:n_pre])
+        pre = x_[:n_pre].cpu().numpy()
+        d_ = O.Demod(O.make_config(None, **kw_))
+        ref_ = d_.feed_u8(pre.reshape(-1)) if is_u8 else d_.feed_cf32(pre.view(np.complex64).reshape(-1))
+        return bool(nb_ == len(ref_) and np.array_equal(bb_[0, :nb_].cpu().numpy().view(np.uint32), ref_.view(np.uint32)))
+
+    u8_all = torch.clamp(torch.round((iq2 + 1.0) * 127.5), 0, 255).to(torch.uint8)
+    variant_name = {0: "built-in immediates", 1: "specialised (hipRTC) immediates", 2: "generic LDS taps"}
+    cases = [("31 / 41 non-default tables", dict(zip(("decim_taps", "chan_taps"), design(31, 41))), _lib.SPECIALIZE_REQUIRE, 31, 41),
+             ("64 / 64 non-default tables", dict(zip(("decim_taps", "chan_taps"), design(64, 64))), _lib.SPECIALIZE_REQUIRE, 64, 64),
+             ("31 / 41 non-default tables, generic fallback", dict(zip(("decim_taps", "chan_taps"), design(31, 41))), _lib.SPECIALIZE_OFF, 31, 41),
+             ("the build's own numbers through hipRTC", {}, _lib.SPECIALIZE_FORCE, 31, 41)]
+    for label, kw, spz, t1, t2 in cases:
+        for is_u8 in (False, True):
+            x = u8_all if is_u8 else iq2
+            t_c = time.perf_counter()
+            fe = FrontEnd(device=dev.index, specialize=spz, **kw)
+            t_create = time.perf_counter() - t_c
+            dib = res = None
+            def step_ct():
+                nonlocal dib, res
+                dib, res = run(fe, x, dib, res)
+            k = steps_for(0.3)
+            dt = timed(torch, step_ct, k, 5, finish=fe.join_dev)
+            k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(x, dibits=dib, result=res), n, BYTES_PER_SAMPLE_U8 if is_u8 else BYTES_PER_SAMPLE)
+            ok = gate(dib, res, truth2) and oracle_prefix_gate(fe, x, kw, is_u8)
+            fl = flops_per_sample(t1, t2, is_u8)
+            tfl = fl * n / (k1 * 1e-3) / 1e12 if k1 > 0 else 0.0
+            bps = BYTES_PER_SAMPLE_U8 if is_u8 else BYTES_PER_SAMPLE
+            ach = bps * n / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
+            roof = ({"bound": "valu", "achieved": round(tfl, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tfl / VALU_PEAK_TFLOPS, 4), "flops_per_sample": fl} if is_u8 else
+                    {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                     "valu_TFLOPs": round(tfl, 2), "flops_per_sample": fl})
+            entry("configs[1] as %s, %s" % ("u8 I/Q pairs" if is_u8 else "cf32", label), n, dt / k * 1e3,
+                  "k_frontend<%s> %s" % ("u8" if is_u8 else "cf32", variant_name[fe.kernel_variant]), k1, bps, ok, steps=k,
+                  kernel_variant=fe.kernel_variant, create_s=round(t_create, 2), roofline=roof,
+                  gate="dibits == modulator symbols AND baseband of the first 2 s == oracle with the same numbers, bit for bit")
+            del fe, dib, res
+    del u8_all
+
     # ---- configs[1] with the tracking symbol clock (SPEC 3.8b; north_star's "symbol-clock interpolator"): the general receiver
     # The capture gets a sample-clock error first -- one IQ sample in 6 667 is dropped (150 ppm), so that sync-to-sync intervals
     # are 8 638 / 8 639 baseband samples, the receiver runs its general D / N arithmetic with non-zero interpolation phases

@@ -456,6 +456,7 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
             }
         } catch (...) {
             ok = false;
+            try { t_jit_log += "exception while specialising\n"; } catch (...) { }
         }
         if (ok) {
             h->variant = P25FE_VARIANT_SPECIALIZED;

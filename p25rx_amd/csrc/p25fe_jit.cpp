@@ -117,6 +117,19 @@ static bool mkdir_p(const std::string& dir)
     return stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
 }
 
+// A cached file is data from outside: before it is handed to the loader it must at least be a complete ELF64 image (the
+// section header table, which sits at the end of a code object, lies inside the file) -- a truncated copy is "not cached".
+static bool elf_complete(const std::vector<char>& d)
+{
+    if (d.size() < 64 || memcmp(d.data(), "\x7f" "ELF", 4) != 0 || d[4] != 2 /* ELFCLASS64 */) return false;
+    uint64_t shoff = 0;
+    uint16_t shentsize = 0, shnum = 0;
+    memcpy(&shoff, d.data() + 0x28, 8);
+    memcpy(&shentsize, d.data() + 0x3a, 2);
+    memcpy(&shnum, d.data() + 0x3c, 2);
+    return shoff >= 64 && shnum > 0 && shoff <= d.size() && (uint64_t)shentsize * shnum <= d.size() - shoff;
+}
+
 static bool read_file(const std::string& path, std::vector<char>& out)
 {
     FILE* f = fopen(path.c_str(), "rb");
@@ -126,7 +139,7 @@ static bool read_file(const std::string& path, std::vector<char>& out)
         const long n = ftell(f);
         if (n > 64 && n < (64L << 20) && fseek(f, 0, SEEK_SET) == 0) {
             out.resize((size_t)n);
-            ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n && memcmp(out.data(), "\x7f" "ELF", 4) == 0;
+            ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n && elf_complete(out);
         }
     }
     fclose(f);

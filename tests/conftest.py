@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Handles created by the tests with non-default tables run the generic kernels unless a test ASKS for the specialised ones
+# (specialize = REQUIRE / FORCE: tests/test_gpu_spec.py): the parity and fuzz suites create hundreds of handles with random
+# tables, and a hipRTC build per table (seconds each) would triple the suite's time.  Read once by the library, at the first
+# p25fe_create of the process.
+os.environ.setdefault("P25FE_JIT", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
