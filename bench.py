@@ -7,11 +7,14 @@ over one resident capture: BASELINE.json configs[1], 1 channel x 600 s of synthe
 `extra` array with the other single-GPU configurations (u8 input, config 3 end to end, config 4, config 5 on one GPU),
 each timed over its own >= 100 ms region after the headline one (`--no-extra` skips them).
 
-N > 1 (one rank per GPU, RCCL): BASELINE.json configs[4] -- ONE 3 600 s capture cut into N contiguous time shards
-(strong scaling: the total is fixed, each rank owns 3 600 / N seconds).  A step = halo send/recv to the right neighbour
-(hidden behind K1) -> pass 1 -> all_gather of the 56-byte shard summaries -> device resolve -> pass 2 -> all_gather of
-the dibit shards to rank 0 (point-to-point) + compaction into one ordered stream.  No host synchronisation inside a step.
-`--scaling weak` keeps 600 s per rank instead.
+N > 1 (one rank per GPU): the time-sharded step of the C ABI -- p25fe_shard_step of include/p25fe_rccl.h, driven through
+ctypes (p25rx_amd/rccl.py), RCCL inside libp25fe_rccl.so: halo send / recv to the right neighbour (hidden behind K1) ->
+pass 1 -> all-gather of the 96-byte shard summaries -> device resolve -> pass 2 -> every shard's valid dibits point-to-point
+to rank 0, received at their offsets of ONE ordered stream.  torch.distributed (gloo) is the control plane only: the
+communicator id, the barriers around the timed region, the max over ranks, the gates.  Default `--scaling weak`: every GPU
+holds configs[1]'s 600 s (the N = 1 line and the N > 1 lines are one curve of fixed per-GPU work); `--scaling strong` is
+BASELINE.json configs[4] as worded, ONE 3 600 s capture cut N ways.  A plain `python bench.py --gpus N` (no WORLD_SIZE in
+the environment) starts the N ranks itself, as children, through torch.distributed.run.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (K1) from HIP
 events recorded inside the library on the launch stream, and `cpu_baseline` from the CPU oracle timed on this box's
@@ -45,6 +48,8 @@ FLOPS_PER_SAMPLE = (2 * 2 * 31 + 2 * 2 * 41 + 30 + 10) / 5.0
 FLOPS_PER_SAMPLE_U8 = FLOPS_PER_SAMPLE + 4.0
 PMC_FILES = [os.path.join("profiles", "r03_k1_pmc.json"), os.path.join("profiles", "r02_k1_pmc.json")]
 PREWARM_MS = 150.0               # untimed steps before the W warm-up steps: the chip reaches its steady clock / power state
+GATHER_WORDS = {"root_exact": "point-to-point to rank 0, exactly the valid bytes, received at their offsets", "root": "point-to-point "
+                "gather of whole rows to rank 0 + compaction", "all": "all_gather of rows", "none": "nothing"}
 
 
 def cpu_baseline(iq_host, seconds_label):
@@ -452,6 +457,30 @@ def bench_channels(args, torch, dist, world, rank, local, dev, staged):
         sys.exit(3)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): start the N ranks as CHILD processes -- one per GPU,
+    through torch.distributed.run exactly as the driver does -- before this process has touched HIP (it never does), relay
+    rank 0's JSON line and exit with the children's code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in pr.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln, file=sys.stderr)
+    if js:
+        print(js[-1], flush=True)
+    sys.exit(pr.returncode if pr.returncode else (0 if js else 4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -468,14 +497,18 @@ def main():
                     help="N > 1: 'time' = configs[4], one capture cut into time shards (default); 'channels' = configs[3], "
                          "a 256-channel batch cut into channel blocks (no communication on the data path)")
     ap.add_argument("--channels", type=int, default=256, help="--workload channels: size of the batch")
-    ap.add_argument("--gather", choices=["root", "all", "none"], default="root",
-                    help="N > 1: dibit shards gathered to rank 0 (default), all-gathered, or left sharded (diagnostic)")
+    ap.add_argument("--gather", choices=["root_exact", "root", "all", "none"], default="root_exact",
+                    help="N > 1: the dibit shards go to rank 0 as exactly their valid bytes, received at their offsets of the "
+                         "ordered stream (default; one host wait for the offsets per step), as whole rows + a compaction pass "
+                         "(root: no host wait), all-gathered, or stay sharded (diagnostics)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: strictly serial steps (K1 -> K2 -> K3 -> K4 on one stream) instead of p25fe_run_dev_pipelined")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
     ap.add_argument("--cpu-seconds", type=float, default=600.0, help="length of the capture prefix timed on the CPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)                                 # (before torch is imported: this process never touches the GPU)
 
     import torch
     from p25rx_amd import c4fm
@@ -492,7 +525,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if staged:
+        if staged or args.workload == "time":
+            # time shards: the DATA path is libp25fe_rccl.so (RCCL inside the C ABI, p25rx_amd/rccl.py); torch.distributed is
+            # the control plane only (communicator id, barrier, max over ranks, gates) and runs on gloo
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -534,14 +569,20 @@ def main():
             def step():
                 fe.run_dev_pipelined(iq, dibits=dibits, result=result)
     else:
-        from p25rx_amd.sharding import HostStagedComm, TimeShard
-        ts = TimeShard(fe, rank, world, n, dist, comm=HostStagedComm(dist, rank, world) if staged else None)
-        ts.setup_device(torch, dev)
-        dibits = torch.zeros((1, ts.dibit_cap), dtype=torch.uint8, device=dev)
-        summ_all = torch.empty((world, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        # the product's N > 1 step: p25fe_shard_create / p25fe_shard_step of include/p25fe_rccl.h through ctypes -- the calls a
+        # Rust host binds.  Bootstrap: rank 0's 128-byte id (or, TEST HOOK, the name of a shared-memory object) over gloo.
+        from p25rx_amd import rccl
+        boot = [None]
+        if rank == 0:
+            boot[0] = ("/p25fe_bench_%d" % os.getpid()) if staged else rccl.unique_id()
+        dist.broadcast_object_list(boot, src=0)
+        if staged:
+            os.environ["P25FE_SHARD_SHM"] = boot[0]
+        ss = rccl.ShardStep(fe, rank, world, n, None if staged else boot[0])
+        dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device=dev)
 
         def step():
-            ts.step_device(buf, result, summ_all, dibits, gather=None if args.gather == "none" else args.gather)
+            ss.step(buf, dibits, result, gather=args.gather)
 
     # untimed pre-warm (not part of W or K): the chip needs ~100 ms of this load to settle at its power-limited clock; the
     # driver's `--steps 20 --warmup 5` is a 6 ms timed region behind 1.5 ms of warm-up and otherwise times the clock ramp
@@ -570,17 +611,8 @@ def main():
     kms, ncalls = fe.profile_read()
     comm_ms = None
     if world > 1 and not staged:
-        # where a step's time goes between the kernels, from a few extra steps with events around every exchange (outside
-        # the timed region: each event is one more packet on the stream)
-        ts.comm_events = []
-        for _ in range(min(args.steps, 8)):
-            step()
-        torch.cuda.synchronize()
-        acc = {}
-        for ph, e0, e1 in ts.comm_events:
-            acc.setdefault(ph, []).append(e0.elapsed_time(e1))
-        comm_ms = {ph: round(sum(v) / len(v), 4) for ph, v in acc.items()}
-        ts.comm_events = None
+        # where a step's time goes between the kernels: the library's own events around the three exchanges (last <= 64 steps)
+        comm_ms = {k_: (round(v_, 4) if isinstance(v_, float) else v_) for k_, v_ in ss.comm_ms().items()}
     # per-kernel split of the other kernels: a few extra steps OUTSIDE the timed region with events around every kernel
     fe.profile_enable(1)
     n_extra_steps = min(args.steps, 8)
@@ -629,7 +661,7 @@ def main():
             sum_gbps = iq.numel() * 4 * 30 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         except Exception:
             copy_gbps = sum_gbps = None
-    cdev = torch.device("cpu") if staged else dev
+    cdev = torch.device("cpu")                                   # (the control plane of the time workload is gloo)
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -659,7 +691,8 @@ def main():
         if args.gather != "none":
             # checksum of checksums: every rank's (length, byte sum, position-weighted sum) of its own dibits must equal
             # what rank 0 finds at that shard's resolved offset in the gathered, ordered stream
-            off = ts.d_offsets.cpu().numpy()
+            off = ss.offsets()
+            d_stream = ss.stream(torch, dev, int(off[world])) if (rank == 0 or args.gather == "all") else None
             w = torch.arange(1, nd + 1, dtype=torch.int64, device=dev) % 65521
             mine = dibits[0, :nd].to(torch.int64)
             sig = torch.stack([torch.tensor(nd, dtype=torch.int64, device=dev), mine.sum(), (mine * w).sum()]).to(cdev)
@@ -668,7 +701,7 @@ def main():
             gather_ok = True
             if rank == 0 or args.gather == "all":
                 for r_ in range(world):
-                    seg = ts.d_stream[int(off[r_]):int(off[r_ + 1])].to(torch.int64)
+                    seg = d_stream[int(off[r_]):int(off[r_ + 1])].to(torch.int64)
                     wr = torch.arange(1, seg.numel() + 1, dtype=torch.int64, device=dev) % 65521
                     got_sig = [seg.numel(), int(seg.sum().item()), int((seg * wr).sum().item())]
                     gather_ok = gather_ok and got_sig == [int(x) for x in sigs[r_].tolist()]
@@ -703,15 +736,15 @@ def main():
                         "decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather (%s)"
                         % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0, args.gather))
             sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries by all_gather, dibits by %s (%s)" % (
-                halo, {"root": "point-to-point gather to rank 0", "all": "all_gather", "none": "nothing"}[args.gather],
-                "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
+                halo, GATHER_WORDS[args.gather],
+                "TEST HOOK: shared-memory staging, all ranks on one GPU" if staged else "RCCL inside libp25fe_rccl.so")
         else:
             workload = ("configs[4]'s partitioning at configs[1]'s per-GPU size: ONE %.0f s capture (%d samples, %.3f GB) cut into %d "
                         "contiguous time shards of %.0f s, decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather (%s)"
                         % (total_s * world, n * world, n * world * 8 / 1e9, world, total_s, args.gather))
             sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries by all_gather, dibits by %s (%s)" % (
-                halo, {"root": "point-to-point gather to rank 0", "all": "all_gather", "none": "nothing"}[args.gather],
-                "TEST HOOK: gloo through host copies, all ranks on one GPU" if staged else "RCCL")
+                halo, GATHER_WORDS[args.gather],
+                "TEST HOOK: shared-memory staging, all ranks on one GPU" if staged else "RCCL inside libp25fe_rccl.so")
         out = {
             "metric": "IQ Msamples/s through FM-demod+C4FM slice",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -754,9 +787,9 @@ def main():
             if serial_ms is not None:
                 out["config"]["serial_ms_per_step"] = round(serial_ms, 4)
         if comm_ms is not None:
-            out["config"]["comm_ms_per_step"] = dict(comm_ms, note="rank 0, stream time from just before each exchange is enqueued "
-                                                     "to its completion on the step's stream (halo_wait_after_k1 is what K1's main launch "
-                                                     "did NOT hide); extra steps after the timed region")
+            out["config"]["comm_ms_per_step"] = dict(comm_ms, note="rank 0, p25fe_shard_comm_ms: HIP events of the library around each "
+                                                     "exchange on its stream (the halo exchange runs beside K1's main launch), averaged "
+                                                     "over the last <= 64 timed steps")
         if gather_ok is not None:
             out["config"]["gather_gate"] = ("gathered stream holds every shard at its resolved offset (length, sum and "
                                             "position-weighted sum of every rank's dibits): %s" % gather_ok)
@@ -776,6 +809,13 @@ def main():
                 out["extra_error"] = "%s: %s" % (type(e).__name__, e)
         print(json.dumps(out))
     if dist:
+        ss.close()
+        dist.barrier()
+        if staged and rank == 0:
+            try:
+                os.unlink("/dev/shm" + boot[0])
+            except OSError:
+                pass
         dist.destroy_process_group()
     if not ok and world == 1:
         sys.exit(3)                        # N = 1: a wrong result is a failed bench (N > 1 reports the gate in the JSON)

@@ -31,7 +31,14 @@ extern "C" {
 
 typedef struct p25fe_shard p25fe_shard_t;
 
-enum { P25FE_GATHER_NONE = 0, P25FE_GATHER_ROOT = 1, P25FE_GATHER_ALL = 2 };
+/* How the shards' dibits reach the consumer:
+ *   ROOT        every rank sends its whole row (p25fe_shard_dibit_cap() bytes: the valid length + <= 0.02 % + 64 bytes of slack)
+ *               to rank 0, which compacts the rows into the ordered stream; no host synchronisation anywhere in the step;
+ *   ROOT_EXACT  every rank sends exactly its offsets[r + 1] - offsets[r] dibits, rank 0 receives them AT offsets[r] of the
+ *               ordered stream (no padding on the wire, no compaction kernel); the counts are host arguments of ncclSend /
+ *               ncclRecv, so the step waits once for the world + 1 offsets (ready before pass 2 runs, which overlaps the wait);
+ *   ALL         all-gather of the rows, every rank compacts (diagnostic). */
+enum { P25FE_GATHER_NONE = 0, P25FE_GATHER_ROOT = 1, P25FE_GATHER_ALL = 2, P25FE_GATHER_ROOT_EXACT = 3 };
 
 /* rank 0: a fresh communicator id (ncclGetUniqueId) */
 int p25fe_rccl_unique_id(void *id128);

@@ -70,10 +70,16 @@ struct p25fe_shard {
     p25fe_anchor_t* d_anc = nullptr;
     uint8_t *d_gathered = nullptr, *d_stream = nullptr;
     char* d_loop = nullptr;               // one-rank RCCL group (tests on a 1-GPU box): where the halo loops back to
+    uint64_t* h_off = nullptr;            // pinned: the world + 1 offsets of the current step (P25FE_GATHER_ROOT_EXACT)
+    hipEvent_t e_res = nullptr, e_off = nullptr;
+    bool broken = false;                  // a collective failed half-way: the communicator's state is unknown, every later step fails
 };
 
 #define HCHK(x) do { if ((x) != hipSuccess) return P25FE_ERR_HIP; } while (0)
 #define NCHK(x) do { if ((x) != ncclSuccess) return P25FE_ERR_HIP; } while (0)
+// inside ncclGroupStart / ncclGroupEnd: close the group before returning (an open group would swallow every later collective
+// of this communicator) and retire the shard object
+#define NCHK_G(s, x) do { if ((x) != ncclSuccess) { (void)ncclGroupEnd(); (s)->broken = true; return P25FE_ERR_HIP; } } while (0)
 
 extern "C" {
 
@@ -98,6 +104,9 @@ void p25fe_shard_destroy(p25fe_shard_t* s)
     if (s->comm) (void)ncclCommDestroy(s->comm);
     if (s->e_fork) (void)hipEventDestroy(s->e_fork);
     if (s->e_join) (void)hipEventDestroy(s->e_join);
+    if (s->e_res) (void)hipEventDestroy(s->e_res);
+    if (s->e_off) (void)hipEventDestroy(s->e_off);
+    if (s->h_off) (void)hipHostFree(s->h_off);
     for (auto& row : s->ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_anc, s->d_gathered, s->d_stream, s->d_loop};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -133,6 +142,10 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     if (hipEventCreateWithFlags(&s->e_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->e_join, hipEventDisableTiming) != hipSuccess) return fail(P25FE_ERR_HIP);
     for (auto& row : s->ev) for (hipEvent_t& e : row) if (hipEventCreate(&e) != hipSuccess) return fail(P25FE_ERR_HIP);
+    if (hipEventCreateWithFlags(&s->e_res, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->e_off, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_off), ((size_t)world + 1) * 8, hipHostMallocDefault) != hipSuccess)
+        return fail(P25FE_ERR_HIP);
     const size_t W = (size_t)world;
     if (hipMalloc(&s->d_summ, W * sizeof(p25fe_result_t)) != hipSuccess || hipMalloc(&s->d_bb0, W * 8) != hipSuccess ||
         hipMalloc(&s->d_bbn, W * 8) != hipSuccess || hipMalloc(&s->d_off, (W + 1) * 8) != hipSuccess ||
@@ -170,7 +183,10 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
 
 int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
 {
-    if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8)) return P25FE_ERR_ARG;
+    if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) || gather < P25FE_GATHER_NONE ||
+        gather > P25FE_GATHER_ROOT_EXACT)
+        return P25FE_ERR_ARG;
+    if (s->broken) return P25FE_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     HCHK(hipSetDevice(p25fe_device(s->h)));
     const size_t eb = fmt == P25FE_FMT_CF32 ? 8 : 2;
@@ -196,13 +212,13 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             HCHK(hipStreamWaitEvent(s->cs, s->e_fork, 0));
             HCHK(hipEventRecord(ev[0], s->cs));
             NCHK(ncclGroupStart());
-            if (s->rank + 1 < s->world) NCHK(ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, s->comm, s->cs));
-            if (s->rank > 0) NCHK(ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, s->comm, s->cs));
+            if (s->rank + 1 < s->world) NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, s->comm, s->cs));
+            if (s->rank > 0) NCHK_G(s, ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, s->comm, s->cs));
             if (s->world == 1) {                                 // one-rank group (tests on a 1-GPU box): loop the halo back
-                NCHK(ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
-                NCHK(ncclRecv(s->d_loop, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
+                NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
+                NCHK_G(s, ncclRecv(s->d_loop, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
             }
-            NCHK(ncclGroupEnd());
+            if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
             HCHK(hipEventRecord(ev[1], s->cs));
             rc = p25fe_shard_pass1_main(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);
             if (rc) return rc;
@@ -229,6 +245,14 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
     }
     rc = p25fe_shard_resolve_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, s->d_anc, s->d_off, st);
     if (rc) return rc;
+    const bool exact = gather == P25FE_GATHER_ROOT_EXACT && multi && !s->staged;
+    if (exact) {
+        // the offsets are final here (before the slicer has even run): they travel to the host beside pass 2
+        HCHK(hipEventRecord(s->e_res, st));
+        HCHK(hipStreamWaitEvent(s->cs, s->e_res, 0));
+        HCHK(hipMemcpyAsync(s->h_off, s->d_off, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost, s->cs));
+        HCHK(hipEventRecord(s->e_off, s->cs));
+    }
     rc = p25fe_shard_pass2(s->h, s->d_anc + s->rank, d_dibits, s->cap, d_result, st);
     if (rc) return rc;
     // ---- 3. the reduced dibit stream
@@ -248,7 +272,25 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             s->shm.barrier();
         } else {
             HCHK(hipEventRecord(ev[4], st));
-            if (gather == P25FE_GATHER_ALL) {
+            if (exact) {
+                // "the reduced dibit stream": exactly offsets[r + 1] - offsets[r] bytes per shard, received AT offsets[r] of the
+                // ordered stream -- no padded rows on the wire, no compaction pass.  Costs the one host wait of the step (the
+                // send / recv counts are host arguments); pass 2 is already enqueued and runs meanwhile.
+                HCHK(hipEventSynchronize(s->e_off));
+                const uint64_t* off = s->h_off;
+                const size_t room = (size_t)s->world * s->cap;
+                for (int r = 0; r < s->world; ++r)
+                    if (off[r + 1] < off[r] || off[r + 1] - off[r] > s->cap || off[r + 1] > room) return P25FE_ERR_CAPACITY;   // (also reported by p25fe_shard_offsets)
+                NCHK(ncclGroupStart());
+                if (s->rank == 0) {
+                    for (int r = 1; r < s->world; ++r)
+                        if (off[r + 1] > off[r]) NCHK_G(s, ncclRecv(s->d_stream + off[r], (size_t)(off[r + 1] - off[r]), ncclUint8, r, s->comm, st));
+                } else if (off[s->rank + 1] > off[s->rank]) {
+                    NCHK_G(s, ncclSend(d_dibits, (size_t)(off[s->rank + 1] - off[s->rank]), ncclUint8, 0, s->comm, st));
+                }
+                if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
+                if (s->rank == 0 && off[1] > off[0]) HCHK(hipMemcpyAsync(s->d_stream + off[0], d_dibits, (size_t)(off[1] - off[0]), hipMemcpyDeviceToDevice, st));
+            } else if (gather == P25FE_GATHER_ALL) {
                 NCHK(ncclAllGather(d_dibits, s->d_gathered, s->cap, ncclUint8, s->comm, st));
                 have_all = true;
             } else {
@@ -256,11 +298,11 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
                 // all-gather would move `world` times the bytes the one consumer needs around a per-link-bound ring)
                 NCHK(ncclGroupStart());
                 if (s->rank == 0) {
-                    for (int r = 1; r < s->world; ++r) NCHK(ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, st));
+                    for (int r = 1; r < s->world; ++r) NCHK_G(s, ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, st));
                 } else {
-                    NCHK(ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, st));
+                    NCHK_G(s, ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, st));
                 }
-                NCHK(ncclGroupEnd());
+                if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
                 if (s->rank == 0) {
                     HCHK(hipMemcpyAsync(s->d_gathered, d_dibits, s->cap, hipMemcpyDeviceToDevice, st));
                     have_all = true;

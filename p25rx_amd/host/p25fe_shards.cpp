@@ -3,8 +3,10 @@
 // drives include/p25fe_rccl.h (halo by ncclSend / ncclRecv behind K1, summaries by ncclAllGather, device resolve, dibit
 // rows to rank 0 + compaction) and rank 0 writes the ORDERED dibit stream -- byte for byte what `p25fe_replay cf32` writes.
 //
-//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [--shm] <in.cf32> <dibits.out>
+//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [--shm] <in.cf32> <dibits.out>
 //
+//   -g      how the dibits reach rank 0 (include/p25fe_rccl.h): exact = each shard's valid bytes, received at their offsets
+//           (default; P25FE_GATHER_ROOT_EXACT), rows = whole rows + a compaction pass (P25FE_GATHER_ROOT)
 //   -c 1    the tracking symbol clock (docs/SPEC.md 3.8b; p25fe_config_t.symbol_clock)
 //   --shm   TEST HOOK: all ranks on GPU 0, exchanges through a shared-memory segment instead of RCCL (a 1-GPU box)
 //   -n 1    runs the same step through a ONE-rank RCCL communicator (self send / recv, all-gather of one)
@@ -31,7 +33,7 @@ static void die(const char* what, int rc)
     std::_Exit(1);
 }
 
-static int child(int rank, int world, int steps, bool shm, int clock, const char* in_path, const char* out_path, const std::string& key)
+static int child(int rank, int world, int steps, bool shm, int clock, int gather, const char* in_path, const char* out_path, const std::string& key)
 {
     FILE* f = std::fopen(in_path, "rb");
     if (!f) { std::fprintf(stderr, "unable to open %s\n", in_path); return 1; }
@@ -87,7 +89,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, const char
     (void)hipMemset(d_buf, 0, halo * 8);
     (void)hipMemcpy(d_buf + 2 * halo, host.data(), n * 8, hipMemcpyHostToDevice);
     for (int k = 0; k < 2; ++k) {                                     // warm-up (communicator set-up, scratch allocation)
-        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, P25FE_GATHER_ROOT, st);
+        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
         if (rc) die("step", rc);
     }
     (void)hipStreamSynchronize(st);
@@ -96,7 +98,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, const char
     (void)p25fe_shard_comm_ms(s, cms, &cn);
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; ++k) {
-        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, P25FE_GATHER_ROOT, st);
+        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
         if (rc) die("step", rc);
     }
     (void)hipStreamSynchronize(st);
@@ -113,8 +115,9 @@ static int child(int rank, int world, int steps, bool shm, int clock, const char
         std::fclose(g);
         std::printf("{\"ranks\":%d,\"samples_per_rank\":%zu,\"dibits\":%" PRIu64 ",\"steps\":%d,\"ms_per_step\":%.4f,"
                     "\"comm_ms_per_step\":{\"halo\":%.4f,\"summaries\":%.4f,\"dibit_gather\":%.4f,\"steps_averaged\":%" PRIu64 "},"
-                    "\"exchange\":\"%s\"}\n",
-                    world, n, off[(size_t)world], steps, ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL");
+                    "\"exchange\":\"%s\",\"gather\":\"%s\"}\n",
+                    world, n, off[(size_t)world], steps, ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL",
+                    gather == P25FE_GATHER_ROOT_EXACT ? "exact" : "rows");
         std::remove(idfile.c_str());
         std::fflush(stdout);                                          // the child leaves through _Exit
     }
@@ -125,17 +128,18 @@ static int child(int rank, int world, int steps, bool shm, int clock, const char
 
 int main(int argc, char** argv)
 {
-    int ranks = 1, steps = 3, clock = 0, a = 1;
+    int ranks = 1, steps = 3, clock = 0, a = 1, gather = P25FE_GATHER_ROOT_EXACT;
     bool shm = false;
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!std::strcmp(argv[a], "-n") && a + 1 < argc) ranks = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "-k") && a + 1 < argc) steps = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "-c") && a + 1 < argc) clock = std::atoi(argv[++a]);
+        else if (!std::strcmp(argv[a], "-g") && a + 1 < argc) gather = !std::strcmp(argv[++a], "rows") ? P25FE_GATHER_ROOT : P25FE_GATHER_ROOT_EXACT;
         else if (!std::strcmp(argv[a], "--shm")) shm = true;
         else break;
     }
     if (argc - a != 2 || ranks < 1 || steps < 1 || (clock != 0 && clock != 1)) {
-        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
         return 2;
     }
     const std::string key = "/p25fe_shards_" + std::to_string((long)getpid());
@@ -144,7 +148,7 @@ int main(int argc, char** argv)
     std::vector<pid_t> kids;
     for (int r = 0; r < ranks; ++r) {
         const pid_t p = fork();
-        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, argv[a], argv[a + 1], key));
+        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, gather, argv[a], argv[a + 1], key));
         kids.push_back(p);
     }
     int bad = 0;

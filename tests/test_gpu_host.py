@@ -251,6 +251,73 @@ def test_bench_two_ranks_time_shards_host_staged(scaling):
 
 
 @pytest.mark.timeout(300)
+def test_bench_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE: the way the driver runs `--gpus 1`): bench.py starts the two
+    ranks itself as children (torch.distributed.run), relays rank 0's line.  The step is the C ABI's (p25fe_shard_step through
+    p25rx_amd/rccl.py); here with the shared-memory test hook, two ranks on this one GPU."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["P25FE_BENCH_HOST_STAGED"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "30"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "launching 2 ranks" in out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "libp25fe_rccl" not in d["config"]["sharding"]     # (the hook says so)
+    assert "TEST HOOK" in d["config"]["sharding"]
+    assert d["config"]["parity_gate"].endswith("True") and d["config"]["gather_gate"].endswith("True")
+
+
+def _rccl_cabi_world1_worker(q):
+    import torch
+    from p25rx_amd import c4fm, rccl
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    torch.cuda.set_device(0)
+    iq = c4fm.synth(2.0, seed=78, snr_db=22.0, frame_dibits=400)[0]
+    n = len(iq) // 8 * 8
+    fe = FrontEnd()
+    ss = rccl.ShardStep(fe, 0, 1, n, rccl.unique_id())              # a ONE-rank RCCL communicator: self send / recv, all-gather of one
+    halo = fe.shard_halo()
+    buf = torch.zeros((halo + n, 2), dtype=torch.float32, device="cuda")
+    buf[halo:] = torch.from_numpy(iq[:n].view(np.float32).reshape(-1, 2)).cuda()
+    result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device="cuda")
+    ref, rres = FrontEnd().run_dev(buf[halo:])
+    nref = int(parse_results(rres)[0]["n_dibits"])
+    oks = []
+    for gather in ("root_exact", "root", "all", "root_exact"):
+        for _ in range(3):
+            ss.step(buf, dibits, result, gather=gather)
+        torch.cuda.synchronize()
+        off = ss.offsets()
+        st = ss.stream(torch, "cuda", int(off[-1]))
+        oks.append(int(off[-1]) == nref and bool(torch.equal(st, ref[0, :nref])))
+    cm = ss.comm_ms()
+    oks.append(cm["steps"] == 12 and cm["halo_send_recv"] > 0 and cm["summary_all_gather"] > 0)
+    ss.close()
+    q.put(oks)
+
+
+@pytest.mark.timeout(300)
+def test_c_abi_shard_step_through_ctypes_rccl_world1():
+    """p25rx_amd/rccl.py (what bench.py --gpus N drives): p25fe_shard_step over a one-rank RCCL communicator, every gather
+    mode -- exact bytes at their offsets, rows + compaction, all-gather -- gives the single-pass stream"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_cabi_world1_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res == [True, True, True, True, True]
+
+
+@pytest.mark.timeout(300)
 def test_bench_two_ranks_channel_blocks_host_staged():
     """config 4 over N GPUs (ChannelShard): bench.py --workload channels with two ranks on one GPU.  5 channels -> blocks
     of 3 and 2; every rank decodes its block with the real kernels, the gathered summary table is complete."""
@@ -400,7 +467,7 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
     ref = O.run_cf32(iq)
     src = tmp_path / "cap.cf32"
     iq.tofile(src)
-    for args in (["-n", "1"], ["-n", "2", "--shm"], ["-n", "3", "--shm"], ["-n", "8", "--shm"]):
+    for args in (["-n", "1"], ["-n", "1", "-g", "rows"], ["-n", "2", "--shm"], ["-n", "3", "--shm"], ["-n", "8", "--shm"]):
         out = tmp_path / ("dib_" + "_".join(a.strip("-") for a in args))
         r = subprocess.run([exe] + args + ["-k", "3", str(src), str(out)], capture_output=True, timeout=280)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -410,6 +477,7 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
         assert np.array_equal(got, ref), args
         if "--shm" not in args:
             assert rep["exchange"] == "RCCL" and rep["comm_ms_per_step"]["steps_averaged"] == 3
+            assert rep["gather"] == ("rows" if "rows" in args else "exact")
             assert rep["comm_ms_per_step"]["halo"] > 0 and rep["comm_ms_per_step"]["summaries"] > 0
     # the same with the tracking symbol clock on a capture whose sample clock is 150 ppm off: every shard's first detection
     # takes its period from the previous shard's anchor (the carry resolution with clocks, p25fe_shard_resolve_dev)

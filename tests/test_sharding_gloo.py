@@ -198,3 +198,24 @@ def test_channel_blocks_partition():
             assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
             sizes = [b - a for a, b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_plain_invocation_reaches_the_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must not die on an assert (round 3 did): bench.py starts
+    the two ranks itself, as children, through torch.distributed.run.  Without a GPU the ranks get as far as the rendezvous
+    (gloo, world size 2) and then refuse to run -- there is no CPU fallback -- which is what this CPU test can see; the same
+    command completes on the GPU box (tests/test_gpu_host.py)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_host.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["P25FE_BENCH_HOST_STAGED"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--seconds", "1",
+                          "--no-extra", "--no-cpu"], env=env, capture_output=True, text=True, timeout=240)
+    assert "launching 2 ranks" in out.stderr and "torch.distributed.run" in out.stderr
+    assert out.returncode != 0                                           # no GPU: the ranks fail loudly ...
+    assert out.stderr.count("No HIP GPUs are available") >= 2           # ... both of them, after the launcher started them
+    assert "--gpus must equal WORLD_SIZE" not in out.stderr
