@@ -201,6 +201,28 @@ int p25fe_slice(p25fe_t *h, const float *bb, size_t n, uint8_t *dibits, size_t c
 int p25fe_run_u8(p25fe_t *h, const uint8_t *iq, size_t n_bytes, uint8_t *dibits, size_t cap, size_t *n_dibits);
 int p25fe_run_cf32(p25fe_t *h, const float *iq, size_t n_samples, uint8_t *dibits, size_t cap, size_t *n_dibits);
 
+/* A LONG capture in host memory through the same path at the speed of the bus: the capture is cut into windows of `window`
+ * samples per channel (0: 64 MB worth; rounded down to a multiple of 8, at least 8 192); window k + 1 travels to the GPU
+ * (hipMemcpyAsync on a copy stream, two device windows) while window k is demodulated and sliced, and window k - 1's dibits
+ * travel back.  Filter and receiver state cross the window boundaries exactly as they cross a time shard's: the last
+ * p25fe_shard_halo() samples stay in front of the next window (device-to-device), the anchor is handed on in device
+ * memory.  The reference's shape is the same pipeline with a 16-deep buffer pool between reader and demodulator
+ * (src/demod.rs:62-70, 103; src/sdr.rs:25-33).  Continues the handle's stream (any chunking of p25fe_run_* and this call
+ * gives the same concatenated dibits) and leaves it ready for more.
+ * iq: [C][n] channel-major.  Pinned memory (hipHostMalloc / hipHostRegister) is copied from directly; pageable memory is
+ * staged through two pinned windows of the library by the calling thread.  dibits: [C][cap]; capacity as for p25fe_run_*.
+ * stats (nullable): where the time went. */
+typedef struct p25fe_windows_stats {
+    uint64_t n_windows;
+    double ms_total;                     /* wall time of the call */
+    double ms_h2d;                       /* the H2D copies' own time (events on the copy stream), summed */
+    double ms_compute;                   /* the windows' kernels (events on the compute stream), summed */
+    int32_t pinned_input;                /* 1: copied straight from the caller's memory, 0: staged by the calling thread */
+    int32_t reserved;
+} p25fe_windows_stats_t;
+int p25fe_run_host_windows(p25fe_t *h, const void *iq, int fmt, size_t n, size_t window, uint8_t *dibits, size_t cap,
+                           size_t *n_dibits, p25fe_windows_stats_t *stats);
+
 /* MessageReceiver::resync (src/recv.rs:136, 179): drop symbol lock at the current position. */
 int p25fe_resync(p25fe_t *h);
 /* The same for device-resident ranges, where "the current position" lies INSIDE the range (RecvTask handles

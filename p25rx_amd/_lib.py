@@ -28,6 +28,11 @@ class Config(C.Structure):
                 ("u8_scale", C.c_float), ("u8_offset", C.c_float), ("u8_lut_valid", C.c_int32), ("u8_lut", C.c_float * 256)]
 
 
+class WindowsStats(C.Structure):
+    _fields_ = [("n_windows", C.c_uint64), ("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_compute", C.c_double),
+                ("pinned_input", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Anchor(C.Structure):
     _fields_ = [("s", C.c_int64), ("hi", C.c_float), ("mid", C.c_float), ("lo", C.c_float), ("valid", C.c_int32),
                 ("period_d", C.c_int32), ("period_n", C.c_int32)]
@@ -63,7 +68,7 @@ SYMBOLS = [
     "p25fe_predecim_dev", "p25fe_n_predecim", "p25fe_shard_resolve_dev", "p25fe_nid_dev",
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
     "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
-    "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log",
+    "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log", "p25fe_run_host_windows",
 ]
 
 
@@ -113,6 +118,7 @@ def load():
     L.p25fe_slice.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp]
     L.p25fe_run_u8.argtypes = [vp, vp, sz, vp, sz, vp]
     L.p25fe_run_cf32.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.p25fe_run_host_windows.argtypes = [vp, vp, C.c_int, sz, sz, vp, sz, vp, C.POINTER(WindowsStats)]
     L.p25fe_resync.argtypes = [vp]
     L.p25fe_reset.argtypes = [vp]
     L.p25fe_state_size.argtypes = [vp, psz]

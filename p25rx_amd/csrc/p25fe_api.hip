@@ -11,8 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <map>
-#include <mutex>
+#include <chrono>
 #include <new>
 #include <utility>
 #include <string>
@@ -139,6 +138,11 @@ struct p25fe {
     hipStream_t rx_joined[2] = {nullptr, nullptr};   // stream that has already been made to wait for ev_rx[l] (valid while rx_pending[l])
     bool rx_joined_any[2] = {false, false};
     int lane = 0;
+    // p25fe_run_host_windows: two device windows, dibit rows and result records in a ring, the copy streams and their events
+    DevBuf win_buf[2], win_dib[2], win_res, win_anc;
+    PinBuf win_stage[2], win_out;
+    hipStream_t win_cs = nullptr, win_os = nullptr;
+    hipEvent_t win_ev[4][5] = {};          // per ring slot: H2D begin / end, compute begin / end, results on the host
     bool ext_events = true;                // events ride on the kernel dispatches (hipExtLaunchKernelGGL) instead of separate records
     int rx_cus = 0;                        // > 0: the receive stream is confined to this many CUs (hipExtStreamCreateWithCUMask)
     // stream state (per channel, channel-major in the device buffers)
@@ -479,6 +483,11 @@ void p25fe_destroy(p25fe_t* h)
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     if (h->rx_stream) { (void)hipStreamSynchronize(h->rx_stream); (void)hipStreamDestroy(h->rx_stream); }
     if (h->jit_mod) (void)hipModuleUnload(h->jit_mod);
+    if (h->win_cs) { (void)hipStreamSynchronize(h->win_cs); (void)hipStreamDestroy(h->win_cs); }
+    if (h->win_os) { (void)hipStreamSynchronize(h->win_os); (void)hipStreamDestroy(h->win_os); }
+    for (auto& slot : h->win_ev) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; ++b) { h->win_buf[b].release(); h->win_dib[b].release(); h->win_stage[b].release(); }
+    h->win_res.release(); h->win_anc.release(); h->win_out.release();
     for (int l = 0; l < 2; ++l) {
         if (h->ev_k1[l]) (void)hipEventDestroy(h->ev_k1[l]);
         if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
@@ -1490,6 +1499,194 @@ int p25fe_run_u8(p25fe_t* h, const uint8_t* iq, size_t n_bytes, uint8_t* dibits,
 int p25fe_run_cf32(p25fe_t* h, const float* iq, size_t n_samples, uint8_t* dibits, size_t cap, size_t* n_dibits)
 {
     return run_host(h, iq, P25FE_FMT_CF32, n_samples, dibits, cap, n_dibits);
+}
+
+// --------------------------------------------------------------------------------------------
+// a long host capture as a pipeline of windows: H2D copy | K1..K4 | dibits D2H, each on its own stream
+// --------------------------------------------------------------------------------------------
+int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t window, uint8_t* dibits, size_t cap,
+                           size_t* n_dibits, p25fe_windows_stats_t* stats)
+{
+    if (!h || (!iq && n) || !dibits || !n_dibits || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8)) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->fmt_locked >= 0 && h->fmt_locked != fmt && h->abs_iq > 0) return P25FE_ERR_FORMAT;
+    const size_t C = (size_t)h->C, eb = fmt_bytes(fmt);
+    if (window == 0) window = (size_t)(64u << 20) / eb;
+    window &= ~(size_t)7;                                           // every window's first sample stays 16-byte aligned
+    if (window < 8192) window = 8192;
+    const size_t nb_total = p25fe_n_baseband(h->abs_iq, n);
+    if (cap < nb_total / SPS + 1) return P25FE_ERR_CAPACITY;        // worst case of an undisturbed lock, before any state moves
+    if (stats) memset(stats, 0, sizeof *stats);
+    for (size_t c = 0; c < C; ++c) n_dibits[c] = 0;
+    if (n == 0) return P25FE_OK;
+    if (n <= window && n <= (size_t)(1u << 20)) {                   // one small window: the streaming call does the same with less set-up
+        const int rc1 = run_host(h, iq, fmt, n, dibits, cap, n_dibits);
+        if (stats) { stats->n_windows = 1; }
+        return rc1;
+    }
+    shard_invalidate(h);
+    if (int jrc = pipe_join(h, h->stream)) return jrc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    constexpr int R = 4;
+    if (!h->win_cs) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->win_cs, hipStreamNonBlocking));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->win_os, hipStreamNonBlocking));
+        for (auto& slot : h->win_ev) for (hipEvent_t& e : slot) HIPCHK(h, hipEventCreate(&e));
+    }
+    hipStream_t st = h->stream, cs = h->win_cs, os = h->win_os;
+    const size_t n_win = (n + window - 1) / window;
+    const size_t stride = SHARD_HALO + window + 8;                  // samples per channel row of a device window: [halo | window]
+    const size_t nb_win = window / DEC + 2;
+    const size_t dstride = round_up(nb_win / (W + 1) + 2, 64);      // hard ceiling of a window's dibits (p25fe_slice's rule)
+    int rc = ensure_slice_scratch(h, nb_win);
+    if (rc) return rc;
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(h, h->win_buf[b].ensure(C * stride * eb));
+        HIPCHK(h, h->win_dib[b].ensure(C * dstride));
+    }
+    HIPCHK(h, h->win_res.ensure((size_t)R * C * sizeof(p25fe_result_t)));
+    HIPCHK(h, h->win_anc.ensure(2 * C * sizeof(p25fe_anchor_t)));
+    // pinned: per ring slot the result records, per parity a dibit row block, the baseband tail, the carry-in anchors, the history
+    const size_t out_bytes = (size_t)R * round_up(C * sizeof(p25fe_result_t), 64) + 2 * round_up(C * dstride, 64) +
+                             round_up(C * TAILN * sizeof(float), 64) + round_up(C * sizeof(p25fe_anchor_t), 64) + round_up(C * SHARD_HALO * eb, 64);
+    HIPCHK(h, h->win_out.ensure(out_bytes));
+    Arena ar(h->win_out);
+    p25fe_result_t *h_res[R], *dv_unused_r;
+    for (int q = 0; q < R; ++q) h_res[q] = ar.take<p25fe_result_t>(C, &dv_unused_r);
+    uint8_t *h_dib[2], *dv_unused_b;
+    for (int b = 0; b < 2; ++b) h_dib[b] = ar.take<uint8_t>(C * dstride, &dv_unused_b);
+    float *d_tail, *h_tail = ar.take<float>(C * TAILN, &d_tail);
+    p25fe_anchor_t *dv_unused_a, *h_anc = ar.take<p25fe_anchor_t>(C, &dv_unused_a);
+    char *dv_unused_h, *h_hist = ar.take<char>(C * SHARD_HALO * eb, &dv_unused_h);
+    // is the caller's memory pinned?  (then the copy engine reads it directly; otherwise this thread stages it)
+    bool pinned = false;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, iq) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    if (!pinned)
+        for (int b = 0; b < 2; ++b) HIPCHK(h, h->win_stage[b].ensure(C * window * eb));
+    memcpy(h_anc, h->anchor.data(), C * sizeof(p25fe_anchor_t));
+    for (size_t c = 0; c < C; ++c) memcpy(h_hist + c * SHARD_HALO * eb, h->hist_iq.data() + c * SHARD_HALO * 8, SHARD_HALO * eb);
+    p25fe_anchor_t* d_anc = h->win_anc.as<p25fe_anchor_t>();        // [2][C]: the carry-in of window k lives in half k & 1
+    const RecvCall rcall = recv_call(h);                             // (a pending lock-drop list holds absolute indices: every window sees it)
+    std::vector<uint64_t> total(C, 0);
+    double ms_h2d = 0.0, ms_comp = 0.0;
+    int status = P25FE_OK;
+    auto drain = [&](size_t j) -> int {                              // window j's dibits are on the host: append them
+        hipEvent_t* ev = h->win_ev[j % R];
+        HIPCHK(h, hipEventSynchronize(ev[4]));
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ev[0], ev[1]) == hipSuccess) ms_h2d += t; else (void)hipGetLastError();
+        if (hipEventElapsedTime(&t, ev[2], ev[3]) == hipSuccess) ms_comp += t; else (void)hipGetLastError();
+        const p25fe_result_t* r = h_res[j % R];
+        for (size_t c = 0; c < C; ++c) {
+            const uint64_t nd = r[c].n_dibits;
+            if (nd > dstride || total[c] + nd > cap) return P25FE_ERR_CAPACITY;
+            memcpy(dibits + c * cap + total[c], h_dib[j & 1] + c * dstride, (size_t)nd);
+            total[c] += nd;
+        }
+        return P25FE_OK;
+    };
+    size_t nb_done = 0;
+    for (size_t k = 0; k < n_win && status == P25FE_OK; ++k) {
+        const size_t off = k * window, wn = n - off < window ? n - off : window;
+        const uint64_t abs0 = h->abs_iq + off;
+        const size_t n_hist = k == 0 ? (h->abs_iq < SHARD_HALO ? (size_t)h->abs_iq : SHARD_HALO) : SHARD_HALO;
+        const int b = (int)(k & 1);
+        hipEvent_t* ev = h->win_ev[k % R];
+        char* dev = h->win_buf[b].as<char>();
+        // ---- copy stream: halo, then the window
+        if (k >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->win_ev[(k - 2) % R][3], 0));      // the kernels of window k - 2 have read this buffer
+        if (k == 0) {
+            HIPCHK(h, hipMemcpy2DAsync(dev, stride * eb, h_hist, SHARD_HALO * eb, SHARD_HALO * eb, C, hipMemcpyHostToDevice, cs));
+        } else {
+            const char* prev = h->win_buf[b ^ 1].as<char>() + window * eb;     // the last SHARD_HALO samples of [halo | window k - 1]
+            HIPCHK(h, hipMemcpy2DAsync(dev, stride * eb, prev, stride * eb, SHARD_HALO * eb, C, hipMemcpyDeviceToDevice, cs));
+        }
+        const char* src = static_cast<const char*>(iq) + off * eb;
+        size_t spitch = n * eb;
+        if (!pinned) {
+            if (k >= 2) HIPCHK(h, hipEventSynchronize(h->win_ev[(k - 2) % R][1]));       // the copy engine is done with this staging window
+            char* sg = static_cast<char*>(h->win_stage[b].p);
+            for (size_t c = 0; c < C; ++c) memcpy(sg + c * wn * eb, src + c * n * eb, wn * eb);
+            src = sg; spitch = wn * eb;
+        }
+        HIPCHK(h, hipEventRecord(ev[0], cs));
+        HIPCHK(h, hipMemcpy2DAsync(dev + SHARD_HALO * eb, stride * eb, src, spitch, wn * eb, C, hipMemcpyHostToDevice, cs));
+        HIPCHK(h, hipEventRecord(ev[1], cs));
+        // ---- compute stream
+        HIPCHK(h, hipStreamWaitEvent(st, ev[1], 0));
+        if (k >= 2) HIPCHK(h, hipStreamWaitEvent(st, h->win_ev[(k - 2) % R][4], 0));      // window k - 2's dibit rows have left this device row block
+        if (k == 0) HIPCHK(h, hipMemcpyAsync(d_anc, h_anc, C * sizeof(p25fe_anchor_t), hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipEventRecord(ev[2], st));
+        const size_t nb = p25fe_n_baseband(abs0, wn);
+        const long view0 = (long)(h->abs_bb + nb_done) - h->look;
+        p25fe_result_t* d_res = h->win_res.as<p25fe_result_t>() + (k % R) * C;
+        uint8_t* d_dib = h->win_dib[b].as<uint8_t>();
+        const PlanarGeo g(nb ? nb : 1);
+        if (nb) {
+            rc = launch_frontend(h, dev + SHARD_HALO * eb, fmt, stride, n_hist, wn, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g);
+            if (!rc) rc = launch_detect(h, nb, view0, st, rcall);
+        }
+        if (!rc) rc = launch_scan_slice(h, nb, view0, d_anc + (size_t)b * C, d_dib, dstride, nullptr, nullptr, 0, d_res, nb != 0, st, rcall);
+        if (rc) { status = rc; break; }
+        hipLaunchKernelGGL(k_anchors_from_results, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, d_res, d_anc + (size_t)(b ^ 1) * C, (int)C);
+        if (k + 1 == n_win && nb) {                                  // the baseband tail for a later p25fe_slice on this handle
+            ChunkRecvArgs cr;
+            memset(&cr, 0, sizeof cr);
+            cr.pl = planar_view(h, g); cr.n = (long)nb; cr.look = (int)h->look; cr.tail = d_tail;
+            hipLaunchKernelGGL(k_tail_extract, dim3((unsigned)C), dim3(WV), 0, st, cr);
+        }
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(ev[3], st));
+        // ---- results leave on their own stream
+        HIPCHK(h, hipStreamWaitEvent(os, ev[3], 0));
+        HIPCHK(h, hipMemcpyAsync(h_res[k % R], d_res, C * sizeof(p25fe_result_t), hipMemcpyDeviceToHost, os));
+        HIPCHK(h, hipMemcpyAsync(h_dib[b], d_dib, C * dstride, hipMemcpyDeviceToHost, os));
+        HIPCHK(h, hipEventRecord(ev[4], os));
+        nb_done += nb;
+        if (k >= 1) status = drain(k - 1);
+    }
+    if (status == P25FE_OK) status = drain(n_win - 1);
+    if (status != P25FE_OK) {                                        // nothing of the stream state has moved
+        (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(os);
+        return status;
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->rs_n = 0;                                                     // a pending lock-drop list is consumed by a call that succeeded
+    // ---- the handle's stream state after the capture
+    const p25fe_result_t* last = h_res[(n_win - 1) % R];
+    for (size_t c = 0; c < C; ++c) {
+        n_dibits[c] = (size_t)total[c];
+        h->anchor[c] = last[c].anchor_out;
+        h->total_dibits[c] += total[c];
+        // the last SHARD_HALO samples of [old history | capture]
+        char* hist = h->hist_iq.data() + c * SHARD_HALO * 8;
+        const char* srcc = static_cast<const char*>(iq) + c * n * eb;
+        if (n >= SHARD_HALO) memcpy(hist, srcc + (n - SHARD_HALO) * eb, SHARD_HALO * eb);
+        else { memmove(hist, hist + n * eb, (SHARD_HALO - n) * eb); memcpy(hist + (SHARD_HALO - n) * eb, srcc, n * eb); }
+        const size_t nb_last = p25fe_n_baseband(h->abs_iq + (n_win - 1) * window, n - (n_win - 1) * window);
+        float* t = h->tail_bb.data() + c * BBPAD;
+        if (nb_last) {
+            float merged[BBPAD];
+            for (size_t j = 0; j < (size_t)BBPAD; ++j) {
+                const long m = (long)nb_last - (long)BBPAD + (long)j;
+                merged[j] = m >= -(long)(HIST_BB + h->look) ? h_tail[c * TAILN + j] : (j + nb_last < (size_t)BBPAD ? t[j + nb_last] : 0.0f);
+            }
+            memcpy(t, merged, sizeof merged);
+        }
+    }
+    h->fmt_locked = fmt;
+    h->abs_iq += n;
+    h->abs_bb += nb_done;
+    if (stats) {
+        stats->n_windows = n_win;
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        stats->ms_h2d = ms_h2d; stats->ms_compute = ms_comp; stats->pinned_input = pinned ? 1 : 0;
+    }
+    return P25FE_OK;
 }
 
 int p25fe_nid_dev(p25fe_t* h, const uint8_t* d_dibits, size_t n_dibits, const uint64_t* d_sync_dibit,

@@ -1758,6 +1758,15 @@ __global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, 
 #endif
 
 #ifndef P25FE_JIT
+// anchor_out of C result records -> a contiguous anchor array (the carry-in of the next window of p25fe_run_host_windows)
+__global__ void k_anchors_from_results(const p25fe_result_t* results, p25fe_anchor_t* anchors, int n_ch)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_ch) anchors[c] = results[c].anchor_out;
+}
+#endif
+
+#ifndef P25FE_JIT
 __global__ void k_shard_resolve(const p25fe_result_t* summaries, const uint64_t* shard_bb0, const uint64_t* shard_bb_n,
                                 int n_shards, int symbol_clock, p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
 {

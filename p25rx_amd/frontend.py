@@ -105,6 +105,33 @@ class FrontEnd:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(self.C, -1)
         return self._run(self.L.p25fe_run_cf32, iq, iq.shape[1], iq.shape[1])
 
+    def run_host_windows(self, iq, window=0, fmt=None):
+        """p25fe_run_host_windows: a LONG host capture through the path as a pipeline of windows (H2D copy | kernels | dibits
+        back).  iq: numpy array (pageable: staged by the library) or a CPU torch tensor (pinned: copied from directly) --
+        complex64 / float32 pairs (cf32) or uint8 pairs (u8), [n] or [C, n].  Returns (dibits per channel, stats dict)."""
+        if hasattr(iq, "data_ptr"):                                  # torch CPU tensor (possibly pinned)
+            import torch
+            assert not iq.is_cuda and iq.is_contiguous()
+            is_u8 = iq.dtype == torch.uint8
+            n_el = iq.numel() // self.C
+            n = n_el // 2
+            ptr = C.c_void_p(iq.data_ptr())
+        else:
+            is_u8 = iq.dtype == np.uint8
+            iq = np.ascontiguousarray(iq if is_u8 else iq.view(np.float32) if iq.dtype == np.complex64 else iq.astype(np.float32))
+            n = iq.size // self.C // 2
+            ptr = _p(iq)
+        fmt = (FMT_U8 if is_u8 else FMT_CF32) if fmt is None else fmt
+        cap = n // 30 + 4
+        dib = np.empty((self.C, cap), dtype=np.uint8)
+        nd = (C.c_size_t * self.C)()
+        st = _lib.WindowsStats()
+        self._chk(self.L.p25fe_run_host_windows(self.h, ptr, fmt, n, int(window), _p(dib), cap, nd, C.byref(st)))
+        outs = [dib[c, :nd[c]].copy() for c in range(self.C)]
+        stats = dict(n_windows=int(st.n_windows), ms_total=st.ms_total, ms_h2d=st.ms_h2d, ms_compute=st.ms_compute,
+                     pinned_input=bool(st.pinned_input))
+        return (outs[0] if self.C == 1 else outs), stats
+
     def resync(self):
         self._chk(self.L.p25fe_resync(self.h))
 

@@ -2,6 +2,7 @@
 // (src/main.rs:95-102, 162-175, 278-283 and src/replay.rs:26-57): a deterministic harness for the hot path.
 //
 //   p25fe_replay [-w BB.f32le] [-j EVENTS.jsonl] [-b CHUNKS] u8|cf32|bb <in> <dibits.out>
+//   p25fe_replay -W WINDOW_BYTES u8|cf32 <in> <dibits.out>
 //
 //     u8    RTL-SDR style interleaved u8 I/Q, the reference's live input (src/consts.rs:6: 32768-byte chunks)
 //     cf32  Complex32 I/Q at 240 ksps
@@ -20,11 +21,23 @@
 //               DemodTask iteration, which also fixes the every-4th-chunk power report of src/demod.rs:67, 95).
 //               The dibits do not depend on N (streaming semantics); only the PCIe transfer size does.
 //
+//     -W BYTES  bulk mode for long captures (p25fe_run_host_windows): a READER THREAD fills pinned blocks of eight windows
+//               from the file while the library pipelines the previous block -- window k + 1 on its way to the GPU,
+//               window k in the kernels, window k - 1's dibits on their way back.  The shape of the reference's own loop (a
+//               reader feeding a pool of buffers to the demodulator, src/sdr.rs:25-33, src/demod.rs:62-70) at bus speed;
+//               same dibits as the chunked modes.  BYTES takes k / M suffixes (64M is the library's default).
+//
 // Wires DemodTask -> RecvTask exactly like src/main.rs:270-287, single-threaded through in-memory channels.
+#include <chrono>
 #include <cinttypes>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <mutex>
+#include <thread>
+
+#include <hip/hip_runtime_api.h>
 
 #include "p25fe_host.hpp"
 
@@ -81,20 +94,81 @@ struct Sink {
 
 static int usage(const char* argv0)
 {
-    std::fprintf(stderr, "usage: %s [-w BB.f32le] [-j EVENTS.jsonl] [-b CHUNKS] u8|cf32|bb <in> <dibits.out>\n", argv0);
+    std::fprintf(stderr, "usage: %s [-w BB.f32le] [-j EVENTS.jsonl] [-b CHUNKS] u8|cf32|bb <in> <dibits.out>\n"
+                         "       %s -W WINDOW_BYTES u8|cf32 <in> <dibits.out>\n", argv0, argv0);
     return 2;
+}
+
+// bulk mode: reader thread -> two pinned blocks -> p25fe_run_host_windows
+static int bulk(Handle& h, const std::string& mode, std::ifstream& in, const char* out_path, size_t window_bytes)
+{
+    const int fmt = mode == "u8" ? P25FE_FMT_U8 : P25FE_FMT_CF32;
+    const size_t eb = fmt == P25FE_FMT_U8 ? 2 : 8;
+    const size_t window = window_bytes / eb / 8 * 8;
+    if (window < 8192) { std::fprintf(stderr, "window too small\n"); return 2; }
+    const size_t block = 8 * window;                                  // samples per pinned block
+    char* buf[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; ++b)
+        if (hipHostMalloc(reinterpret_cast<void**>(&buf[b]), block * eb, hipHostMallocDefault) != hipSuccess) {
+            std::fprintf(stderr, "unable to allocate pinned blocks\n");
+            return 1;
+        }
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t filled[2] = {0, 0};
+    bool full[2] = {false, false}, eof = false;
+    std::thread reader([&] {
+        for (int b = 0;; b ^= 1) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !full[b]; }); }
+            in.read(buf[b], (std::streamsize)(block * eb));
+            const size_t got = (size_t)in.gcount() / eb;
+            std::lock_guard<std::mutex> lk(mu);
+            filled[b] = got; full[b] = true; eof = got < block;
+            cv.notify_all();
+            if (got < block) return;
+        }
+    });
+    std::ofstream out(out_path, std::ios::binary);
+    std::vector<uint8_t> dib(block / 30 + 4);
+    size_t total = 0, samples = 0, windows = 0;
+    double ms_h2d = 0.0, ms_comp = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int b = 0;; b ^= 1) {
+        size_t n;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return full[b]; }); n = filled[b]; }
+        size_t nd = 0;
+        p25fe_windows_stats_t st;
+        expect(p25fe_run_host_windows(h.get(), buf[b], fmt, n, window, dib.data(), dib.size(), &nd, &st), "unable to run the capture");
+        out.write(reinterpret_cast<const char*>(dib.data()), (std::streamsize)nd);
+        total += nd; samples += n; windows += st.n_windows; ms_h2d += st.ms_h2d; ms_comp += st.ms_compute;
+        bool last;
+        { std::lock_guard<std::mutex> lk(mu); full[b] = false; last = eof && n < block; cv.notify_all(); }
+        if (last || n < block) break;
+    }
+    reader.join();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int b = 0; b < 2; ++b) (void)hipHostFree(buf[b]);
+    std::fprintf(stderr, "p25fe_replay: %zu dibits from %zu samples in %zu windows, %.1f ms (%.1f Msamples/s, %.2f GB/s; H2D copies %.1f ms, "
+                         "kernels %.1f ms)\n", total, samples, windows, ms, samples / ms / 1e3, samples * eb / ms / 1e6, ms_h2d, ms_comp);
+    return 0;
 }
 
 int main(int argc, char** argv)
 {
     const char *wpath = nullptr, *jpath = nullptr;
-    size_t batch = 64;
+    size_t batch = 64, window_bytes = 0;
     int a = 1;
     for (; a < argc && argv[a][0] == '-' && argv[a][1] != '\0'; a += 2) {
         if (a + 1 >= argc) return usage(argv[0]);
         if (!std::strcmp(argv[a], "-w")) wpath = argv[a + 1];
         else if (!std::strcmp(argv[a], "-j")) jpath = argv[a + 1];
         else if (!std::strcmp(argv[a], "-b")) batch = (size_t)std::strtoull(argv[a + 1], nullptr, 10);
+        else if (!std::strcmp(argv[a], "-W")) {
+            char* end = nullptr;
+            window_bytes = (size_t)std::strtoull(argv[a + 1], &end, 10);
+            if (end && (*end == 'k' || *end == 'K')) window_bytes <<= 10;
+            else if (end && (*end == 'm' || *end == 'M')) window_bytes <<= 20;
+        }
         else return usage(argv[0]);
     }
     if (argc - a != 3 || batch == 0) return usage(argv[0]);
@@ -102,6 +176,10 @@ int main(int argc, char** argv)
     std::ifstream in(argv[a + 1], std::ios::binary);
     if (!in) { std::fprintf(stderr, "unable to open %s\n", argv[a + 1]); return 1; }
     Handle h(0, 1);
+    if (window_bytes) {
+        if (wpath || jpath || (mode != "u8" && mode != "cf32")) return usage(argv[0]);
+        return bulk(h, mode, in, argv[a + 2], window_bytes);
+    }
     Chan<std::vector<uint8_t>> reader;
     Hub hub;
     Chan<Baseband> chan;

@@ -250,6 +250,63 @@ def test_bench_two_ranks_time_shards_host_staged(scaling):
     assert ("ONE 120 s capture" if scaling == "weak" else "ONE 60 s capture") in d["config"]["workload"] and d["value"] > 0
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_run_host_windows_equals_one_pass(mode, tmp_path):
+    """p25fe_run_host_windows (a long HOST capture as a pipeline of windows: H2D copy | kernels | dibits back): filter and
+    receiver state cross the window boundaries like a shard's (halo + anchor), so any window size gives the dibits of one
+    resident pass -- cf32 and u8, pageable (staged) and pinned (copied from directly) input, both symbol clocks, lock kept
+    and handed on to the streaming calls, and the C++ replay driver's bulk mode on a file."""
+    import torch
+    from oracle import oracle as O
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import FrontEnd
+    iq, _, _ = c4fm.synth(6.0, seed=61, snr_db=20.0, frame_dibits=600, clock_ppm=120.0 if mode else 0.0)
+    cfg = O.make_config(symbol_clock=mode)
+    ref = O.Recv(cfg).feed(O.Demod().feed_cf32(iq))[0]
+    u8 = c4fm.to_u8(iq)
+    ref8 = O.Recv(cfg).feed(O.Demod().feed_u8(u8))[0]
+    for window in (8192, 100000, 1 << 19, 0):                        # many windows ... one (0 = the library's 64 MB)
+        fe = FrontEnd(symbol_clock=mode)
+        got, st = fe.run_host_windows(iq, window=window)
+        assert np.array_equal(got, ref), window
+        if window:
+            assert st["n_windows"] == -(-len(iq) // (window // 8 * 8)) and not st["pinned_input"] and st["ms_h2d"] > 0
+    fe = FrontEnd(symbol_clock=mode)
+    got8, _ = fe.run_host_windows(u8, window=65536)
+    assert np.array_equal(got8, ref8)
+    # pinned input: the copy engine reads the caller's memory
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).pin_memory()
+    fe = FrontEnd(symbol_clock=mode)
+    got, st = fe.run_host_windows(t, window=1 << 18)
+    assert st["pinned_input"] and np.array_equal(got, ref)
+    # the call continues a stream and leaves it ready for more: chunked call | windows | chunked call == one pass
+    fe = FrontEnd(symbol_clock=mode)
+    a, b = 123457, 1000003
+    parts = [fe.run_cf32(iq[:a]), fe.run_host_windows(iq[a:b], window=200000)[0], fe.run_cf32(iq[b:])]
+    assert np.array_equal(np.concatenate(parts), ref)
+    # ... and the baseband tail it leaves serves a later p25fe_slice
+    fe = FrontEnd(symbol_clock=mode)
+    d1, _ = fe.run_host_windows(iq[:b], window=300000)
+    bb_rest = O.Demod().feed_cf32(iq)[len(O.Demod().feed_cf32(iq[:b])):]
+    d2 = fe.slice(bb_rest)[0]
+    assert np.array_equal(np.concatenate([d1, d2]), ref)
+    if mode == 0:
+        # two channels, channel-major
+        iq2, _, _ = c4fm.synth(6.0, seed=62, snr_db=20.0, frame_dibits=600)
+        n = min(len(iq), len(iq2))
+        both = np.stack([iq[:n], iq2[:n]])
+        fe = FrontEnd(n_channels=2)
+        outs, _ = fe.run_host_windows(both, window=250000)
+        assert np.array_equal(outs[0], O.run_cf32(iq[:n])) and np.array_equal(outs[1], O.run_cf32(iq2[:n]))
+        # the replay driver's bulk mode: reader thread + pinned blocks + the same call
+        exe = os.path.join(ROOT, "build", "p25fe_replay")
+        src, out = tmp_path / "cap.cf32", tmp_path / "dib.out"
+        iq.tofile(src)
+        r = subprocess.run([exe, "-W", "256k", "cf32", str(src), str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        assert np.array_equal(np.fromfile(out, dtype=np.uint8), ref) and "windows" in r.stderr
+
+
 @pytest.mark.timeout(300)
 def test_bench_plain_invocation_starts_its_own_ranks():
     """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE: the way the driver runs `--gpus 1`): bench.py starts the two
