@@ -232,7 +232,8 @@ int p25fe_resync(p25fe_t *h);
  * p25fe_run_u8 / _cf32, whose range is the chunk) drops lock before each listed sample -- exactly as
  * if resync() had been called between feeding samples q - 1 and q.  d_idx: device array, n_idx ascending ABSOLUTE
  * baseband indices per channel, channel c at d_idx + c * idx_stride (pad a shorter list with INT64_MAX); it must stay
- * valid and unchanged until that call's kernels have run.  n_idx = 0 cancels.  The list is consumed by that call. */
+ * valid and unchanged until that call's kernels have run.  n_idx = 0 cancels.  The list is consumed by that call -- a host-buffer
+ * call that returns P25FE_ERR_CAPACITY has consumed nothing, the list included; p25fe_reset and p25fe_state_import drop it. */
 int p25fe_resync_at_dev(p25fe_t *h, const int64_t *d_idx, size_t n_idx, size_t idx_stride);
 /* Forget all stream state (a new DemodTask + MessageReceiver). */
 int p25fe_reset(p25fe_t *h);

@@ -377,6 +377,7 @@ int p25fe_reset(p25fe_t* h)
     h->abs_iq = 0;
     h->fmt_locked = -1;
     h->abs_bb = 0;
+    h->rs_idx = nullptr; h->rs_n = 0; h->rs_stride = 0;             // a pending lock-drop list belonged to the old stream
     try {                                                           // no exception crosses the C boundary
         h->anchor.assign((size_t)h->C, p25fe_anchor_t{0, 0.f, 0.f, 0.f, 0, SPS, 1});
         h->total_dibits.assign((size_t)h->C, 0);
@@ -1395,8 +1396,7 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
         hipLaunchKernelGGL(k_recv_chunk, dim3((unsigned)C), dim3(WV), 0, h->stream, a);
         HIPCHK(h, hipGetLastError());
     } else {
-        const RecvCall rcall = recv_call(h);
-        h->rs_n = 0;                                                 // a pending p25fe_resync_at_dev list belongs to this call
+        const RecvCall rcall = recv_call(h);                        // (a pending p25fe_resync_at_dev list belongs to this call: cleared below, once it has succeeded)
         rc = launch_planarize(h, db + BBPAD, bb_stride, hist, n, h->stream);
         if (rc) return rc;
         rc = launch_detect(h, n, view0, h->stream, rcall);
@@ -1408,7 +1408,8 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
     rc = chunk_wait(h, o, polled);
     if (rc) return rc;
     rc = recv_finish(h, o, n, dibits, cap, n_dibits, sync_pos, sync_dibit, sync_cap, n_sync);
-    if (rc) return rc;
+    if (rc) return rc;                                               // (P25FE_ERR_CAPACITY: nothing has moved, the lock-drop list included -- repeat the call)
+    h->rs_n = 0;
     for (size_t c = 0; c < C; ++c)                                   // the tail: last BBPAD samples of [tail | new]
         memcpy(h->tail_bb.data() + c * BBPAD, hb + c * bb_stride + n, BBPAD * sizeof(float));
     return P25FE_OK;
@@ -1459,7 +1460,6 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     } else {
         // the baseband stays in HBM; the receiver's history is recomputed from the IQ history, like a shard's from its halo
         const RecvCall rcall = recv_call(h);
-        h->rs_n = 0;
         rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)PLPAD - h->look, nullptr, 0,
                              nullptr, h->stream, &g);
         if (rc) return rc;
@@ -1475,6 +1475,7 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     if (rc) return rc;
     rc = recv_finish(h, o, nb, dibits, cap, n_dibits, nullptr, nullptr, 0, nullptr);
     if (rc) return rc;
+    h->rs_n = 0;                                                     // the lock-drop list is consumed by a call that succeeded
     commit_iq(h, fmt, n, sg);
     // baseband tail for a later p25fe_slice on this handle: the newest TAILN samples, those older than what the planes hold
     // (a very short chunk) come from the previous tail
@@ -1881,7 +1882,9 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
         for (size_t c = 0; c < C; ++c) {
             p25fe_anchor_t a;
             memcpy(&a, pa + c * sizeof a, sizeof a);
-            if (a.period_d <= 0 || a.period_n <= 0) return P25FE_ERR_ARG;
+            // (0 / 0 reads as 10 / 1: include/p25fe.h)
+            if (!(a.period_d == 0 && a.period_n == 0) && !clock_plausible(a.period_d, a.period_n)) return P25FE_ERR_ARG;
+            if (!h->track && a.valid != 0 && !(a.period_d == 0 && a.period_n == 0) && !(a.period_d == SPS && a.period_n == 1)) return P25FE_ERR_ARG;
         }
     }
     memcpy(h->hist_iq.data(), p, C * SHARD_HALO * 8); p += C * SHARD_HALO * 8;
@@ -1889,6 +1892,7 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
     memcpy(h->anchor.data(), p, C * sizeof(p25fe_anchor_t)); p += C * sizeof(p25fe_anchor_t);
     memcpy(h->total_dibits.data(), p, C * sizeof(uint64_t));
     h->fmt_locked = hd.fmt_locked; h->abs_iq = hd.abs_iq; h->abs_bb = hd.abs_bb;
+    h->rs_idx = nullptr; h->rs_n = 0; h->rs_stride = 0;             // (absolute indices of another stream position)
     return P25FE_OK;
 }
 

@@ -1730,7 +1730,7 @@ __host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summari
         if (R.carry_end >= 0) {                                   // the shard has an event: the carry changes
             if (R.anchor_out.valid) {
                 p25fe_anchor_t nxt = R.anchor_out;
-                if (nxt.period_n <= 0 || nxt.period_d <= 0) { nxt.period_d = SPS; nxt.period_n = 1; }
+                if (!clock_plausible(nxt.period_d, nxt.period_n)) { nxt.period_d = SPS; nxt.period_n = 1; }
                 if (R.flags & P25FE_RES_OUT_PERIOD_FROM_CARRY)
                     clock_period(track, tracks, cur.s, frac3((unsigned)cur.valid >> 8), nxt.s, frac3((unsigned)nxt.valid >> 8), nxt.period_d, nxt.period_n);
                 cur = nxt;

@@ -132,6 +132,18 @@ __host__ __device__ inline void clock_period(bool track, bool prev_valid, long s
         }
     }
 }
+// Could clock_period have produced (D, N)?  Anchors also arrive from outside (p25fe_state_import, a caller's d_anchor_in): a clock
+// such as 1 / 2^30 would put 2^43 instants into a tile and wrap the 32-bit counts of the slicer.  Anything implausible is
+// refused (import) or read as the nominal 10 / 1 (kernels).
+__host__ __device__ inline bool clock_plausible(int D, int N)
+{
+    if (N == 1 && D == SPS) return true;
+    if (N < 4 || (N & 3) != 0 || D <= 0) return false;
+    const long nn = N / 4, d4 = D, nom = 4L * SPS * nn;
+    if (d4 > 4 * (1L << P25FE_CLK_DMAX_LOG2) + 4) return false;
+    const long err = d4 > nom ? d4 - nom : nom - d4;                 // quarter samples: 4 |dd - 10 nn| + |f_new - f_prev| <= 4 (10 nn >> shift) + 4
+    return err <= 4 * ((SPS * nn) >> P25FE_CLK_TOL_SHIFT) + 4;
+}
 // number of instants j >= 1 of a clock (D, N) with floor(j D / N) < x
 __host__ __device__ inline long clock_J(long x, int D, int N)
 {
@@ -1008,7 +1020,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
     p25fe_anchor_t Ain;
     Ain.valid = 0; Ain.s = 0; Ain.hi = Ain.mid = Ain.lo = 0.f; Ain.period_d = SPS; Ain.period_n = 1;
     if (a.anchor_in) Ain = a.anchor_in[ch];
-    if (Ain.period_n <= 0 || Ain.period_d <= 0) { Ain.period_d = SPS; Ain.period_n = 1; }
+    if (!clock_plausible(Ain.period_d, Ain.period_n)) { Ain.period_d = SPS; Ain.period_n = 1; }
     const bool track = a.track != 0;
     if (tid == 0) {
         c_top.a = c_top.b = -1;
@@ -1152,7 +1164,9 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         p25fe_anchor_t A = Ain;
         if (st.src >= 0) {
             const TileRec t = recs[st.src];
-            A.valid = 1 | ((st.f & 7) << 8);                         // bit 0: locked; bits 8..10: the sync position's fraction (SPEC 3.8b)
+            // bit 0: locked; bits 8..10: the sync position's fraction (SPEC 3.8b) -- only when the clock tracks: with the fixed
+            // stride the general receiver (a lock-drop list) hands on the same `valid = 1` as the one-tile fast path
+            A.valid = track ? (1 | ((st.f & 7) << 8)) : 1;
             A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo; A.period_d = st.D; A.period_n = st.N;
         } else if (st.src == -2) {
             A.valid = 0;
@@ -1245,7 +1259,9 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
         if (lo_ < s + W + 1) lo_ = s + W + 1;
         if (hi_ <= lo_) return 0;
         const long j_lo = clock_J(lo_ - s, D, N) + 1, j_hi = clock_J(hi_ - s, D, N);     // inclusive
-        const int count = (int)(j_hi - j_lo + 1);
+        long cnt_l = j_hi - j_lo + 1;                               // a tile holds at most TS / 6 instants under any clock the library makes;
+        cnt_l = cnt_l < 0 ? 0 : (cnt_l > (long)TS ? (long)TS : cnt_l);   // clamp whatever a foreign anchor got past the plausibility test
+        const int count = (int)cnt_l;
         uint8_t* dst = out + rank;
         for (int j0 = 0; j0 < count; j0 += WV) {
             const int idx = j0 + lane;
@@ -1273,7 +1289,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
                     const long sy = p / SPS;
                     v = f[planar_index(sy, (int)(p - sy * SPS))];
                 }
-                if (rank + idx < room) dst[idx] = slice_dibit(v, h, m, l);
+                if (rank >= 0 && rank + idx < room) dst[idx] = slice_dibit(v, h, m, l);
             }
         }
         return count;
@@ -1371,7 +1387,7 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     const TileRec rc = c.recs[ch];
     const unsigned long long u = c.tsum[ch];
     p25fe_anchor_t A = c.anchor_in[ch];
-    if (A.period_n <= 0 || A.period_d <= 0) { A.period_d = SPS; A.period_n = 1; }
+    if (!clock_plausible(A.period_d, A.period_n)) { A.period_d = SPS; A.period_n = 1; }
     const bool own = rc.n_events > 0;
     const unsigned long long pre = A.valid ? (unsigned long long)count_instants(A.s, c.abs0, own ? rc.first_event + 1 : c.abs0 + c.n) : 0ull;
     if (lane == 0) {

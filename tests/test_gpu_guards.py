@@ -191,3 +191,83 @@ def test_shard_and_wideband_outputs_stay_inside_their_buffers(scene):
     fe.channelise_dev(wide, out=gc.view(torch.float32, (CHZ_CHANNELS, stride, 2)))
     torch.cuda.synchronize()
     gc.check("channelise_dev")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_foreign_anchors_cannot_drive_the_slicer_out_of_bounds(mode):
+    """Anchors also arrive from outside -- a caller's d_anchor_in, a state blob -- and their clock (period_d / period_n) sizes the
+    slicer's loops: a period such as 1 / 2^30 would mean 2^43 instants per tile.  A clock the library could not
+    have produced is refused by p25fe_state_import and read as the nominal 10 / 1 by the kernels; the dibit row stays
+    inside its guard bands whatever the anchor says."""
+    import torch
+    from oracle import oracle as O
+    from p25rx_amd import _lib, c4fm
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    iq, _, _ = c4fm.synth(0.6, seed=14, snr_db=25.0, frame_dibits=300)
+    bb = O.Demod().feed_cf32(iq)
+    t = torch.from_numpy(bb).cuda()
+    n_bb = len(bb)
+    fe = FrontEnd(symbol_clock=mode)
+    ref, rres, _, _ = fe.slice_dev(t, n_bb, anchor_in=[(-40, 0.24, 0.0, -0.24, 1, 10, 1)])
+    torch.cuda.synchronize()
+    nref = int(parse_results(rres)[0]["n_dibits"])
+    for d, n in ((1, 1 << 30), (1, 4), (-7, 4), (10, 0), (0x7fffffff, 1), (400, 44), (39, 4), (10, 3), (1 << 30, 4 << 20)):
+        cap = (n_bb // 10 + 64 + 15) // 16 * 16
+        g = Guarded(cap)
+        res = torch.empty((1, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        a_in = torch.from_numpy(np.frombuffer(np.array([(-40, 0.24, 0.0, -0.24, 1, d, n)], dtype=_lib.ANCHOR_DTYPE).tobytes(),
+                                              dtype=np.uint8).copy()).cuda()
+        fe._chk(fe.L.p25fe_slice_dev(fe.h, C.c_void_p(t.data_ptr()), n_bb, 0, n_bb, 0, C.c_void_p(a_in.data_ptr()),
+                                     C.c_void_p(g.t.data_ptr()), cap, None, None, 0, C.c_void_p(res.data_ptr()), None))
+        torch.cuda.synchronize()
+        g.check("slice_dev with the clock %d / %d" % (d, n))
+        # an implausible clock reads as 10 / 1: the same dibits as the nominal anchor
+        assert int(parse_results(res)[0]["n_dibits"]) == nref and torch.equal(g.t[:nref], ref[0, :nref]), (d, n)
+    # the state blob: every anchor's clock is checked before anything is taken over
+    blob = fe.state_export()
+    off = len(blob) - 8 - _lib.ANCHOR_DTYPE.itemsize                  # [... | anchors (C = 1) | totals]
+    for d, n, ok in ((10, 1, True), (0, 0, True), (1, 1 << 30, False), (10, -1, False), (41, 4, mode == 1), (10 * 4 * 864 + 3, 4 * 864, mode == 1),
+                     (10 * 4 * 864 + 90, 4 * 864, False)):
+        bad = blob.copy()
+        a = np.zeros(1, dtype=_lib.ANCHOR_DTYPE)
+        a[0] = (1000, 0.2, 0.0, -0.2, 1, d, n)
+        bad[off:off + _lib.ANCHOR_DTYPE.itemsize] = np.frombuffer(a.tobytes(), dtype=np.uint8)
+        if ok:
+            fe.state_import(bad)
+        else:
+            with pytest.raises(_lib.P25feError) as e:
+                fe.state_import(bad)
+            assert e.value.status == _lib.ERR_ARG
+
+
+def test_resync_list_survives_a_capacity_error_and_dies_with_the_stream():
+    """p25fe_resync_at_dev's list is consumed by the call that SUCCEEDS: a host-buffer call that returns P25FE_ERR_CAPACITY has
+    moved nothing -- repeating it with more room gives the dibits of one good call (the list used to be dropped on
+    the way in) -- and p25fe_reset forgets a pending list together with the stream it indexed."""
+    import torch
+    from oracle import oracle as O
+    from p25rx_amd import _lib, c4fm
+    from p25rx_amd.frontend import FrontEnd
+    iq, _, _ = c4fm.synth(0.5, seed=15, snr_db=25.0, frame_dibits=100)
+    bb = O.Demod().feed_cf32(iq)
+    n = len(bb)
+    drops = np.array([n // 3, 2 * n // 3], dtype=np.int64)
+    r = O.Recv()
+    ref = np.concatenate([r.feed(bb[:drops[0]])[0], (r.resync(), r.feed(bb[drops[0]:drops[1]])[0])[1],
+                          (r.resync(), r.feed(bb[drops[1]:])[0])[1]])
+    assert len(ref) < len(O.Recv().feed(bb)[0])                      # the drops cost dibits: the list matters
+    fe = FrontEnd()
+    idx = torch.from_numpy(drops).cuda()
+    fe.resync_at_dev(idx)
+    bbc = np.ascontiguousarray(bb)
+    dib = np.empty(n // 10 + 1, dtype=np.uint8)
+    nd = (C.c_size_t * 1)()
+    # too little room is refused before anything moves (the in-flight form of the error needs back-to-back re-anchors)
+    rc = fe.L.p25fe_slice(fe.h, bbc.ctypes.data_as(C.c_void_p), n, dib.ctypes.data_as(C.c_void_p), n // 10, nd, None, None, 0, None)
+    assert rc == _lib.ERR_CAPACITY
+    got = fe.slice(bb)[0]                                            # the repeat still has the list
+    assert np.array_equal(got, ref)
+    # a list pending at p25fe_reset is gone: the next call is an undisturbed pass
+    fe.resync_at_dev(idx)
+    fe.reset()
+    assert np.array_equal(fe.slice(bb)[0], O.Recv().feed(bb)[0])
