@@ -17,6 +17,8 @@ os.environ.setdefault("P25FE_JIT", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "pin: compares with dumps of the real kchmck/p25rx under tests/golden/pin/ (tools/pin/README.md); "
+                                       "skipped while that directory is empty")
 
 
 @pytest.fixture(scope="session")

@@ -45,6 +45,25 @@ def test_rccl_library_exports_its_header(lib):
     assert os.path.exists(os.path.join(ROOT, "build", "p25fe_shards"))
 
 
+def test_rust_binding_file_declares_the_whole_abi(lib):
+    """bindings/p25fe.rs (uncompiled here: no Rust toolchain) is the `extern "C"` block a p25rx maintainer drops in: it must name
+    every symbol of both headers, carry the ABI version, and its #[repr(C)] Config must list the C struct's fields in order."""
+    from p25rx_amd import rccl
+    rs = open(os.path.join(ROOT, "bindings", "p25fe.rs")).read()
+    declared = set(re.findall(r"pub fn (p25fe_[a-z0-9_]+)\(", rs))
+    assert declared == set(lib.SYMBOLS) | set(rccl.SYMBOLS), declared ^ (set(lib.SYMBOLS) | set(rccl.SYMBOLS))
+    assert "pub const ABI_VERSION: i32 = %d;" % lib.ABI_VERSION in rs
+    body = rs[rs.index("pub struct Config {"):]
+    body = body[:body.index("}")]
+    fields = re.findall(r"pub (\w+):", body)
+    assert fields == [f[0] for f in lib.Config._fields_], fields
+    hdr = open(os.path.join(ROOT, "include", "p25fe.h")).read()
+    cstruct = hdr[hdr.index("typedef struct p25fe_config {"):hdr.index("} p25fe_config_t;")]
+    cstruct = re.sub(r"/\*.*?\*/", "", cstruct, flags=re.S)
+    cfields = re.findall(r"(\w+)(?:\[[^\]]*\])?\s*[;,]", cstruct)
+    assert [f for f in cfields if f not in ("p25fe_config",)] == fields, cfields
+
+
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
     assert cfg.abi_version == lib.ABI_VERSION == 4 and cfg.n_channels == 1 and cfg.symbol_clock == 0
