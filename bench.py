@@ -851,6 +851,9 @@ def main():
         }
         if world == 1:
             out["config"]["prewarm"] = "%d untimed steps (>= %.0f ms) before the W warm-up steps" % (n_prewarm, PREWARM_MS)
+            # for tools/prof_summary.py: which k_frontend dispatches of this process (0-based, in launch order) are the timed ones,
+            # so that a rocprofv3 kernel trace of this command is summarised over the same launches `roofline.kernel_ms` covers
+            out["config"]["k1_launch_range"] = [n_prewarm + args.warmup, args.steps]
             out["config"]["step"] = ("serial: K1 -> K2 -> K3 -> K4 on one stream" if args.no_pipeline else
                                      "pipelined two deep (p25fe_run_dev_pipelined): K2-K4 of step i on the handle's stream overlap "
                                      "K1 of step i + 1; join + device synchronize inside the timed region")

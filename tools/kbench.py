@@ -21,7 +21,14 @@ for c in range(C):
 iq8 = None
 if any(m.endswith("u8") for m in modes):
     iq8 = torch.clamp(torch.round((iq + 1.0) * 127.5), 0, 255).to(torch.uint8)
-fe = FrontEnd(n_channels=C)
+kw = {}
+if os.environ.get("P25FE_KBENCH_TAPS"):                    # e.g. "31,41": other Kaiser designs of the two filters -> specialised kernels
+    from scipy import signal as sps
+    import numpy as np
+    n1, n2 = (int(x) for x in os.environ["P25FE_KBENCH_TAPS"].split(","))
+    kw = dict(decim_taps=sps.firwin(n1, 11000.0, window=("kaiser", 6.0), fs=240000.0).astype(np.float32).tolist(),
+              chan_taps=sps.firwin(n2, 6500.0, window=("kaiser", 4.5), fs=48000.0).astype(np.float32).tolist(), specialize=1)
+fe = FrontEnd(n_channels=C, **kw)
 bb = None
 def step(m):
     global bb
