@@ -59,6 +59,11 @@ def scene(seed):
     # ragged lengths: around multiples of a receiver tile (7 680 baseband = 38 400 IQ samples), of a K1 sub-tile (1 600) and anything
     s["extra"] = int(rng.choice([0, 8, 1600, 1608, 38400 - 8, 38400, 38400 + 8, 2 * 38400, int(rng.integers(0, 50000)) // 8 * 8]))
     s["cut"] = int(rng.choice([0, 0, 1]))                    # 1: the capture is cut down to (a multiple of 38 400) + extra
+    # ABI 4: the run-time arguments of the reference's constructors (drawn LAST: the scenes of earlier rounds keep their numbers)
+    s["fm"] = int(rng.choice([0, 0, 0, 1, 2]))               # 0: 5 kHz / 48 kHz, 1: another deviation, 2: an explicit scale
+    s["u8tab"] = int(rng.choice([0, 0, 0, 1, 2, 3]))         # 0: fma(b, 2/255, -1), 1: (b - 127) / 128 as scale / offset,
+    #                                                          2: correctly rounded (b - 127.5) / 127.5 as a TABLE (not affine), 3: a random monotone table
+    s["kernels"] = int(rng.choice([0, 0, 0, 0, 0, 1]))       # 1: kernels specialised for the scene's numbers (hipRTC: seconds per scene)
     return s, rng
 
 
@@ -91,8 +96,22 @@ def run_scene(seed, O, FE, torch, verbose=False):
         dt, ct = random_taps(rng, int(rng.integers(1, 32))), random_taps(rng, int(rng.integers(1, 42)))
     elif s["taps"] == 2:
         dt, ct = random_taps(rng, int(rng.integers(32, 65))), random_taps(rng, int(rng.integers(42, 65)))
-    cfg = O.make_config(decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"])
-    mk = lambda C_=Cn: FE(n_channels=C_, decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"])
+    xkw = {}
+    if s["fm"] == 1:
+        xkw["fm_deviation_hz"] = int(rng.choice([2500, 4000, 6250]))
+    elif s["fm"] == 2:
+        xkw["fm_gain"] = float(np.float32(rng.uniform(0.5, 3.0)))
+    if s["u8tab"] == 1:
+        xkw["u8_scale"], xkw["u8_offset"] = float(np.float32(1 / 128.0)), float(np.float32(-127 / 128.0))
+    elif s["u8tab"] == 2:
+        xkw["u8_lut"] = ((np.arange(256, dtype=np.float64) - 127.5) / 127.5).astype(np.float32)
+    elif s["u8tab"] == 3:
+        xkw["u8_lut"] = (np.cumsum(rng.uniform(0.0, 0.016, 256)) - 1.0).astype(np.float32)
+    cfg = O.make_config(decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"], **xkw)
+    fkw = dict(xkw)
+    if s["kernels"] == 1:
+        fkw["specialize"] = 2                                        # FORCE: the build's own numbers go through hipRTC too
+    mk = lambda C_=Cn: FE(n_channels=C_, decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"], **fkw)
     what = []
 
     def check(name, ok):

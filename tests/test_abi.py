@@ -105,22 +105,17 @@ def test_specialize_compiles_without_a_gpu_and_caches(lib, tmp_path):
     want = {"p25jit_k1_cf32_lin", "p25jit_k1_u8_lin", "p25jit_k1_cf32_pl", "p25jit_k1_u8_pl", "p25jit_chunk_cf32", "p25jit_chunk_u8"}
     assert set(k) == want, set(k) ^ want
     assert all(s_ == 0 for _, s_ in k.values()), k                     # ScratchSize 0 everywhere
-    # any number that differs gives another code object: one tap bit, the deviation, the u8 offset, a non-affine table
-    dt2 = dt.copy()
-    dt2[3] = np.nextafter(dt2[3], np.float32(1))
-    names = {os.path.basename(f1)}
-    for kw in (dict(decim_taps=list(dt2), chan_taps=list(ct)), dict(decim_taps=list(dt), chan_taps=list(ct), fm_deviation_hz=4000),
-               dict(u8_offset=-0.996), dict(u8_lut=np.tanh((np.arange(256) - 127.5) / 90.0))):
-        names.add(os.path.basename(lib.specialize(lib.make_config(**kw), d)))
-    assert len(names) == 5
-    # 64 / 64 tables: the long geometry, still no scratch
+    # a 64 / 64 table with a non-affine u8 table and another deviation: the long geometry with the LDS table, still no scratch,
+    # and another code object
     f64 = lib.specialize(lib.make_config(decim_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
-                                         chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32))), d)
-    assert all(s_ == 0 for _, s_ in _hsaco_kernels(f64).values())
+                                         chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
+                                         u8_lut=np.tanh((np.arange(256) - 127.5) / 90.0), fm_deviation_hz=4000), d)
+    assert f64 != f1 and all(s_ == 0 for _, s_ in _hsaco_kernels(f64).values())
     # a table that IS fma(b, s, o) runs as arithmetic: the same code object as naming (s, o) directly
     sc, of = np.float32(1.0 / 128.0), np.float32(-127.0 / 128.0)
     lut = (np.arange(256, dtype=np.float32) * sc + of).astype(np.float32)       # exact in fp32: products of small integers by 2^-7
-    assert lib.specialize(lib.make_config(u8_lut=lut), d) == lib.specialize(lib.make_config(u8_scale=sc, u8_offset=of), d)
+    fa = lib.specialize(lib.make_config(u8_lut=lut), d)
+    assert fa not in (f1, f64) and lib.specialize(lib.make_config(u8_scale=sc, u8_offset=of), d) == fa
     # argument errors: a NaN tap, a zero deviation, an unknown specialize mode, the old ABI
     for bad in (dict(decim_taps=[float("nan")] * 31), dict(fm_deviation_hz=0), dict(specialize=7), dict(fm_gain=float("inf"))):
         with pytest.raises(lib.P25feError) as e:
