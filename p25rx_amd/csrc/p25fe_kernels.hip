@@ -1295,8 +1295,11 @@ __global__ __launch_bounds__(WV, P25FE_K0_WPS) void k_predecim(K0Args a)
 constexpr int CZ_M = P25FE_CHZ_CHANNELS;                        // 192
 constexpr int CZ_C1 = 12, CZ_C2 = 16, CZ_P1 = T0 / CZ_C2;       // c = c1 + 12 c2; p = 16 p1 + p2, p1 < 5
 static_assert(T0 == CZ_C2 * CZ_P1 && CZ_M == CZ_C1 * CZ_C2 && CZ_P1 == 5, "factorisation of the 192-point DFT");
+// c1 values whose partial sums are held at once.  Round 4, same box, three interleaved rounds (tools/k6_ab.sh, profiles/
+// r04_k6_k0_ab.txt): 4 -> 4.91 - 4.93 ms with 168 VGPRs + 96 B / lane of scratch in the twiddle loop; 3 -> 4.43 ms, 157 VGPRs,
+// no scratch (one more pass over the 80 window products per instant, which the stores hide); 2 -> 4.48 ms.
 #ifndef P25FE_CZ_G
-#define P25FE_CZ_G 4
+#define P25FE_CZ_G 3
 #endif
 #ifndef P25FE_CZ_WPS
 #define P25FE_CZ_WPS 3
