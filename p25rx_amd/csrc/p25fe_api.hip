@@ -1567,7 +1567,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         else (void)hipGetLastError();
     }
     if (!pinned)
-        for (int b = 0; b < 2; ++b) HIPCHK(h, h->win_stage[b].ensure(C * window * eb));
+        for (int b = 0; b < 2; ++b) HIPCHK(h, h->win_stage[b].ensure(C * (SHARD_HALO + window) * eb));
     memcpy(h_anc, h->anchor.data(), C * sizeof(p25fe_anchor_t));
     for (size_t c = 0; c < C; ++c) memcpy(h_hist + c * SHARD_HALO * eb, h->hist_iq.data() + c * SHARD_HALO * 8, SHARD_HALO * eb);
     p25fe_anchor_t* d_anc = h->win_anc.as<p25fe_anchor_t>();        // [2][C]: the carry-in of window k lives in half k & 1
@@ -1598,24 +1598,24 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         const int b = (int)(k & 1);
         hipEvent_t* ev = h->win_ev[k % R];
         char* dev = h->win_buf[b].as<char>();
-        // ---- copy stream: halo, then the window
+        // ---- copy stream: [halo | window] in ONE copy.  The halo of window k >= 1 is simply the SHARD_HALO samples in front of
+        // it in the caller's capture (16 KB more per window); only window 0 takes it from the handle's history.  (A device-to-
+        // device copy of the previous window's tail put a second operation between every two H2D copies: 7 - 9 % of the call.)
         if (k >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->win_ev[(k - 2) % R][3], 0));      // the kernels of window k - 2 have read this buffer
-        if (k == 0) {
-            HIPCHK(h, hipMemcpy2DAsync(dev, stride * eb, h_hist, SHARD_HALO * eb, SHARD_HALO * eb, C, hipMemcpyHostToDevice, cs));
-        } else {
-            const char* prev = h->win_buf[b ^ 1].as<char>() + window * eb;     // the last SHARD_HALO samples of [halo | window k - 1]
-            HIPCHK(h, hipMemcpy2DAsync(dev, stride * eb, prev, stride * eb, SHARD_HALO * eb, C, hipMemcpyDeviceToDevice, cs));
-        }
-        const char* src = static_cast<const char*>(iq) + off * eb;
+        const size_t lead = k == 0 ? 0 : SHARD_HALO;                // samples in front of the window that travel with it
+        if (k == 0) HIPCHK(h, hipMemcpy2DAsync(dev, stride * eb, h_hist, SHARD_HALO * eb, SHARD_HALO * eb, C, hipMemcpyHostToDevice, cs));
+        const char* src = static_cast<const char*>(iq) + (off - lead) * eb;
         size_t spitch = n * eb;
         if (!pinned) {
             if (k >= 2) HIPCHK(h, hipEventSynchronize(h->win_ev[(k - 2) % R][1]));       // the copy engine is done with this staging window
             char* sg = static_cast<char*>(h->win_stage[b].p);
-            for (size_t c = 0; c < C; ++c) memcpy(sg + c * wn * eb, src + c * n * eb, wn * eb);
-            src = sg; spitch = wn * eb;
+            for (size_t c = 0; c < C; ++c) memcpy(sg + c * (lead + wn) * eb, src + c * n * eb, (lead + wn) * eb);
+            src = sg; spitch = (lead + wn) * eb;
         }
+        char* dst = dev + (SHARD_HALO - lead) * eb;
         HIPCHK(h, hipEventRecord(ev[0], cs));
-        HIPCHK(h, hipMemcpy2DAsync(dev + SHARD_HALO * eb, stride * eb, src, spitch, wn * eb, C, hipMemcpyHostToDevice, cs));
+        if (C == 1) HIPCHK(h, hipMemcpyAsync(dst, src, (lead + wn) * eb, hipMemcpyHostToDevice, cs));
+        else HIPCHK(h, hipMemcpy2DAsync(dst, stride * eb, src, spitch, (lead + wn) * eb, C, hipMemcpyHostToDevice, cs));
         HIPCHK(h, hipEventRecord(ev[1], cs));
         // ---- compute stream
         HIPCHK(h, hipStreamWaitEvent(st, ev[1], 0));
