@@ -109,7 +109,7 @@ static bool mkdir_p(const std::string& dir)
     std::string cur;
     for (size_t i = 0; i <= dir.size(); ++i) {
         if (i == dir.size() || dir[i] == '/') {
-            if (!cur.empty() && mkdir(cur.c_str(), 0755) != 0 && errno != EEXIST) return false;
+            if (!cur.empty() && mkdir(cur.c_str(), 0700) != 0 && errno != EEXIST) return false;   // (private: code objects get loaded from here)
         }
         if (i < dir.size()) cur.push_back(dir[i]);
     }

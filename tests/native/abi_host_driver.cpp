@@ -4,8 +4,11 @@
 // staging / state code is host code.  Exit code 0 and no sanitizer report = pass (tests/test_sanitizers.py).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include <unistd.h>
 
 #include "p25fe.h"
 
@@ -30,6 +33,41 @@ int main()
     EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG);
     bad = cfg; bad.symbol_clock = 7;
     EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG);
+    // ABI 4: the numbers of the reference's constructors are validated before any device is looked for
+    bad = cfg; bad.decim_taps[3] = NAN;
+    EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG && p25fe_specialize(&bad, nullptr, nullptr, 0) == P25FE_ERR_ARG);
+    bad = cfg; bad.fm_deviation_hz = 0;
+    EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG);
+    bad = cfg; bad.fm_gain = INFINITY;
+    EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG);
+    bad = cfg; bad.specialize = 9;
+    EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG);
+    bad = cfg; bad.u8_lut_valid = 1; bad.u8_lut[200] = -INFINITY;
+    EXPECT(p25fe_create(&bad, &h) == P25FE_ERR_ARG);
+    EXPECT(p25fe_kernel_variant(nullptr) < 0 && p25fe_run_host_windows(nullptr, nullptr, 0, 0, 0, nullptr, 0, nullptr, nullptr) == P25FE_ERR_ARG);
+    {
+        // kernel specialisation needs no GPU: header generation, hashing, the cache's file handling and hipRTC itself
+        char dir[] = "/tmp/p25fe_asan_XXXXXX", path[512], log[256];
+        EXPECT(mkdtemp(dir) != nullptr);
+        EXPECT(p25fe_specialize(&cfg, dir, path, sizeof path) == P25FE_OK && path[0] == '\0');      // the build's own numbers: nothing to do
+        p25fe_config_t cust = cfg;
+        cust.n_decim_taps = 40; cust.n_chan_taps = 17;
+        for (int k = 0; k < 40; ++k) cust.decim_taps[k] = 0.02f * (float)std::sin(0.3 * k) + (k == 5 ? -0.0f : 0.f);
+        for (int k = 0; k < 17; ++k) cust.chan_taps[k] = 1.0f / 17.0f;
+        cust.fm_deviation_hz = 4000;
+        cust.u8_lut_valid = 1;
+        for (int b = 0; b < 256; ++b) cust.u8_lut[b] = std::tanh((b - 127.5f) / 90.0f);
+        EXPECT(p25fe_specialize(&cust, dir, path, 8) == P25FE_OK);                                     // a short path buffer is truncated, not overrun
+        EXPECT(p25fe_specialize(&cust, dir, path, sizeof path) == P25FE_OK && std::strstr(path, ".hsaco") != nullptr);
+        FILE* f = std::fopen(path, "rb");
+        EXPECT(f != nullptr);
+        std::fclose(f);
+        EXPECT(p25fe_specialize(&cust, dir, path, sizeof path) == P25FE_OK);                           // found, not rebuilt
+        EXPECT(p25fe_specialize_log(log, sizeof log) < sizeof log && p25fe_specialize_log(nullptr, 0) == 0);
+        EXPECT(p25fe_specialize(&cust, "/proc/this/cannot/be/created", path, sizeof path) == P25FE_ERR_JIT);
+        std::remove(path);
+        rmdir(dir);
+    }
     EXPECT(p25fe_reset(nullptr) == P25FE_ERR_ARG && p25fe_resync(nullptr) == P25FE_ERR_ARG && p25fe_last_hip_error(nullptr) == 0);
     size_t nn = 0;
     EXPECT(p25fe_state_size(nullptr, &nn) == P25FE_ERR_ARG && p25fe_run_u8(nullptr, nullptr, 3, nullptr, 0, nullptr) == P25FE_ERR_ARG);
@@ -85,6 +123,24 @@ int main()
     EXPECT(p25fe_state_import(h, blob.data(), nn) == P25FE_OK && p25fe_state_import(h, blob.data(), nn - 1) == P25FE_ERR_ARG);
     EXPECT(p25fe_resync(h) == P25FE_OK);
     p25fe_destroy(h);
+    {
+        // a long host capture as windows (pageable input: staged by this thread), with other tables: kernels specialised at create
+        p25fe_config_t cust = cfg;
+        cust.n_decim_taps = 20;
+        cust.specialize = P25FE_SPECIALIZE_REQUIRE;
+        p25fe_t* hw = nullptr;
+        EXPECT(p25fe_create(&cust, &hw) == P25FE_OK && p25fe_kernel_variant(hw) == P25FE_VARIANT_SPECIALIZED);
+        std::vector<float> big(2 * 3000000);
+        for (size_t i = 0; i < big.size(); ++i) big[i] = iq[i % iq.size()];
+        std::vector<uint8_t> dw(big.size() / 2 / 30 + 4);
+        p25fe_windows_stats_t st;
+        size_t ndw = 0;
+        EXPECT(p25fe_run_host_windows(hw, big.data(), P25FE_FMT_CF32, big.size() / 2, 1 << 20, dw.data(), dw.size(), &ndw, &st) == P25FE_OK);
+        EXPECT(st.n_windows == 3 && st.pinned_input == 0);
+        EXPECT(p25fe_run_host_windows(hw, big.data(), P25FE_FMT_CF32, big.size() / 2, 1 << 20, dw.data(), 10, &ndw, &st) == P25FE_ERR_CAPACITY);
+        EXPECT(p25fe_run_host_windows(hw, big.data(), P25FE_FMT_U8, 1000, 0, dw.data(), dw.size(), &ndw, nullptr) == P25FE_ERR_FORMAT);
+        p25fe_destroy(hw);
+    }
     std::printf("abi host driver ok (device present: streaming entry points exercised)\n");
     return 0;
 }
