@@ -8,7 +8,11 @@
  *
  *   reference item (file:line in /root/reference)                  replaced by
  *   -------------------------------------------------------------  ---------------------------
- *   DemodTask::new   src/demod.rs:44-59  (decim 5, avg 10, FM 5k)   p25fe_create
+ *   DemodTask::new   src/demod.rs:44-59  (decim 5, avg 10)          p25fe_create
+ *     DecimFir / BandpassFir tables     :27-29                      p25fe_config_t.decim_taps / chan_taps
+ *     FmDemod::new(5000, 48000)         :54                         p25fe_config_t.fm_deviation_hz / fm_sample_rate_hz / fm_gain
+ *     rtlsdr_iq::IQ                     :83                         p25fe_config_t.u8_scale / u8_offset / u8_lut
+ *     (type-level FIRs = compile-time tables)                       p25fe_specialize / p25fe_kernel_variant
  *   DemodTask::run   src/demod.rs:70-117 loop body, u8 chunk        p25fe_demod_u8
  *     IQ[s] LUT                         :74-84
  *     decim.decim_in_place              :87-90
@@ -18,6 +22,8 @@
  *   RecvTask::run sample loop  src/recv.rs:148-150, 204-210         p25fe_slice
  *     msg.feed(s) down to "a dibit exists" (p25 crate, un-vendored)
  *   MessageReceiver::resync    src/recv.rs:136, 179                 p25fe_resync
+ *   reader -> pool -> demodulator pipeline  src/sdr.rs:25-33,        p25fe_run_host_windows (a long host capture as a
+ *     src/demod.rs:62-70, 103                                         pipeline of windows at the speed of the bus)
  *   (state hand-off for time-sharded captures; no reference item)   p25fe_state_export/import,
  *                                                                   p25fe_shard_*
  *

@@ -290,6 +290,19 @@ def test_run_host_windows_equals_one_pass(mode, tmp_path):
     bb_rest = O.Demod().feed_cf32(iq)[len(O.Demod().feed_cf32(iq[:b])):]
     d2 = fe.slice(bb_rest)[0]
     assert np.array_equal(np.concatenate([d1, d2]), ref)
+    # lock drops INSIDE the capture (p25fe_resync_at_dev: absolute baseband indices): every window sees the list
+    bb_all = O.Demod().feed_cf32(iq)
+    drops = np.array([len(bb_all) // 5, len(bb_all) // 2 + 3, len(bb_all) - 4000], dtype=np.int64)
+    r = O.Recv(cfg)
+    pieces, prev = [], 0
+    for q in list(drops) + [len(bb_all)]:
+        pieces.append(r.feed(bb_all[prev:q])[0])
+        r.resync()
+        prev = q
+    fe = FrontEnd(symbol_clock=mode)
+    fe.resync_at_dev(torch.from_numpy(drops).cuda())
+    got, _ = fe.run_host_windows(iq, window=150000)
+    assert np.array_equal(got, np.concatenate(pieces))
     if mode == 0:
         # two channels, channel-major
         iq2, _, _ = c4fm.synth(6.0, seed=62, snr_db=20.0, frame_dibits=600)
