@@ -97,25 +97,42 @@ def test_specialize_compiles_without_a_gpu_and_caches(lib, tmp_path):
     assert lib.specialize(lib.default_config(), d) == ""              # the library's own kernels carry these
     dt, ct = (rng.standard_normal(31) * 0.1).astype(np.float32), (rng.standard_normal(41) * 0.1).astype(np.float32)
     cfg = lib.make_config(decim_taps=list(dt), chan_taps=list(ct))
-    f1 = lib.specialize(cfg, d)
+    # three sets of numbers compiled CONCURRENTLY (one process per GPU, or one thread per tuner, may create handles at the same
+    # time: hipRTC and the cache's write-then-rename must cope): other 31 / 41 tables; 64 / 64 tables + a non-affine u8 table +
+    # another deviation (the long geometry with the LDS table); an affine u8 table given as a TABLE
+    import threading
+    sc, of = np.float32(1.0 / 128.0), np.float32(-127.0 / 128.0)
+    lut = (np.arange(256, dtype=np.float32) * sc + of).astype(np.float32)       # exact in fp32: small integers times 2^-7
+    cfgs = [cfg,
+            lib.make_config(decim_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
+                            chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
+                            u8_lut=np.tanh((np.arange(256) - 127.5) / 90.0), fm_deviation_hz=4000),
+            lib.make_config(u8_lut=lut)]
+    out = [None] * 3
+
+    def work(i):
+        try:
+            out[i] = lib.specialize(cfgs[i], d)
+        except Exception as e:                                      # noqa: BLE001 -- reported by the assert below
+            out[i] = e
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(isinstance(o, str) and o for o in out), out
+    f1, f64, fa = out
+    assert len({f1, f64, fa}) == 3
     assert os.path.dirname(f1) == d and re.fullmatch(r"p25fe-[0-9a-f]{16}\.hsaco", os.path.basename(f1))
     t1 = os.path.getmtime(f1)
     assert lib.specialize(cfg, d) == f1 and os.path.getmtime(f1) == t1  # second call: found, not rebuilt
-    k = _hsaco_kernels(f1)
     want = {"p25jit_k1_cf32_lin", "p25jit_k1_u8_lin", "p25jit_k1_cf32_pl", "p25jit_k1_u8_pl", "p25jit_chunk_cf32", "p25jit_chunk_u8"}
-    assert set(k) == want, set(k) ^ want
-    assert all(s_ == 0 for _, s_ in k.values()), k                     # ScratchSize 0 everywhere
-    # a 64 / 64 table with a non-affine u8 table and another deviation: the long geometry with the LDS table, still no scratch,
-    # and another code object
-    f64 = lib.specialize(lib.make_config(decim_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
-                                         chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
-                                         u8_lut=np.tanh((np.arange(256) - 127.5) / 90.0), fm_deviation_hz=4000), d)
-    assert f64 != f1 and all(s_ == 0 for _, s_ in _hsaco_kernels(f64).values())
+    for f in (f1, f64, fa):
+        k = _hsaco_kernels(f)
+        assert set(k) == want, set(k) ^ want
+        assert all(s_ == 0 for _, s_ in k.values()), k                 # ScratchSize 0 everywhere
     # a table that IS fma(b, s, o) runs as arithmetic: the same code object as naming (s, o) directly
-    sc, of = np.float32(1.0 / 128.0), np.float32(-127.0 / 128.0)
-    lut = (np.arange(256, dtype=np.float32) * sc + of).astype(np.float32)       # exact in fp32: products of small integers by 2^-7
-    fa = lib.specialize(lib.make_config(u8_lut=lut), d)
-    assert fa not in (f1, f64) and lib.specialize(lib.make_config(u8_scale=sc, u8_offset=of), d) == fa
+    assert lib.specialize(lib.make_config(u8_scale=sc, u8_offset=of), d) == fa
     # argument errors: a NaN tap, a zero deviation, an unknown specialize mode, the old ABI
     for bad in (dict(decim_taps=[float("nan")] * 31), dict(fm_deviation_hz=0), dict(specialize=7), dict(fm_gain=float("inf"))):
         with pytest.raises(lib.P25feError) as e:
