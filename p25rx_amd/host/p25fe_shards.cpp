@@ -101,6 +101,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
         rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
         if (rc) die("step", rc);
     }
+    const double enq_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;   // host time to ENQUEUE a step
     (void)hipStreamSynchronize(st);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
     (void)p25fe_shard_comm_ms(s, cms, &cn);
@@ -113,10 +114,10 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
         FILE* g = std::fopen(out_path, "wb");
         std::fwrite(stream.data(), 1, stream.size(), g);
         std::fclose(g);
-        std::printf("{\"ranks\":%d,\"samples_per_rank\":%zu,\"dibits\":%" PRIu64 ",\"steps\":%d,\"ms_per_step\":%.4f,"
+        std::printf("{\"ranks\":%d,\"samples_per_rank\":%zu,\"dibits\":%" PRIu64 ",\"steps\":%d,\"ms_per_step\":%.4f,\"host_enqueue_ms_per_step\":%.4f,"
                     "\"comm_ms_per_step\":{\"halo\":%.4f,\"summaries\":%.4f,\"dibit_gather\":%.4f,\"steps_averaged\":%" PRIu64 "},"
                     "\"exchange\":\"%s\",\"gather\":\"%s\"}\n",
-                    world, n, off[(size_t)world], steps, ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL",
+                    world, n, off[(size_t)world], steps, ms, enq_ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL",
                     gather == P25FE_GATHER_ROOT_EXACT ? "exact" : "rows");
         std::remove(idfile.c_str());
         std::fflush(stdout);                                          // the child leaves through _Exit
