@@ -597,6 +597,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: gloo must not try to resolve the container's hostname
         if staged or args.workload == "time":
             # time shards: the DATA path is libp25fe_rccl.so (RCCL inside the C ABI, p25rx_amd/rccl.py); torch.distributed is
             # the control plane only (communicator id, barrier, max over ranks, gates) and runs on gloo
