@@ -106,7 +106,9 @@ static int bulk(Handle& h, const std::string& mode, std::ifstream& in, const cha
     const size_t eb = fmt == P25FE_FMT_U8 ? 2 : 8;
     const size_t window = window_bytes / eb / 8 * 8;
     if (window < 8192) { std::fprintf(stderr, "window too small\n"); return 2; }
-    const size_t block = 8 * window;                                  // samples per pinned block
+    const size_t block = 8 * window;                                  // samples per pinned block: the reader fills one while the library pipelines the other
+                                                                      // (measured on a 1.15 GB file from the page cache: 8 windows 78 ms, 2 windows 93 - 105 ms;
+                                                                      // the single reader thread's ~15 GB/s is what bounds this mode, not the bus)
     char* buf[2] = {nullptr, nullptr};
     for (int b = 0; b < 2; ++b)
         if (hipHostMalloc(reinterpret_cast<void**>(&buf[b]), block * eb, hipHostMallocDefault) != hipSuccess) {
