@@ -107,6 +107,23 @@ def test_pin_harness_recovers_what_is_in_a_dump(standin):
     assert rep["nid_mine"] == rep["nid_theirs"] and len(rep["nid_mine"]) >= 10 and all(x == (0x293, 0x3) for x in rep["nid_mine"])
 
 
+def test_ahead_of_time_specialisation_from_a_dump(standin, tmp_path):
+    """`make spec SPEC=consts.json SPEC_DIR=dir` (tools/specialize.py): the dump's numbers -> the code object a deployment's
+    p25fe_create finds through $P25FE_SPEC_DIR.  No GPU needed; the file name is the one p25fe_specialize gives for the same config."""
+    from p25rx_amd import _lib
+    d = str(tmp_path / "aot")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "specialize.py"), os.path.join(standin, "consts.json"), "-o", d],
+                                  text=True).strip()
+    assert os.path.dirname(out) == d and os.path.exists(out)
+    lp = _load("load_pin")
+    kw = lp.config_kwargs(lp.load_consts(os.path.join(standin, "consts.json")))
+    assert _lib.specialize(_lib.make_config(**kw), d) == out
+    js = tmp_path / "numbers.json"
+    js.write_text('{"fm_deviation_hz": 5000, "u8_offset": -1.0}')     # the build's own numbers: nothing to compile
+    msg = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "specialize.py"), str(js), "-o", d], text=True)
+    assert "own numbers" in msg
+
+
 @pytest.mark.gpu
 def test_pin_harness_gpu_leg_on_the_stand_in(standin):
     """STAND-IN (pins nothing): the dump's numbers reach the GPU through p25fe_config_t (ABI 4: tables, the u8 table, the
