@@ -2,11 +2,12 @@
 //
 // Host-only C++ (no device code here).  The kernel source is the library's own: p25fe_kernels.hip, p25fe_recv.hip,
 // p25fe.h and p25fe_spec.h are embedded as strings at build time (p25fe_embed.inc, written by tools/embed_src.py), so a
-// deployed libp25fe.so needs no source tree -- only libhiprtc, which every ROCm installation carries.  The reference
+// deployed libp25fe.so needs no source tree -- only libhiprtc (every ROCm installation carries it; loaded on first use).  The reference
 // fixes the same numbers at ITS compile time (type-level FIR tables, src/demod.rs:27-29; FmDemod::new(5000, 48000),
 // src/demod.rs:54; the rtlsdr_iq table, src/demod.rs:83).
 #include "p25fe_jit.h"
 
+#include <dlfcn.h>
 #include <errno.h>
 #include <hip/hiprtc.h>
 #include <math.h>
@@ -48,6 +49,46 @@ static const char WRAPPER[] =
     "extern \"C\" __global__ __launch_bounds__(WV, 2) void p25jit_chunk_u8(K1Args a, const Taps* __restrict__ t, ChunkTail c) "
     "{ chunk_body<P25FE_FMT_U8, true, P25FE_JIT_TX>(a, t, c); }\n";
 
+// hipRTC is loaded on first use (dlopen), not linked: a deployment without it still loads libp25fe.so -- its handles with
+// non-default numbers then run cached / ahead-of-time code objects or the generic kernels.
+namespace rtc {
+struct Api {
+    void* lib = nullptr;
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    decltype(&hiprtcGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+static const Api& api()
+{
+    static const Api a = [] {
+        Api x;
+        // (a process that has torch loaded already holds torch's own libhiprtc under the same soname: dlopen hands that one back)
+        // $P25FE_HIPRTC names the library explicitly (and is then the only one tried)
+        const char* env = getenv("P25FE_HIPRTC");
+        const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+        if (env && *env) x.lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char* n : names)
+                if ((x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+        if (!x.lib) return x;
+#define P25_SYM(field, name) x.field = reinterpret_cast<decltype(x.field)>(dlsym(x.lib, name))
+        P25_SYM(create, "hiprtcCreateProgram"); P25_SYM(compile, "hiprtcCompileProgram");
+        P25_SYM(log_size, "hiprtcGetProgramLogSize"); P25_SYM(log, "hiprtcGetProgramLog"); P25_SYM(code_size, "hiprtcGetCodeSize");
+        P25_SYM(code, "hiprtcGetCode"); P25_SYM(destroy, "hiprtcDestroyProgram"); P25_SYM(error_string, "hiprtcGetErrorString");
+#undef P25_SYM
+        x.ok = x.create && x.compile && x.log_size && x.log && x.code_size && x.code && x.destroy && x.error_string;
+        return x;
+    }();
+    return a;
+}
+}  // namespace rtc
+
 static uint64_t fnv(uint64_t h, const void* p, size_t n)
 {
     const unsigned char* b = static_cast<const unsigned char*>(p);
@@ -58,7 +99,7 @@ static uint64_t fnv(uint64_t h, const void* p, size_t n)
 uint64_t spec_hash(const Spec& s)
 {
     uint64_t h = 0xcbf29ce484222325ull;
-    // everything the code object depends on: the source, the options, the compiler, the numbers
+    // everything the code object depends on: the source, the options, the numbers
     h = fnv(h, "p25fe-jit-1", 11);
     h = fnv(h, P25FE_SRC_KERNELS, sizeof P25FE_SRC_KERNELS);
     h = fnv(h, P25FE_SRC_RECV, sizeof P25FE_SRC_RECV);
@@ -66,8 +107,8 @@ uint64_t spec_hash(const Spec& s)
     h = fnv(h, P25FE_SRC_SPEC_H, sizeof P25FE_SRC_SPEC_H);
     h = fnv(h, WRAPPER, sizeof WRAPPER);
     for (int i = 0; i < N_OPTIONS; ++i) h = fnv(h, OPTIONS[i], strlen(OPTIONS[i]) + 1);
-    int vmaj = 0, vmin = 0;
-    if (hiprtcVersion(&vmaj, &vmin) == HIPRTC_SUCCESS) { h = fnv(h, &vmaj, sizeof vmaj); h = fnv(h, &vmin, sizeof vmin); }
+    // (NOT the compiler's version: a process without hipRTC must find the objects an ahead-of-time run left, and any compiler
+    // that honours the options above produces the same bits from the same source -- fp32, explicit fma only)
     h = fnv(h, &s.tx, sizeof s.tx);
     h = fnv(h, &s.t1, sizeof s.t1);
     h = fnv(h, &s.t2, sizeof s.t2);
@@ -204,26 +245,28 @@ static bool compile(const Spec& s, std::vector<char>& code, std::string& log)
     const std::string spec_h = gen_header(s);
     const char* headers[] = {spec_h.c_str(), P25FE_SRC_KERNELS, P25FE_SRC_RECV, P25FE_SRC_P25FE_H, P25FE_SRC_SPEC_H};
     const char* names[] = {"p25fe_jit_spec.h", "p25fe_kernels.hip", "p25fe_recv.hip", "p25fe.h", "p25fe_spec.h"};
+    const rtc::Api& R = rtc::api();
+    if (!R.ok) { log += "libhiprtc is not available in this process: cannot compile (ahead-of-time code objects are still looked up)\n"; return false; }
     hiprtcProgram prog = nullptr;
-    hiprtcResult r = hiprtcCreateProgram(&prog, WRAPPER, "p25fe_jit.hip", 5, headers, names);
-    if (r != HIPRTC_SUCCESS) { log += std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r) + "\n"; return false; }
-    r = hiprtcCompileProgram(prog, N_OPTIONS, const_cast<const char**>(OPTIONS));
+    hiprtcResult r = R.create(&prog, WRAPPER, "p25fe_jit.hip", 5, headers, names);
+    if (r != HIPRTC_SUCCESS) { log += std::string("hiprtcCreateProgram: ") + R.error_string(r) + "\n"; return false; }
+    r = R.compile(prog, N_OPTIONS, const_cast<const char**>(OPTIONS));
     size_t ls = 0;
-    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+    if (R.log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         std::string l(ls, '\0');
-        if (hiprtcGetProgramLog(prog, &l[0]) == HIPRTC_SUCCESS) log += l.c_str();
+        if (R.log(prog, &l[0]) == HIPRTC_SUCCESS) log += l.c_str();
     }
     bool ok = false;
     if (r == HIPRTC_SUCCESS) {
         size_t cs = 0;
-        if (hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0) {
+        if (R.code_size(prog, &cs) == HIPRTC_SUCCESS && cs > 0) {
             code.resize(cs);
-            ok = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+            ok = R.code(prog, code.data()) == HIPRTC_SUCCESS;
         }
     } else {
-        log += std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n";
+        log += std::string("hiprtcCompileProgram: ") + R.error_string(r) + "\n";
     }
-    hiprtcDestroyProgram(&prog);
+    R.destroy(&prog);
     if (!ok) code.clear();
     return ok;
 }

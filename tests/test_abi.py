@@ -144,6 +144,25 @@ def test_specialize_compiles_without_a_gpu_and_caches(lib, tmp_path):
         lib.specialize(old, d)
 
 
+def test_library_loads_and_degrades_without_hiprtc(lib, tmp_path):
+    """hipRTC is loaded on first use, not linked: libp25fe.so has no NEEDED entry for it, and a process that cannot find it
+    still finds code objects an ahead-of-time run left (the file name does not depend on the compiler) -- only compiling fails,
+    loudly (P25FE_ERR_JIT with a log that says why)."""
+    import sys
+    needed = subprocess.check_output(["readelf", "-d", lib.LIB_PATH]).decode()
+    assert "hiprtc" not in needed
+    d = str(tmp_path / "aot")
+    cfg_src = "from p25rx_amd import _lib; cfg = _lib.make_config(fm_deviation_hz=4321); "
+    made = subprocess.check_output([sys.executable, "-c", cfg_src + "print(_lib.specialize(cfg, %r))" % d], cwd=ROOT, text=True).strip()
+    assert os.path.exists(made)
+    env = dict(os.environ, P25FE_HIPRTC="/nonexistent/libhiprtc.so")
+    found = subprocess.check_output([sys.executable, "-c", cfg_src + "print(_lib.specialize(cfg, %r))" % d], cwd=ROOT, text=True, env=env).strip()
+    assert found == made                                              # looked up, no compiler needed
+    r = subprocess.run([sys.executable, "-c", cfg_src.replace("4321", "4322") + "print(_lib.specialize(cfg, %r))" % d], cwd=ROOT, text=True, env=env,
+                       capture_output=True)
+    assert r.returncode != 0 and "libhiprtc is not available" in r.stderr and "status -7" in r.stderr
+
+
 def test_generic_kernels_do_not_spill(lib):
     """No k_frontend / k_chunk instantiation of the library may use scratch memory (a spilled FIR loop is ~2x the time)."""
     k = _hsaco_kernels_of_library(lib.LIB_PATH)
