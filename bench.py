@@ -569,10 +569,10 @@ def main():
                     help="N > 1: 'time' = configs[4], one capture cut into time shards (default); 'channels' = configs[3], "
                          "a 256-channel batch cut into channel blocks (no communication on the data path)")
     ap.add_argument("--channels", type=int, default=256, help="--workload channels: size of the batch")
-    ap.add_argument("--gather", choices=["root_exact", "root", "all", "none"], default="root_exact",
-                    help="N > 1: the dibit shards go to rank 0 as exactly their valid bytes, received at their offsets of the "
-                         "ordered stream (default; one host wait for the offsets per step), as whole rows + a compaction pass "
-                         "(root: no host wait), all-gathered, or stay sharded (diagnostics)")
+    ap.add_argument("--gather", choices=["root_exact", "root", "all", "none"], default="root",
+                    help="N > 1: the dibit shards go to rank 0 as whole rows + a compaction pass (root, the default: no host wait "
+                         "anywhere in the step), as exactly their valid bytes received at their offsets of the ordered stream "
+                         "(root_exact: one host wait for the offsets per step), all-gathered, or stay sharded (diagnostics)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: strictly serial steps (K1 -> K2 -> K3 -> K4 on one stream) instead of p25fe_run_dev_pipelined")
@@ -765,6 +765,8 @@ def main():
         if args.gather != "none":
             # checksum of checksums: every rank's (length, byte sum, position-weighted sum) of its own dibits must equal
             # what rank 0 finds at that shard's resolved offset in the gathered, ordered stream
+            if os.environ.get("P25FE_BENCH_INJECT_FAULT") == "gather" and rank == world - 1 and nd > 0:
+                dibits[0, 0] ^= 1                                     # TEST HOOK: the gate must see it and the run must exit non-zero
             off = ss.offsets()
             d_stream = ss.stream(torch, dev, int(off[world])) if (rank == 0 or args.gather == "all") else None
             w = torch.arange(1, nd + 1, dtype=torch.int64, device=dev) % 65521
@@ -784,6 +786,7 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok, gather_ok = bool(okt[0].item()), (None if args.gather == "none" else bool(okt[1].item()))
 
+    gather_ran = ss.gather_ran() if world > 1 else "none"           # the mode the library EXECUTED (p25fe_shard_gather_ran)
     if rank == 0:
         total_samples = float(n) * world * args.steps
         value = total_samples / dt / 1e6
@@ -808,16 +811,16 @@ def main():
         elif strong:
             workload = ("configs[4]: ONE %.0f s capture (%d samples, %.3f GB) cut into %d contiguous time shards of %.1f s, "
                         "decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather (%s)"
-                        % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0, args.gather))
+                        % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0, gather_ran))
             sharding = "time shards (strong), halo %d samples by send/recv behind K1, summaries by all_gather, dibits by %s (%s)" % (
-                halo, GATHER_WORDS[args.gather],
+                halo, GATHER_WORDS[gather_ran],
                 "TEST HOOK: shared-memory staging, all ranks on one GPU" if staged else "RCCL inside libp25fe_rccl.so")
         else:
             workload = ("configs[4]'s partitioning at configs[1]'s per-GPU size: ONE %.0f s capture (%d samples, %.3f GB) cut into %d "
                         "contiguous time shards of %.0f s, decimating FIR + FM + boxcar + sync + 4-level slice + dibit gather (%s)"
-                        % (total_s * world, n * world, n * world * 8 / 1e9, world, total_s, args.gather))
+                        % (total_s * world, n * world, n * world * 8 / 1e9, world, total_s, gather_ran))
             sharding = "time shards (weak), halo %d samples by send/recv behind K1, summaries by all_gather, dibits by %s (%s)" % (
-                halo, GATHER_WORDS[args.gather],
+                halo, GATHER_WORDS[gather_ran],
                 "TEST HOOK: shared-memory staging, all ranks on one GPU" if staged else "RCCL inside libp25fe_rccl.so")
         out = {
             "metric": "IQ Msamples/s through FM-demod+C4FM slice",
@@ -865,8 +868,9 @@ def main():
                 out["config"]["serial_ms_per_step"] = round(serial_ms, 4)
         if comm_ms is not None:
             out["config"]["comm_ms_per_step"] = dict(comm_ms, note="rank 0, p25fe_shard_comm_ms: HIP events of the library around each "
-                                                     "exchange on its stream (the halo exchange runs beside K1's main launch), averaged "
-                                                     "over the last <= 64 timed steps")
+                                                     "exchange on its stream (the halo exchange runs beside K1's main launch), on every "
+                                                     "16th step of the timed region only (p25fe_shard_comm_timing: four of these "
+                                                     "events are packets between the kernels of the step's critical path)")
         if gather_ok is not None:
             out["config"]["gather_gate"] = ("gathered stream holds every shard at its resolved offset (length, sum and "
                                             "position-weighted sum of every rank's dibits): %s" % gather_ok)
@@ -894,8 +898,8 @@ def main():
             except OSError:
                 pass
         dist.destroy_process_group()
-    if not ok and world == 1:
-        sys.exit(3)                        # N = 1: a wrong result is a failed bench (N > 1 reports the gate in the JSON)
+    if not ok or gather_ok is False:
+        sys.exit(3)                        # a wrong result is a failed bench at every N (the gates are in the JSON line as well)
 
 
 if __name__ == "__main__":

@@ -182,14 +182,22 @@ extern "C" {
                                   abs0: u64, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass1_finish(h: *mut Handle, d_iq: *const c_void, fmt: c_int, ch_stride: usize, n_hist: usize, n: usize,
                                     abs0: u64, d_result: *mut ResultRec, stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_pass1_head(h: *mut Handle, d_iq: *const c_void, fmt: c_int, ch_stride: usize, n_hist: usize, n: usize,
+                                  abs0: u64, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass2(h: *mut Handle, d_anchor_in: *const Anchor, d_dibits: *mut u8, dibit_stride: usize,
                              d_result: *mut ResultRec, stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_pass2_dev(h: *mut Handle, d_summaries: *const ResultRec, d_shard_bb0: *const u64, d_shard_bb_n: *const u64,
+                                 n_shards: usize, rank: usize, d_anchor_in: *mut Anchor, d_dibit_offset: *mut u64, d_dibits: *mut u8,
+                                 dibit_stride: usize, d_dibits_dup: *mut u8, d_result: *mut ResultRec, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_resolve(summaries: *const ResultRec, shard_bb0: *const u64, shard_bb_n: *const u64, n_shards: usize,
                                symbol_clock: c_int, anchor_in: *mut Anchor, dibit_offset: *mut u64) -> c_int;
     pub fn p25fe_shard_resolve_dev(h: *mut Handle, d_summaries: *const ResultRec, d_shard_bb0: *const u64, d_shard_bb_n: *const u64,
                                    n_shards: usize, d_anchor_in: *mut Anchor, d_dibit_offset: *mut u64, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_compact_dev(h: *mut Handle, d_gathered: *const u8, cap: usize, d_dibit_offset: *const u64, n_shards: usize,
                                    d_out: *mut u8, out_cap: usize, stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_compact_from_dev(h: *mut Handle, d_gathered: *const u8, cap: usize, d_dibit_offset: *const u64,
+                                        first_shard: usize, n_shards: usize, d_out: *mut u8, out_cap: usize,
+                                        stream: *mut c_void) -> c_int;
     pub fn p25fe_nid_dev(h: *mut Handle, d_dibits: *const u8, n_dibits: usize, d_sync_dibit: *const u64, d_sync_pos: *const i64,
                          n_sync: usize, d_out: *mut Nid, stream: *mut c_void) -> c_int;
     pub fn p25fe_nid(h: *mut Handle, dibits: *const u8, n_dibits: usize, sync_dibit: *const u64, sync_pos: *const i64, n_sync: usize,
@@ -216,6 +224,8 @@ extern "C" {
     pub fn p25fe_shard_offsets(s: *mut Shard, offsets: *mut u64) -> c_int;
     pub fn p25fe_shard_stream_dev(s: *const Shard) -> *const u8;
     pub fn p25fe_shard_comm_ms(s: *mut Shard, ms: *mut f64, n_steps: *mut u64) -> c_int;
+    pub fn p25fe_shard_comm_timing(s: *mut Shard, every: c_int) -> c_int;
+    pub fn p25fe_shard_gather_ran(s: *const Shard) -> c_int;
 }
 
 /// Owning wrapper of one handle.  One per thread, like the tasks of the reference (src/main.rs:270-287).

@@ -325,6 +325,12 @@ int p25fe_shard_pass1_main(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stri
                            uint64_t abs0, void *stream);
 int p25fe_shard_pass1_finish(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                              uint64_t abs0, p25fe_result_t *d_result, void *stream);
+/* The head alone (same arguments, after the halo has arrived), so that it can run on ANOTHER stream beside the main launch
+ * -- the stream the halo arrives on: the two launches share no byte of their outputs.  p25fe_shard_pass1_finish then only
+ * enqueues the sync detection and the scan; its stream must have been made to wait for the head's.  Optional: without it
+ * _finish launches the head itself. */
+int p25fe_shard_pass1_head(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
+                           uint64_t abs0, void *stream);
 
 /* Host-side combine: summaries[r] for r = 0..n_shards-1 in time order (one channel) ->
  * anchor_in[r] (n_shards entries) and dibit_offset[r] (n_shards + 1 entries: shard r's dibits occupy
@@ -339,6 +345,20 @@ int p25fe_shard_resolve_dev(p25fe_t *h, const p25fe_result_t *d_summaries, const
                             const uint64_t *d_shard_bb_n, size_t n_shards, p25fe_anchor_t *d_anchor_in,
                             uint64_t *d_dibit_offset, void *stream);
 
+/* Pass 2 with the combine on the device and INSIDE the pass: d_summaries = the n_shards pass-1 summaries in time order
+ * (the all-gathered records, device memory), `rank` = this handle's shard.  One-channel handles.  With the fixed-stride
+ * receiver and no lock drops inside the shard this is ONE launch: no second scan and no resolve kernel -- every slicer
+ * workgroup derives its carry-in from the summaries and applies it in closed form (ShardFix, p25fe_recv.hip); otherwise it
+ * enqueues p25fe_shard_resolve_dev + p25fe_shard_pass2.  Also written: d_anchor_in[n_shards] and
+ * d_dibit_offset[n_shards + 1] (what p25fe_shard_resolve_dev writes), *d_result = this shard's final record.
+ * d_dibits_dup (nullable): a second destination of every dibit with the same row layout -- rank 0's shard starts at offset
+ * 0 of the capture's ordered stream, so it can slice straight into it.
+ * Same ordering rule as p25fe_shard_pass2: it follows its shard's pass 1 on this handle. */
+int p25fe_shard_pass2_dev(p25fe_t *h, const p25fe_result_t *d_summaries, const uint64_t *d_shard_bb0,
+                          const uint64_t *d_shard_bb_n, size_t n_shards, size_t rank, p25fe_anchor_t *d_anchor_in,
+                          uint64_t *d_dibit_offset, uint8_t *d_dibits, size_t dibit_stride, uint8_t *d_dibits_dup,
+                          p25fe_result_t *d_result, void *stream);
+
 /* Dibit gather, receiving side (BASELINE.json config 5: "RCCL ... carrying ... the reduced dibit stream"): after an
  * all-gather of the shards' dibit buffers (each `cap` bytes, shard r at d_gathered + r * cap, its first
  * dibit_offset[r + 1] - dibit_offset[r] bytes valid) write the contiguous stream to d_out[0 .. dibit_offset[n_shards]).
@@ -346,6 +366,10 @@ int p25fe_shard_resolve_dev(p25fe_t *h, const p25fe_result_t *d_summaries, const
  * RecvTask feeds into MessageReceiver (src/recv.rs:148-150). */
 int p25fe_shard_compact_dev(p25fe_t *h, const uint8_t *d_gathered, size_t cap, const uint64_t *d_dibit_offset,
                             size_t n_shards, uint8_t *d_out, size_t out_cap, void *stream);
+/* the same for shards first_shard .. n_shards - 1 only (first_shard = 1: rank 0 has sliced its own shard into d_out already,
+ * p25fe_shard_pass2_dev's d_dibits_dup; first_shard == n_shards: nothing to do) */
+int p25fe_shard_compact_from_dev(p25fe_t *h, const uint8_t *d_gathered, size_t cap, const uint64_t *d_dibit_offset,
+                                 size_t first_shard, size_t n_shards, uint8_t *d_out, size_t out_cap, void *stream);
 
 /* Network identifier that follows each frame sync (next row after the dibits, SURVEY.md section 8f: what
  * p25::MessageReceiver reports as MessageEvent::PacketNID, src/recv.rs:216-222, consumed by

@@ -8,12 +8,16 @@
  * DemodTask / MessageReceiver carry from chunk to chunk (src/demod.rs:25-40, the receiver's lock), cut at shard boundaries.
  *
  *   rank r owns samples [r * n_per_rank, (r + 1) * n_per_rank) of ONE capture, resident in HBM as [halo | owned];
- *   one step (all enqueued, no host synchronisation):
- *     1. the last p25fe_shard_halo() samples go to rank r + 1 (ncclSend / ncclRecv on a side stream) WHILE K1 runs over
- *        everything that does not touch the halo (p25fe_shard_pass1_main); then the head + sync detection + scan;
- *     2. ncclAllGather of one p25fe_result_t per rank; p25fe_shard_resolve_dev: carry-in anchors, dibit offsets;
- *     3. pass 2 (scan with the carry-in + slicer); the shards' dibit rows go to rank 0 point-to-point (xGMI is a full mesh)
- *        and are compacted there into ONE ordered stream -- what RecvTask feeds into MessageReceiver (src/recv.rs:148-150).
+ *   one step (all enqueued; no host synchronisation unless P25FE_GATHER_ROOT_EXACT is asked for):
+ *     1. on a side stream: the last p25fe_shard_halo() samples go to rank r + 1 (ncclSend / ncclRecv), then the shard's head
+ *        segment (p25fe_shard_pass1_head) -- WHILE K1 runs over everything that does not touch the halo on the caller's
+ *        stream (p25fe_shard_pass1_main); then sync detection + scan (p25fe_shard_pass1_finish);
+ *     2. ncclAllGather of one p25fe_result_t per rank;
+ *     3. pass 2 with the combine inside the slicer (p25fe_shard_pass2_dev: carry-in anchor and dibit offsets from the
+ *        gathered summaries, no second scan, no resolve launch); rank 0 slices straight into the ordered stream as well;
+ *     4. the other shards' dibit rows go to rank 0 point-to-point (xGMI is a full mesh) and are compacted there behind
+ *        rank 0's own -- ONE ordered stream, what RecvTask feeds into MessageReceiver (src/recv.rs:148-150).
+ *   Dependent launches behind K1 on rank 0: detection, scan, all-gather, slicer, receive, compaction.
  *
  * Bootstrap: rank 0 obtains a 128-byte id (p25fe_rccl_unique_id) and gives it to the other ranks by any means (file,
  * pipe, socket); every rank calls p25fe_shard_create with it.
@@ -32,12 +36,16 @@ extern "C" {
 typedef struct p25fe_shard p25fe_shard_t;
 
 /* How the shards' dibits reach the consumer:
- *   ROOT        every rank sends its whole row (p25fe_shard_dibit_cap() bytes: the valid length + <= 0.02 % + 64 bytes of slack)
- *               to rank 0, which compacts the rows into the ordered stream; no host synchronisation anywhere in the step;
+ *   ROOT        (the default of every driver in this repository) every rank sends its whole row (p25fe_shard_dibit_cap() bytes:
+ *               the valid length + <= 0.02 % + 64 bytes of slack) to rank 0, which compacts the rows into the ordered stream; no
+ *               host synchronisation anywhere in the step;
  *   ROOT_EXACT  every rank sends exactly its offsets[r + 1] - offsets[r] dibits, rank 0 receives them AT offsets[r] of the
- *               ordered stream (no padding on the wire, no compaction kernel); the counts are host arguments of ncclSend /
- *               ncclRecv, so the step waits once for the world + 1 offsets (ready before pass 2 runs, which overlaps the wait);
- *   ALL         all-gather of the rows, every rank compacts (diagnostic). */
+ *               ordered stream (no padding on the wire, no compaction kernel).  CONTRACT CHANGE against ROOT: the counts are
+ *               host arguments of ncclSend / ncclRecv, so p25fe_shard_step BLOCKS the calling thread once per step until the
+ *               world + 1 offsets are on the host (a one-thread resolve + a 72-byte copy on the side stream, ready before
+ *               pass 2 ends) -- and a rank that fails before that point leaves its peers waiting in their receives;
+ *   ALL         all-gather of the rows, every rank compacts (diagnostic).
+ * The one-rank communicator of the tests plays its own peer: it sends its row / its exact bytes to itself. */
 enum { P25FE_GATHER_NONE = 0, P25FE_GATHER_ROOT = 1, P25FE_GATHER_ALL = 2, P25FE_GATHER_ROOT_EXACT = 3 };
 
 /* rank 0: a fresh communicator id (ncclGetUniqueId) */
@@ -60,15 +68,24 @@ size_t p25fe_shard_dibit_cap(const p25fe_shard_t *s);
 int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,
                      void *stream);
 
+/* HIP events around the three exchanges (p25fe_shard_comm_ms) ride on every `every`-th step only (default 16; 0: never;
+ * 1: every step): the four around the all-gather and the gather are packets between the kernels of the step's critical
+ * path, ~4 us each. */
+int p25fe_shard_comm_timing(p25fe_shard_t *s, int every);
+
+/* P25FE_GATHER_* as the LAST step executed it (a shard without a communicator -- world 1, id128 NULL and no test hook --
+ * has nothing to gather: ROOT). */
+int p25fe_shard_gather_ran(const p25fe_shard_t *s);
+
 /* After `stream` has been synchronised: the world + 1 dibit offsets of the capture (shard r holds
  * [offsets[r], offsets[r + 1]); returns P25FE_ERR_CAPACITY if a shard outgrew its row), and the device pointer of the
  * ordered stream (rank 0, or every rank with P25FE_GATHER_ALL; offsets[world] bytes). */
 int p25fe_shard_offsets(p25fe_shard_t *s, uint64_t *offsets);
 const uint8_t *p25fe_shard_stream_dev(const p25fe_shard_t *s);
 
-/* Average milliseconds per step spent in the three exchanges since the last call (HIP events around them on their
- * streams): ms[0] halo send / recv, ms[1] summary all-gather, ms[2] dibit gather; *n_steps = steps averaged.  Reading
- * synchronises those events. */
+/* Average milliseconds per TIMED step (p25fe_shard_comm_timing) spent in the three exchanges since the last call (HIP events
+ * around them on their streams): ms[0] halo send / recv, ms[1] summary all-gather, ms[2] dibit gather; *n_steps = steps
+ * averaged (at most the last 64 timed ones).  Reading synchronises those events. */
 int p25fe_shard_comm_ms(p25fe_shard_t *s, double ms[3], uint64_t *n_steps);
 
 #ifdef __cplusplus

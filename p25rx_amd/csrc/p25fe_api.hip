@@ -167,9 +167,15 @@ struct p25fe {
     bool sh_valid = false;
     size_t sh_main_nbb = (size_t)-1;       // shard whose main K1 launch is out, waiting for p25fe_shard_pass1_finish
     uint64_t sh_main_abs0 = 0;
+    bool sh_head_done = false;             // ... and whose head segment has been launched too (p25fe_shard_pass1_head)
+    bool sh_head_flagged = false;          // ... by p25fe_shard_pass1_head: the detection's first tiles wait for sh_flag == sh_seq
+    DevBuf sh_flag;                        // one word a one-thread kernel behind the head writes
+    unsigned sh_seq = 0;
+    int sh_head_tile_max = -1;
     size_t sh_nbb = 0;
     long sh_abs_bb0 = 0;
     bool sh_gen = false;                   // pass 1 ran the general receiver (pass 2 reads its summaries)
+    bool sh_scan_fresh = false;            // the per-tile carry-ins in `outs` are still pass 1's (no carry-in): p25fe_shard_pass2 rewrites them
 };
 
 // geometry of the planar scratch for n_bb owned baseband samples (p25fe_recv.hip: Planar)
@@ -496,7 +502,7 @@ void p25fe_destroy(p25fe_t* h)
     DevBuf* alt[] = {&h->alt_pl_f, &h->alt_pl_bits, &h->alt_evl, &h->alt_evthr, &h->alt_recs, &h->alt_tsum, &h->alt_outs,
                      &h->alt_gsum, &h->alt_gouts, &h->alt_evg, &h->gsum, &h->gouts, &h->evg};
     for (DevBuf* b : alt) b->release();
-    DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps};
+    DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps, &h->sh_flag};
     for (DevBuf* b : bufs) b->release();
     h->hin.release(); h->hbb.release(); h->hout.release();
     for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
@@ -548,8 +554,11 @@ static int ensure_chunk_scratch(p25fe_t* h)
 static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, long m_begin, float* d_bb, size_t bb_stride, float* d_power_dbm,
                            hipStream_t st, const PlanarGeo* planar = nullptr, int part = 0, hipEvent_t ev0 = nullptr,
-                           hipEvent_t ev1 = nullptr, const ChunkRecvArgs* chunk = nullptr)
+                           hipEvent_t ev1 = nullptr, const ChunkRecvArgs* chunk = nullptr, long* head_end = nullptr,
+                           unsigned* done_flag = nullptr, unsigned done_seq = 0u)
 {
+    // head_end (nullable, part 2): receives the planar position up to which this launch's segments write
+    // done_flag (nullable, planar): the launch's last workgroup publishes done_flag[0] = done_seq (K1Args.done_flag)
     // chunk (nullable, planar only): launch k_chunk -- K1 plus the one-tile receiver run by each channel's last workgroup
     // ev0 / ev1 (nullable): events attached to K1's dispatch (begin / end of the kernel)
     // part: 0 = every segment; 1 = only the segments whose input window lies inside the owned samples (a shard's main
@@ -585,7 +594,15 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const long seg_len = pro ? subs * sub : (sub - SEG_HALO) + (subs - 1) * sub;
     // what a segment needs in front of its first output: the prologue's decimator outputs, or the recomputed halo
     const long nd = pro ? HALO_Y + (h->long_taps ? TMAX : T2) - 1 : SEG_HALO;
-    const long n_seg = (total + seg_len - 1) / seg_len;
+    // a time shard's launches (part != 0): the segments in front of the first one whose input lies inside the owned samples
+    // are ONE sub-tile long (K1Args.lead_segs) -- the head is then a few one-sub-tile workgroups side by side
+    const long lead_len = pro ? sub : sub - SEG_HALO;
+    const long o0l = (long)((4 + 5 - abs0 % 5) % 5);
+    long lead = 0;
+    if (part && subs > 1 && !chunk)
+        while (lead < 64 && o0l + DEC * (m_begin + lead * lead_len - nd) - (t1 - 1) < 0 && lead * lead_len < total) ++lead;
+    auto seg_start = [&](long k) { return k < lead ? m_begin + k * lead_len : m_begin + lead * lead_len + (k - lead) * seg_len; };
+    const long n_seg = lead * lead_len >= total ? (total + lead_len - 1) / lead_len : lead + (total - lead * lead_len + seg_len - 1) / seg_len;
     const long pl_shift = PLPAD + h->look;       // the general receiver sees the range h->look samples late (p25fe_recv.hip)
     if (planar && pro && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % PL_BLK != 0 || seg_len % PL_BLK != 0)) return P25FE_ERR_ARG;
     if (planar && !pro && (m_begin + pl_shift < SEG_HALO || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
@@ -605,12 +622,12 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     long seg_count = n_seg;
     if (part) {
         if (d_power_dbm) return P25FE_ERR_ARG;
-        // segment k reads input from o0 + 5 (m_begin + k seg_len - nd) - (T1 - 1) on
-        const long o0 = (long)((4 + 5 - abs0 % 5) % 5);
+        // segment k reads input from o0 + 5 (its first output - nd) - (T1 - 1) on
         long k_min = 0;
-        while (k_min < n_seg && o0 + DEC * (m_begin + k_min * seg_len - nd) - (t1 - 1) < 0) ++k_min;
+        while (k_min < n_seg && o0l + DEC * (seg_start(k_min) - nd) - (t1 - 1) < 0) ++k_min;
         if (part == 1) { a.seg_first = (int)k_min; seg_count = n_seg - k_min; }
         else seg_count = k_min;
+        if (head_end) *head_end = seg_start(k_min) - m_begin;
         if (seg_count <= 0) return P25FE_OK;
     }
     a.seg_count = (int)seg_count;
@@ -618,6 +635,8 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.m_begin = m_begin;
     a.power_partial = nullptr;
     a.bbp = nullptr; a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_ch_stride = 0; a.pl_shift = (int)pl_shift;
+    a.done_flag = planar ? done_flag : nullptr; a.done_seq = done_seq;
+    a.lead_segs = (int)lead;
     if (planar) {
         a.bbp = h->pl_f.as<float>(); a.bbp_ch_stride = (long)planar->floats();
         a.bits = h->pl_bits.as<uint8_t>(); a.bits_ch_stride = (long)(4 * planar->words());
@@ -749,10 +768,12 @@ static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, siz
 }
 
 // K2 on the planar scratch.  abs_bb0: absolute index of the first PROCESSED sample (owned sample 0 minus h->look).
-static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc)
+static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc, bool wait_head_flag = false)
 {
     const PlanarGeo g(n_bb);
     DetArgs d;
+    d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1;
+    if (wait_head_flag) { d.head_flag = h->sh_flag.as<unsigned>(); d.head_seq = h->sh_seq; d.head_tile_max = h->sh_head_tile_max; }
     d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = abs_bb0; d.n_tiles = (int)g.n_tiles;
     d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>(); d.evthr = h->evthr.as<float>();
     d.opt = rc.opt; d.gsum = h->gsum.as<TileSumG>(); d.evg = h->evg.as<uint32_t>();
@@ -766,9 +787,12 @@ static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, 
 static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_anchor_t* d_anchor_in,
                              uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit,
                              size_t sync_stride, p25fe_result_t* d_result, bool do_slice, hipStream_t st,
-                             const RecvCall& rc, hipEvent_t ev_done = nullptr)
+                             const RecvCall& rc, hipEvent_t ev_done = nullptr, uint8_t* d_dibits2 = nullptr,
+                             const ShardFix* fix = nullptr)
 {
     // ev_done (nullable): attached to the LAST kernel this function launches (its completion = the receive side is done)
+    // d_dibits2 (nullable): second destination of the dibits; fix (nullable, fixed-stride receiver only): pass 2 of a time
+    // shard on pass 1's scan -- no scan launch, the slicer applies the carry-in in closed form (ShardFix in p25fe_recv.hip)
     const PlanarGeo g(n_bb);
     const int n_tiles = n_bb ? (int)g.n_tiles : 0;
     const bool slice = do_slice && n_tiles != 0;
@@ -787,7 +811,7 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         l.evl = h->evl.as<uint16_t>(); l.evg = h->evg.as<uint32_t>(); l.evthr = h->evthr.as<float>(); l.anchor_in = d_anchor_in;
         l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
         l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
-        l.sync_stride = (long)sync_stride; l.track = h->track;
+        l.sync_stride = (long)sync_stride; l.track = h->track; l.dibits2 = d_dibits2;
         launch_ev(k_slice_g, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, l);
         HIPCHK(h, hipGetLastError());
         prof_mark(h, 4, st);
@@ -797,8 +821,10 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
     c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>();
     c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
     c.n_baseband = n_bb;
-    launch_ev(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
-    HIPCHK(h, hipGetLastError());
+    if (!fix) {
+        launch_ev(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
+        HIPCHK(h, hipGetLastError());
+    }
     prof_mark(h, 3, st);
     if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
     SliceArgs l;
@@ -808,7 +834,10 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
     l.dibits = d_dibits; l.dibit_stride = (long)dibit_stride;
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
-    launch_ev(k_slice, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, l);
+    l.dibits2 = d_dibits2;
+    if (fix) l.fix = *fix; else memset(&l.fix, 0, sizeof l.fix);
+    // (pass 2 of a time shard: one extra workgroup runs the combine for the record beside the slicing ones)
+    launch_ev(k_slice, dim3((unsigned)n_tiles + (fix ? 1u : 0u), (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, l);
     HIPCHK(h, hipGetLastError());
     prof_mark(h, 4, st);
     return P25FE_OK;
@@ -819,6 +848,7 @@ static void shard_invalidate(p25fe_t* h)
 {
     h->sh_valid = false;
     h->sh_main_nbb = (size_t)-1;             // a later p25fe_shard_pass1_finish must not pair with a main launch whose planes are gone
+    h->sh_head_done = false; h->sh_head_flagged = false;
 }
 
 static int pipe_join(p25fe_t* h, hipStream_t st);
@@ -1068,9 +1098,13 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
 // --------------------------------------------------------------------------------------------
 // time shards
 // --------------------------------------------------------------------------------------------
+// what: bit 0 = the main K1 launch, bit 1 = the head segment(s), bit 2 = sync detection + scan
+enum { SH_MAIN = 1, SH_HEAD = 2, SH_RECV = 4 };
 static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
-                            p25fe_result_t* d_result, hipStream_t st, bool do_main, bool do_finish)
+                            p25fe_result_t* d_result, hipStream_t st, int what)
 {
+    const bool do_main = (what & SH_MAIN) != 0, do_finish = (what & SH_RECV) != 0;
+    bool do_head = (what & SH_HEAD) != 0;
     if (!h || !d_iq || (do_finish && !d_result) || p25fe_n_baseband(abs0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     if (do_main) shard_invalidate(h);
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
@@ -1091,51 +1125,82 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
             hipEvent_t e0, e1;
             prof_k1_events(h, &e0, &e1);
             rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g,
-                                 do_finish ? 0 : 1, e0, e1);
+                                 do_head ? 0 : 1, e0, e1);
             if (rc) return rc;
         }
         h->sh_main_nbb = n_bb; h->sh_main_abs0 = abs0;
+        h->sh_head_done = do_head;
+        do_head = false;                                            // (part 0 = every segment)
+    } else {
+        if (h->sh_main_nbb != n_bb || h->sh_main_abs0 != abs0) return P25FE_ERR_ARG;     // head / finish without its main launch
+    }
+    if ((do_head || do_finish) && !h->sh_head_done) {
+        // the segments whose input reaches into the halo.  They share no byte of the planes with the main launch's
+        // (SEG_HALO in p25fe_kernels.hip), so this launch may run BESIDE it on another stream (p25fe_shard_pass1_head).
+        long head_end = 0;                                          // planar positions [0, head_end) are the head's
+        const bool own_stream = !do_finish;                         // launched on its own (another stream's)
+        h->sh_head_flagged = false;
+        if (n_bb) {
+            if (own_stream) {
+                // the launch's last workgroup publishes "the head is in memory"; the detection's first tiles wait for that
+                // word instead of the whole stream waiting for an event
+                if (!h->sh_flag.p) {
+                    HIPCHK(h, h->sh_flag.ensure(2 * sizeof(unsigned)));
+                    HIPCHK(h, hipMemsetAsync(h->sh_flag.p, 0, 2 * sizeof(unsigned), st));
+                }
+                ++h->sh_seq;
+                if (h->sh_seq == 0u) ++h->sh_seq;
+            }
+            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 2, nullptr, nullptr,
+                                 nullptr, &head_end, own_stream ? h->sh_flag.as<unsigned>() : nullptr, h->sh_seq);
+            if (rc) return rc;
+            if (own_stream && head_end > 0) {                       // (no head workgroup, no flag: nothing to wait for)
+                h->sh_head_flagged = true;
+                h->sh_head_tile_max = (int)(head_end / TS);         // a tile reads planes up to its own end (+ one sign word): tiles past the head's never touch it
+            }
+        }
+        h->sh_head_done = true;
     }
     if (!do_finish) return P25FE_OK;
-    if (!do_main) {
-        if (h->sh_main_nbb != n_bb || h->sh_main_abs0 != abs0) return P25FE_ERR_ARG;     // finish without its main launch
-        if (n_bb) {
-            rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 2);
-            if (rc) return rc;
-        }
-    }
     prof_mark(h, 1, st);
     const RecvCall rcall = recv_call(h);
     h->rs_n = 0;
     if (n_bb) {
-        rc = launch_detect(h, n_bb, abs_bb0, st, rcall);
+        rc = launch_detect(h, n_bb, abs_bb0, st, rcall, h->sh_head_flagged);
         if (rc) return rc;
     }
+    h->sh_head_flagged = false;
     prof_mark(h, 2, st);
     rc = launch_scan_slice(h, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0, d_result, false, st, rcall);
     h->prof_slot = -1;
     if (rc) return rc;
-    h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0; h->sh_gen = rcall.gen;
-    h->sh_main_nbb = (size_t)-1;
+    h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0; h->sh_gen = rcall.gen; h->sh_scan_fresh = true;
+    h->sh_main_nbb = (size_t)-1; h->sh_head_done = false;
     return P25FE_OK;
 }
 
 int p25fe_shard_pass1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
                       p25fe_result_t* d_result, void* stream)
 {
-    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, true, true);
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, SH_MAIN | SH_HEAD | SH_RECV);
 }
 
 int p25fe_shard_pass1_main(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
                            void* stream)
 {
-    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, nullptr, (hipStream_t)stream, true, false);
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, nullptr, (hipStream_t)stream, SH_MAIN);
+}
+
+int p25fe_shard_pass1_head(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                           void* stream)
+{
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, nullptr, (hipStream_t)stream, SH_HEAD);
 }
 
 int p25fe_shard_pass1_finish(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
                              p25fe_result_t* d_result, void* stream)
 {
-    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, false, true);
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, SH_RECV);
 }
 
 int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride,
@@ -1147,8 +1212,54 @@ int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_
     prof_mark(h, 2, (hipStream_t)stream);
     RecvCall rcall = recv_call(h);
     rcall.gen = h->sh_gen;                               // K3 / K4 read what pass 1's K2 left (the lock drops are in its summaries)
+    h->sh_scan_fresh = false;                            // the scan below rewrites the per-tile carry-ins with THIS carry-in
     const int rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr,
                                      0, d_result, true, (hipStream_t)stream, rcall);
+    h->prof_slot = -1;
+    return rc;
+}
+
+int p25fe_shard_pass2_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const uint64_t* d_shard_bb0, const uint64_t* d_shard_bb_n,
+                          size_t n_shards, size_t rank, p25fe_anchor_t* d_anchor_in, uint64_t* d_dibit_offset, uint8_t* d_dibits,
+                          size_t dibit_stride, uint8_t* d_dibits_dup, p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_summaries || !d_shard_bb0 || !d_shard_bb_n || !d_anchor_in || !d_dibit_offset || !d_dibits || !d_result || !h->sh_valid ||
+        n_shards == 0 || n_shards > 0x7fffffffu || rank >= n_shards || h->C != 1)
+        return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    RecvCall rcall = recv_call(h);
+    rcall.gen = h->sh_gen;
+    if (rcall.gen || !h->sh_scan_fresh) {
+        // tracking clock / lock drops inside the shard (or a p25fe_shard_pass2 has already rewritten pass 1's scan): the combine
+        // as its own (one-thread) launch, then scan + slicer with that carry-in
+        h->sh_scan_fresh = false;
+        hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, st, d_summaries, d_shard_bb0, d_shard_bb_n, (int)n_shards, h->track,
+                           d_anchor_in, d_dibit_offset);
+        HIPCHK(h, hipGetLastError());
+        prof_begin(h);
+        prof_mark(h, 2, st);
+        const int rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, d_anchor_in + rank, d_dibits, dibit_stride, nullptr, nullptr, 0,
+                                         d_result, true, st, rcall, nullptr, d_dibits_dup);
+        h->prof_slot = -1;
+        return rc;
+    }
+    ShardFix fx;
+    fx.summ = d_summaries; fx.bb0 = d_shard_bb0; fx.bbn = d_shard_bb_n; fx.n_shards = (int)n_shards; fx.rank = (int)rank;
+    fx.anc_out = d_anchor_in; fx.off_out = d_dibit_offset; fx.result = d_result;
+    prof_begin(h);
+    prof_mark(h, 2, st);
+    int rc;
+    if (h->sh_nbb == 0) {
+        // a shard without a baseband sample has no slicer tile to run the combine in: separate launches (never the hot path)
+        hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, st, d_summaries, d_shard_bb0, d_shard_bb_n, (int)n_shards, h->track,
+                           d_anchor_in, d_dibit_offset);
+        HIPCHK(h, hipGetLastError());
+        rc = launch_scan_slice(h, 0, h->sh_abs_bb0, d_anchor_in + rank, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall);
+    } else {
+        rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall,
+                               nullptr, d_dibits_dup, &fx);
+    }
     h->prof_slot = -1;
     return rc;
 }
@@ -1180,7 +1291,20 @@ int p25fe_shard_compact_dev(p25fe_t* h, const uint8_t* d_gathered, size_t cap, c
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const unsigned bx = (unsigned)((cap + 256 * 16 - 1) / (256 * 16));
     hipLaunchKernelGGL(k_shard_compact, dim3(bx ? bx : 1, (unsigned)n_shards), dim3(256), 0, (hipStream_t)stream, d_gathered,
-                       (unsigned long long)cap, d_dibit_offset, (int)n_shards, d_out, (unsigned long long)out_cap);
+                       (unsigned long long)cap, d_dibit_offset, 0, (int)n_shards, d_out, (unsigned long long)out_cap);
+    HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+int p25fe_shard_compact_from_dev(p25fe_t* h, const uint8_t* d_gathered, size_t cap, const uint64_t* d_dibit_offset, size_t first_shard,
+                                 size_t n_shards, uint8_t* d_out, size_t out_cap, void* stream)
+{
+    if (!h || !d_gathered || !d_dibit_offset || !d_out || n_shards == 0 || n_shards > 65535 || first_shard > n_shards) return P25FE_ERR_ARG;
+    if (first_shard == n_shards) return P25FE_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const unsigned bx = (unsigned)((cap + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(k_shard_compact, dim3(bx ? bx : 1, (unsigned)(n_shards - first_shard)), dim3(256), 0, (hipStream_t)stream, d_gathered,
+                       (unsigned long long)cap, d_dibit_offset, (int)first_shard, (int)n_shards, d_out, (unsigned long long)out_cap);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }

@@ -569,6 +569,15 @@ struct K1Args {
     long bits_ch_stride;    // bytes per channel
     int pl_shift;           // output m sits at planar position m + pl_shift: PLPAD, or PLPAD + 2 when the receiver runs with
                             // the tracking clock's lookahead (p25fe_recv.hip)
+    // OUT_PLANAR, nullable: the launch's LAST workgroup to finish publishes done_flag[0] = done_seq (agent-scope release;
+    // done_flag[1] is the ticket counter, zero between launches).  A time shard's head segment runs on another stream than
+    // the sync detection that reads its planes: the detection's first tile polls this word (p25fe_recv.hip, k_detect).
+    unsigned* done_flag;
+    unsigned done_seq;
+    // The first lead_segs segments of the range are ONE sub-tile long (the rest subs_per_seg): a time shard's head -- the
+    // outputs that depend on the halo, launched on their own after it has arrived -- is then two or three one-sub-tile
+    // workgroups side by side (~6 us) instead of one workgroup walking a whole segment alone (15 - 45 us).
+    int lead_segs;
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
@@ -690,9 +699,13 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     const int ch = grid2d ? (int)blockIdx.y : (int)((unsigned)item / (unsigned)a.seg_count);
     const long seg_rel = grid2d ? (long)blockIdx.x : item - (long)ch * a.seg_count;
     const long seg = seg_rel + a.seg_first;
-    const long m_seg0 = a.m_begin + seg * seg_len;
+    const bool lead = seg < (long)a.lead_segs;                      // uniform
+    constexpr long LEAD_LEN = PRO ? (long)SUB : (long)(SUB - SEG_HALO);
+    const long this_len = lead ? LEAD_LEN : seg_len;
+    const int subs_this = lead ? 1 : a.subs_per_seg;
+    const long m_seg0 = a.m_begin + (lead ? seg * LEAD_LEN : (long)a.lead_segs * LEAD_LEN + (seg - a.lead_segs) * seg_len);
     if (m_seg0 >= a.n_out) continue;
-    const long m_seg1 = (m_seg0 + seg_len < a.n_out) ? m_seg0 + seg_len : a.n_out;
+    const long m_seg1 = (m_seg0 + this_len < a.n_out) ? m_seg0 + this_len : a.n_out;
     const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)ch * a.ch_stride * (FMT == P25FE_FMT_CF32 ? 8 : 2);
     float* bb = a.bb + (size_t)ch * a.bb_stride;
     phase_sync();                                                   // the previous item's LDS reads precede this item's writes
@@ -1073,14 +1086,14 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         return true;
     };
     if constexpr (PF == 1) {
-        for (int it = 0; it < a.subs_per_seg; ++it, dlo += SUB)
+        for (int it = 0; it < subs_this; ++it, dlo += SUB)
             if (!sub_tile(ld0)) break;
     } else {
         // two register sets, two windows in flight per wave: the loop is unrolled by two so that each set keeps its registers
-        for (int it = 0; it < a.subs_per_seg; it += 2) {
+        for (int it = 0; it < subs_this; it += 2) {
             if (!sub_tile(ld0)) break;
             dlo += SUB;
-            if (it + 1 >= a.subs_per_seg || !sub_tile(ld1)) break;
+            if (it + 1 >= subs_this || !sub_tile(ld1)) break;
             dlo += SUB;
         }
     }
@@ -1093,6 +1106,23 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         if (tid == 0) a.power_partial[(size_t)ch * a.seg_count + seg_rel] = pw;     // any order: summed by k_power_finish
     }
     }   // work items
+    if constexpr (OM == OUT_PLANAR) {
+        if (a.done_flag) {                                          // uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the compiler may drop the wait behind the write-back
+            unsigned ticket = 0u;
+            if (tid == 0) ticket = __hip_atomic_fetch_add(a.done_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (ticket == gridDim.x * gridDim.y - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (tid == 0) {
+                    __hip_atomic_store(a.done_flag + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
 #ifdef P25FE_K1_STAMP
     if (tid == 0) {
         unsigned long long st_t1, st_r1;
@@ -1697,61 +1727,15 @@ __global__ __launch_bounds__(WV, 2) void k_chunk(K1Args a, const Taps* __restric
     chunk_body<FMT, CT, TX>(a, gtaps, t);
 }
 
-// Carry resolution across time shards (BASELINE.json config 5): the same "latest anchor wins" rule as K3, one level
-// up.  summaries[r] were produced assuming no carry-in; shard r's carry-in is the anchor_out of the latest earlier
-// shard that has an event of its own, and its dibit offset adds the closed-form count of instants that the carry-in
-// governs before the shard's first own event.  Shared by the host entry point and the one-thread device kernel.
-__host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summaries, const uint64_t* shard_bb0,
-                                                    const uint64_t* shard_bb_n, int n_shards, int symbol_clock,
-                                                    p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
-{
-    // With the tracking clock (SPEC 3.8b) a shard that owns baseband [lo, hi) processes [lo - L, hi - L), and the first
-    // own detection of a shard takes its period from the carry-in, which pass 1 did not know: its share of
-    // n_dibits_after_first (counted at the nominal 10 / 1) is replaced by the count under the real clock.
-    const bool track = symbol_clock != 0;
-    const long L = track ? CLK_L : 0;
-    p25fe_anchor_t cur;
-    cur.s = 0; cur.hi = cur.mid = cur.lo = 0.f; cur.valid = 0; cur.period_d = SPS; cur.period_n = 1;
-    uint64_t off = 0;
-    for (int r = 0; r < n_shards; ++r) {
-        anchor_in[r] = cur;
-        dibit_offset[r] = off;
-        const p25fe_result_t& R = summaries[r];
-        const long lo = (long)shard_bb0[r] - L, hi = (long)(shard_bb0[r] + shard_bb_n[r]) - L;
-        const long pre_hi = R.carry_end >= 0 ? (long)R.carry_end : hi;
-        const uint64_t pre = cur.valid ? (uint64_t)clock_count(cur.s, cur.period_d, cur.period_n, lo, pre_hi) : 0;
-        uint64_t own = R.first_event >= 0 ? R.n_dibits_after_first : 0;
-        const bool tracks = track && (R.flags & P25FE_RES_FIRST_TRACKS_CARRY) && cur.valid;
-        if (R.first_event >= 0 && tracks) {
-            const long s0 = (long)R.first_event - W;
-            int D0, N0;
-            clock_period(true, true, cur.s, frac3((unsigned)cur.valid >> 8), s0, frac3(R.reserved), D0, N0);
-            own = own - (uint64_t)clock_count(s0, SPS, 1, s0 + W + 1, (long)R.first_seg_end) +
-                  (uint64_t)clock_count(s0, D0, N0, s0 + W + 1, (long)R.first_seg_end);
-        }
-        off += pre + own;
-        if (R.carry_end >= 0) {                                   // the shard has an event: the carry changes
-            if (R.anchor_out.valid) {
-                p25fe_anchor_t nxt = R.anchor_out;
-                if (!clock_plausible(nxt.period_d, nxt.period_n)) { nxt.period_d = SPS; nxt.period_n = 1; }
-                if (R.flags & P25FE_RES_OUT_PERIOD_FROM_CARRY)
-                    clock_period(track, tracks, cur.s, frac3((unsigned)cur.valid >> 8), nxt.s, frac3((unsigned)nxt.valid >> 8), nxt.period_d, nxt.period_n);
-                cur = nxt;
-            } else {
-                cur.valid = 0;
-            }
-        }
-    }
-    dibit_offset[n_shards] = off;            // total: shard r holds offset[r + 1] - offset[r] dibits
-}
+// (shard_resolve_impl, the carry resolution across time shards, lives in p25fe_recv.hip: the slicer runs it too)
 
 // Dibit gather, second half: the all-gathered, padded per-shard streams -> one contiguous stream.  Shard r's dibits
 // are gathered[r * cap .. + offset[r + 1] - offset[r]) and belong at out[offset[r] ..).
 #ifndef P25FE_JIT
 __global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, unsigned long long cap, const uint64_t* offset,
-                                                        int n_shards, uint8_t* out, unsigned long long out_cap)
+                                                        int first_shard, int n_shards, uint8_t* out, unsigned long long out_cap)
 {
-    const int r = blockIdx.y;
+    const int r = first_shard + (int)blockIdx.y;                   // (rank 0 slices its own shard straight into the stream: first_shard = 1)
     if (r >= n_shards) return;
     const unsigned long long o0 = offset[r], n = offset[r + 1] - o0;
     const uint8_t* src = gathered + (unsigned long long)r * cap;

@@ -60,18 +60,22 @@ struct p25fe_shard {
     bool staged = false;
     ncclComm_t comm = nullptr;
     Shm shm;
-    hipStream_t cs = nullptr;             // the halo exchange runs beside K1
-    hipEvent_t e_fork = nullptr, e_join = nullptr;
-    hipEvent_t ev[RING][6];               // halo begin / end, all-gather begin / end, gather begin / end
-    uint64_t steps = 0, read_from = 0;
+    hipStream_t cs = nullptr;             // the halo exchange and the shard's head segment run beside K1's main launch
+    hipEvent_t e_fork = nullptr, e_head = nullptr;
+    hipEvent_t ev[RING][6];               // halo begin / end, all-gather begin / end, gather begin / end (timed steps only)
+    int timing_every = 16;                // every k-th step carries those events (0: none): four of them sit between the kernels of
+                                          // the step's critical path and cost ~4 us each there
+    uint64_t steps = 0, timed = 0, read_from = 0;
     std::vector<uint64_t> bb0, bbn;
     p25fe_result_t* d_summ = nullptr;
-    uint64_t *d_bb0 = nullptr, *d_bbn = nullptr, *d_off = nullptr;
-    p25fe_anchor_t* d_anc = nullptr;
+    uint64_t *d_bb0 = nullptr, *d_bbn = nullptr, *d_off = nullptr, *d_off_x = nullptr;
+    p25fe_anchor_t *d_anc = nullptr, *d_anc_x = nullptr;
     uint8_t *d_gathered = nullptr, *d_stream = nullptr;
     char* d_loop = nullptr;               // one-rank RCCL group (tests on a 1-GPU box): where the halo loops back to
     uint64_t* h_off = nullptr;            // pinned: the world + 1 offsets of the current step (P25FE_GATHER_ROOT_EXACT)
     hipEvent_t e_res = nullptr, e_off = nullptr;
+    int gather_ran = P25FE_GATHER_NONE;   // how the last step's dibits actually travelled
+    bool head_event_wait = false;         // measurement knob (P25FE_SHARD_HEAD_WAIT=event)
     bool broken = false;                  // a collective failed half-way: the communicator's state is unknown, every later step fails
 };
 
@@ -103,12 +107,12 @@ void p25fe_shard_destroy(p25fe_shard_t* s)
     if (s->cs) { (void)hipStreamSynchronize(s->cs); (void)hipStreamDestroy(s->cs); }
     if (s->comm) (void)ncclCommDestroy(s->comm);
     if (s->e_fork) (void)hipEventDestroy(s->e_fork);
-    if (s->e_join) (void)hipEventDestroy(s->e_join);
+    if (s->e_head) (void)hipEventDestroy(s->e_head);
     if (s->e_res) (void)hipEventDestroy(s->e_res);
     if (s->e_off) (void)hipEventDestroy(s->e_off);
     if (s->h_off) (void)hipHostFree(s->h_off);
     for (auto& row : s->ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
-    void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_anc, s->d_gathered, s->d_stream, s->d_loop};
+    void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_off_x, s->d_anc, s->d_anc_x, s->d_gathered, s->d_stream, s->d_loop};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->shm.base) munmap(s->shm.base, s->shm.bytes);
     delete s;
@@ -138,9 +142,22 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     // a receiver that re-anchors on every sync word follows the TRANSMITTER's symbol clock: proportional slack (200 ppm)
     s->cap = ((bbmax / 10 + bbmax / 50000 + 64) + 15) / 16 * 16;
     auto fail = [&](int code) { p25fe_shard_destroy(s); return code; };
-    if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess) return fail(P25FE_ERR_HIP);
+    {
+        // measurement knob P25FE_SHARD_CS_PRIO=1: the side stream at the highest priority.  Its halo exchange competes with K1's
+        // 33 000 one-wave workgroups for wave slots and gets in when K1 drains either way (same box, interleaved: 0.3280 /
+        // 0.3281 ms per step with, 0.3240 / 0.3261 without -- profiles/r05_shard_step_ab.txt)
+        const char* pe = getenv("P25FE_SHARD_CS_PRIO");
+        int lo = 0, hi = 0;
+        if (pe && atoi(pe) == 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&s->cs, hipStreamNonBlocking, hi) == hipSuccess) {
+        } else {
+            (void)hipGetLastError();
+            s->cs = nullptr;
+            if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess) return fail(P25FE_ERR_HIP);
+        }
+    }
     if (hipEventCreateWithFlags(&s->e_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->e_join, hipEventDisableTiming) != hipSuccess) return fail(P25FE_ERR_HIP);
+        hipEventCreateWithFlags(&s->e_head, hipEventDisableTiming) != hipSuccess) return fail(P25FE_ERR_HIP);
     for (auto& row : s->ev) for (hipEvent_t& e : row) if (hipEventCreate(&e) != hipSuccess) return fail(P25FE_ERR_HIP);
     if (hipEventCreateWithFlags(&s->e_res, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->e_off, hipEventDisableTiming) != hipSuccess ||
@@ -149,9 +166,16 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     const size_t W = (size_t)world;
     if (hipMalloc(&s->d_summ, W * sizeof(p25fe_result_t)) != hipSuccess || hipMalloc(&s->d_bb0, W * 8) != hipSuccess ||
         hipMalloc(&s->d_bbn, W * 8) != hipSuccess || hipMalloc(&s->d_off, (W + 1) * 8) != hipSuccess ||
+        hipMalloc(&s->d_off_x, (W + 1) * 8) != hipSuccess || hipMalloc(&s->d_anc_x, W * sizeof(p25fe_anchor_t)) != hipSuccess ||
         hipMalloc(&s->d_anc, W * sizeof(p25fe_anchor_t)) != hipSuccess || hipMalloc(&s->d_gathered, W * s->cap) != hipSuccess ||
         hipMalloc(&s->d_stream, W * s->cap) != hipSuccess)
         return fail(P25FE_ERR_NOMEM);
+    {
+        const char* te = getenv("P25FE_SHARD_TIMING");                // (measurement knob; p25fe_shard_comm_timing is the API)
+        if (te && *te) s->timing_every = atoi(te) < 0 ? 0 : atoi(te);
+        const char* hw = getenv("P25FE_SHARD_HEAD_WAIT");
+        s->head_event_wait = hw && !strcmp(hw, "event");
+    }
     if (hipMemcpy(s->d_bb0, s->bb0.data(), W * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(s->d_bbn, s->bbn.data(), W * 8, hipMemcpyHostToDevice) != hipSuccess)
         return fail(P25FE_ERR_HIP);
@@ -181,6 +205,37 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     return P25FE_OK;
 }
 
+int p25fe_shard_comm_timing(p25fe_shard_t* s, int every)
+{
+    if (!s || every < 0) return P25FE_ERR_ARG;
+    s->timing_every = every;
+    return P25FE_OK;
+}
+
+int p25fe_shard_gather_ran(const p25fe_shard_t* s) { return s ? s->gather_ran : P25FE_ERR_ARG; }
+
+// The world + 1 offsets of this step on the HOST (P25FE_GATHER_ROOT_EXACT: the counts are host arguments of the sends and
+// receives): a one-thread resolve beside pass 2, into buffers of its own, then one small copy to pinned memory.
+static int exact_offsets_begin(p25fe_shard_t* s, hipStream_t st)
+{
+    HCHK(hipEventRecord(s->e_res, st));                              // the summaries are in d_summ
+    HCHK(hipStreamWaitEvent(s->cs, s->e_res, 0));
+    const int rc = p25fe_shard_resolve_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, s->d_anc_x, s->d_off_x, s->cs);
+    if (rc) return rc;
+    HCHK(hipMemcpyAsync(s->h_off, s->d_off_x, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost, s->cs));
+    HCHK(hipEventRecord(s->e_off, s->cs));
+    return P25FE_OK;
+}
+static int exact_offsets_wait(p25fe_shard_t* s)
+{
+    HCHK(hipEventSynchronize(s->e_off));                             // the step's ONE host wait
+    const uint64_t* off = s->h_off;
+    const size_t room = (size_t)s->world * s->cap;
+    for (int r = 0; r < s->world; ++r)
+        if (off[r + 1] < off[r] || off[r + 1] - off[r] > s->cap || off[r + 1] > room) return P25FE_ERR_CAPACITY;   // (also reported by p25fe_shard_offsets)
+    return P25FE_OK;
+}
+
 int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
 {
     if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) || gather < P25FE_GATHER_NONE ||
@@ -194,8 +249,13 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
     char* owned = buf + s->halo * eb;
     const size_t n_hist = s->rank > 0 ? s->halo : 0;
     const uint64_t abs0 = (uint64_t)s->rank * s->n;
-    hipEvent_t* ev = s->ev[s->steps % RING];
     const bool multi = s->world > 1 || s->comm != nullptr;
+    const bool rccl = multi && !s->staged;
+    const bool loopback = rccl && s->world == 1;                     // a one-rank communicator (tests on a 1-GPU box): the root plays its own peer
+    // HIP events around the three exchanges: only on every timing_every-th step -- four of them are packets BETWEEN the
+    // kernels of the step's critical path
+    const bool timed = rccl && s->timing_every > 0 && (s->steps % (uint64_t)s->timing_every) == 0;
+    hipEvent_t* ev = s->ev[s->timed % RING];
     int rc;
     if (multi) {
         // ---- 1. halo: my last `halo` samples -> rank + 1, rank - 1's -> the front of my buffer, beside K1's main launch
@@ -210,19 +270,29 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
         } else {
             HCHK(hipEventRecord(s->e_fork, st));                 // the exchange may not overtake earlier users of the buffers
             HCHK(hipStreamWaitEvent(s->cs, s->e_fork, 0));
-            HCHK(hipEventRecord(ev[0], s->cs));
+            if (timed) HCHK(hipEventRecord(ev[0], s->cs));
             NCHK(ncclGroupStart());
             if (s->rank + 1 < s->world) NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, s->comm, s->cs));
             if (s->rank > 0) NCHK_G(s, ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, s->comm, s->cs));
-            if (s->world == 1) {                                 // one-rank group (tests on a 1-GPU box): loop the halo back
+            if (loopback) {                                      // loop the halo back
                 NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
                 NCHK_G(s, ncclRecv(s->d_loop, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
             }
             if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
-            HCHK(hipEventRecord(ev[1], s->cs));
+            if (timed) HCHK(hipEventRecord(ev[1], s->cs));
             rc = p25fe_shard_pass1_main(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);
             if (rc) return rc;
-            HCHK(hipStreamWaitEvent(st, ev[1], 0));
+            // the head segment (the one workgroup whose input reaches into the halo) follows the halo on ITS stream, beside
+            // the main launch; the compute stream only waits for it before the sync detection
+            rc = p25fe_shard_pass1_head(s->h, owned, fmt, s->n, n_hist, s->n, abs0, s->cs);
+            if (rc) return rc;
+            // No event wait between the streams here: the detection's first tile waits for a word a one-thread kernel behind
+            // the head writes (p25fe_shard_pass1_head); P25FE_SHARD_HEAD_WAIT=event restores the stream-level wait (A / B:
+            // it costs ~10 us of idle GPU between K1 and the detection).
+            if (s->head_event_wait) {
+                HCHK(hipEventRecord(s->e_head, s->cs));
+                HCHK(hipStreamWaitEvent(st, s->e_head, 0));
+            }
             rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
             if (rc) return rc;
         }
@@ -234,88 +304,96 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             HCHK(hipMemcpy(s->d_summ, s->shm.summ(0), (size_t)s->world * sizeof(p25fe_result_t), hipMemcpyHostToDevice));
             s->shm.barrier();
         } else {
-            HCHK(hipEventRecord(ev[2], st));
+            if (timed) HCHK(hipEventRecord(ev[2], st));
             NCHK(ncclAllGather(d_result, s->d_summ, sizeof(p25fe_result_t), ncclUint8, s->comm, st));
-            HCHK(hipEventRecord(ev[3], st));
+            if (timed) HCHK(hipEventRecord(ev[3], st));
         }
     } else {
         rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
         if (rc) return rc;
         HCHK(hipMemcpyAsync(s->d_summ, d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToDevice, st));
     }
-    rc = p25fe_shard_resolve_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, s->d_anc, s->d_off, st);
-    if (rc) return rc;
-    const bool exact = gather == P25FE_GATHER_ROOT_EXACT && multi && !s->staged;
+    const bool exact = gather == P25FE_GATHER_ROOT_EXACT && multi;
     if (exact) {
-        // the offsets are final here (before the slicer has even run): they travel to the host beside pass 2
-        HCHK(hipEventRecord(s->e_res, st));
-        HCHK(hipStreamWaitEvent(s->cs, s->e_res, 0));
-        HCHK(hipMemcpyAsync(s->h_off, s->d_off, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost, s->cs));
-        HCHK(hipEventRecord(s->e_off, s->cs));
+        rc = exact_offsets_begin(s, st);
+        if (rc) return rc;
     }
-    rc = p25fe_shard_pass2(s->h, s->d_anc + s->rank, d_dibits, s->cap, d_result, st);
+    // ---- 3. pass 2 with the combine inside it (carry-in anchor, dibit offsets).  Rank 0's shard starts at offset 0 of the
+    // ordered stream: it slices straight into it as well (the loopback test ranks send to themselves instead)
+    const bool to_root = gather == P25FE_GATHER_ROOT || gather == P25FE_GATHER_ROOT_EXACT;
+    uint8_t* dup = (s->rank == 0 && !loopback && (to_root || !multi) && gather != P25FE_GATHER_NONE) ? s->d_stream : nullptr;
+    rc = p25fe_shard_pass2_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, (size_t)s->rank, s->d_anc, s->d_off, d_dibits, s->cap,
+                               dup, d_result, st);
     if (rc) return rc;
-    // ---- 3. the reduced dibit stream
-    if (gather != P25FE_GATHER_NONE) {
-        bool have_all = false;
-        if (!multi) {
-            HCHK(hipMemcpyAsync(s->d_gathered, d_dibits, s->cap, hipMemcpyDeviceToDevice, st));
-            have_all = true;
+    s->gather_ran = multi ? gather : (gather == P25FE_GATHER_NONE ? P25FE_GATHER_NONE : P25FE_GATHER_ROOT);
+    // ---- 4. the reduced dibit stream
+    if (gather != P25FE_GATHER_NONE && multi) {
+        size_t first_row = 1;                                        // rows the compaction pass has to move (ROOT / ALL)
+        bool compact = false;
+        if (exact) {
+            // "the reduced dibit stream": exactly offsets[r + 1] - offsets[r] bytes per shard, received AT offsets[r] of the
+            // ordered stream -- no padded rows on the wire, no compaction pass.  Costs the one host wait of the step (the
+            // send / recv counts are host arguments); pass 2 is already enqueued and runs meanwhile.
+            rc = exact_offsets_wait(s);
+            if (rc) return rc;
+            const uint64_t* off = s->h_off;
+            if (s->staged) {
+                HCHK(hipStreamSynchronize(st));
+                const size_t mine = (size_t)(off[s->rank + 1] - off[s->rank]);
+                if (s->rank > 0 && mine) HCHK(hipMemcpy(s->shm.row(s->rank), d_dibits, mine, hipMemcpyDeviceToHost));
+                s->shm.barrier();
+                if (s->rank == 0)
+                    for (int r = 1; r < s->world; ++r)
+                        if (off[r + 1] > off[r]) HCHK(hipMemcpy(s->d_stream + off[r], s->shm.row(r), (size_t)(off[r + 1] - off[r]), hipMemcpyHostToDevice));
+                s->shm.barrier();
+            } else {
+                if (timed) HCHK(hipEventRecord(ev[4], st));
+                NCHK(ncclGroupStart());
+                if (s->rank == 0) {
+                    for (int r = loopback ? 0 : 1; r < s->world; ++r)
+                        if (off[r + 1] > off[r]) NCHK_G(s, ncclRecv(s->d_stream + off[r], (size_t)(off[r + 1] - off[r]), ncclUint8, r, s->comm, st));
+                }
+                if ((s->rank > 0 || loopback) && off[s->rank + 1] > off[s->rank])
+                    NCHK_G(s, ncclSend(d_dibits, (size_t)(off[s->rank + 1] - off[s->rank]), ncclUint8, 0, s->comm, st));
+                if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
+                if (timed) HCHK(hipEventRecord(ev[5], st));
+            }
         } else if (s->staged) {
             HCHK(hipStreamSynchronize(st));
             HCHK(hipMemcpy(s->shm.row(s->rank), d_dibits, s->cap, hipMemcpyDeviceToHost));
             s->shm.barrier();
             if (s->rank == 0 || gather == P25FE_GATHER_ALL) {
-                HCHK(hipMemcpy(s->d_gathered, s->shm.row(0), (size_t)s->world * s->cap, hipMemcpyHostToDevice));
-                have_all = true;
+                first_row = gather == P25FE_GATHER_ALL ? 0 : 1;
+                if ((size_t)s->world > first_row)
+                    HCHK(hipMemcpy(s->d_gathered + first_row * s->cap, s->shm.row((int)first_row), ((size_t)s->world - first_row) * s->cap, hipMemcpyHostToDevice));
+                compact = true;
             }
             s->shm.barrier();
         } else {
-            HCHK(hipEventRecord(ev[4], st));
-            if (exact) {
-                // "the reduced dibit stream": exactly offsets[r + 1] - offsets[r] bytes per shard, received AT offsets[r] of the
-                // ordered stream -- no padded rows on the wire, no compaction pass.  Costs the one host wait of the step (the
-                // send / recv counts are host arguments); pass 2 is already enqueued and runs meanwhile.
-                HCHK(hipEventSynchronize(s->e_off));
-                const uint64_t* off = s->h_off;
-                const size_t room = (size_t)s->world * s->cap;
-                for (int r = 0; r < s->world; ++r)
-                    if (off[r + 1] < off[r] || off[r + 1] - off[r] > s->cap || off[r + 1] > room) return P25FE_ERR_CAPACITY;   // (also reported by p25fe_shard_offsets)
-                NCHK(ncclGroupStart());
-                if (s->rank == 0) {
-                    for (int r = 1; r < s->world; ++r)
-                        if (off[r + 1] > off[r]) NCHK_G(s, ncclRecv(s->d_stream + off[r], (size_t)(off[r + 1] - off[r]), ncclUint8, r, s->comm, st));
-                } else if (off[s->rank + 1] > off[s->rank]) {
-                    NCHK_G(s, ncclSend(d_dibits, (size_t)(off[s->rank + 1] - off[s->rank]), ncclUint8, 0, s->comm, st));
-                }
-                if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
-                if (s->rank == 0 && off[1] > off[0]) HCHK(hipMemcpyAsync(s->d_stream + off[0], d_dibits, (size_t)(off[1] - off[0]), hipMemcpyDeviceToDevice, st));
-            } else if (gather == P25FE_GATHER_ALL) {
+            if (timed) HCHK(hipEventRecord(ev[4], st));
+            if (gather == P25FE_GATHER_ALL) {
                 NCHK(ncclAllGather(d_dibits, s->d_gathered, s->cap, ncclUint8, s->comm, st));
-                have_all = true;
+                first_row = 0;
+                compact = true;
             } else {
                 // point-to-point to the root: every rank has its own xGMI link to it, the shards arrive in parallel (an
                 // all-gather would move `world` times the bytes the one consumer needs around a per-link-bound ring)
                 NCHK(ncclGroupStart());
-                if (s->rank == 0) {
-                    for (int r = 1; r < s->world; ++r) NCHK_G(s, ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, st));
-                } else {
-                    NCHK_G(s, ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, st));
-                }
+                if (s->rank == 0)
+                    for (int r = loopback ? 0 : 1; r < s->world; ++r) NCHK_G(s, ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, st));
+                if (s->rank > 0 || loopback) NCHK_G(s, ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, st));
                 if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
-                if (s->rank == 0) {
-                    HCHK(hipMemcpyAsync(s->d_gathered, d_dibits, s->cap, hipMemcpyDeviceToDevice, st));
-                    have_all = true;
-                }
+                if (s->rank == 0) { first_row = loopback ? 0 : 1; compact = true; }
             }
-            HCHK(hipEventRecord(ev[5], st));
+            if (timed) HCHK(hipEventRecord(ev[5], st));
         }
-        if (have_all) {
-            rc = p25fe_shard_compact_dev(s->h, s->d_gathered, s->cap, s->d_off, (size_t)s->world, s->d_stream,
-                                         (size_t)s->world * s->cap, st);
+        if (compact) {
+            rc = p25fe_shard_compact_from_dev(s->h, s->d_gathered, s->cap, s->d_off, first_row, (size_t)s->world, s->d_stream,
+                                              (size_t)s->world * s->cap, st);
             if (rc) return rc;
         }
     }
+    if (timed) ++s->timed;
     ++s->steps;
     return P25FE_OK;
 }
@@ -338,9 +416,9 @@ int p25fe_shard_comm_ms(p25fe_shard_t* s, double ms[3], uint64_t* n_steps)
     ms[0] = ms[1] = ms[2] = 0.0;
     HCHK(hipSetDevice(p25fe_device(s->h)));
     uint64_t from = s->read_from, cnt = 0;
-    if (s->steps - from > (uint64_t)RING) from = s->steps - RING;
+    if (s->timed - from > (uint64_t)RING) from = s->timed - RING;
     if (s->comm && !s->staged) {
-        for (uint64_t k = from; k < s->steps; ++k) {
+        for (uint64_t k = from; k < s->timed; ++k) {
             hipEvent_t* ev = s->ev[k % RING];
             for (int q = 0; q < 3; ++q) {
                 float t = 0.f;
@@ -352,7 +430,7 @@ int p25fe_shard_comm_ms(p25fe_shard_t* s, double ms[3], uint64_t* n_steps)
     }
     for (int q = 0; q < 3; ++q) ms[q] = cnt ? ms[q] / (double)cnt : 0.0;
     if (n_steps) *n_steps = cnt;
-    s->read_from = s->steps;
+    s->read_from = s->timed;
     return P25FE_OK;
 }
 

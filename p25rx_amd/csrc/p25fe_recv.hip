@@ -289,6 +289,12 @@ struct DetArgs {
     RecvOpt opt;
     TileSumG* gsum;         // [ch][n_tiles]
     uint32_t* evg;          // [ch][n_tiles][EVCAP] per detection: end offset of its governed interval | (tracks its predecessor) << 15 | fraction of its sync position (3 bits) << 16
+    // time shards whose head segment runs on ANOTHER stream (p25fe_shard_pass1_head): the tiles that read the head's planes
+    // (tile <= head_tile_max) wait for the word the head launch's last workgroup writes (K1Args.done_flag) -- no cross-stream
+    // event wait in front of this launch (that wait costs ~10 - 20 us of an otherwise idle GPU)
+    const unsigned* head_flag;  // nullable
+    unsigned head_seq;
+    int head_tile_max;
 };
 
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
@@ -574,8 +580,15 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
 // (GEN: 21 KB of LDS per one-wave workgroup -- the per-offset fraction table -- bounds it at 7 workgroups per CU)
 template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 2 : 4) void k_detect(DetArgs a)
 {
+    if (a.head_flag && (int)blockIdx.x <= a.head_tile_max) {       // uniform
+        // every head workgroup released its stores (agent scope) before it took its ticket; the acquire after seeing the
+        // flag keeps this wave from reading lines its caches held before that
+        while (__hip_atomic_load(a.head_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.head_seq) __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     detect_tile<GEN>(a, (int)blockIdx.x, (int)blockIdx.y);
 }
+
 
 // ------------------------------------------------------------------------------------------
 // K3: scan of the tile summaries.  One workgroup per channel walks the tiles in chunks of K3_CHUNK; inside a chunk
@@ -822,6 +835,72 @@ __global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
 // carry-in anchor, then one per own detection -- and inside a segment the symbol instants are CONSECUTIVE floats of one
 // plane: lane-consecutive loads, lane-consecutive byte stores.
 // ------------------------------------------------------------------------------------------
+// Carry resolution across time shards (BASELINE.json config 5): the same "latest anchor wins" rule as K3, one level
+// up.  summaries[r] were produced assuming no carry-in; shard r's carry-in is the anchor_out of the latest earlier
+// shard that has an event of its own, and its dibit offset adds the closed-form count of instants that the carry-in
+// governs before the shard's first own event.  Shared by the host entry point and the one-thread device kernel.
+__host__ __device__ inline void shard_resolve_impl(const p25fe_result_t* summaries, const uint64_t* shard_bb0,
+                                                    const uint64_t* shard_bb_n, int n_shards, int symbol_clock,
+                                                    p25fe_anchor_t* anchor_in, uint64_t* dibit_offset)
+{
+    // With the tracking clock (SPEC 3.8b) a shard that owns baseband [lo, hi) processes [lo - L, hi - L), and the first
+    // own detection of a shard takes its period from the carry-in, which pass 1 did not know: its share of
+    // n_dibits_after_first (counted at the nominal 10 / 1) is replaced by the count under the real clock.
+    const bool track = symbol_clock != 0;
+    const long L = track ? CLK_L : 0;
+    p25fe_anchor_t cur;
+    cur.s = 0; cur.hi = cur.mid = cur.lo = 0.f; cur.valid = 0; cur.period_d = SPS; cur.period_n = 1;
+    uint64_t off = 0;
+    for (int r = 0; r < n_shards; ++r) {
+        anchor_in[r] = cur;
+        dibit_offset[r] = off;
+        const p25fe_result_t& R = summaries[r];
+        const long lo = (long)shard_bb0[r] - L, hi = (long)(shard_bb0[r] + shard_bb_n[r]) - L;
+        const long pre_hi = R.carry_end >= 0 ? (long)R.carry_end : hi;
+        const uint64_t pre = cur.valid ? (uint64_t)clock_count(cur.s, cur.period_d, cur.period_n, lo, pre_hi) : 0;
+        uint64_t own = R.first_event >= 0 ? R.n_dibits_after_first : 0;
+        const bool tracks = track && (R.flags & P25FE_RES_FIRST_TRACKS_CARRY) && cur.valid;
+        if (R.first_event >= 0 && tracks) {
+            const long s0 = (long)R.first_event - W;
+            int D0, N0;
+            clock_period(true, true, cur.s, frac3((unsigned)cur.valid >> 8), s0, frac3(R.reserved), D0, N0);
+            own = own - (uint64_t)clock_count(s0, SPS, 1, s0 + W + 1, (long)R.first_seg_end) +
+                  (uint64_t)clock_count(s0, D0, N0, s0 + W + 1, (long)R.first_seg_end);
+        }
+        off += pre + own;
+        if (R.carry_end >= 0) {                                   // the shard has an event: the carry changes
+            if (R.anchor_out.valid) {
+                p25fe_anchor_t nxt = R.anchor_out;
+                if (!clock_plausible(nxt.period_d, nxt.period_n)) { nxt.period_d = SPS; nxt.period_n = 1; }
+                if (R.flags & P25FE_RES_OUT_PERIOD_FROM_CARRY)
+                    clock_period(track, tracks, cur.s, frac3((unsigned)cur.valid >> 8), nxt.s, frac3((unsigned)nxt.valid >> 8), nxt.period_d, nxt.period_n);
+                cur = nxt;
+            } else {
+                cur.valid = 0;
+            }
+        }
+    }
+    dibit_offset[n_shards] = off;            // total: shard r holds offset[r + 1] - offset[r] dibits
+}
+
+// Pass 2 of a time shard WITHOUT a second scan and without a separate resolve launch (fixed-stride receiver, no lock drops
+// inside the shard).  Pass 1's scan ran with no carry-in; the carry-in anchor `cur` (the anchor the nearest earlier shard
+// with an event of its own ended on -- shard_resolve_impl's rule) changes exactly two things, both in closed form:
+//   * tiles in front of the shard's first own detection (ScanOut.src < 0) are governed by `cur`: their dibit offset is
+//     the number of instants of `cur` between the shard's start and the tile's start;
+//   * every later tile's offset grows by the number of instants `cur` governs in the shard, [start, first_event].
+// Every slicer workgroup derives `cur` from the all-gathered summaries itself (one backward step in practice); the
+// workgroup of tile 0 also runs the full combine for the record: anchors, the n_shards + 1 offsets, the final result.
+struct ShardFix {
+    const p25fe_result_t* summ; // nullable: [n_shards] pass-1 summaries of all shards in time order (device memory)
+    const uint64_t* bb0;        // [n_shards] first owned baseband index of each shard
+    const uint64_t* bbn;        // [n_shards] owned baseband samples
+    int n_shards, rank;
+    p25fe_anchor_t* anc_out;    // [n_shards] every shard's carry-in anchor
+    uint64_t* off_out;          // [n_shards + 1] every shard's dibit offset in the capture's stream, last = total
+    p25fe_result_t* result;     // this shard's final record (what a pass-2 scan would have written)
+};
+
 struct SliceArgs {
     Planar pl;
     long n;
@@ -838,6 +917,9 @@ struct SliceArgs {
     int64_t* sync_pos;          // nullable
     uint64_t* sync_dibit;       // nullable
     long sync_stride;
+    uint8_t* dibits2;           // nullable: a second destination of every dibit, same row layout (rank 0 of a time-sharded capture
+                                // slices straight into the ordered stream as well: its shard starts at offset 0)
+    ShardFix fix;               // fix.summ != nullptr: pass 2 of a time shard, the combine done here (p25fe_shard_pass2_dev)
 };
 
 // so: the tile's carry-in record; u: its packed summary; (valid, s_abs, hi, mid, lo): the anchor in force at its first sample
@@ -860,6 +942,7 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
         phase_sync();
     }
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
+    uint8_t* out2 = a.dibits2 ? a.dibits2 + (size_t)ch * a.dibit_stride + so.dibit_off : nullptr;
     // room left in this channel's row from the tile's first dibit on (<= 0: the row is full).  A receiver that re-anchors
     // on every sync word follows the transmitter's symbol clock, so a range can hold more than n / 10 dibits (up to
     // n / (W + 1) under dense detections): the count in p25fe_result_t stays exact, the stores stop at the capacity.
@@ -875,6 +958,7 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
         const float* src = f + (i0 >> 5) * PL_BLK + (int)(p - i0 * SPS) * 32;     // block of symbol i0, row of the plane
         const int o0 = (int)(i0 & 31);
         uint8_t* dst = out + rank;
+        uint8_t* dst2 = out2 ? out2 + rank : nullptr;               // uniform
         for (int j0 = 0; j0 < count; j0 += 4 * WV) {
             float v[4];
 #pragma unroll
@@ -886,7 +970,11 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = j0 + q * WV + lane;
-                if (j < count && rank + j < room) dst[j] = slice_dibit(v[q], h, m, l);
+                if (j < count && rank + j < room) {
+                    const unsigned char db = slice_dibit(v[q], h, m, l);
+                    dst[j] = db;
+                    if (dst2) dst2[j] = db;
+                }
             }
         }
         return count;
@@ -925,7 +1013,34 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
 __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
 {
     const int tile = blockIdx.x, ch = blockIdx.y;
-    const ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
+    const ShardFix& x = a.fix;
+    const bool fixm = x.summ != nullptr;                            // uniform: pass 2 of a time shard (one channel), see ShardFix
+    if (fixm && tile == a.n_tiles) {
+        // the grid's EXTRA workgroup: the full combine for the record (every shard's carry-in anchor, the n_shards + 1 dibit
+        // offsets, this shard's final result) -- beside the slicing workgroups, none of which waits for it
+        if (threadIdx.x == 0) {
+            shard_resolve_impl(x.summ, x.bb0, x.bbn, x.n_shards, 0, x.anc_out, x.off_out);
+            p25fe_result_t r = x.summ[x.rank];
+            const p25fe_anchor_t cur = x.anc_out[x.rank];           // (this thread's own stores)
+            const long r_lo = a.abs0, r_hi = a.abs0 + a.n;
+            const long pre_hi = r.first_event >= 0 ? r.first_event + 1 : r_hi;
+            const unsigned long long pre_total = cur.valid ? (unsigned long long)count_instants(cur.s, r_lo, pre_hi) : 0ull;
+            r.n_dibits = pre_total + (r.first_event >= 0 ? r.n_dibits_after_first : 0ull);
+            if (r.first_event < 0) r.anchor_out = cur;              // no detection of its own: the shard ends on what it started with
+            r.anchor_out.period_d = SPS; r.anchor_out.period_n = 1;
+            *x.result = r;
+        }
+        return;
+    }
+    // the shard's own summary and its predecessor's are requested together with the tile's records: one memory latency
+    long sh_first_event = -1;
+    p25fe_result_t prev;
+    prev.carry_end = -1; prev.anchor_out.valid = 0;
+    if (fixm) {
+        sh_first_event = x.summ[x.rank].first_event;
+        if (x.rank > 0) prev = x.summ[x.rank - 1];
+    }
+    ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
     const unsigned long long u = a.tsum[(size_t)ch * a.n_tiles + tile];
     // carry-in anchor
     int valid = 0;
@@ -937,6 +1052,26 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
     } else if (a.anchor_in) {
         const p25fe_anchor_t A = a.anchor_in[ch];
         valid = A.valid; s_abs = A.s; hi = A.hi; mid = A.mid; lo = A.lo;
+    }
+    if (fixm) {
+        // the anchor the nearest earlier shard with an event of its own ended on (normally the one right before)
+        p25fe_anchor_t cur;
+        cur.s = 0; cur.hi = cur.mid = cur.lo = 0.f; cur.valid = 0; cur.period_d = SPS; cur.period_n = 1;
+        for (int r = x.rank - 1; r >= 0; --r) {
+            const p25fe_result_t R = r == x.rank - 1 ? prev : x.summ[r];
+            if (R.carry_end >= 0) {
+                if (R.anchor_out.valid) cur = R.anchor_out;
+                break;
+            }
+        }
+        const long r_lo = a.abs0, r_hi = a.abs0 + a.n;
+        if (so.src < 0) {
+            valid = cur.valid != 0; s_abs = cur.s; hi = cur.hi; mid = cur.mid; lo = cur.lo;
+            so.dibit_off = valid ? (unsigned long long)count_instants(cur.s, r_lo, r_lo + (long)tile * TS) : 0ull;
+        } else if (cur.valid) {
+            // the instant AT the first decision index is still the carry-in's
+            so.dibit_off += (unsigned long long)count_instants(cur.s, r_lo, sh_first_event >= 0 ? sh_first_event + 1 : r_hi);
+        }
     }
     slice_tile(a, tile, ch, so, u, valid, s_abs, hi, mid, lo);
 }
@@ -1214,6 +1349,7 @@ struct SliceArgsG {
     uint64_t* sync_dibit;
     long sync_stride;
     int track;
+    uint8_t* dibits2;           // nullable: second destination, as in SliceArgs
 };
 
 #ifndef P25FE_JIT
@@ -1251,6 +1387,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
     }
     phase_sync();
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
+    uint8_t* out2 = a.dibits2 ? a.dibits2 + (size_t)ch * a.dibit_stride + so.dibit_off : nullptr;
     const long room = a.dibit_stride - (long)so.dibit_off;
     const long T0 = a.abs0 + t0, TE = T0 + tn;
 
@@ -1289,7 +1426,11 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
                     const long sy = p / SPS;
                     v = f[planar_index(sy, (int)(p - sy * SPS))];
                 }
-                if (rank >= 0 && rank + idx < room) dst[idx] = slice_dibit(v, h, m, l);
+                if (rank >= 0 && rank + idx < room) {
+                    const unsigned char db = slice_dibit(v, h, m, l);
+                    dst[idx] = db;
+                    if (out2) out2[rank + idx] = db;
+                }
             }
         }
         return count;
@@ -1381,6 +1522,7 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     d.pl = c.pl; d.n = c.n; d.abs0 = c.abs0; d.n_tiles = 1;
     d.recs = c.recs; d.tsum = c.tsum; d.evl = c.evl; d.evthr = c.evthr;
     d.opt.track = 0; d.opt.n_resync = 0; d.opt.resync = nullptr; d.opt.resync_stride = 0; d.gsum = nullptr; d.evg = nullptr;
+    d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1;
     detect_tile<false>(d, 0, ch);
     wave_global_sync();
     // the scan of a one-tile range
@@ -1409,6 +1551,7 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     l.outs = nullptr; l.recs = c.recs; l.tsum = c.tsum; l.evl = c.evl; l.evthr = c.evthr; l.anchor_in = c.anchor_in;
     l.dibits = c.dibits; l.dibit_stride = c.dibit_stride;
     l.sync_pos = (c.sync_pos && c.sync_dibit) ? c.sync_pos : nullptr; l.sync_dibit = c.sync_dibit; l.sync_stride = c.sync_stride;
+    l.dibits2 = nullptr; l.fix.summ = nullptr;
     ScanOut so;
     so.src = -1; so.event_off = 0u; so.dibit_off = 0ull;
     slice_tile(l, 0, ch, so, u, A.valid, A.s, A.hi, A.mid, A.lo);

@@ -374,6 +374,39 @@ class FrontEnd:
                                                   C.c_void_p(result.data_ptr()), self._stream()))
         return result
 
+    def shard_pass1_head(self, iq, offset, n_hist, abs0):
+        """The shard's head segment alone (needs the halo); may run on another stream beside shard_pass1_main's launch."""
+        fmt, n_total, stride = self._iq_view(iq)
+        ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
+        self._chk(self.L.p25fe_shard_pass1_head(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0,
+                                                self._stream()))
+
+    def shard_pass2_dev(self, summ_all, d_bb0, d_bbn, rank, n_bb, dibits=None, dup=None, result=None):
+        """Pass 2 with the combine inside it (p25fe_shard_pass2_dev): summ_all uint8 [n_shards, sizeof(result)] on the device.
+        Returns (dibits, result, anchors uint8 [n_shards, sizeof(anchor)], offsets int64 [n_shards + 1])."""
+        import torch
+        n = summ_all.shape[0]
+        dev = summ_all.device
+        cap = (n_bb // 10 + 64 + 15) // 16 * 16
+        dib = dibits if dibits is not None else torch.empty((1, cap), dtype=torch.uint8, device=dev)
+        if result is None:
+            result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        anchors = torch.empty((n, ANCHOR_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        self._chk(self.L.p25fe_shard_pass2_dev(self.h, C.c_void_p(summ_all.data_ptr()), C.c_void_p(d_bb0.data_ptr()),
+                                               C.c_void_p(d_bbn.data_ptr()), n, rank, C.c_void_p(anchors.data_ptr()),
+                                               C.c_void_p(offsets.data_ptr()), C.c_void_p(dib.data_ptr()), dib.stride(0),
+                                               C.c_void_p(dup.data_ptr()) if dup is not None else None,
+                                               C.c_void_p(result.data_ptr()), self._stream()))
+        return dib, result, anchors, offsets
+
+    def shard_compact_from_dev(self, gathered, offsets, first, out):
+        """shard_compact_dev for shards first .. n - 1 only (rank 0 has sliced its own shard into `out` already)."""
+        self._chk(self.L.p25fe_shard_compact_from_dev(self.h, C.c_void_p(gathered.data_ptr()), gathered.shape[1],
+                                                      C.c_void_p(offsets.data_ptr()), first, gathered.shape[0],
+                                                      C.c_void_p(out.data_ptr()), out.numel(), self._stream()))
+        return out
+
     def shard_compact_dev(self, gathered, offsets, out):
         """gathered uint8 [n_shards, cap] (all-gathered shard streams), offsets int64 [n_shards + 1] -> out uint8 [total]."""
         self._chk(self.L.p25fe_shard_compact_dev(self.h, C.c_void_p(gathered.data_ptr()), gathered.shape[1],

@@ -3,10 +3,12 @@
 // drives include/p25fe_rccl.h (halo by ncclSend / ncclRecv behind K1, summaries by ncclAllGather, device resolve, dibit
 // rows to rank 0 + compaction) and rank 0 writes the ORDERED dibit stream -- byte for byte what `p25fe_replay cf32` writes.
 //
-//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [--shm] <in.cf32> <dibits.out>
+//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [-t EVERY] [--shm] <in.cf32> <dibits.out>
 //
-//   -g      how the dibits reach rank 0 (include/p25fe_rccl.h): exact = each shard's valid bytes, received at their offsets
-//           (default; P25FE_GATHER_ROOT_EXACT), rows = whole rows + a compaction pass (P25FE_GATHER_ROOT)
+//   -g      how the dibits reach rank 0 (include/p25fe_rccl.h): rows = whole rows + a compaction pass (default;
+//           P25FE_GATHER_ROOT, no host wait in the step), exact = each shard's valid bytes, received at their offsets
+//           (P25FE_GATHER_ROOT_EXACT: one host wait per step).  The JSON line reports the mode that RAN.
+//   -t      HIP events around the exchanges on every EVERY-th step (p25fe_shard_comm_timing; 0 = never, default: the library's 16)
 //   -c 1    the tracking symbol clock (docs/SPEC.md 3.8b; p25fe_config_t.symbol_clock)
 //   --shm   TEST HOOK: all ranks on GPU 0, exchanges through a shared-memory segment instead of RCCL (a 1-GPU box)
 //   -n 1    runs the same step through a ONE-rank RCCL communicator (self send / recv, all-gather of one)
@@ -33,7 +35,7 @@ static void die(const char* what, int rc)
     std::_Exit(1);
 }
 
-static int child(int rank, int world, int steps, bool shm, int clock, int gather, const char* in_path, const char* out_path, const std::string& key)
+static int child(int rank, int world, int steps, bool shm, int clock, int gather, int timing, const char* in_path, const char* out_path, const std::string& key)
 {
     FILE* f = std::fopen(in_path, "rb");
     if (!f) { std::fprintf(stderr, "unable to open %s\n", in_path); return 1; }
@@ -73,6 +75,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
     p25fe_shard_t* s = nullptr;
     rc = p25fe_shard_create(h, rank, world, shm ? nullptr : id, n, &s);
     if (rc) die("unable to create the shard", rc);
+    if (timing >= 0 && (rc = p25fe_shard_comm_timing(s, timing)) != 0) die("comm timing", rc);
     const size_t halo = p25fe_shard_halo(), cap = p25fe_shard_dibit_cap(s);
     // resident capture of this rank: [halo | owned]
     std::vector<float> host(2 * n);
@@ -108,6 +111,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
     std::vector<uint64_t> off((size_t)world + 1);
     rc = p25fe_shard_offsets(s, off.data());
     if (rc) die("offsets", rc);
+    const int ran = p25fe_shard_gather_ran(s);
     if (rank == 0) {
         std::vector<uint8_t> stream((size_t)off[(size_t)world]);
         (void)hipMemcpy(stream.data(), p25fe_shard_stream_dev(s), stream.size(), hipMemcpyDeviceToHost);
@@ -118,7 +122,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
                     "\"comm_ms_per_step\":{\"halo\":%.4f,\"summaries\":%.4f,\"dibit_gather\":%.4f,\"steps_averaged\":%" PRIu64 "},"
                     "\"exchange\":\"%s\",\"gather\":\"%s\"}\n",
                     world, n, off[(size_t)world], steps, ms, enq_ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL",
-                    gather == P25FE_GATHER_ROOT_EXACT ? "exact" : "rows");
+                    ran == P25FE_GATHER_ROOT_EXACT ? "exact" : (ran == P25FE_GATHER_ROOT ? "rows" : "other"));
         std::remove(idfile.c_str());
         std::fflush(stdout);                                          // the child leaves through _Exit
     }
@@ -129,18 +133,19 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
 
 int main(int argc, char** argv)
 {
-    int ranks = 1, steps = 3, clock = 0, a = 1, gather = P25FE_GATHER_ROOT_EXACT;
+    int ranks = 1, steps = 3, clock = 0, a = 1, gather = P25FE_GATHER_ROOT, timing = -1;
     bool shm = false;
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!std::strcmp(argv[a], "-n") && a + 1 < argc) ranks = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "-k") && a + 1 < argc) steps = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "-c") && a + 1 < argc) clock = std::atoi(argv[++a]);
-        else if (!std::strcmp(argv[a], "-g") && a + 1 < argc) gather = !std::strcmp(argv[++a], "rows") ? P25FE_GATHER_ROOT : P25FE_GATHER_ROOT_EXACT;
+        else if (!std::strcmp(argv[a], "-g") && a + 1 < argc) gather = !std::strcmp(argv[++a], "exact") ? P25FE_GATHER_ROOT_EXACT : P25FE_GATHER_ROOT;
+        else if (!std::strcmp(argv[a], "-t") && a + 1 < argc) timing = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "--shm")) shm = true;
         else break;
     }
     if (argc - a != 2 || ranks < 1 || steps < 1 || (clock != 0 && clock != 1)) {
-        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [-t EVERY] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
         return 2;
     }
     const std::string key = "/p25fe_shards_" + std::to_string((long)getpid());
@@ -149,7 +154,7 @@ int main(int argc, char** argv)
     std::vector<pid_t> kids;
     for (int r = 0; r < ranks; ++r) {
         const pid_t p = fork();
-        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, gather, argv[a], argv[a + 1], key));
+        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, gather, timing, argv[a], argv[a + 1], key));
         kids.push_back(p);
     }
     int bad = 0;

@@ -16,7 +16,7 @@ ID_BYTES = 128
 GATHER = {"none": 0, "root": 1, "all": 2, "root_exact": 3}
 
 SYMBOLS = ["p25fe_rccl_unique_id", "p25fe_shard_create", "p25fe_shard_destroy", "p25fe_shard_dibit_cap", "p25fe_shard_step",
-           "p25fe_shard_offsets", "p25fe_shard_stream_dev", "p25fe_shard_comm_ms"]
+           "p25fe_shard_offsets", "p25fe_shard_stream_dev", "p25fe_shard_comm_ms", "p25fe_shard_comm_timing", "p25fe_shard_gather_ran"]
 
 _LIB = None
 
@@ -41,6 +41,8 @@ def load():
     L.p25fe_shard_stream_dev.argtypes = [vp]
     L.p25fe_shard_stream_dev.restype = vp
     L.p25fe_shard_comm_ms.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_uint64)]
+    L.p25fe_shard_comm_timing.argtypes = [vp, C.c_int]
+    L.p25fe_shard_gather_ran.argtypes = [vp]
     _LIB = L
     return L
 
@@ -77,7 +79,7 @@ class ShardStep:
 
     __del__ = close
 
-    def step(self, buf, dibits, result, gather="root_exact", fmt=_lib.FMT_CF32):
+    def step(self, buf, dibits, result, gather="root", fmt=_lib.FMT_CF32):
         """buf: device tensor [halo + n_per_rank, 2] (the halo part is overwritten); dibits: uint8 device row of dibit_cap bytes;
         result: uint8 device tensor of one p25fe_result_t.  Enqueues on torch's current stream."""
         import torch
@@ -103,6 +105,17 @@ class ShardStep:
         raw.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "version": 2,
                                         "data": (int(self.L.p25fe_shard_stream_dev(self.h)), False)}
         return torch.as_tensor(raw, device=device).clone()
+
+    def comm_timing(self, every):
+        """HIP events around the exchanges on every `every`-th step (0: never; library default 16)"""
+        rc = self.L.p25fe_shard_comm_timing(self.h, int(every))
+        if rc:
+            raise _lib.P25feError(rc, "p25fe_shard_comm_timing")
+
+    def gather_ran(self):
+        """the gather mode the last step executed, as a key of GATHER"""
+        v = int(self.L.p25fe_shard_gather_ran(self.h))
+        return {b: a for a, b in GATHER.items()}.get(v, "?")
 
     def comm_ms(self):
         ms = (C.c_double * 3)()

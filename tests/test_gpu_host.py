@@ -238,7 +238,7 @@ def test_bench_two_ranks_time_shards_host_staged(scaling):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "60"]
-                         + (["--scaling", "strong"] if scaling == "strong" else []),     # weak is the default (the driver's command)
+                         + (["--scaling", "strong", "--gather", "root_exact"] if scaling == "strong" else []),     # weak + rows are the defaults (the driver's command)
                          env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -246,8 +246,25 @@ def test_bench_two_ranks_time_shards_host_staged(scaling):
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 3
     assert d["config"]["parity_gate"].endswith("True") and d["config"]["gather_gate"].endswith("True")
+    # the line names the gather mode the library executed (the shared-memory hook runs the exact-bytes form too)
+    assert ("exactly the valid bytes" if scaling == "strong" else "whole rows") in d["config"]["sharding"]
     # weak: 60 s per rank = one 120 s capture; strong: the 60 s are the whole capture
     assert ("ONE 120 s capture" if scaling == "weak" else "ONE 60 s capture") in d["config"]["workload"] and d["value"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_n2_exits_nonzero_on_a_false_gate():
+    """A wrong multi-GPU result must not land in the driver's SCALE record as rc 0: with a fault injected into the last rank's
+    dibits after the timed steps (TEST HOOK) the gather gate reads False in the JSON line and every rank exits non-zero."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(P25FE_BENCH_HOST_STAGED="1", P25FE_BENCH_INJECT_FAULT="gather")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--seconds", "20"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode != 0
+    line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1 and json.loads(line[0])["config"]["gather_gate"].endswith("False")
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -359,15 +376,22 @@ def _rccl_cabi_world1_worker(q):
     ref, rres = FrontEnd().run_dev(buf[halo:])
     nref = int(parse_results(rres)[0]["n_dibits"])
     oks = []
+    ss.comm_timing(1)                                               # events around the exchanges on every step
     for gather in ("root_exact", "root", "all", "root_exact"):
         for _ in range(3):
             ss.step(buf, dibits, result, gather=gather)
         torch.cuda.synchronize()
         off = ss.offsets()
         st = ss.stream(torch, "cuda", int(off[-1]))
-        oks.append(int(off[-1]) == nref and bool(torch.equal(st, ref[0, :nref])))
+        oks.append(int(off[-1]) == nref and bool(torch.equal(st, ref[0, :nref])) and ss.gather_ran() == gather)
     cm = ss.comm_ms()
-    oks.append(cm["steps"] == 12 and cm["halo_send_recv"] > 0 and cm["summary_all_gather"] > 0)
+    # (the one-rank communicator sends its dibits to itself: the sized send / recv of the exact mode runs here)
+    oks.append(cm["steps"] == 12 and cm["halo_send_recv"] > 0 and cm["summary_all_gather"] > 0 and cm["dibit_gather"] > 0)
+    ss.comm_timing(16)
+    for _ in range(20):
+        ss.step(buf, dibits, result, gather="root")
+    torch.cuda.synchronize()
+    oks.append(ss.comm_ms()["steps"] in (1, 2))                     # steps 12 .. 31: the 16th (and possibly the 32nd) carry events
     ss.close()
     q.put(oks)
 
@@ -384,7 +408,7 @@ def test_c_abi_shard_step_through_ctypes_rccl_world1():
     res = q.get(timeout=240)
     p.join(60)
     assert p.exitcode == 0
-    assert res == [True, True, True, True, True]
+    assert res == [True, True, True, True, True, True]
 
 
 @pytest.mark.timeout(300)
@@ -537,7 +561,9 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
     ref = O.run_cf32(iq)
     src = tmp_path / "cap.cf32"
     iq.tofile(src)
-    for args in (["-n", "1"], ["-n", "1", "-g", "rows"], ["-n", "2", "--shm"], ["-n", "3", "--shm"], ["-n", "8", "--shm"]):
+    for args in (["-n", "1", "-t", "1"], ["-n", "1", "-g", "exact", "-t", "1"], ["-n", "1"], ["-n", "2", "--shm"], ["-n", "3", "--shm"],
+                 ["-n", "8", "--shm"], ["-n", "2", "--shm", "-g", "exact"], ["-n", "3", "--shm", "-g", "exact"],
+                 ["-n", "8", "--shm", "-g", "exact"]):
         out = tmp_path / ("dib_" + "_".join(a.strip("-") for a in args))
         r = subprocess.run([exe] + args + ["-k", "3", str(src), str(out)], capture_output=True, timeout=280)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -545,10 +571,17 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
         got = np.fromfile(out, dtype=np.uint8)
         assert rep["dibits"] == len(got) == len(ref), (args, rep)
         assert np.array_equal(got, ref), args
+        # the mode that RAN (p25fe_shard_gather_ran), also through the shared-memory hook, which now executes the exact-bytes
+        # gather's offset arithmetic with 2, 3 and 8 ranks
+        assert rep["gather"] == ("exact" if "exact" in args else "rows"), (args, rep)
         if "--shm" not in args:
-            assert rep["exchange"] == "RCCL" and rep["comm_ms_per_step"]["steps_averaged"] == 3
-            assert rep["gather"] == ("rows" if "rows" in args else "exact")
-            assert rep["comm_ms_per_step"]["halo"] > 0 and rep["comm_ms_per_step"]["summaries"] > 0
+            assert rep["exchange"] == "RCCL"
+            if "-t" in args:                                        # events on every step: three timed steps
+                assert rep["comm_ms_per_step"]["steps_averaged"] == 3
+                assert rep["comm_ms_per_step"]["halo"] > 0 and rep["comm_ms_per_step"]["summaries"] > 0
+                assert rep["comm_ms_per_step"]["dibit_gather"] > 0   # the one-rank communicator sends to itself
+            else:                                                   # library default: every 16th step (step 0 of the warm-up)
+                assert rep["comm_ms_per_step"]["steps_averaged"] <= 1
     # the same with the tracking symbol clock on a capture whose sample clock is 150 ppm off: every shard's first detection
     # takes its period from the previous shard's anchor (the carry resolution with clocks, p25fe_shard_resolve_dev)
     iq2, _, _ = c4fm.synth(2.0, seed=92, snr_db=24.0, frame_dibits=700, clock_ppm=150.0)

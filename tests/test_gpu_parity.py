@@ -252,6 +252,8 @@ def test_time_shards_equal_single_pass(O, FE):
         h = min(a, halo)
         if r % 2:                                               # the two-launch form (halo exchange hidden behind K1)
             fes[r].shard_pass1_main(t[a - h:b], offset=h, n_hist=h, abs0=a)
+            if r == 3:                                          # ... and the three-launch form: the head on its own (another stream's)
+                fes[r].shard_pass1_head(t[a - h:b], offset=h, n_hist=h, abs0=a)
             res = fes[r].shard_pass1_finish(t[a - h:b], offset=h, n_hist=h, abs0=a)
         else:
             res = fes[r].shard_pass1(t[a - h:b], offset=h, n_hist=h, abs0=a)
@@ -259,18 +261,33 @@ def test_time_shards_equal_single_pass(O, FE):
         bb0.append(n_baseband(0, a))
         bbn.append(n_baseband(a, b - a))
     anc, off = fe.shard_resolve(np.array(summ), bb0, bbn)
+    # pass 2 with the combine INSIDE the slicer (p25fe_shard_pass2_dev: no second scan, no resolve launch), straight after
+    # pass 1 as the product runs it: rank 0 also slices into the ordered stream, the rest is compacted behind it
+    summ_t = torch.from_numpy(np.frombuffer(np.array(summ).tobytes(), dtype=np.uint8).copy()).view(len(summ), -1).cuda()
+    d_bb0 = torch.tensor(bb0, dtype=torch.int64, device="cuda")
+    d_bbn = torch.tensor(bbn, dtype=torch.int64, device="cuda")
+    cap = max((b // 10 + 64 + 15) // 16 * 16 for b in bbn)
+    gathered = torch.zeros((len(cuts) - 1, cap), dtype=torch.uint8, device="cuda")
+    stream = torch.full((len(ref) + 64,), 255, dtype=torch.uint8, device="cuda")
+    fused = []
+    for r in range(len(cuts) - 1):
+        dib, res, anc3, off3 = fes[r].shard_pass2_dev(summ_t, d_bb0, d_bbn, r, bbn[r], dibits=gathered[r:r + 1],
+                                                      dup=(stream[None, :] if r == 0 else None))
+        assert np.array_equal(off3.cpu().numpy().astype(np.uint64), off) and anc3.cpu().numpy().tobytes() == anc.tobytes()
+        fused.append((parse_results(res)[0], gathered[r, :int(parse_results(res)[0]["n_dibits"])].cpu().numpy()))
+    assert np.array_equal(np.concatenate([f[1] for f in fused]), ref)
+    fe.shard_compact_from_dev(gathered, torch.from_numpy(off.astype(np.int64)).cuda(), 1, stream)
+    assert np.array_equal(stream[:len(ref)].cpu().numpy(), ref) and bool((stream[len(ref):] == 255).all())
     out = []
     for r in range(len(cuts) - 1):
         dib, res = fes[r].shard_pass2(anc[r:r + 1], bbn[r], t.device)
+        assert parse_results(res)[0].tobytes() == fused[r][0].tobytes(), (r, parse_results(res)[0], fused[r][0])   # the same final record
         k = int(parse_results(res)[0]["n_dibits"])
         assert off[r] == sum(len(x) for x in out)
         out.append(dib[0, :k].cpu().numpy())
     assert np.array_equal(np.concatenate(out), ref)
     # the same combine on the device (no host sync), and pass 2 fed with the device anchors
-    summ_t = torch.from_numpy(np.frombuffer(np.array(summ).tobytes(), dtype=np.uint8).copy()).view(len(summ), -1).cuda()
     # (pass 2 above overwrote nothing the summaries depend on: they were parsed before)
-    d_bb0 = torch.tensor(bb0, dtype=torch.int64, device="cuda")
-    d_bbn = torch.tensor(bbn, dtype=torch.int64, device="cuda")
     d_anc, d_off = fe.shard_resolve_dev(summ_t, d_bb0, d_bbn)
     assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), off)
     assert d_anc.cpu().numpy().tobytes() == anc.tobytes()
@@ -279,6 +296,11 @@ def test_time_shards_equal_single_pass(O, FE):
         dib, res = fes[r].shard_pass2(d_anc[r:r + 1], bbn[r], t.device)
         out2.append(dib[0, :int(parse_results(res)[0]["n_dibits"])].cpu().numpy())
     assert np.array_equal(np.concatenate(out2), ref)
+    # ... and p25fe_shard_pass2_dev AFTER a p25fe_shard_pass2 (which rewrote pass 1's scan): falls back to resolve + scan + slicer
+    for r in range(len(cuts) - 1):
+        dib, res, _, _ = fes[r].shard_pass2_dev(summ_t, d_bb0, d_bbn, r, bbn[r])
+        assert parse_results(res)[0].tobytes() == fused[r][0].tobytes()
+        assert np.array_equal(dib[0, :len(out2[r])].cpu().numpy(), out2[r])
 
 
 def test_custom_taps_zero_padded(O, FE, c4fm_1s):

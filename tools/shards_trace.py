@@ -37,6 +37,7 @@ buf = torch.zeros((halo + n, 2), dtype=torch.float32, device="cuda")
 c4fm.synth_torch(n, seed=3, device=torch.device("cuda", 0), out=buf[halo:])
 result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
 dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device="cuda")
+ss.comm_timing(int(os.environ.get("SHARDS_TRACE_TIMING", "0")))   # no event packets between the kernels of the traced steps
 for _ in range(300):
     ss.step(buf, dibits, result, gather=gather)
 torch.cuda.synchronize()
