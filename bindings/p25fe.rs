@@ -142,6 +142,7 @@ extern "C" {
     pub fn p25fe_device(h: *const Handle) -> c_int;
     pub fn p25fe_kernel_variant(h: *const Handle) -> c_int;
     pub fn p25fe_specialize(cfg: *const Config, dir: *const c_char, path_out: *mut c_char, path_cap: usize) -> c_int;
+    pub fn p25fe_probe_variant(cfg: *const Config) -> c_int;
     pub fn p25fe_specialize_log(buf: *mut c_char, cap: usize) -> usize;
     // streaming, host buffers: the bodies of DemodTask::run (src/demod.rs:70-117) and RecvTask::run (src/recv.rs:148-150)
     pub fn p25fe_demod_u8(h: *mut Handle, iq: *const u8, n_bytes: usize, bb: *mut f32, bb_cap: usize, n_out: *mut usize,

@@ -171,9 +171,18 @@ int p25fe_kernel_variant(const p25fe_t *h);      /* < 0: null handle */
 /* Ahead-of-time form of what p25fe_create does for non-default numbers (the `make SPEC=` step; needs no GPU): compile the
  * front-end kernels for cfg's tables and constants and store the code object as <dir>/p25fe-<hash>.hsaco (dir NULL: the
  * cache directory -- $P25FE_CACHE_DIR, else $XDG_CACHE_HOME/p25fe, else $HOME/.cache/p25fe, else /tmp/p25fe-cache-<uid>;
- * p25fe_create looks in $P25FE_SPEC_DIR first, then there).  path_out (nullable) receives the file name.  Returns P25FE_OK
+ * p25fe_create looks in $P25FE_SPEC_DIR first, then there; what IT compiles is stored as p25fe-<hash>-rtc<version>.hsaco and
+ * looked for before the plain name, so another toolchain's object is never preferred over this one's).  path_out (nullable) receives the file name.  Returns P25FE_OK
  * (also when cfg holds the build's own numbers: nothing to do, path_out = ""), P25FE_ERR_JIT or P25FE_ERR_ARG. */
 int p25fe_specialize(const p25fe_config_t *cfg, const char *dir, char *path_out, size_t path_cap);
+/* Which kernels a handle made from cfg would run ON THIS HOST (P25FE_VARIANT_*), by the same steps p25fe_create takes --
+ * $P25FE_SPEC_DIR, the cache, hipRTC (the object is stored in the cache), else the fallback -- but without a device: a
+ * deployment check.  When P25FE_SPECIALIZE_AUTO ends on the generic kernels, p25fe_create and this call say so ONCE per
+ * process on stderr (P25FE_QUIET=1 silences it).  P25FE_ERR_JIT if cfg->specialize demands what cannot be had.
+ * Code objects are read from / written to directories that are real directories owned by the caller (or root) and
+ * writable by their owner only; every file carries a trailer that ties its content to cfg's numbers and is verified
+ * before it reaches the loader; files under $P25FE_SPEC_DIR are never deleted. */
+int p25fe_probe_variant(const p25fe_config_t *cfg);
 /* compiler log of the calling thread's last p25fe_specialize / p25fe_create; returns the length copied (NUL-terminated) */
 size_t p25fe_specialize_log(char *buf, size_t cap);
 

@@ -69,7 +69,7 @@ SYMBOLS = [
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
     "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
     "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log", "p25fe_run_host_windows",
-    "p25fe_shard_pass1_head", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev",
+    "p25fe_shard_pass1_head", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant",
 ]
 
 
@@ -112,6 +112,7 @@ def load():
     L.p25fe_device.argtypes = [vp]
     L.p25fe_kernel_variant.argtypes = [vp]
     L.p25fe_specialize.argtypes = [C.POINTER(Config), C.c_char_p, C.c_char_p, sz]
+    L.p25fe_probe_variant.argtypes = [C.POINTER(Config)]
     L.p25fe_specialize_log.argtypes = [C.c_char_p, sz]
     L.p25fe_specialize_log.restype = sz
     L.p25fe_demod_u8.argtypes = [vp, vp, sz, vp, sz, psz, vp]
@@ -212,6 +213,15 @@ def specialize(cfg, directory=None):
     if rc != OK:
         raise P25feError(rc, L.p25fe_strerror(rc).decode() + ": " + specialize_log()[-2000:])
     return out.value.decode()
+
+
+def probe_variant(cfg):
+    """p25fe_probe_variant: the kernels a handle made from cfg would run on this host (VARIANT_*); no GPU needed"""
+    L = load()
+    rc = L.p25fe_probe_variant(C.byref(cfg))
+    if rc < 0:
+        raise P25feError(rc, L.p25fe_strerror(rc).decode() + ": " + specialize_log()[-2000:])
+    return rc
 
 
 def check(L, h, rc):

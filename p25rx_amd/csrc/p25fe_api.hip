@@ -292,6 +292,44 @@ static std::vector<std::string> jit_dirs()
     return d;
 }
 
+// P25FE_SPECIALIZE_AUTO fell back to the generic kernels (1.2 - 2.3 x slower): say so once per process, on stderr -- a caller
+// that never polls p25fe_kernel_variant would otherwise not know.  P25FE_QUIET=1 silences it.
+static void fallback_notice()
+{
+    static bool said = false;
+    if (said) return;
+    said = true;
+    const char* q = getenv("P25FE_QUIET");
+    if (q && atoi(q) != 0) return;
+    fprintf(stderr, "p25fe: no specialised kernels for this configuration's numbers (no usable cached code object and hipRTC did not "
+                    "deliver one): running the GENERIC kernels, 1.2 - 2.3 x slower.  p25fe_specialize_log() has the details; "
+                    "p25fe_specialize() / $P25FE_SPEC_DIR is the ahead-of-time form.\n");
+}
+
+// Which front-end kernels a handle made from cfg gets on this host, and -- for P25FE_VARIANT_SPECIALIZED -- the code object
+// (looked up in $P25FE_SPEC_DIR and the cache, else compiled and stored).  Needs no device.  Returns the variant or P25FE_ERR_JIT.
+static int choose_variant(const p25fe_config_t* cfg, const Resolved& rs, std::vector<char>* code, std::string* path, bool* from_cache)
+{
+    // P25FE_JIT=0 in the environment switches the AUTO mode off for a whole process.
+    static const bool jit_env_off = [] { const char* v = getenv("P25FE_JIT"); return v && atoi(v) == 0; }();
+    const bool must = cfg->specialize >= P25FE_SPECIALIZE_REQUIRE;
+    const bool want_jit = (!rs.dflt || cfg->specialize == P25FE_SPECIALIZE_FORCE) && cfg->specialize != P25FE_SPECIALIZE_OFF && !(jit_env_off && !must);
+    const int plain = rs.dflt ? P25FE_VARIANT_BUILTIN : P25FE_VARIANT_GENERIC;
+    if (!want_jit) return plain;
+    bool ok = false;
+    try {
+        t_jit_log.clear();
+        ok = p25jit::get_code(jit_spec(rs), jit_dirs(), true, p25jit::default_cache_dir(), false, *code, *path, t_jit_log, from_cache);
+    } catch (...) {
+        ok = false;
+        try { t_jit_log += "exception while specialising\n"; } catch (...) { }
+    }
+    if (ok) return P25FE_VARIANT_SPECIALIZED;
+    if (must) return P25FE_ERR_JIT;
+    if (plain == P25FE_VARIANT_GENERIC) fallback_notice();
+    return plain;
+}
+
 #define HIPCHK(h, expr)                                                        \
     do {                                                                       \
         hipError_t e__ = (expr);                                               \
@@ -361,12 +399,27 @@ int p25fe_specialize(const p25fe_config_t* cfg, const char* dir, char* path_out,
         const std::string d = (dir && *dir) ? std::string(dir) : p25jit::default_cache_dir();
         std::vector<char> code;
         std::string path;
-        if (!p25jit::get_code(jit_spec(r), {d}, true, d, code, path, t_jit_log) || path.empty()) return P25FE_ERR_JIT;
+        if (!p25jit::get_code(jit_spec(r), {d}, true, d, /*aot=*/true, code, path, t_jit_log) || path.empty()) return P25FE_ERR_JIT;
         if (path_out && path_cap) snprintf(path_out, path_cap, "%s", path.c_str());
     } catch (...) {
         return P25FE_ERR_NOMEM;
     }
     return P25FE_OK;
+}
+
+int p25fe_probe_variant(const p25fe_config_t* cfg)
+{
+    if (!cfg) return P25FE_ERR_ARG;
+    Resolved r;
+    const int rc = resolve_config(cfg, &r);
+    if (rc) return rc;
+    std::vector<char> code;
+    std::string path;
+    try {
+        return choose_variant(cfg, r, &code, &path, nullptr);
+    } catch (...) {
+        return P25FE_ERR_NOMEM;
+    }
 }
 
 size_t p25fe_n_baseband(uint64_t abs0, size_t n)
@@ -438,44 +491,42 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     if (e != hipSuccess) { (void)hipStreamDestroy(h->stream); h->d_taps.release(); delete h; return P25FE_ERR_HIP; }
     // Numbers other than the build's own: the same kernels with THOSE numbers as immediates (cached code object, else
     // hipRTC -- seconds, once per set of numbers and library build); the generic LDS-tap kernels if that is off or fails.
-    // P25FE_JIT=0 in the environment switches the AUTO mode off for a whole process.
-    static const bool jit_env_off = [] { const char* v = getenv("P25FE_JIT"); return v && atoi(v) == 0; }();
-    const bool must = cfg->specialize >= P25FE_SPECIALIZE_REQUIRE;
-    const bool want_jit = (!rs.dflt || cfg->specialize == P25FE_SPECIALIZE_FORCE) && cfg->specialize != P25FE_SPECIALIZE_OFF && !(jit_env_off && !must);
-    if (want_jit) {
-        bool ok = false;
-        try {
-            t_jit_log.clear();
-            std::vector<char> code;
-            std::string path;
-            const std::string store = p25jit::default_cache_dir();
-            if (p25jit::get_code(jit_spec(rs), jit_dirs(), true, store, code, path, t_jit_log)) {
+    {
+        std::vector<char> code;
+        std::string path;
+        bool from_cache = false;
+        int var = choose_variant(cfg, rs, &code, &path, &from_cache);
+        if (var < 0) { p25fe_destroy(h); return var; }
+        if (var == P25FE_VARIANT_SPECIALIZED) {
+            bool ok = false;
+            try {
                 hipError_t me = hipModuleLoadData(&h->jit_mod, code.data());
-                if (me != hipSuccess && !path.empty()) {
-                    // a stale or damaged cache entry: compile afresh, replace it
+                if (me != hipSuccess && from_cache) {
+                    // a verified file the loader still refuses (another architecture's object under this name): compile afresh;
+                    // the stale entry is removed only from the cache -- never from a deployment's $P25FE_SPEC_DIR
                     (void)hipGetLastError();
                     t_jit_log += "cached code object " + path + " did not load: recompiling\n";
-                    (void)remove(path.c_str());
+                    const std::string store = p25jit::default_cache_dir();
+                    if (path.compare(0, store.size() + 1, store + "/") == 0) (void)remove(path.c_str());
                     h->jit_mod = nullptr;
-                    if (p25jit::get_code(jit_spec(rs), {}, true, store, code, path, t_jit_log)) me = hipModuleLoadData(&h->jit_mod, code.data());
+                    if (p25jit::get_code(jit_spec(rs), {}, true, store, false, code, path, t_jit_log)) me = hipModuleLoadData(&h->jit_mod, code.data());
                 }
                 ok = me == hipSuccess;
                 for (int f = 0; f < 2 && ok; ++f)
                     for (int k = 0; k < 3 && ok; ++k)
                         ok = hipModuleGetFunction(&h->jit_fn[f][k], h->jit_mod, p25jit::KERNEL_NAMES[f][k]) == hipSuccess;
                 if (!ok) { (void)hipGetLastError(); t_jit_log += "loading the specialised code object failed\n"; }
+            } catch (...) {
+                ok = false;
             }
-        } catch (...) {
-            ok = false;
-            try { t_jit_log += "exception while specialising\n"; } catch (...) { }
+            if (!ok) {
+                if (h->jit_mod) { (void)hipModuleUnload(h->jit_mod); h->jit_mod = nullptr; }
+                if (cfg->specialize >= P25FE_SPECIALIZE_REQUIRE) { p25fe_destroy(h); return P25FE_ERR_JIT; }
+                var = rs.dflt ? P25FE_VARIANT_BUILTIN : P25FE_VARIANT_GENERIC;
+                if (var == P25FE_VARIANT_GENERIC) fallback_notice();
+            }
         }
-        if (ok) {
-            h->variant = P25FE_VARIANT_SPECIALIZED;
-        } else {
-            if (h->jit_mod) { (void)hipModuleUnload(h->jit_mod); h->jit_mod = nullptr; }
-            if (must) { p25fe_destroy(h); return P25FE_ERR_JIT; }
-            h->variant = rs.dflt ? P25FE_VARIANT_BUILTIN : P25FE_VARIANT_GENERIC;
-        }
+        h->variant = var;
     }
     int rc = p25fe_reset(h);
     if (rc != P25FE_OK) { p25fe_destroy(h); return rc; }

@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <hip/hiprtc.h>
 #include <math.h>
 #include <stdio.h>
@@ -62,6 +63,7 @@ struct Api {
     decltype(&hiprtcGetCode) code = nullptr;
     decltype(&hiprtcDestroyProgram) destroy = nullptr;
     decltype(&hiprtcGetErrorString) error_string = nullptr;
+    decltype(&hiprtcVersion) version = nullptr;                    // (optional)
     bool ok = false;
 };
 static const Api& api()
@@ -81,6 +83,7 @@ static const Api& api()
         P25_SYM(create, "hiprtcCreateProgram"); P25_SYM(compile, "hiprtcCompileProgram");
         P25_SYM(log_size, "hiprtcGetProgramLogSize"); P25_SYM(log, "hiprtcGetProgramLog"); P25_SYM(code_size, "hiprtcGetCodeSize");
         P25_SYM(code, "hiprtcGetCode"); P25_SYM(destroy, "hiprtcDestroyProgram"); P25_SYM(error_string, "hiprtcGetErrorString");
+        P25_SYM(version, "hiprtcVersion");
 #undef P25_SYM
         x.ok = x.create && x.compile && x.log_size && x.log && x.code_size && x.code && x.destroy && x.error_string;
         return x;
@@ -107,8 +110,8 @@ uint64_t spec_hash(const Spec& s)
     h = fnv(h, P25FE_SRC_SPEC_H, sizeof P25FE_SRC_SPEC_H);
     h = fnv(h, WRAPPER, sizeof WRAPPER);
     for (int i = 0; i < N_OPTIONS; ++i) h = fnv(h, OPTIONS[i], strlen(OPTIONS[i]) + 1);
-    // (NOT the compiler's version: a process without hipRTC must find the objects an ahead-of-time run left, and any compiler
-    // that honours the options above produces the same bits from the same source -- fp32, explicit fma only)
+    // (NOT the compiler's version: a process without hipRTC must find the objects an ahead-of-time run left.  The version is
+    // the SECOND key, versioned_file_name(): what p25fe_create stores and looks for first)
     h = fnv(h, &s.tx, sizeof s.tx);
     h = fnv(h, &s.t1, sizeof s.t1);
     h = fnv(h, &s.t2, sizeof s.t2);
@@ -132,6 +135,20 @@ std::string file_name(uint64_t hash)
     return b;
 }
 
+// The second key: the same hash + the version of the hipRTC that compiled the object.  p25fe_create stores what it compiles
+// under THIS name and looks for it first, so a code object another toolchain left in the cache is never picked up by a
+// process that can compile its own; the plain name stays the key of ahead-of-time objects (p25fe_specialize), which a
+// process WITHOUT hipRTC must be able to find.  Empty when hipRTC is not available.
+std::string versioned_file_name(uint64_t hash)
+{
+    const rtc::Api& R = rtc::api();
+    int major = 0, minor = 0;
+    if (!R.ok || !R.version || R.version(&major, &minor) != HIPRTC_SUCCESS) return std::string();
+    char b[96];
+    snprintf(b, sizeof b, "p25fe-%016llx-rtc%d_%d.hsaco", (unsigned long long)hash, major, minor);
+    return b;
+}
+
 std::string default_cache_dir()
 {
     const char* e = getenv("P25FE_CACHE_DIR");
@@ -141,8 +158,22 @@ std::string default_cache_dir()
     e = getenv("HOME");
     if (e && *e && access(e, W_OK) == 0) return std::string(e) + "/.cache/p25fe";
     char b[64];
-    snprintf(b, sizeof b, "/tmp/p25fe-cache-%u", (unsigned)getuid());
+    snprintf(b, sizeof b, "/tmp/p25fe-cache-%u", (unsigned)geteuid());      // (used only if it passes dir_trusted: ours, private)
     return b;
+}
+
+// Code objects are LOADED INTO THE GPU PROCESS from these directories: a directory (or a file in it) that somebody else
+// can write is not a cache, it is an attack surface -- the file name is a public hash, anybody can compute it.  Trusted =
+// a real directory (no symlink) owned by the caller or by root, writable by its owner only.  /tmp/p25fe-cache-<uid>
+// pre-created by another user fails this; so does any world- or group-writable deployment directory.
+static bool owner_ok(const struct stat& st) { return (st.st_uid == geteuid() || st.st_uid == 0) && (st.st_mode & 022) == 0; }
+bool dir_trusted(const std::string& dir, std::string* why)
+{
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) { if (why) *why = dir + ": does not exist"; return false; }
+    if (!S_ISDIR(st.st_mode)) { if (why) *why = dir + ": not a directory (symbolic links are not followed)"; return false; }
+    if (!owner_ok(st)) { if (why) *why = dir + ": owned by another user or writable by group / others -- not used for code objects"; return false; }
+    return true;
 }
 
 static bool mkdir_p(const std::string& dir)
@@ -154,51 +185,72 @@ static bool mkdir_p(const std::string& dir)
         }
         if (i < dir.size()) cur.push_back(dir[i]);
     }
-    struct stat st;
-    return stat(dir.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+    return dir_trusted(dir, nullptr);                              // (EEXIST is not enough: it must be OURS and private)
 }
 
 // A cached file is data from outside: before it is handed to the loader it must at least be a complete ELF64 image (the
 // section header table, which sits at the end of a code object, lies inside the file) -- a truncated copy is "not cached".
-static bool elf_complete(const std::vector<char>& d)
+static bool elf_complete(const char* d, size_t n)
 {
-    if (d.size() < 64 || memcmp(d.data(), "\x7f" "ELF", 4) != 0 || d[4] != 2 /* ELFCLASS64 */) return false;
+    if (n < 64 || memcmp(d, "\x7f" "ELF", 4) != 0 || d[4] != 2 /* ELFCLASS64 */) return false;
     uint64_t shoff = 0;
     uint16_t shentsize = 0, shnum = 0;
-    memcpy(&shoff, d.data() + 0x28, 8);
-    memcpy(&shentsize, d.data() + 0x3a, 2);
-    memcpy(&shnum, d.data() + 0x3c, 2);
-    return shoff >= 64 && shnum > 0 && shoff <= d.size() && (uint64_t)shentsize * shnum <= d.size() - shoff;
+    memcpy(&shoff, d + 0x28, 8);
+    memcpy(&shentsize, d + 0x3a, 2);
+    memcpy(&shnum, d + 0x3c, 2);
+    return shoff >= 64 && shnum > 0 && shoff <= n && (uint64_t)shentsize * shnum <= n - shoff;
 }
 
-static bool read_file(const std::string& path, std::vector<char>& out)
+// File = the code object + a 32-byte trailer that ties the content to its name: the spec hash the object was built for and
+// a hash of the image.  A well-formed code object for OTHER numbers under this name (a copy, a rename), a flipped bit, or
+// a file some other writer produced fails here and is "not cached"; nothing unverified reaches hipModuleLoadData.
+struct Trailer { char magic[8]; uint64_t spec, content, length; };
+static const char TRAILER_MAGIC[8] = {'P', '2', '5', 'F', 'E', 'H', 'S', '1'};
+static uint64_t content_hash(const char* d, size_t n) { return fnv(fnv(0xcbf29ce484222325ull, "p25fe-obj", 9), d, n); }
+
+static bool read_file(const std::string& path, uint64_t spec, std::vector<char>& out, std::string* why)
 {
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) return false;                // (absent: the normal miss, no words)
+    if (!S_ISREG(st.st_mode) || !owner_ok(st)) { if (why) *why += path + ": not a private regular file -- ignored\n"; return false; }
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     bool ok = false;
     if (fseek(f, 0, SEEK_END) == 0) {
         const long n = ftell(f);
-        if (n > 64 && n < (64L << 20) && fseek(f, 0, SEEK_SET) == 0) {
+        if (n > 64 + (long)sizeof(Trailer) && n < (64L << 20) && fseek(f, 0, SEEK_SET) == 0) {
             out.resize((size_t)n);
-            ok = fread(out.data(), 1, (size_t)n, f) == (size_t)n && elf_complete(out);
+            if (fread(out.data(), 1, (size_t)n, f) == (size_t)n) {
+                Trailer t;
+                const size_t len = (size_t)n - sizeof t;
+                memcpy(&t, out.data() + len, sizeof t);
+                ok = memcmp(t.magic, TRAILER_MAGIC, 8) == 0 && t.length == len && t.spec == spec && elf_complete(out.data(), len) &&
+                     t.content == content_hash(out.data(), len);
+                if (ok) out.resize(len);
+            }
         }
     }
     fclose(f);
-    if (!ok) out.clear();
+    if (!ok) { out.clear(); if (why) *why += path + ": truncated, damaged or built for other numbers -- ignored\n"; }
     return ok;
 }
 
 // write to a temporary name, then rename: concurrent creators (one process per GPU, all with the same numbers) never
 // see a half-written file
-static bool write_file_atomic(const std::string& dir, const std::string& name, const std::vector<char>& data)
+static bool write_file_atomic(const std::string& dir, const std::string& name, uint64_t spec, const std::vector<char>& data)
 {
     if (!mkdir_p(dir)) return false;
     char tmp[64];
     snprintf(tmp, sizeof tmp, "/.tmp-%ld-%p", (long)getpid(), (const void*)&data);
     const std::string t = dir + tmp, final_ = dir + "/" + name;
-    FILE* f = fopen(t.c_str(), "wb");
-    if (!f) return false;
-    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    Trailer tr;
+    memcpy(tr.magic, TRAILER_MAGIC, 8);
+    tr.spec = spec; tr.content = content_hash(data.data(), data.size()); tr.length = data.size();
+    const int fd = open(t.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    if (fd < 0) return false;
+    FILE* f = fdopen(fd, "wb");
+    if (!f) { close(fd); unlink(t.c_str()); return false; }
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size() && fwrite(&tr, 1, sizeof tr, f) == sizeof tr;
     if (fclose(f) != 0 || !ok || rename(t.c_str(), final_.c_str()) != 0) { unlink(t.c_str()); return false; }
     return true;
 }
@@ -271,21 +323,35 @@ static bool compile(const Spec& s, std::vector<char>& code, std::string& log)
     return ok;
 }
 
-bool get_code(const Spec& s, const std::vector<std::string>& dirs, bool do_compile, const std::string& store_dir,
-              std::vector<char>& code, std::string& path, std::string& log)
+bool get_code(const Spec& s, const std::vector<std::string>& dirs, bool do_compile, const std::string& store_dir, bool aot,
+              std::vector<char>& code, std::string& path, std::string& log, bool* from_file)
 {
-    const std::string name = file_name(spec_hash(s));
+    if (from_file) *from_file = false;
+    const uint64_t hash = spec_hash(s);
+    const std::string plain = file_name(hash), versioned = versioned_file_name(hash);
     for (const std::string& d : dirs) {
         if (d.empty()) continue;
-        const std::string p = d + "/" + name;
-        if (read_file(p, code)) { path = p; return true; }
+        std::string why;
+        if (!dir_trusted(d, &why)) {
+            struct stat st;
+            if (lstat(d.c_str(), &st) == 0) log += why + "\n";      // (a directory that does not exist yet is the normal cold start)
+            continue;
+        }
+        for (const std::string* name : {&versioned, &plain}) {      // this toolchain's own object first, then an ahead-of-time one
+            if (name->empty()) continue;
+            const std::string p = d + "/" + *name;
+            if (read_file(p, hash, code, &log)) { path = p; if (from_file) *from_file = true; return true; }
+        }
     }
-    if (!do_compile) { log += "no cached code object " + name + " and compilation is switched off\n"; return false; }
+    if (!do_compile) { log += "no cached code object " + plain + " and compilation is switched off\n"; return false; }
     if (!compile(s, code, log)) return false;
     path.clear();
     if (!store_dir.empty()) {
-        if (write_file_atomic(store_dir, name, code)) path = store_dir + "/" + name;
-        else log += "could not store " + store_dir + "/" + name + " (the code object is used from memory)\n";
+        // ahead of time (p25fe_specialize): the plain name, which a process without hipRTC can find; at p25fe_create: this
+        // toolchain's versioned name
+        const std::string& name = (aot || versioned.empty()) ? plain : versioned;
+        if (write_file_atomic(store_dir, name, hash, code)) path = store_dir + "/" + name;
+        else log += "could not store " + store_dir + "/" + name + " (not writable, or not a private directory of this user: the code object is used from memory)\n";
     }
     return true;
 }

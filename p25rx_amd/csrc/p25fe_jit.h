@@ -30,12 +30,19 @@ extern const char* const KERNEL_NAMES[2][3];
 
 uint64_t spec_hash(const Spec& s);
 std::string default_cache_dir();                       // $P25FE_CACHE_DIR, $XDG_CACHE_HOME/p25fe, $HOME/.cache/p25fe, /tmp/p25fe-cache-<uid>
-std::string file_name(uint64_t hash);                  // "p25fe-<16 hex>.hsaco"
+std::string file_name(uint64_t hash);                  // "p25fe-<16 hex>.hsaco": the key of ahead-of-time objects
+std::string versioned_file_name(uint64_t hash);        // "p25fe-<16 hex>-rtc<major>_<minor>.hsaco": what p25fe_create stores; "" without hipRTC
+// a real directory owned by the caller (or root), writable by its owner only -- the only kind code objects are read from or
+// written to; *why (nullable) says what is wrong
+bool dir_trusted(const std::string& dir, std::string* why);
 
-// Code object for `s`: looked up in `dirs` (first hit wins); if absent and `compile`, built with hipRTC and stored in
-// `store_dir` (empty: not stored).  Returns true on success; `log` receives the compiler's words / what was tried.
-bool get_code(const Spec& s, const std::vector<std::string>& dirs, bool compile, const std::string& store_dir,
-              std::vector<char>& code, std::string& path, std::string& log);
+// Code object for `s`: looked up in `dirs` (first hit wins; per directory this toolchain's versioned name first, then the
+// plain one; directories and files that are not private to the caller are skipped, files are verified against the trailer
+// that ties their content to `s`); if absent and `compile`, built with hipRTC and stored in `store_dir` (empty: not
+// stored) under the plain name (`aot`, p25fe_specialize) or the versioned one.  Returns true on success; `log` receives
+// the compiler's words / what was tried and refused; *from_file (nullable): the object was read from `path`, not compiled.
+bool get_code(const Spec& s, const std::vector<std::string>& dirs, bool compile, const std::string& store_dir, bool aot,
+              std::vector<char>& code, std::string& path, std::string& log, bool* from_file = nullptr);
 
 }  // namespace p25jit
 #endif

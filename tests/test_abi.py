@@ -163,6 +163,97 @@ def test_library_loads_and_degrades_without_hiprtc(lib, tmp_path):
     assert r.returncode != 0 and "libhiprtc is not available" in r.stderr and "status -7" in r.stderr
 
 
+def _spec_run(code, env_extra, cwd=ROOT):
+    import sys
+    env = dict(os.environ, **env_extra)
+    env.pop("P25FE_JIT", None)
+    return subprocess.run([sys.executable, "-c", "from p25rx_amd import _lib; cfg = _lib.make_config(fm_deviation_hz=4444); " + code],
+                          cwd=cwd, text=True, env=env, capture_output=True)
+
+
+def test_cache_refuses_directories_that_are_not_private(lib, tmp_path):
+    """Code objects are loaded into the GPU process from the cache: a directory somebody else could have written (foreign owner,
+    or writable by group / others -- e.g. a pre-created /tmp/p25fe-cache-<uid>) is neither read from nor written to; the
+    object is then compiled and used from memory, and the log says why."""
+    good = tmp_path / "good"
+    made = _spec_run("print(_lib.specialize(cfg, %r))" % str(good), {})
+    assert made.returncode == 0, made.stderr
+    name = os.path.basename(made.stdout.strip())
+    assert (os.stat(good).st_mode & 0o77) == 0                       # created private
+    # the same object in a world-writable directory: ignored as a source ...
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    (bad / name).write_bytes((good / name).read_bytes())
+    os.chmod(bad / name, 0o600)
+    os.chmod(bad, 0o777)
+    cache = tmp_path / "cache"
+    r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_SPEC_DIR": str(bad), "P25FE_CACHE_DIR": str(cache)})
+    assert r.returncode == 0 and r.stdout.split()[0] == str(lib.VARIANT_SPECIALIZED), r.stderr
+    assert "writable by group / others" in r.stdout and len(os.listdir(cache)) == 1          # compiled afresh into the private cache
+    # ... and as a store: nothing is written there, the object is used from memory
+    before = sorted(os.listdir(bad))
+    r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_CACHE_DIR": str(bad)})
+    assert r.returncode == 0 and r.stdout.split()[0] == str(lib.VARIANT_SPECIALIZED), r.stderr
+    assert "used from memory" in r.stdout and sorted(os.listdir(bad)) == before
+    # a world-writable FILE in a private directory, and a symbolic link in place of the directory: ignored too
+    os.chmod(good / name, 0o666)
+    r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_SPEC_DIR": str(good), "P25FE_CACHE_DIR": str(tmp_path / "c2")})
+    assert r.returncode == 0 and "not a private regular file" in r.stdout
+    os.chmod(good / name, 0o600)
+    link = tmp_path / "link"
+    os.symlink(good, link)
+    r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_SPEC_DIR": str(link), "P25FE_CACHE_DIR": str(tmp_path / "c3")})
+    assert r.returncode == 0 and "symbolic links are not followed" in r.stdout
+    if os.geteuid() == 0:                                            # (root can stage the foreign-owner case itself)
+        own = tmp_path / "foreign"
+        own.mkdir(mode=0o700)
+        (own / name).write_bytes((good / name).read_bytes())
+        os.chown(own, 12345, 12345)
+        r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_SPEC_DIR": str(own), "P25FE_CACHE_DIR": str(tmp_path / "c4")})
+        assert r.returncode == 0 and "owned by another user" in r.stdout and len(os.listdir(tmp_path / "c4")) == 1
+
+
+def test_cache_verifies_content_against_the_numbers(lib, tmp_path):
+    """Nothing ties a file's NAME to its content but the trailer the library writes: a complete, well-formed code object with
+    one flipped bit, or one built for other numbers and renamed, is 'not cached' -- recompiled, never loaded; a deployment's
+    $P25FE_SPEC_DIR is never cleaned up by the library."""
+    aot = tmp_path / "aot"
+    made = _spec_run("print(_lib.specialize(cfg, %r))" % str(aot), {}).stdout.strip()
+    other = _spec_run("cfg = _lib.make_config(fm_deviation_hz=4445); print(_lib.specialize(cfg, %r))" % str(aot), {}).stdout.strip()
+    assert os.path.exists(made) and os.path.exists(other) and made != other
+    good = open(made, "rb").read()
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0x10                                  # still a complete ELF: the section table is intact
+    for label, content in (("bit flip", bytes(flipped)), ("other numbers", open(other, "rb").read()), ("no trailer", good[:-32])):
+        open(made, "wb").write(content)
+        cache = tmp_path / ("cache_" + label.replace(" ", "_"))
+        r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_SPEC_DIR": str(aot), "P25FE_CACHE_DIR": str(cache)})
+        assert r.returncode == 0 and r.stdout.split()[0] == str(lib.VARIANT_SPECIALIZED), (label, r.stderr)
+        assert "damaged or built for other numbers" in r.stdout, label
+        assert open(made, "rb").read() == content, label              # the deployment's file is left alone
+        stored = os.listdir(cache)
+        assert len(stored) == 1 and re.fullmatch(r"p25fe-[0-9a-f]{16}-rtc\d+_\d+\.hsaco", stored[0]), stored   # this toolchain's key
+    # the versioned key is looked for first: with both present the ahead-of-time file is not even opened
+    open(made, "wb").write(good)
+    r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.specialize_log())", {"P25FE_SPEC_DIR": str(aot), "P25FE_CACHE_DIR": str(cache)})
+    assert r.stdout.split()[0] == str(lib.VARIANT_SPECIALIZED) and "ignored" not in r.stdout
+
+
+def test_auto_fallback_to_the_generic_kernels_is_announced(lib, tmp_path):
+    """P25FE_SPECIALIZE_AUTO without hipRTC and without an ahead-of-time object ends on kernels 1.2 - 2.3 x slower: said once on
+    stderr (not only to callers that poll p25fe_kernel_variant); REQUIRE fails instead; the build's own numbers say nothing."""
+    env = {"P25FE_HIPRTC": "/nonexistent/libhiprtc.so", "P25FE_CACHE_DIR": str(tmp_path / "c")}
+    r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.probe_variant(cfg))", env)
+    assert r.returncode == 0 and r.stdout.split() == [str(lib.VARIANT_GENERIC)] * 2, r.stderr
+    assert r.stderr.count("running the GENERIC kernels") == 1
+    r = _spec_run("print(_lib.probe_variant(cfg))", dict(env, P25FE_QUIET="1"))
+    assert r.returncode == 0 and "GENERIC" not in r.stderr
+    r = _spec_run("cfg = _lib.make_config(fm_deviation_hz=4444, specialize=_lib.SPECIALIZE_REQUIRE); print(_lib.probe_variant(cfg))", env)
+    assert r.returncode != 0 and "status -7" in r.stderr
+    r = _spec_run("print(_lib.probe_variant(_lib.default_config()))", env)
+    assert r.returncode == 0 and r.stdout.split() == [str(lib.VARIANT_BUILTIN)] and "GENERIC" not in r.stderr
+
+
 def test_generic_kernels_do_not_spill(lib):
     """No k_frontend / k_chunk instantiation of the library may use scratch memory (a spilled FIR loop is ~2x the time)."""
     k = _hsaco_kernels_of_library(lib.LIB_PATH)

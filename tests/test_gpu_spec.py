@@ -170,3 +170,64 @@ def test_cache_is_used_and_survives_damage(FE, lib, tmp_path, monkeypatch):
     assert fe3.kernel_variant == lib.VARIANT_SPECIALIZED and os.path.getsize(d / files[0]) > 4096
     x = np.zeros(16384, dtype=np.complex64)
     assert len(fe3.demod_cf32(x)) == 3276
+
+
+_AUTO_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import oracle as O
+from p25rx_amd import _lib, c4fm
+from p25rx_amd.frontend import FrontEnd
+rng = np.random.default_rng(%(seed)d)
+taps = lambda n: (rng.standard_normal(n) * np.hanning(n + 2)[1:-1] / 6).astype(np.float32).tolist()
+dt, ct = taps(31), taps(41)
+iq = c4fm.synth(0.5, seed=9, snr_db=25.0)[0]
+ocfg = O.make_config(O.load_spec(), dt, ct)
+ref = O.Demod(ocfg).feed_cf32(iq)
+dref = O.Recv(ocfg).feed(ref)[0]
+fe = FrontEnd(decim_taps=dt, chan_taps=ct)                         # specialize = AUTO, P25FE_JIT unset: the production default
+got = fe.demod_cf32(iq)
+fe.reset()
+dib = np.concatenate([fe.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)])
+print(json.dumps({"variant": fe.kernel_variant, "bb": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))),
+                  "dib": bool(np.array_equal(dib, dref)), "log": _lib.specialize_log()[-1500:]}))
+'''
+
+
+def _auto_run(env_extra, seed=41):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    env.pop("P25FE_JIT", None)                                      # conftest.py switches AUTO off for the suite's own process
+    env.pop("P25FE_SPEC_DIR", None)
+    r = subprocess.run([sys.executable, "-c", _AUTO_WORKER % {"root": root, "seed": seed}], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+@pytest.mark.timeout(600)
+def test_auto_mode_is_the_production_default_and_degrades_loudly(lib, tmp_path):
+    """The suite runs with P25FE_JIT=0 (tests/conftest.py); the PRODUCTION default is specialize = AUTO with nothing in the
+    environment: cache lookup, then hipRTC, then the generic kernels.  Each leg in a process of its own: (a) cold cache ->
+    compiled, stored, specialised kernels; (b) warm cache -> found; (c) hipRTC missing and nothing cached -> the generic kernels,
+    announced on stderr; (d) a cache directory that cannot be written -> compiled and used from memory.  Same bits as the
+    oracle on every leg."""
+    cache = tmp_path / "cache"
+    a, _ = _auto_run({"P25FE_CACHE_DIR": str(cache)})
+    assert a["variant"] == lib.VARIANT_SPECIALIZED and a["bb"] and a["dib"] and len(os.listdir(cache)) == 1
+    b, _ = _auto_run({"P25FE_CACHE_DIR": str(cache), "P25FE_HIPRTC": "/nonexistent/libhiprtc.so"})
+    # (without hipRTC the versioned key cannot even be formed: only ahead-of-time objects are found -- this one is not)
+    assert b["variant"] == lib.VARIANT_GENERIC and b["bb"] and b["dib"]
+    b2, _ = _auto_run({"P25FE_CACHE_DIR": str(cache)})
+    assert b2["variant"] == lib.VARIANT_SPECIALIZED and b2["bb"] and b2["dib"] and len(os.listdir(cache)) == 1
+    c, err = _auto_run({"P25FE_CACHE_DIR": str(tmp_path / "empty"), "P25FE_HIPRTC": "/nonexistent/libhiprtc.so"})
+    assert c["variant"] == lib.VARIANT_GENERIC and c["bb"] and c["dib"] and "running the GENERIC kernels" in err
+    ro = tmp_path / "readonly"
+    ro.mkdir(mode=0o500)
+    d, _ = _auto_run({"P25FE_CACHE_DIR": str(ro)}, seed=42)
+    assert d["bb"] and d["dib"]
+    if os.geteuid() != 0:                                           # (root writes through a 0500 directory)
+        assert d["variant"] == lib.VARIANT_SPECIALIZED and "used from memory" in d["log"] and os.listdir(ro) == []
