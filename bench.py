@@ -305,12 +305,31 @@ def run_extras(torch, dev, args, iq2, truth2):
         ref_ = d_.feed_u8(pre.reshape(-1)) if is_u8 else d_.feed_cf32(pre.view(np.complex64).reshape(-1))
         return bool(nb_ == len(ref_) and np.array_equal(bb_[0, :nb_].cpu().numpy().view(np.uint32), ref_.view(np.uint32)))
 
+    def oracle_dibit_prefix_gate(fe_, x_, kw_, is_u8, n_pre=480000):
+        """... and the dibits of that prefix == the oracle's receiver on the oracle's baseband (for filters whose delay moves
+        the frame against the modulator's symbol list)"""
+        from oracle import oracle as O
+        pre = x_[:n_pre].cpu().numpy()
+        cfg_ = O.make_config(None, **kw_)
+        d_ = O.Demod(cfg_)
+        ref_ = d_.feed_u8(pre.reshape(-1)) if is_u8 else d_.feed_cf32(pre.view(np.complex64).reshape(-1))
+        want = O.Recv(cfg_).feed(ref_)[0]
+        dib_, res_ = fe_.run_dev(x_[:n_pre])
+        nd_ = int(parse_results(res_)[0]["n_dibits"])
+        return bool(nd_ == len(want) and np.array_equal(dib_[0, :nd_].cpu().numpy(), want))
+
     u8_all = torch.clamp(torch.round((iq2 + 1.0) * 127.5), 0, 255).to(torch.uint8)
     variant_name = {0: "built-in immediates", 1: "specialised (hipRTC) immediates", 2: "generic LDS taps"}
+    with open(os.path.join(ROOT, "tests", "golden", "spec.json")) as f_:
+        rc_taps = json.load(f_)["rc_avg_taps"]
     cases = [("31 / 41 non-default tables", dict(zip(("decim_taps", "chan_taps"), design(31, 41))), _lib.SPECIALIZE_REQUIRE, 31, 41),
              ("64 / 64 non-default tables", dict(zip(("decim_taps", "chan_taps"), design(64, 64))), _lib.SPECIALIZE_REQUIRE, 64, 64),
              ("31 / 41 non-default tables, generic fallback", dict(zip(("decim_taps", "chan_taps"), design(31, 41))), _lib.SPECIALIZE_OFF, 31, 41),
-             ("the build's own numbers through hipRTC", {}, _lib.SPECIALIZE_FORCE, 31, 41)]
+             ("the build's own numbers through hipRTC", {}, _lib.SPECIALIZE_FORCE, 31, 41),
+             # ABI 5: MovingAverage::new(10) replaced by the raised-cosine filter north_star names (41 taps, tools/gen_spec.py) and
+             # the decimator on another phase: the last two constructor numbers of DemodTask::new as data
+             ("raised-cosine post-discriminator filter (41 taps, avg_taps) + decim_phase 2", dict(avg_taps=rc_taps, decim_phase=2),
+              _lib.SPECIALIZE_REQUIRE, 31, 41)]
     for label, kw, spz, t1, t2 in cases:
         for is_u8 in (False, True):
             x = u8_all if is_u8 else iq2
@@ -324,8 +343,12 @@ def run_extras(torch, dev, args, iq2, truth2):
             k = steps_for(0.3)
             dt = timed(torch, step_ct, k, 5, finish=fe.join_dev)
             k1, _, _ = k1_frac(fe, torch, lambda: fe.run_dev(x, dibits=dib, result=res), n, BYTES_PER_SAMPLE_U8 if is_u8 else BYTES_PER_SAMPLE)
-            ok = gate(dib, res, truth2) and oracle_prefix_gate(fe, x, kw, is_u8)
-            fl = flops_per_sample(t1, t2, is_u8)
+            rc_case = "avg_taps" in kw
+            if rc_case:
+                ok = oracle_prefix_gate(fe, x, kw, is_u8) and oracle_dibit_prefix_gate(fe, x, kw, is_u8)
+            else:
+                ok = gate(dib, res, truth2) and oracle_prefix_gate(fe, x, kw, is_u8)
+            fl = flops_per_sample(t1, t2, is_u8) + (2.0 * (len(kw["avg_taps"]) - 10) / 5.0 if rc_case else 0.0)
             tfl = fl * n / (k1 * 1e-3) / 1e12 if k1 > 0 else 0.0
             bps = BYTES_PER_SAMPLE_U8 if is_u8 else BYTES_PER_SAMPLE
             ach = bps * n / (k1 * 1e-3) / 1e9 if k1 > 0 else 0.0
@@ -336,7 +359,8 @@ def run_extras(torch, dev, args, iq2, truth2):
             entry("configs[1] as %s, %s" % ("u8 I/Q pairs" if is_u8 else "cf32", label), n, dt / k * 1e3,
                   "k_frontend<%s> %s" % ("u8" if is_u8 else "cf32", variant_name[fe.kernel_variant]), k1, bps, ok, steps=k,
                   kernel_variant=fe.kernel_variant, create_s=round(t_create, 2), roofline=roof,
-                  gate="dibits == modulator symbols AND baseband of the first 2 s == oracle with the same numbers, bit for bit")
+                  gate=("baseband AND dibits of the first 2 s == oracle with the same numbers, bit for bit" if rc_case else
+                        "dibits == modulator symbols AND baseband of the first 2 s == oracle with the same numbers, bit for bit"))
             del fe, dib, res
     del u8_all
 

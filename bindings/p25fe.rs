@@ -15,7 +15,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ABI_VERSION: i32 = 4;
+pub const ABI_VERSION: i32 = 5;
 pub const MAX_TAPS: usize = 64;
 pub const FMT_CF32: c_int = 0;
 pub const FMT_U8: c_int = 1;
@@ -53,6 +53,9 @@ pub struct Config {
     pub u8_offset: f32,
     pub u8_lut_valid: i32,             // ... or as the table itself
     pub u8_lut: [f32; 256],
+    pub decim_phase: i32,              // Decimator::new(5), src/demod.rs:50, 87-90: output m comes from input 5 m + decim_phase (4)
+    pub n_avg_taps: i32,               // MovingAverage::new(10), src/demod.rs:52, 114, as a table (ten equal taps of 0.1)
+    pub avg_taps: [f32; MAX_TAPS],
 }
 
 /// p25fe_anchor_t
@@ -210,6 +213,7 @@ extern "C" {
                                 d_power_dbm: *const f32, d_stats: *mut ChanStats, stream: *mut c_void) -> c_int;
     pub fn p25fe_channelise_dev(h: *mut Handle, d_iq: *const f32, n_hist: usize, n: usize, abs0: u64, d_out: *mut f32,
                                 out_stride: usize, stream: *mut c_void) -> c_int;
+    pub fn p25fe_n_baseband_h(h: *const Handle, abs0: u64, n: usize) -> usize;
     pub fn p25fe_profile_enable(h: *mut Handle, on: c_int) -> c_int;
     pub fn p25fe_profile_read(h: *mut Handle, ms: *mut f64, n_calls: *mut u64) -> c_int;
 }

@@ -8,7 +8,9 @@
  *
  *   reference item (file:line in /root/reference)                  replaced by
  *   -------------------------------------------------------------  ---------------------------
- *   DemodTask::new   src/demod.rs:44-59  (decim 5, avg 10)          p25fe_create
+ *   DemodTask::new   src/demod.rs:44-59                             p25fe_create
+ *     Decimator::new(5)                 :50, 87-90                  p25fe_config_t.decim_phase (the factor 5 is the build's)
+ *     MovingAverage::new(10)            :52, 114                    p25fe_config_t.n_avg_taps / avg_taps
  *     DecimFir / BandpassFir tables     :27-29                      p25fe_config_t.decim_taps / chan_taps
  *     FmDemod::new(5000, 48000)         :54                         p25fe_config_t.fm_deviation_hz / fm_sample_rate_hz / fm_gain
  *     rtlsdr_iq::IQ                     :83                         p25fe_config_t.u8_scale / u8_offset / u8_lut
@@ -51,11 +53,15 @@ extern "C" {
 #endif
 
 #define P25FE_MAX_TAPS 64
-#define P25FE_ABI_VERSION 4        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
+#define P25FE_ABI_VERSION 5        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
                                       flags in p25fe_result_t, p25fe_resync_at_dev, symbol_clock argument of p25fe_shard_resolve
                                       4: the run-time arguments of the reference's constructors in the config (FM deviation / rate,
                                       the u8 -> float LUT), `specialize`, p25fe_specialize / p25fe_kernel_variant,
-                                      p25fe_run_host_windows */
+                                      p25fe_run_host_windows
+                                      5: the LAST constructor numbers: the post-discriminator filter as a table (avg_taps:
+                                      MovingAverage::new(10)) and the decimator's phase (decim_phase: Decimator::new(5));
+                                      p25fe_n_baseband_h; p25fe_shard_halo() is 2 560; p25fe_shard_pass1_head / _pass2_dev /
+                                      _compact_from_dev; p25fe_probe_variant */
 
 typedef enum p25fe_status {
     P25FE_OK = 0,
@@ -73,9 +79,9 @@ typedef enum p25fe_format {
     P25FE_FMT_U8 = 1           /* interleaved uint8 I,Q (RTL-SDR; src/demod.rs:74-76) */
 } p25fe_format;
 
-/* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54), the type-level tap tables of p25_filts
- * (DecimFir / BandpassFir, src/demod.rs:27-29), the arguments of FmDemod::new (src/demod.rs:54) and the rtlsdr_iq::IQ lookup
- * table (src/demod.rs:83).  Up to P25FE_MAX_TAPS = 64 taps per filter; a table of n taps is evaluated as 31 / 41 taps (64 / 64
+/* Replaces the compile-time DSP parameters of DemodTask::new (src/demod.rs:49-54: every constructor argument of the four DSP
+ * objects, ABI 5), the type-level tap tables of p25_filts (DecimFir / BandpassFir, src/demod.rs:27-29), the arguments of
+ * FmDemod::new (src/demod.rs:54) and the rtlsdr_iq::IQ lookup table (src/demod.rs:83).  Up to P25FE_MAX_TAPS = 64 taps per filter; a table of n taps is evaluated as 31 / 41 taps (64 / 64
  * as soon as either table is longer) with zero coefficients at the old end: the same filter on finite samples; a NaN / Inf
  * sample reaches that many taps' worth of outputs (docs/SPEC.md 3.3).
  *
@@ -114,6 +120,18 @@ typedef struct p25fe_config {
                                             ignored.  A table that equals fma(b, s, o) bit for bit for some (s, o) the library
                                             finds runs as arithmetic; any other table is looked up in LDS. */
     float u8_lut[256];
+    /* ---- ABI 5 ---- */
+    int32_t decim_phase;                 /* Decimator::new(5) / decim_in_place (src/demod.rs:50, 87-90): output m of the 5:1 decimator
+                                            is produced by the input sample with absolute index 5 m + decim_phase, 0..4.  Default 4
+                                            (the 5th, 10th, ... sample: 16 384-sample chunks give 3 276, 3 277, 3 277, ... outputs). */
+    int32_t n_avg_taps;                  /* MovingAverage::new(10) (src/demod.rs:52, 114) as a table: the real FIR behind the
+                                            discriminator, 1 .. P25FE_MAX_TAPS taps, tap 0 on the newest sample (docs/SPEC.md 3.5).
+                                            A table whose taps are ALL EQUAL is a moving average and is evaluated as one: the
+                                            samples summed newest first, then one multiply by the tap -- the default, ten taps of
+                                            (float)0.1, gives the bits of every earlier ABI.  Any other table (e.g. the raised
+                                            cosine P25FE_RC_AVG_TAPS of p25fe_spec.h) is evaluated like the other two FIRs: one
+                                            accumulator from +0, fma in tap order. */
+    float avg_taps[P25FE_MAX_TAPS];
 } p25fe_config_t;
 
 #define P25FE_CLOCK_FIXED 0
@@ -465,8 +483,10 @@ int p25fe_chan_stats_dev(p25fe_t *h, const p25fe_result_t *d_result, const p25fe
 int p25fe_profile_enable(p25fe_t *h, int on);
 int p25fe_profile_read(p25fe_t *h, double ms[4], uint64_t *n_calls);
 
-/* Number of baseband samples produced by n input samples starting at absolute index abs0. */
+/* Number of baseband samples produced by n input samples starting at absolute index abs0 -- with the default decimator
+ * phase (p25fe_config_t.decim_phase = 4), and with the handle's. */
 size_t p25fe_n_baseband(uint64_t abs0, size_t n);
+size_t p25fe_n_baseband_h(const p25fe_t *h, uint64_t abs0, size_t n);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@ class Config(C.Structure):
         ("symbol_clock", C.c_int32), ("clk_lookahead", C.c_int32), ("clk_tol_shift", C.c_int32), ("clk_dmax_log2", C.c_int32),
         ("clk_interp", C.c_float * 256),
         ("u8_offset", C.c_float), ("u8_lut_valid", C.c_int32), ("u8_lut", C.c_float * 256),
+        ("decim_phase", C.c_int32), ("n_avg", C.c_int32), ("avg_uniform", C.c_int32), ("avg_taps", C.c_float * MAX_TAPS),
     ]
 
 
@@ -45,7 +46,7 @@ def fm_gain_from(deviation_hz, sample_rate_hz):
 
 
 def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0, fm_deviation_hz=None, fm_sample_rate_hz=None,
-                fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None):
+                fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None, decim_phase=None, avg_taps=None):
     """The oracle's numbers: the build's (tests/golden/spec.json) unless overridden -- same keyword names and meaning as
     the p25fe_config_t fields (p25rx_amd/_lib.make_config)."""
     s = spec or load_spec()
@@ -85,6 +86,13 @@ def make_config(spec=None, decim_taps=None, chan_taps=None, symbol_clock=0, fm_d
         c.u8_lut_valid = 1
         for i, v in enumerate(np.asarray(u8_lut, dtype=np.float32)):
             c.u8_lut[i] = v
+    # ABI 5: Decimator::new(5)'s phase and MovingAverage::new(10) as a table (docs/SPEC.md 3.2, 3.5)
+    c.decim_phase = s.get("decim_phase", 4) if decim_phase is None else int(decim_phase)
+    at = np.asarray(s.get("avg_taps", [s["boxcar_scale"]] * s["boxcar_len"]) if avg_taps is None else avg_taps, dtype=np.float32)
+    c.n_avg = len(at)
+    c.avg_uniform = 1 if bool(np.all(at.view(np.uint32) == at.view(np.uint32)[0])) else 0
+    for i, v in enumerate(at):
+        c.avg_taps[i] = v
     c.pi, c.half_pi = s["pi"], s["half_pi"]
     c.inv_npos, c.inv_nneg = s["sync_inv_npos"], s["sync_inv_nneg"]
     c.rho2_n, c.e_min, c.slice_frac = s["sync_rho2_n"], s["sync_e_min"], s["slice_frac"]

@@ -58,6 +58,14 @@ typedef struct {
     float u8_offset;
     int32_t u8_lut_valid;
     float u8_lut[256];
+    /* the last two constructor numbers of DemodTask::new as data (p25fe_config_t ABI 5):
+     * Decimator::new(5) (src/demod.rs:50): output m comes from the input with absolute index 5 m + decim_phase (SPEC 3.2: 4);
+     * MovingAverage::new(10) (src/demod.rs:52) as a table (SPEC 3.5): n_avg taps; all equal (avg_uniform) = a moving average,
+     * summed newest first then scaled once -- `boxcar` / `boxcar_scale` above are that case's length and tap and stay in use
+     * when n_avg == 0 --, otherwise a FIR: acc = +0, fma in tap order. */
+    int32_t decim_phase;
+    int32_t n_avg, avg_uniform;
+    float avg_taps[P25O_MAX_TAPS];
 } p25o_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -157,7 +165,7 @@ static inline float fm_feed(const p25o_config *c, cf32 *prev, cf32 s)
  * newest first, then one multiply by 1/10 -- no running sum, so it cannot drift and has
  * finite memory.
  * ---------------------------------------------------------------------------------------- */
-typedef struct { int len, pos; float hist[2 * 32]; } boxcar;
+typedef struct { int len, pos, uniform; float taps[P25O_MAX_TAPS]; float hist[2 * P25O_MAX_TAPS]; } boxcar;
 
 static inline float boxcar_feed(boxcar *b, float scale, float x)
 {
@@ -165,10 +173,16 @@ static inline float boxcar_feed(boxcar *b, float scale, float x)
     b->hist[b->pos] = x;
     b->hist[b->pos + b->len] = x;
     const float *h = b->hist + b->pos;
-    float acc = h[0];
-    for (int i = 1; i < b->len; i++)
-        acc = acc + h[i];
-    return acc * scale;
+    if (b->uniform) {                    /* MovingAverage: the reference's object */
+        float acc = h[0];
+        for (int i = 1; i < b->len; i++)
+            acc = acc + h[i];
+        return acc * scale;
+    }
+    float acc = 0.0f;                    /* any other table: a FIR like the two in front (SPEC 3.5, section 2) */
+    for (int k = 0; k < b->len; k++)
+        acc = fmaf(b->taps[k], h[k], acc);
+    return acc;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -189,7 +203,8 @@ typedef struct {
 
 p25o_demod *p25o_demod_create(const p25o_config *cfg)
 {
-    if (cfg->t1 > P25O_MAX_TAPS || cfg->t2 > P25O_MAX_TAPS || cfg->boxcar > 32)
+    if (cfg->t1 > P25O_MAX_TAPS || cfg->t2 > P25O_MAX_TAPS || cfg->boxcar > P25O_MAX_TAPS || cfg->n_avg < 0 || cfg->n_avg > P25O_MAX_TAPS ||
+        cfg->decim_phase < 0 || cfg->decim_phase >= cfg->decim)
         return NULL;
     p25o_demod *d = calloc(1, sizeof *d);
     d->cfg = *cfg;
@@ -198,6 +213,15 @@ p25o_demod *p25o_demod_create(const p25o_config *cfg)
     fir_init(&d->decim, cfg->decim_taps, cfg->t1);       /* Decimator::new(5)  :50 */
     fir_init(&d->bandpass, cfg->chan_taps, cfg->t2);     /* FirFilter::new()   :51 */
     d->avg.len = cfg->boxcar;                            /* MovingAverage::new(10) :52 */
+    d->avg.uniform = 1;
+    if (cfg->n_avg > 0) {                                /* ... as a table */
+        d->avg.len = cfg->n_avg;
+        d->avg.uniform = cfg->avg_uniform;
+        memcpy(d->avg.taps, cfg->avg_taps, sizeof(float) * (size_t)cfg->n_avg);
+        if (cfg->avg_uniform) d->cfg.boxcar_scale = cfg->avg_taps[0];
+    }
+    /* Decimator: an output whenever the counter reaches `decim`; it starts so that the first one falls on input decim_phase */
+    d->decim_phase = cfg->decim - 1 - cfg->decim_phase;
     return d;
 }
 
@@ -211,7 +235,7 @@ void p25o_demod_destroy(p25o_demod *d)
 
 /* static_decimate::Decimator::decim_in_place (src/demod.rs:87): filter + keep every 5th,
  * in place, return the new length.  Phase persists, so 16384-sample chunks give 3276 or
- * 3277 outputs (src/demod.rs:87-90).  SPEC 3.2: output m is produced by input n = 5m + 4. */
+ * 3277 outputs (src/demod.rs:87-90).  SPEC 3.2: output m is produced by input n = 5m + decim_phase (4). */
 static size_t decim_in_place(p25o_demod *d, cf32 *buf, size_t n)
 {
     size_t len = 0;

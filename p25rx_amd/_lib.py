@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libp25fe.so")
 MAX_TAPS = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 FMT_CF32, FMT_U8 = 0, 1
 
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM, ERR_JIT = 0, -1, -2, -3, -4, -5, -6, -7
@@ -25,7 +25,8 @@ class Config(C.Structure):
                 ("decim_taps", C.c_float * MAX_TAPS), ("chan_taps", C.c_float * MAX_TAPS),
                 ("symbol_clock", C.c_int32), ("specialize", C.c_int32),
                 ("fm_deviation_hz", C.c_uint32), ("fm_sample_rate_hz", C.c_uint32), ("fm_gain", C.c_float),
-                ("u8_scale", C.c_float), ("u8_offset", C.c_float), ("u8_lut_valid", C.c_int32), ("u8_lut", C.c_float * 256)]
+                ("u8_scale", C.c_float), ("u8_offset", C.c_float), ("u8_lut_valid", C.c_int32), ("u8_lut", C.c_float * 256),
+                ("decim_phase", C.c_int32), ("n_avg_taps", C.c_int32), ("avg_taps", C.c_float * MAX_TAPS)]
 
 
 class WindowsStats(C.Structure):
@@ -69,7 +70,7 @@ SYMBOLS = [
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
     "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
     "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log", "p25fe_run_host_windows",
-    "p25fe_shard_pass1_head", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant",
+    "p25fe_shard_pass1_head", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant", "p25fe_n_baseband_h",
 ]
 
 
@@ -156,6 +157,8 @@ def load():
     L.p25fe_n_predecim.restype = sz
     L.p25fe_n_baseband.argtypes = [u64, sz]
     L.p25fe_n_baseband.restype = sz
+    L.p25fe_n_baseband_h.argtypes = [vp, u64, sz]
+    L.p25fe_n_baseband_h.restype = sz
     _LIB = L
     return L
 
@@ -173,7 +176,8 @@ def specialize_log():
 
 
 def make_config(n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_clock=0, specialize=SPECIALIZE_AUTO,
-                fm_deviation_hz=None, fm_sample_rate_hz=None, fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None):
+                fm_deviation_hz=None, fm_sample_rate_hz=None, fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None,
+                decim_phase=None, avg_taps=None):
     """p25fe_config_t from keyword arguments (None = the build's default)."""
     cfg = default_config()
     cfg.device, cfg.n_channels, cfg.symbol_clock, cfg.specialize = device, n_channels, symbol_clock, specialize
@@ -201,6 +205,12 @@ def make_config(n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_
         cfg.u8_lut_valid = 1
         for i in range(256):
             cfg.u8_lut[i] = lut[i]
+    if decim_phase is not None:
+        cfg.decim_phase = int(decim_phase)
+    if avg_taps is not None:
+        cfg.n_avg_taps = len(avg_taps)                           # the library rejects counts above P25FE_MAX_TAPS
+        for i, v in enumerate(list(avg_taps)[:MAX_TAPS]):
+            cfg.avg_taps[i] = v
     return cfg
 
 

@@ -23,12 +23,13 @@ using namespace p25k;
 
 namespace {
 
-constexpr size_t HISTPAD = 448;      // >= HIST_IQ_MAX (432 with 64 + 64 taps), multiple of 8: keeps 16-B alignment for u8 and cf32
+constexpr size_t HISTPAD = 704;      // >= HIST_IQ_MAX (702 with 64 + 64 + 64 taps), multiple of 8: keeps 16-B alignment for u8 and cf32
 static_assert(HISTPAD >= (size_t)HIST_IQ_MAX && HISTPAD % 8 == 0, "stream history covers the longest filters");
 constexpr size_t BBPAD = 256;        // >= HIST_BB (240) + the tracking clock's lookahead, multiple of 4
-constexpr size_t SHARD_HALO = 2048;                     // samples (16 KB of cf32): K1 recomputes one block (320 + 2) of baseband history in front of a
-                                                       // shard and needs 73 decimator outputs and 63 samples in front of that with 64-tap tables
-static_assert(SHARD_HALO >= (size_t)(DEC * (PLPAD + CLK_L + HALO_Y + TMAX - 1) + TMAX) && SHARD_HALO % 8 == 0, "shard halo");
+constexpr size_t SHARD_HALO = 2560;                     // samples (20 KB of cf32): K1 recomputes one block (320 + 2) of baseband history in front of a
+                                                       // shard and needs up to 127 decimator outputs (64-tap post-discriminator and channel filters;
+                                                       // 160 when a segment recomputes its halo) and 63 samples in front of that
+static_assert(SHARD_HALO >= (size_t)(DEC * (PLPAD + CLK_L + 160) + TMAX) && 160 >= TMAX + TMAX - 1 && SHARD_HALO % 8 == 0, "shard halo");
 constexpr uint32_t STATE_MAGIC = 0x50323546u;          // "P25F"
 
 struct DevBuf {
@@ -113,6 +114,8 @@ struct p25fe {
     int k1_p = 5;                          // FIR outputs per thread
     int variant = P25FE_VARIANT_BUILTIN;   // which front-end kernels run (p25fe_kernel_variant)
     bool long_taps = false;                // more than P25FE_T1 / P25FE_T2 taps -> the 64 / 64 geometry (Geo<5, 1>)
+    int phase = P25FE_DECIM_PHASE;         // p25fe_config_t.decim_phase: baseband sample m comes from input 5 m + phase
+    int n_avg = BOX;                       // post-discriminator filter: taps in use (the table is taps.avg)
     bool u8_lut_mode = false;              // the u8 table is not affine: the specialised kernels look it up in LDS (the generic ones always do)
     DevBuf d_taps;                         // device copy (generic kernels: everything; specialised ones: the u8 table, if not affine)
     hipModule_t jit_mod = nullptr;         // specialised kernels (p25fe_jit.cpp): [format][linear, planar, chunk]
@@ -202,7 +205,7 @@ constexpr int PROF_SAMPLE = 8;
 // p25fe_config_t -> the numbers the kernels run with.  No device needed (p25fe_specialize runs on a build host).
 // --------------------------------------------------------------------------------------------
 struct Resolved {
-    Taps taps;              // tables zero-padded to the evaluation length, the u8 table, the discriminator's scale
+    Taps taps;              // tables zero-padded to the evaluation length, the u8 table, the discriminator's scale, the post-discriminator filter
     bool long_taps;         // 64 / 64 evaluation
     bool lut_affine;        // the u8 table is fma(b, u8_scale, u8_offset) for every byte
     float u8_scale, u8_offset;
@@ -223,9 +226,18 @@ static int resolve_config(const p25fe_config_t* cfg, Resolved* r)
 {
     if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_decim_taps < 1 || cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 ||
         cfg->n_chan_taps > P25FE_MAX_TAPS || (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING) ||
-        cfg->specialize < P25FE_SPECIALIZE_OFF || cfg->specialize > P25FE_SPECIALIZE_FORCE)
+        cfg->specialize < P25FE_SPECIALIZE_OFF || cfg->specialize > P25FE_SPECIALIZE_FORCE || cfg->decim_phase < 0 || cfg->decim_phase >= DEC ||
+        cfg->n_avg_taps < 1 || cfg->n_avg_taps > P25FE_MAX_TAPS)
         return P25FE_ERR_ARG;
     memset(&r->taps, 0, sizeof r->taps);                             // zero padding at the old end is bit-neutral on finite samples
+    // MovingAverage::new(10), src/demod.rs:52 (docs/SPEC.md 3.5): all taps equal -> a moving average, summed then scaled once
+    r->taps.n_avg = cfg->n_avg_taps;
+    r->taps.avg_uniform = 1;
+    for (int k = 0; k < cfg->n_avg_taps; ++k) {
+        if (!finite_f(cfg->avg_taps[k])) return P25FE_ERR_ARG;
+        r->taps.avg[k] = cfg->avg_taps[k];
+        if (!same_bits(cfg->avg_taps[k], cfg->avg_taps[0])) r->taps.avg_uniform = 0;
+    }
     for (int k = 0; k < cfg->n_decim_taps; ++k) { if (!finite_f(cfg->decim_taps[k])) return P25FE_ERR_ARG; r->taps.dec[k] = cfg->decim_taps[k]; }
     for (int k = 0; k < cfg->n_chan_taps; ++k) { if (!finite_f(cfg->chan_taps[k])) return P25FE_ERR_ARG; r->taps.ch[k] = cfg->chan_taps[k]; }
     r->long_taps = cfg->n_decim_taps > P25FE_T1 || cfg->n_chan_taps > P25FE_T2;
@@ -259,7 +271,9 @@ static int resolve_config(const p25fe_config_t* cfg, Resolved* r)
     memset(&def, 0, sizeof def);
     memcpy(def.dec, P25FE_DEFAULT_DECIM_TAPS, sizeof(float) * P25FE_T1);
     memcpy(def.ch, P25FE_DEFAULT_CHAN_TAPS, sizeof(float) * P25FE_T2);
+    memcpy(def.avg, P25FE_DEFAULT_AVG_TAPS, sizeof(float) * BOX);
     r->dflt = !r->long_taps && memcmp(def.dec, r->taps.dec, sizeof def.dec) == 0 && memcmp(def.ch, r->taps.ch, sizeof def.ch) == 0 &&
+              r->taps.n_avg == BOX && memcmp(def.avg, r->taps.avg, sizeof def.avg) == 0 &&
               same_bits(r->taps.fm_gain, P25FE_FM_GAIN) && r->lut_affine && same_bits(r->u8_scale, P25FE_U8_SCALE) &&
               same_bits(r->u8_offset, P25FE_U8_OFFSET);
     return P25FE_OK;
@@ -277,6 +291,8 @@ static p25jit::Spec jit_spec(const Resolved& r)
     s.fm_gain = r.taps.fm_gain;
     s.u8_lut = r.lut_affine ? 0 : 1;
     s.u8_scale = r.u8_scale; s.u8_offset = r.u8_offset;
+    s.n_avg = r.taps.n_avg; s.avg_uniform = r.taps.avg_uniform;
+    memcpy(s.avg, r.taps.avg, sizeof s.avg);
     return s;
 }
 
@@ -356,6 +372,9 @@ void p25fe_default_config(p25fe_config_t* cfg)
     cfg->u8_scale = P25FE_U8_SCALE;
     cfg->u8_offset = P25FE_U8_OFFSET;
     cfg->u8_lut_valid = 0;
+    cfg->decim_phase = P25FE_DECIM_PHASE;                            // Decimator::new(5): the 5th sample of every five, src/demod.rs:50, 87-90
+    cfg->n_avg_taps = P25FE_BOXCAR;                                  // MovingAverage::new(10), src/demod.rs:52
+    memcpy(cfg->avg_taps, P25FE_DEFAULT_AVG_TAPS, sizeof(float) * P25FE_BOXCAR);
 }
 
 const char* p25fe_strerror(int status)
@@ -422,11 +441,13 @@ int p25fe_probe_variant(const p25fe_config_t* cfg)
     }
 }
 
-size_t p25fe_n_baseband(uint64_t abs0, size_t n)
+static inline size_t n_baseband_ph(int phase, uint64_t abs0, size_t n)
 {
-    const size_t o0 = (size_t)((4 + 5 - abs0 % 5) % 5);
+    const size_t o0 = (size_t)(((uint64_t)phase + 5 - abs0 % 5) % 5);       // first decimation instant inside the range
     return n > o0 ? (n - o0 - 1) / 5 + 1 : 0;
 }
+size_t p25fe_n_baseband(uint64_t abs0, size_t n) { return n_baseband_ph(P25FE_DECIM_PHASE, abs0, n); }
+size_t p25fe_n_baseband_h(const p25fe_t* h, uint64_t abs0, size_t n) { return n_baseband_ph(h ? h->phase : P25FE_DECIM_PHASE, abs0, n); }
 
 size_t p25fe_shard_halo(void) { return SHARD_HALO; }
 
@@ -471,6 +492,8 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     h->look = cfg->symbol_clock ? CLK_L : 0;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->taps = rs.taps;
+    h->phase = cfg->decim_phase;
+    h->n_avg = rs.taps.n_avg;
     h->long_taps = rs.long_taps;
     h->u8_lut_mode = !rs.lut_affine;
     h->variant = rs.dflt ? P25FE_VARIANT_BUILTIN : P25FE_VARIANT_GENERIC;
@@ -621,7 +644,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     // planar output: the first output K1 produces is the form's (a block boundary of the layout, or 80 outputs in front of
     // the receiver's 240-sample history) -- the caller's value is ignored
     if (planar) m_begin = pro ? -(long)PLPAD - h->look : -(long)HIST_BB - h->look;
-    const size_t n_out = p25fe_n_baseband(abs0, n);
+    const size_t n_out = p25fe_n_baseband_h(h, abs0, n);
     const long total = (long)n_out - m_begin;
     if (total <= 0) {
         // power_dbm of an empty chunk: the reference divides 0 by 0 (src/demod.rs:123-134) -> NaN (0xffffffff is a quiet NaN)
@@ -642,13 +665,20 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     long subs = subs_env > 0 ? subs_env : (fmt == P25FE_FMT_U8 ? 9 : 3);
     if (chunk) subs = 1;                                            // a chunk is latency: every sub-tile its own workgroup
     if (subs > 32768) subs = 32768;
-    const long seg_len = pro ? subs * sub : (sub - SEG_HALO) + (subs - 1) * sub;
+    // the post-discriminator filter's length as far as the kernel's GEOMETRY goes (frontend_body's T3): the handle's own for the
+    // immediate-coefficient kernels, the ABI's ceiling for the generic ones; the halo form's recomputed halo follows the
+    // handle's real length either way (the generic kernels take it as an argument)
+    const bool ct_k = h->variant != P25FE_VARIANT_GENERIC;
+    const int t2e = h->long_taps ? TMAX : T2;
+    const int t3geo = ct_k ? h->n_avg : TMAX;
+    const long segh = seg_halo_for(h->n_avg, t2e);
+    const long seg_len = pro ? subs * sub : (sub - segh) + (subs - 1) * sub;
     // what a segment needs in front of its first output: the prologue's decimator outputs, or the recomputed halo
-    const long nd = pro ? HALO_Y + (h->long_taps ? TMAX : T2) - 1 : SEG_HALO;
+    const long nd = pro ? t3geo + t2e - 1 : segh;
     // a time shard's launches (part != 0): the segments in front of the first one whose input lies inside the owned samples
     // are ONE sub-tile long (K1Args.lead_segs) -- the head is then a few one-sub-tile workgroups side by side
-    const long lead_len = pro ? sub : sub - SEG_HALO;
-    const long o0l = (long)((4 + 5 - abs0 % 5) % 5);
+    const long lead_len = pro ? sub : sub - segh;
+    const long o0l = (long)(((uint64_t)h->phase + 5 - abs0 % 5) % 5);
     long lead = 0;
     if (part && subs > 1 && !chunk)
         while (lead < 64 && o0l + DEC * (m_begin + lead * lead_len - nd) - (t1 - 1) < 0 && lead * lead_len < total) ++lead;
@@ -656,7 +686,9 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     const long n_seg = lead * lead_len >= total ? (total + lead_len - 1) / lead_len : lead + (total - lead * lead_len + seg_len - 1) / seg_len;
     const long pl_shift = PLPAD + h->look;       // the general receiver sees the range h->look samples late (p25fe_recv.hip)
     if (planar && pro && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % PL_BLK != 0 || seg_len % PL_BLK != 0)) return P25FE_ERR_ARG;
-    if (planar && !pro && (m_begin + pl_shift < SEG_HALO || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
+    // (halo form: the outputs a segment recomputes and drops may lie in front of planar position 0 -- with a 160-output halo the
+    // range's first segment starts 80 positions in front of it; they are never stored, only whole bytes of the planes are)
+    if (planar && !pro && (m_begin + pl_shift < 0 || (m_begin + pl_shift) % 80 != 0 || seg_len % 80 != 0)) return P25FE_ERR_ARG;
     if (planar && n_out > MAX_RANGE_BB) return P25FE_ERR_ARG;
 
     K1Args a;
@@ -664,7 +696,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.ch_stride = (long)ch_stride;
     a.n_hist = (long)n_hist;
     a.n_new = (long)n;
-    a.o0 = (int)((4 + 5 - abs0 % 5) % 5);
+    a.o0 = (int)o0l;
     a.bb = d_bb;
     a.bb_stride = (long)bb_stride;
     a.n_out = (long)n_out;
@@ -688,6 +720,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     a.bbp = nullptr; a.bbp_ch_stride = 0; a.bits = nullptr; a.bits_ch_stride = 0; a.pl_shift = (int)pl_shift;
     a.done_flag = planar ? done_flag : nullptr; a.done_seq = done_seq;
     a.lead_segs = (int)lead;
+    a.seg_halo = (int)segh;
     if (planar) {
         a.bbp = h->pl_f.as<float>(); a.bbp_ch_stride = (long)planar->floats();
         a.bits = h->pl_bits.as<uint8_t>(); a.bits_ch_stride = (long)(4 * planar->words());
@@ -706,9 +739,7 @@ static int launch_frontend(p25fe_t* h, const void* d_x, int fmt, size_t ch_strid
     // allocated.  (13 376 B per wave is 11 waves per CU; a 12th would need 13 312 -- trimming to that changed nothing.)
     const bool ct = h->variant != P25FE_VARIANT_GENERIC;
     const bool lut = u8 && (!ct || h->u8_lut_mode);
-    size_t lds = h->long_taps ? Geo<5, 1>::LDS_BYTES : (pk == 3 ? Geo<3>::LDS_BYTES : Geo<5>::LDS_BYTES);
-    if (lut) lds += sizeof(float) * 256;
-    else if (ct) lds -= sizeof(float) * (size_t)((h->long_taps ? 2 * TMAX : T1 + T2) + 3);
+    size_t lds = h->long_taps ? k1_lds_bytes<Geo<5, 1>>(ct, lut, t3geo) : (pk == 3 ? k1_lds_bytes<Geo<3>>(ct, lut, t3geo) : k1_lds_bytes<Geo<5>>(ct, lut, t3geo));
     // (experiments: extra dynamic LDS per workgroup = fewer resident waves per CU; the occupancy sensitivity of docs/MEASUREMENTS.md)
     static const size_t lds_pad_env = [] { const char* e = getenv("P25FE_K1_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     lds += lds_pad_env;
@@ -1021,7 +1052,7 @@ int p25fe_join_dev(p25fe_t* h, void* stream)
 int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
                             size_t dibit_stride, p25fe_result_t* d_result, void* stream)
 {
-    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband(0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
+    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband_h(h, 0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     shard_invalidate(h);
@@ -1074,7 +1105,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
         h->rx_pending[lane] = false;
     }
     h->rx_joined_any[lane] = false;
-    const size_t n_bb = p25fe_n_baseband(0, n);
+    const size_t n_bb = p25fe_n_baseband_h(h, 0, n);
     int rc = P25FE_OK;
     const PlanarGeo g(n_bb);
     hipEvent_t k1_done = h->ev_k1[lane];
@@ -1116,12 +1147,12 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
 int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
                   size_t dibit_stride, p25fe_result_t* d_result, void* stream)
 {
-    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband(0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
+    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband_h(h, 0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     shard_invalidate(h);
     if (int jrc = pipe_join(h, st)) return jrc;
-    const size_t n_bb = p25fe_n_baseband(0, n);
+    const size_t n_bb = p25fe_n_baseband_h(h, 0, n);
     int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
     const RecvCall rcall = recv_call(h);
@@ -1156,13 +1187,13 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
 {
     const bool do_main = (what & SH_MAIN) != 0, do_finish = (what & SH_RECV) != 0;
     bool do_head = (what & SH_HEAD) != 0;
-    if (!h || !d_iq || (do_finish && !d_result) || p25fe_n_baseband(abs0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
+    if (!h || !d_iq || (do_finish && !d_result) || p25fe_n_baseband_h(h, abs0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
     if (do_main) shard_invalidate(h);
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (int jrc = pipe_join(h, st)) return jrc;
-    const size_t n_bb = p25fe_n_baseband(abs0, n);
-    const long abs_bb0 = (long)p25fe_n_baseband(0, (size_t)abs0) - h->look;      // first processed baseband index of this shard
+    const size_t n_bb = p25fe_n_baseband_h(h, abs0, n);
+    const long abs_bb0 = (long)p25fe_n_baseband_h(h, 0, (size_t)abs0) - h->look;      // first processed baseband index of this shard
     int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
     const PlanarGeo g(n_bb);
@@ -1402,7 +1433,7 @@ static int demod_host(p25fe_t* h, const void* iq, int fmt, size_t n, float* bb, 
 {
     if (!h || (!iq && n) || !bb || !n_out) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    const size_t nb = p25fe_n_baseband(h->abs_iq, n);
+    const size_t nb = p25fe_n_baseband_h(h, h->abs_iq, n);
     if (nb > bb_cap) return P25FE_ERR_CAPACITY;
     const size_t C = (size_t)h->C;
     Staged sg;
@@ -1594,7 +1625,7 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
 static int launch_chunk(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
                         const ChunkRecvArgs& r)
 {
-    const PlanarGeo g(p25fe_n_baseband(abs0, n));
+    const PlanarGeo g(p25fe_n_baseband_h(h, abs0, n));
     return launch_frontend(h, d_x, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, h->stream, &g, 0,
                            nullptr, nullptr, &r);
 }
@@ -1604,7 +1635,7 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
     if (!h || (!iq && n) || !dibits || !n_dibits) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
-    const size_t nb = p25fe_n_baseband(h->abs_iq, n);
+    const size_t nb = p25fe_n_baseband_h(h, h->abs_iq, n);
     if (cap < nb / SPS + 1) return P25FE_ERR_CAPACITY;              // worst case of an undisturbed lock, checked before any state moves
     shard_invalidate(h);
     if (int jrc = pipe_join(h, h->stream)) return jrc;
@@ -1690,7 +1721,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
     if (window == 0) window = (size_t)(64u << 20) / eb;
     window &= ~(size_t)7;                                           // every window's first sample stays 16-byte aligned
     if (window < 8192) window = 8192;
-    const size_t nb_total = p25fe_n_baseband(h->abs_iq, n);
+    const size_t nb_total = p25fe_n_baseband_h(h, h->abs_iq, n);
     if (cap < nb_total / SPS + 1) return P25FE_ERR_CAPACITY;        // worst case of an undisturbed lock, before any state moves
     if (stats) memset(stats, 0, sizeof *stats);
     for (size_t c = 0; c < C; ++c) n_dibits[c] = 0;
@@ -1797,7 +1828,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         if (k >= 2) HIPCHK(h, hipStreamWaitEvent(st, h->win_ev[(k - 2) % R][4], 0));      // window k - 2's dibit rows have left this device row block
         if (k == 0) HIPCHK(h, hipMemcpyAsync(d_anc, h_anc, C * sizeof(p25fe_anchor_t), hipMemcpyHostToDevice, st));
         HIPCHK(h, hipEventRecord(ev[2], st));
-        const size_t nb = p25fe_n_baseband(abs0, wn);
+        const size_t nb = p25fe_n_baseband_h(h, abs0, wn);
         const long view0 = (long)(h->abs_bb + nb_done) - h->look;
         p25fe_result_t* d_res = h->win_res.as<p25fe_result_t>() + (k % R) * C;
         uint8_t* d_dib = h->win_dib[b].as<uint8_t>();
@@ -1843,7 +1874,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         const char* srcc = static_cast<const char*>(iq) + c * n * eb;
         if (n >= SHARD_HALO) memcpy(hist, srcc + (n - SHARD_HALO) * eb, SHARD_HALO * eb);
         else { memmove(hist, hist + n * eb, (SHARD_HALO - n) * eb); memcpy(hist + (SHARD_HALO - n) * eb, srcc, n * eb); }
-        const size_t nb_last = p25fe_n_baseband(h->abs_iq + (n_win - 1) * window, n - (n_win - 1) * window);
+        const size_t nb_last = p25fe_n_baseband_h(h, h->abs_iq + (n_win - 1) * window, n - (n_win - 1) * window);
         float* t = h->tail_bb.data() + c * BBPAD;
         if (nb_last) {
             float merged[BBPAD];

@@ -44,7 +44,7 @@ static const char WRAPPER[] =
     "P25JIT_K1(p25jit_k1_cf32_lin, P25FE_FMT_CF32, OUT_LINEAR, Geo<5>::WAVES_PER_SIMD)\n"
     "P25JIT_K1(p25jit_k1_u8_lin, P25FE_FMT_U8, OUT_LINEAR, Geo<5>::WAVES_PER_SIMD)\n"
     "P25JIT_K1(p25jit_k1_cf32_pl, P25FE_FMT_CF32, OUT_PLANAR, P25FE_K1_PLANAR_WPS)\n"
-    "P25JIT_K1(p25jit_k1_u8_pl, P25FE_FMT_U8, OUT_PLANAR, P25FE_K1_PLANAR_WPS_U8)\n"
+    "P25JIT_K1(p25jit_k1_u8_pl, P25FE_FMT_U8, OUT_PLANAR, (P25FE_JIT_AVG_N > AVG_DPP_MAX ? 2 : P25FE_K1_PLANAR_WPS_U8))\n"
     "extern \"C\" __global__ __launch_bounds__(WV, 2) void p25jit_chunk_cf32(K1Args a, const Taps* __restrict__ t, ChunkTail c) "
     "{ chunk_body<P25FE_FMT_CF32, true, P25FE_JIT_TX>(a, t, c); }\n"
     "extern \"C\" __global__ __launch_bounds__(WV, 2) void p25jit_chunk_u8(K1Args a, const Taps* __restrict__ t, ChunkTail c) "
@@ -103,7 +103,7 @@ uint64_t spec_hash(const Spec& s)
 {
     uint64_t h = 0xcbf29ce484222325ull;
     // everything the code object depends on: the source, the options, the numbers
-    h = fnv(h, "p25fe-jit-1", 11);
+    h = fnv(h, "p25fe-jit-2", 11);
     h = fnv(h, P25FE_SRC_KERNELS, sizeof P25FE_SRC_KERNELS);
     h = fnv(h, P25FE_SRC_RECV, sizeof P25FE_SRC_RECV);
     h = fnv(h, P25FE_SRC_P25FE_H, sizeof P25FE_SRC_P25FE_H);
@@ -125,6 +125,9 @@ uint64_t spec_hash(const Spec& s)
         h = fnv(h, &s.u8_scale, sizeof s.u8_scale);
         h = fnv(h, &s.u8_offset, sizeof s.u8_offset);
     }
+    h = fnv(h, &s.n_avg, sizeof s.n_avg);
+    h = fnv(h, &s.avg_uniform, sizeof s.avg_uniform);
+    h = fnv(h, s.avg, sizeof(float) * (size_t)s.n_avg);
     return h;
 }
 
@@ -272,7 +275,7 @@ static std::string gen_header(const Spec& s)
          "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
          "typedef unsigned long size_t; typedef unsigned long uintptr_t;\n"
          "#define P25FE_JIT 1\n";
-    char b[128];
+    char b[256];
     snprintf(b, sizeof b, "#define P25FE_JIT_TX %d\n", s.tx);
     o += b;
     snprintf(b, sizeof b, "static constexpr float P25FE_JIT_DECIM_TAPS[%d] = {", s.t1);
@@ -288,7 +291,11 @@ static std::string gen_header(const Spec& s)
     put_float(o, s.u8_lut ? 0.0f : s.u8_scale);
     o += "\n#define P25FE_JIT_U8_OFFSET ";
     put_float(o, s.u8_lut ? 0.0f : s.u8_offset);
-    o += "\n";
+    snprintf(b, sizeof b, "\n#define P25FE_JIT_AVG_N %d\n#define P25FE_JIT_AVG_UNIFORM %d\nstatic constexpr float P25FE_JIT_AVG_TAPS[%d] = {", s.n_avg,
+             s.avg_uniform ? 1 : 0, s.n_avg);
+    o += b;
+    for (int k = 0; k < s.n_avg; ++k) { if (k) o += ", "; put_float(o, s.avg[k]); }
+    o += "};\n";
     return o;
 }
 

@@ -23,6 +23,8 @@ struct Spec {
     int u8_lut;             // 1: the u8 table is not affine -> LDS lookup; the VALUES come from the handle's device table, so
                             // one code object serves every such table
     float u8_scale, u8_offset;      // the affine table: byte b -> fma(b, scale, offset) (ignored when u8_lut)
+    int n_avg, avg_uniform;         // post-discriminator filter (docs/SPEC.md 3.5): taps, all-equal flag
+    float avg[64];
 };
 
 // names of the extern "C" kernels of a specialised module: [fmt 0 = cf32, 1 = u8][0 = linear, 1 = planar, 2 = chunk]

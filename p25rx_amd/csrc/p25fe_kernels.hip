@@ -46,6 +46,9 @@ template <class A, class C> struct cond<false, A, C> { using type = C; };
 #define K1_CT_U8_SCALE P25FE_JIT_U8_SCALE
 #define K1_CT_U8_OFFSET P25FE_JIT_U8_OFFSET
 #define K1_CT_U8_LUT P25FE_JIT_U8_LUT             /* 1: the u8 table is not affine -> looked up in LDS */
+#define K1_CT_AVG_N P25FE_JIT_AVG_N               /* post-discriminator filter (docs/SPEC.md 3.5): taps, */
+#define K1_CT_AVG_TAPS P25FE_JIT_AVG_TAPS
+#define K1_CT_AVG_UNIFORM P25FE_JIT_AVG_UNIFORM   /* 1: all taps equal = MovingAverage::new(n): sum, then ONE multiply */
 #else
 #define K1_CT_DECIM_TAPS P25FE_DEFAULT_DECIM_TAPS
 #define K1_CT_CHAN_TAPS P25FE_DEFAULT_CHAN_TAPS
@@ -53,6 +56,9 @@ template <class A, class C> struct cond<false, A, C> { using type = C; };
 #define K1_CT_U8_SCALE P25FE_U8_SCALE
 #define K1_CT_U8_OFFSET P25FE_U8_OFFSET
 #define K1_CT_U8_LUT 0
+#define K1_CT_AVG_N P25FE_BOXCAR
+#define K1_CT_AVG_TAPS P25FE_DEFAULT_AVG_TAPS
+#define K1_CT_AVG_UNIFORM 1
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -64,10 +70,13 @@ constexpr int WV = 64;                       // lanes per workgroup
 constexpr int DEC = P25FE_DECIM;
 constexpr int T1 = P25FE_T1;
 constexpr int T2 = P25FE_T2;
-constexpr int BOX = P25FE_BOXCAR;
-constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9])
+constexpr int BOX = P25FE_BOXCAR;            // the build's own post-discriminator filter: MovingAverage::new(10), src/demod.rs:52
+constexpr int HALO_Y = BOX;                  // y needed from m0-10 (fm needs y[m-1], boxcar needs fm[m-9]) -- with the build's own numbers;
+                                             // a kernel's own value is its T3 (frontend_body): the post-discriminator filter's length
 constexpr int HALO_D = HALO_Y + (T2 - 1);    // 50: d needed from m0-50 (the build's own tap counts; Geo<PK, 1> has its own)
 constexpr int TMAX = P25FE_MAX_TAPS;         // 64: tap-count ceiling of the ABI (p25fe_config_t), the generic kernels' geometry
+constexpr int AVG_DPP_MAX = 11;              // post-discriminator filters up to this length run in registers (DPP + SGPR carries: two
+                                             // lanes back); longer ones through an LDS window like the other FIRs
 // A segment (the consecutive sub-tiles one workgroup walks) needs, in front of its first output, the HALO_Y + (T2 - 1)
 // decimator outputs its first channel-filter / discriminator / boxcar results depend on.  Two forms, chosen per input
 // format by measurement (seg_prologue() below):
@@ -81,8 +90,10 @@ constexpr int TMAX = P25FE_MAX_TAPS;         // 64: tap-count ceiling of the ABI
 //    3 % (0.2021 - 0.2029 against 0.2075 - 0.2101 ms); the cf32 kernel, whose time follows neither its instruction count
 //    nor its bytes, LOSES 1.5 - 2 % (0.2570 - 0.2590 against 0.2519 - 0.2550 ms: the prologue's
 //    registers push it from 156 to 168 - 174 VGPRs) and keeps the halo form.
-constexpr int SEG_HALO = 80;
-static_assert(SEG_HALO >= HALO_Y + (TMAX - 1) && SEG_HALO % 80 == 0, "segment halo covers the filter memory (64 taps too) and is byte-aligned per plane");
+constexpr int SEG_HALO = 80;                 // ... with post-discriminator filters of up to 17 taps (80 >= T3 + 64 - 1); 160 beyond:
+// the halo a segment recomputes, for a post-discriminator filter of t3 taps behind a channel filter evaluated at t2 taps
+__host__ __device__ constexpr int seg_halo_for(int t3, int t2) { return t3 + t2 - 1 <= 80 ? 80 : 160; }
+static_assert(SEG_HALO == seg_halo_for(BOX, TMAX) && seg_halo_for(TMAX, TMAX) >= TMAX + TMAX - 1, "segment halo covers the filter memory and is byte-aligned per plane");
 __host__ __device__ constexpr bool seg_prologue(int fmt) { return fmt == P25FE_FMT_U8; }
 
 // Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
@@ -100,7 +111,7 @@ constexpr int PL_BLK = 32 * P25FE_SPS;       // floats per block
 __host__ __device__ inline long planar_index(long i, int r) { return (i >> 5) * PL_BLK + r * 32 + (i & 31); }
 // history (input samples before the first owned one) needed for exact results
 constexpr int HIST_IQ = DEC * HALO_D + (T1 - 1) + (DEC - 1);   // 284
-constexpr int HIST_IQ_MAX = DEC * (HALO_Y + TMAX - 1) + (TMAX - 1) + (DEC - 1);   // 432 with 64 + 64 taps
+constexpr int HIST_IQ_MAX = DEC * (TMAX + TMAX - 1) + (TMAX - 1) + (DEC - 1);   // 702 with 64 + 64 + 64 taps
 
 // PK = consecutive FIR outputs per lane (odd: lane stride 2*5*PK / 2*PK dwords -> conflict-free ds_read_b64)
 // TX = 0: the tap counts of docs/SPEC.md (31 / 41); TX = 1: the ABI's ceiling, 64 / 64, for caller-supplied tables such as
@@ -117,10 +128,11 @@ template <int PK, int TX = 0> struct Geo {
     // LDS: [d carry 40][window region XIN_N][taps].  The sub-tile's new d samples and the output transpose OVERWRITE the
     // front of the window region once the decimator has consumed it (one wave: program order), so that 11 one-wave
     // workgroups fit a CU's 160 KB instead of 9 (occupancy is what bounds the overlap of HBM, LDS and VALU work).
-    static constexpr size_t LDS_BYTES = sizeof(float2) * (D_CARRY + XIN_N) + sizeof(float) * (T1 + T2 + 3);
-    static constexpr size_t LDS_BYTES_LUT = LDS_BYTES + sizeof(float) * 256;     // + the u8 table (generic u8 kernels, non-affine specialised ones)
+    // then, as far as the kernel variant needs them (k1_lds_bytes): [taps: decimator | channel | 3 | post-discriminator TMAX + 1]
+    // (generic kernels) [u8 table 256] [fm window T3 - 1 + SUB] (post-discriminator filters longer than AVG_DPP_MAX)
+    static constexpr int TAPS_N = T1 + T2 + 3 + TMAX + 1;  // floats of the generic kernels' taps area
+    static constexpr size_t LDS_BASE = sizeof(float2) * (D_CARRY + XIN_N);
     static_assert(sizeof(float2) * XIN_N >= sizeof(float2) * SUB + sizeof(float) * SUB, "d and the transpose fit the window region");
-    static constexpr int NBACK = (BOX - 1 + PK - 1) / PK; // lanes to the left whose fm values the boxcar needs
     static constexpr int WAVES_PER_SIMD = PK <= 3 ? 4 : 2;   // register budget the kernel is compiled for (128 / 256 VGPRs)
 };
 
@@ -131,8 +143,16 @@ struct Taps {
     float ch[TMAX];
     float lut[256];         // rtlsdr_iq::IQ as one byte -> float table (src/demod.rs:83); I and Q alike
     float fm_gain;          // FmDemod's output scale (src/demod.rs:54)
-    float pad_[3];
+    int n_avg;              // post-discriminator filter (MovingAverage::new(10), src/demod.rs:52; docs/SPEC.md 3.5): taps in use,
+    int avg_uniform;        // 1: all of them equal -> sum newest first, then one multiply by avg[0]; 0: fma chain in tap order
+    float pad_;
+    float avg[TMAX];
 };
+// dynamic LDS of a K1 workgroup (host and kernel agree through this one formula)
+template <class G> __host__ __device__ constexpr size_t k1_lds_bytes(bool ct, bool lut, int t3)
+{
+    return G::LDS_BASE + sizeof(float) * (size_t)((ct ? 0 : G::TAPS_N) + (lut ? 256 : 0) + (t3 > AVG_DPP_MAX || !ct ? t3 - 1 + G::SUB : 0));
+}
 
 // SPEC 3.4: polynomial atan2, identical operation sequence to the oracle's restatement.
 __device__ __forceinline__ float spec_atan2f(float y, float x)
@@ -561,7 +581,7 @@ struct K1Args {
     long m_begin;           // first output to produce (<= 0: also outputs that lie in the history)
     float* power_partial;   // nullable: [n_channels][seg_count] partial sums of |y|^2
     // OUT_PLANAR only (bb unused): polyphase baseband + sign planes, see PLPAD.  Prologue form: m_begin + pl_shift >= 0 and a
-    // multiple of 320 (every sub-tile is one block of the layout); halo form: m_begin + pl_shift >= SEG_HALO, a multiple
+    // multiple of 320 (every sub-tile is one block of the layout); halo form: m_begin + pl_shift >= 0, a multiple
     // of 80, and a segment length that is a multiple of 80.
     float* bbp;             // channel 0
     long bbp_ch_stride;     // floats per channel (a whole number of blocks)
@@ -578,6 +598,8 @@ struct K1Args {
     // outputs that depend on the halo, launched on their own after it has arrived -- is then two or three one-sub-tile
     // workgroups side by side (~6 us) instead of one workgroup walking a whole segment alone (15 - 45 us).
     int lead_segs;
+    int seg_halo;           // generic kernels, halo form: outputs a segment recomputes in front of its first one (seg_halo_for; the
+                            // immediate-coefficient kernels know theirs at compile time)
 };
 
 // CT = true: the handle's taps are the build's default tables (p25fe_spec.h) -> immediates, no
@@ -646,14 +668,22 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     using G = Geo<PK, TX>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
-    constexpr int NBACK = G::NBACK;
     constexpr int T1 = G::T1, T2 = G::T2, D_CARRY = G::D_CARRY;      // this instantiation's tap counts (shadow the build's)
+    // Post-discriminator filter (src/demod.rs:31, 52, 114; docs/SPEC.md 3.5).  T3 = its length as far as the GEOMETRY goes: the
+    // handle's own for the immediate-coefficient kernels, the ABI's ceiling for the generic ones (n_avg at run time).  Up to
+    // AVG_DPP_MAX taps it runs in registers (DPP, SGPR carries); longer filters through an LDS window of fm values.
+    constexpr int T3 = CT ? K1_CT_AVG_N : TMAX;
+    constexpr bool AVG_DPP = CT && T3 <= AVG_DPP_MAX;
+    constexpr int HY = T3;                                          // channel outputs needed in front of a segment's first output
+    constexpr int NBACK = AVG_DPP ? ((T3 - 1 + PK - 1) / PK > 0 ? (T3 - 1 + PK - 1) / PK : 1) : 1;   // lanes to the left whose fm values the filter needs
+    static_assert(T3 >= 1 && T3 <= TMAX && NBACK <= 3, "post-discriminator filter length");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* D = reinterpret_cast<float2*>(smem);                    // [D_CARRY | SUB]: the SUB part aliases the window region (register loader)
     float2* XIN = D + D_CARRY;                                      // 16-B aligned: staged with ds_write_b128
     float* OUT = reinterpret_cast<float*>(D + G::D_N);              // [SUB] output transpose: inside the window region
-    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // [T1 | T2 | 3 | u8 table 256]: taps only when !CT, table only when LUTM
-    float* const LUT = TAPS + (T1 + T2 + 3);
+    float* TAPS = reinterpret_cast<float*>(D + D_CARRY + G::XIN_N); // generic kernels only: [T1 | T2 | 3 | post-discriminator TMAX + 1]
+    float* const LUT = TAPS + (CT ? 0 : G::TAPS_N);                 // [256] u8 table, when LUTM
+    float* const AVT = TAPS + (T1 + T2 + 3);                        // generic kernels: the post-discriminator taps
     // u8 -> float: arithmetic with immediate constants (CT, affine table) or a table in LDS (the generic kernels always:
     // one code path for every table; a specialised build only when its table is not affine)
     constexpr bool LUTM = FMT == P25FE_FMT_U8 && (!CT || K1_CT_U8_LUT != 0);
@@ -661,18 +691,27 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     if (!CT) {
         for (int k = tid; k < T1; k += WV) TAPS[k] = gtaps->dec[k];
         for (int k = tid; k < T2; k += WV) TAPS[T1 + k] = gtaps->ch[k];
+        for (int k = tid; k < TMAX; k += WV) AVT[k] = gtaps->avg[k];
     }
     if constexpr (LUTM)
         for (int k = tid; k < 256; k += WV) LUT[k] = gtaps->lut[k];
+    float* const FM = LUT + (FMT == P25FE_FMT_U8 && (!CT || K1_CT_U8_LUT != 0) ? 256 : 0);   // [T3 - 1 | SUB] fm window, when !AVG_DPP
     float fm_gain = K1_CT_FM_GAIN;
-    if constexpr (!CT) fm_gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gtaps->fm_gain)));
+    int n_avg = T3, avg_uniform = K1_CT_AVG_UNIFORM;               // run-time values of the generic kernels
+    if constexpr (!CT) {
+        fm_gain = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(gtaps->fm_gain)));
+        n_avg = __builtin_amdgcn_readfirstlane(gtaps->n_avg);
+        avg_uniform = __builtin_amdgcn_readfirstlane(gtaps->avg_uniform);
+    }
+    // segment halo of the halo form (cf32): 80 outputs, 160 when the two filters behind the decimator remember more than that
+    const int SEGH = CT ? seg_halo_for(T3, T2) : a.seg_halo;
     auto tap_dec = [&](int k) -> float { return CT ? K1_CT_DECIM_TAPS[k] : TAPS[k]; };
     auto tap_ch = [&](int k) -> float { return CT ? K1_CT_CHAN_TAPS[k] : TAPS[T1 + k]; };
 
     constexpr bool PRO = seg_prologue(FMT);                         // segment prologue (u8) or recomputed halo (cf32), see SEG_HALO
-    const long seg_len = PRO ? (long)a.subs_per_seg * SUB : (long)(SUB - SEG_HALO) + (long)(a.subs_per_seg - 1) * SUB;
+    const long seg_len = PRO ? (long)a.subs_per_seg * SUB : (long)(SUB - SEGH) + (long)(a.subs_per_seg - 1) * SUB;
     // segment prologue: the ND decimator outputs in front of the segment, from a window of PWIN input samples
-    constexpr int ND = HALO_Y + (T2 - 1);                           // 50 (73 with 64-tap tables)
+    constexpr int ND = HY + (T2 - 1);                               // 50 with the build's numbers
     constexpr int PWIN = DEC * (ND - 1) + T1;                       // 276 (424)
     constexpr int NVP = (PWIN + 2 + 2 * WV - 1) / (2 * WV);         // 16-B vectors per lane: 3 (4)
     constexpr int PBASE = 2 * WV * NVP;                             // the d's are parked behind the staged prologue window
@@ -700,7 +739,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     const long seg_rel = grid2d ? (long)blockIdx.x : item - (long)ch * a.seg_count;
     const long seg = seg_rel + a.seg_first;
     const bool lead = seg < (long)a.lead_segs;                      // uniform
-    constexpr long LEAD_LEN = PRO ? (long)SUB : (long)(SUB - SEG_HALO);
+    const long LEAD_LEN = PRO ? (long)SUB : (long)(SUB - SEGH);
     const long this_len = lead ? LEAD_LEN : seg_len;
     const int subs_this = lead ? 1 : a.subs_per_seg;
     const long m_seg0 = a.m_begin + (lead ? seg * LEAD_LEN : (long)a.lead_segs * LEAD_LEN + (seg - a.lead_segs) * seg_len);
@@ -713,7 +752,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     using LoaderT = Loader<FMT, PK, TX>;
     using LoaderP = Loader<FMT, PK, TX, NVP>;
     LoaderT ld0, ld1;
-    long dlo = PRO ? m_seg0 : m_seg0 - SEG_HALO;                   // first d index of this sub-tile
+    long dlo = PRO ? m_seg0 : m_seg0 - SEGH;                       // first d index of this sub-tile
     const long i_last = (long)a.o0 + DEC * (m_seg1 - 1);          // newest input sample this segment needs
     float pw = 0.f;
     // context carried across sub-tiles in wave-uniform registers: the last channel output and the
@@ -721,8 +760,10 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     float2 y_carry = make_float2(0.f, 0.f);
     float f_carry[NBACK][P];
     if constexpr (!PRO) {
-        // halo form: zero carries; the first sub-tile's first SEG_HALO outputs absorb the filters' start-up and are dropped
+        // halo form: zero carries; the first sub-tile's first SEGH outputs absorb the filters' start-up and are dropped
         for (int k = tid; k < D_CARRY; k += WV) D[k] = make_float2(0.f, 0.f);
+        if constexpr (!AVG_DPP)
+            for (int k = tid; k < T3 - 1; k += WV) FM[k] = 0.f;
         ld0.init(xb, (long)a.o0 + DEC * dlo - (T1 - 1), a.n_hist, a.n_new, i_last);
         ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
         if constexpr (PF == 2) {
@@ -775,8 +816,8 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         }
         phase_sync();
         v2f yv = v2f{0.f, 0.f};
-        if (tid < HALO_Y) {
-            const float2* w = PD_ + (ND - HALO_Y) - (T2 - 1) + tid; // d[m - k] = w[T2 - 1 - k] for m = m_seg0 - 10 + tid
+        if (tid < HY) {
+            const float2* w = PD_ + (ND - HY) - (T2 - 1) + tid;     // d[m - k] = w[T2 - 1 - k] for m = m_seg0 - HY + tid
             lds_walk<T2, CT>(w, [&](auto jc, v2f sv) {
                 constexpr int j = decltype(jc)::value;
                 yv = cfma(tap_ch(T2 - 1 - j), sv, yv);
@@ -785,18 +826,20 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         float2 yp;
         yp.x = wave_shr1(yv.x, 0.f);
         yp.y = wave_shr1(yv.y, 0.f);
-        const float fmv = fm_discriminate(make_float2(yv.x, yv.y), yp, fm_gain);     // lane l: fm[m_seg0 - 10 + l], l = 1..9 (lane 0: unused)
-        y_carry.x = lane_bcast<HALO_Y - 1>(yv.x);
-        y_carry.y = lane_bcast<HALO_Y - 1>(yv.y);
+        const float fmv = fm_discriminate(make_float2(yv.x, yv.y), yp, fm_gain);     // lane l: fm[m_seg0 - HY + l], l = 1..HY-1 (lane 0: unused)
+        y_carry.x = lane_bcast<HY - 1>(yv.x);
+        y_carry.y = lane_bcast<HY - 1>(yv.y);
         static_for<0, NBACK>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             static_for<0, P>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
-                constexpr int l = HALO_Y - (b + 1) * P + p;          // f_carry[b][p] = fm of lane 63 - b, output p, of the sub-tile before
-                if constexpr (l >= 1) f_carry[b][p] = lane_bcast<l>(fmv);
-                else f_carry[b][p] = 0.f;                            // further back than the boxcar reaches
+                constexpr int l = HY - (b + 1) * P + p;              // f_carry[b][p] = fm of lane 63 - b, output p, of the sub-tile before
+                if constexpr (AVG_DPP && l >= 1) f_carry[b][p] = lane_bcast<l>(fmv);
+                else f_carry[b][p] = 0.f;                            // further back than the filter reaches
             });
         });
+        if constexpr (!AVG_DPP)
+            if (tid >= 1 && tid < HY) FM[tid - 1] = fmv;             // the fm window's history: fm[m_seg0 - (T3 - 1) .. m_seg0)
         for (int k = tid; k < D_CARRY; k += WV) D[k] = PD_[ND - D_CARRY + k];
         phase_sync();
     }
@@ -843,7 +886,8 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             if (tid < SPS_ && out_rel >= 0 && out_rel < seg_n)
                 reinterpret_cast<unsigned*>(bits_ch)[(size_t)blk * SPS_ + tid] = bitsv;
             } else {
-            const int i_sub = i_seg + out_rel / SPS_;               // symbol index of the sub-tile (multiple of 8, >= 0)
+            const int i_sub = i_seg + out_rel / SPS_;               // symbol index of the sub-tile (multiple of 8; negative only for
+                                                                    // recomputed-halo outputs in front of the range, which r >= 0 below keeps from being stored)
             const int i = i_sub + pl_sym;
             float* const row = bbp_ch + (size_t)(i >> 5) * PL_BLK + (i & 31) + 32 * pl_h5;
 #pragma unroll
@@ -1011,7 +1055,10 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         for (int p = 0; p < P; ++p) asm volatile("" ::"v"(f[p]));
         return true;
 #endif
-        // ---- stage 5: boxcar (src/demod.rs:114): b[m] = (fm[m] + fm[m-1] + ... + fm[m-9]) / 10, newest first.
+        // ---- stage 5: post-discriminator filter (src/demod.rs:114; docs/SPEC.md 3.5).  The reference's is MovingAverage::new(10):
+        // b[m] = (fm[m] + fm[m-1] + ... + fm[m-9]) * 0.1, summed newest first -- the rule for every table whose taps are all
+        // equal; any other table is a FIR like the two before it: acc = +0, acc = fma(h[k], fm[m - k], acc) in tap order.
+        if constexpr (AVG_DPP) {
         // fm[P tid + p - j] lives in this lane (q = p - j >= 0) or in lane - b, b = ceil(-q / P): prevf[b-1][q + b P].
         {
             float prevf[NBACK][P];
@@ -1021,23 +1068,29 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             for (int b = 1; b < NBACK; ++b)
 #pragma unroll
                 for (int p = 0; p < P; ++p) prevf[b][p] = wave_shr1(prevf[b - 1][p], f_carry[b][p]);
+            auto fm_back = [&](int p, int j) -> float {              // fm[P tid + p - j]
+                const int q = p - j;
+                if (q >= 0) return f[q];
+                const int b = (-q + P - 1) / P;                     // 1 .. NBACK
+                return prevf[b - 1][q + b * P];
+            };
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                float acc = f[p];
+                float acc;
+                if constexpr (K1_CT_AVG_UNIFORM) {
+                    acc = f[p];
 #pragma unroll
-                for (int j = 1; j < BOX; ++j) {
-                    const int q = p - j;
-                    if (q >= 0) {
-                        acc = acc + f[q];
-                    } else {
-                        const int b = (-q + P - 1) / P;             // 1 .. NBACK
-                        acc = acc + prevf[b - 1][q + b * P];
-                    }
+                    for (int j = 1; j < T3; ++j) acc = acc + fm_back(p, j);
+                    acc = acc * K1_CT_AVG_TAPS[0];
+                } else {
+                    acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < T3; ++j) acc = __builtin_fmaf(K1_CT_AVG_TAPS[j], fm_back(p, j), acc);
                 }
 #if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
                 asm volatile("" ::"v"(acc));
 #else
-                OUT[P * tid + p] = acc * P25FE_BOXCAR_SCALE;        // lane stride P dwords (odd): conflict-free
+                OUT[P * tid + p] = acc;                             // lane stride P dwords (odd): conflict-free
 #endif
             }
             // next sub-tile's lane 0 / 1 / ... read these: lane 63 is one lane back, lane 62 two, ...
@@ -1047,6 +1100,70 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
                 if constexpr (NBACK >= 2) f_carry[1][p] = lane_bcast<WV - 2>(f[p]);
                 f_carry[0][p] = lane_bcast<WV - 1>(f[p]);
             }
+        }
+        } else {
+            // longer filters (and the generic kernels, whose length is a run-time number): the sub-tile's fm values go behind
+            // the T3 - 1 carried ones in LDS, every lane walks the window of its P outputs (lane stride P dwords: conflict-free)
+#pragma unroll
+            for (int p = 0; p < P; ++p) FM[(T3 - 1) + P * tid + p] = f[p];
+            phase_sync();
+            const float* w = FM + (T3 - 1) + P * tid;                // w[p - k] = fm[m - k] for the lane's output p
+            float acc[P];
+            if constexpr (CT) {
+                // one window value per step: v = fm[m0 + P - 1 - i] feeds output p at tap j = p + i - (P - 1); a scheduling
+                // barrier every 8 steps keeps the compiler from hoisting all T3 + P - 1 reads (and their registers) to the top
+                if constexpr (K1_CT_AVG_UNIFORM) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = 0.f;
+                    static_for<0, T3 + P - 1>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const float v = w[(P - 1) - i];
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            const int j = p + i - (P - 1);
+                            if (j == 0) acc[p] = v;                 // the newest sample starts the sum (SPEC 3.5: no +0 in front)
+                            else if (j > 0 && j < T3) acc[p] = acc[p] + v;
+                        }
+                        if constexpr (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                    });
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = acc[p] * K1_CT_AVG_TAPS[0];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = 0.f;
+                    static_for<0, T3 + P - 1>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const float v = w[(P - 1) - i];
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            const int j = p + i - (P - 1);
+                            if (j >= 0 && j < T3) acc[p] = __builtin_fmaf(K1_CT_AVG_TAPS[j], v, acc[p]);
+                        }
+                        if constexpr (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+            } else if (avg_uniform) {                               // uniform: the handle's numbers
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = w[p];
+                for (int j = 1; j < n_avg; ++j)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = acc[p] + w[p - j];
+                const float sc = AVT[0];
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = acc[p] * sc;
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = 0.f;
+                for (int j = 0; j < n_avg; ++j) {
+                    const float hj = AVT[j];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = __builtin_fmaf(hj, w[p - j], acc[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) OUT[P * tid + p] = acc[p];
+            phase_sync();                                           // every lane's window reads precede the carry's rewrite
+            for (int k = tid; k < T3 - 1; k += WV) FM[k] = FM[SUB + k];
         }
 #if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
         return true;

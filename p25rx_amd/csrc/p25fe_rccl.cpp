@@ -131,8 +131,8 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
     size_t bbmax = 0;
     try {                                                           // no exception crosses the C boundary
         for (int r = 0; r < world; ++r) {
-            s->bb0.push_back(p25fe_n_baseband(0, (size_t)r * n_per_rank));
-            s->bbn.push_back(p25fe_n_baseband((uint64_t)r * n_per_rank, n_per_rank));
+            s->bb0.push_back(p25fe_n_baseband_h(h, 0, (size_t)r * n_per_rank));
+            s->bbn.push_back(p25fe_n_baseband_h(h, (uint64_t)r * n_per_rank, n_per_rank));
             if (s->bbn.back() > bbmax) bbmax = (size_t)s->bbn.back();
         }
     } catch (...) {

@@ -21,7 +21,8 @@ def _p(a):
 class FrontEnd:
     def __init__(self, n_channels=1, device=0, decim_taps=None, chan_taps=None, symbol_clock=0, **spec):
         """spec: the other p25fe_config_t fields by name (specialize, fm_deviation_hz, fm_sample_rate_hz, fm_gain, u8_scale,
-        u8_offset, u8_lut) -- the run-time arguments of the reference's constructors (src/demod.rs:54, 83)."""
+        u8_offset, u8_lut, decim_phase, avg_taps) -- the run-time arguments of the reference's constructors
+        (src/demod.rs:50, 52, 54, 83)."""
         self.L = _lib.load()
         # symbol_clock 0: fixed stride (the reference's receiver), 1: SPEC 3.8b
         cfg = _lib.make_config(n_channels=n_channels, device=device, decim_taps=decim_taps, chan_taps=chan_taps,
@@ -239,7 +240,7 @@ class FrontEnd:
         import torch
         fmt, n_total, stride = self._iq_view(iq)
         n = n_total - offset
-        nb = self.L.p25fe_n_baseband(abs0, n)
+        nb = self.L.p25fe_n_baseband_h(self.h, abs0, n)
         if bb is None:
             bb = torch.empty((self.C, (nb + 7) // 4 * 4), dtype=torch.float32, device=iq.device)
         pw = torch.empty(self.C, dtype=torch.float32, device=iq.device) if want_power else None
@@ -341,6 +342,10 @@ class FrontEnd:
         n = C.c_uint64(0)
         self._chk(self.L.p25fe_profile_read(self.h, C.byref(ms), C.byref(n)))
         return [ms[i] for i in range(4)], n.value
+
+    def n_baseband(self, abs0, n):
+        """baseband samples n input samples from absolute index abs0 give, with THIS handle's decimator phase"""
+        return int(self.L.p25fe_n_baseband_h(self.h, abs0, n))
 
     def shard_halo(self):
         return self.L.p25fe_shard_halo()

@@ -127,7 +127,8 @@ class TimeShard:
         self.comm_events = None          # bench: list that receives (phase, start event, end event) per exchange of a step
         self.halo = int(fe.shard_halo())
         self.abs0 = rank * n_per_rank
-        from .frontend import n_baseband
+        from .frontend import n_baseband as _nb_default
+        n_baseband = getattr(fe, "n_baseband", _nb_default)      # (the handle's own decimator phase; test doubles have none)
         self.bb0 = [n_baseband(0, r * n_per_rank) for r in range(world)]
         self.bbn = [n_baseband(r * n_per_rank, n_per_rank) for r in range(world)]
         # per-shard dibit buffer (gather granule): n / 10 plus proportional slack -- a receiver that re-anchors on every sync

@@ -64,13 +64,20 @@ def scene(seed):
     s["u8tab"] = int(rng.choice([0, 0, 0, 1, 2, 3]))         # 0: fma(b, 2/255, -1), 1: (b - 127) / 128 as scale / offset,
     #                                                          2: correctly rounded (b - 127.5) / 127.5 as a TABLE (not affine), 3: a random monotone table
     s["kernels"] = int(rng.choice([0, 0, 0, 0, 0, 1]))       # 1: kernels specialised for the scene's numbers (hipRTC: seconds per scene)
+    # ABI 5 (drawn after everything above, for the same reason): MovingAverage::new(10) as a table, Decimator::new(5)'s phase
+    s["avg"] = int(rng.choice([0, 0, 0, 0, 1, 2, 3]))        # 0: ten taps of 0.1, 1: another moving average, 2: random <= 11 taps, 3: random 12 .. 64 taps
+    s["phase"] = int(rng.choice([4, 4, 4, 0, 1, 2, 3]))
     return s, rng
 
 
 def run_scene(seed, O, FE, torch, verbose=False):
     from p25rx_amd import c4fm
-    from p25rx_amd.frontend import parse_results, n_baseband
+    from p25rx_amd.frontend import parse_results
     s, rng = scene(seed)
+
+    def n_baseband(a, n, ph=s["phase"]):                            # docs/SPEC.md 3.2 with the scene's decimator phase
+        o0 = (ph + 5 - a % 5) % 5
+        return (n - o0 - 1) // 5 + 1 if n > o0 else 0
     Cn = s["channels"]
     n_iq = int(round(s["seconds"] * 240000)) // 8 * 8
     if s["cut"]:
@@ -107,6 +114,15 @@ def run_scene(seed, O, FE, torch, verbose=False):
         xkw["u8_lut"] = ((np.arange(256, dtype=np.float64) - 127.5) / 127.5).astype(np.float32)
     elif s["u8tab"] == 3:
         xkw["u8_lut"] = (np.cumsum(rng.uniform(0.0, 0.016, 256)) - 1.0).astype(np.float32)
+    if s["avg"] == 1:
+        L = int(rng.integers(1, 33))
+        xkw["avg_taps"] = [float(np.float32(1.0 / L))] * L
+    elif s["avg"] == 2:
+        xkw["avg_taps"] = random_taps(rng, int(rng.integers(2, 12)))
+    elif s["avg"] == 3:
+        xkw["avg_taps"] = random_taps(rng, int(rng.integers(12, 65)))
+    if s["phase"] != 4:
+        xkw["decim_phase"] = s["phase"]
     cfg = O.make_config(decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"], **xkw)
     fkw = dict(xkw)
     if s["kernels"] == 1:

@@ -242,7 +242,8 @@ def padded_tables(spec, decim_taps=None, chan_taps=None):
     return h1, h2
 
 
-def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None, fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None):
+def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None, fm_gain=None, u8_scale=None, u8_offset=None, u8_lut=None,
+          decim_phase=None, avg_taps=None):
     """48 kHz baseband of a whole capture (SPEC 3.1 - 3.5; the build's own numbers unless others are given: the same
     keywords as p25fe_config_t -- fm_gain is the resolved output scale)"""
     if u8 is not None:
@@ -257,7 +258,8 @@ def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None, fm_gain=None,
         xr, xi = z.real.astype(F), z.imag.astype(F)
     h1, h2 = padded_tables(spec, decim_taps, chan_taps)
     dec = int(spec["decim"])
-    dr, di = _fir(xr, h1, dec, dec - 1), _fir(xi, h1, dec, dec - 1)
+    ph = int(spec.get("decim_phase", dec - 1) if decim_phase is None else decim_phase)    # SPEC 3.2: output m from input 5 m + phase
+    dr, di = _fir(xr, h1, dec, ph), _fir(xi, h1, dec, ph)
     yr, yi = _fir(dr, h2, 1, 0), _fir(di, h2, 1, 0)
     pr, pi_ = np.concatenate([[F(0)], yr[:-1]]), np.concatenate([[F(0)], yi[:-1]])        # y[m - 1], y[-1] = 0
     t = (yi * pi_).astype(F)
@@ -266,11 +268,16 @@ def demod(spec, iq=None, u8=None, decim_taps=None, chan_taps=None, fm_gain=None,
     im = fma(yi, pr, -u)
     fmv = (atan2s(spec, im, re) * F(spec["fm_gain"] if fm_gain is None else fm_gain)).astype(F)
     n = len(fmv)
-    fp = np.concatenate([np.zeros(int(spec["boxcar_len"]), dtype=F), fmv])
+    # SPEC 3.5: a table of equal taps is a moving average (summed newest first, one multiply); any other table a FIR
+    h3 = np.asarray([spec["boxcar_scale"]] * int(spec["boxcar_len"]) if avg_taps is None else avg_taps, dtype=F)
+    if len(set(h3.view(np.uint32).tolist())) > 1:
+        return _fir(fmv, list(h3), 1, 0)
+    L = len(h3)
+    fp = np.concatenate([np.zeros(L, dtype=F), fmv])
     acc = fmv.copy()
-    for j in range(1, int(spec["boxcar_len"])):
-        acc = (acc + fp[int(spec["boxcar_len"]) - j:int(spec["boxcar_len"]) - j + n]).astype(F)
-    return (acc * F(spec["boxcar_scale"])).astype(F)
+    for j in range(1, L):
+        acc = (acc + fp[L - j:L - j + n]).astype(F)
+    return (acc * h3[0]).astype(F)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -66,7 +66,16 @@ def test_rust_binding_file_declares_the_whole_abi(lib):
 
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
-    assert cfg.abi_version == lib.ABI_VERSION == 4 and cfg.n_channels == 1 and cfg.symbol_clock == 0
+    assert cfg.abi_version == lib.ABI_VERSION == 5 and cfg.n_channels == 1 and cfg.symbol_clock == 0
+    # ABI 5: Decimator::new(5)'s phase and MovingAverage::new(10) as a table (src/demod.rs:50, 52) default to the build's numbers
+    assert cfg.decim_phase == spec["decim_phase"] == 4 and cfg.n_avg_taps == spec["boxcar_len"] == 10
+    assert np.array_equal(np.array(cfg.avg_taps[:10], dtype=np.float32), np.array(spec["avg_taps"], dtype=np.float32))
+    assert all(np.float32(v) == np.float32(spec["boxcar_scale"]) for v in spec["avg_taps"])
+    for bad in (dict(decim_phase=5), dict(decim_phase=-1), dict(avg_taps=[]), dict(avg_taps=[0.1] * 65), dict(avg_taps=[float("nan")])):
+        with pytest.raises(lib.P25feError) as e:
+            lib.probe_variant(lib.make_config(**bad))
+        assert e.value.status == lib.ERR_ARG
+    assert lib.probe_variant(lib.make_config(decim_phase=0)) == lib.VARIANT_BUILTIN      # the phase is the host's: the built-in kernels
     # ABI 4: the run-time arguments of the reference's constructors (src/demod.rs:54, 83) default to the build's numbers
     assert cfg.fm_deviation_hz == spec["fm_deviation_hz"] == 5000 and cfg.fm_sample_rate_hz == spec["fm_sample_rate_hz"] == 48000
     assert cfg.fm_gain == 0.0 and cfg.specialize == lib.SPECIALIZE_AUTO and cfg.u8_lut_valid == 0
@@ -107,27 +116,31 @@ def test_specialize_compiles_without_a_gpu_and_caches(lib, tmp_path):
             lib.make_config(decim_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
                             chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
                             u8_lut=np.tanh((np.arange(256) - 127.5) / 90.0), fm_deviation_hz=4000),
-            lib.make_config(u8_lut=lut)]
-    out = [None] * 3
+            lib.make_config(u8_lut=lut),
+            # ABI 5: a 64-tap post-discriminator filter behind 64 / 64 tables (the fm window in LDS, a 160-output segment halo)
+            lib.make_config(decim_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
+                            chan_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)),
+                            avg_taps=list((rng.standard_normal(64) * 0.1).astype(np.float32)), decim_phase=2)]
+    out = [None] * 4
 
     def work(i):
         try:
             out[i] = lib.specialize(cfgs[i], d)
         except Exception as e:                                      # noqa: BLE001 -- reported by the assert below
             out[i] = e
-    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
     for t in th:
         t.start()
     for t in th:
         t.join()
     assert all(isinstance(o, str) and o for o in out), out
-    f1, f64, fa = out
-    assert len({f1, f64, fa}) == 3
+    f1, f64, fa, f5 = out
+    assert len({f1, f64, fa, f5}) == 4
     assert os.path.dirname(f1) == d and re.fullmatch(r"p25fe-[0-9a-f]{16}\.hsaco", os.path.basename(f1))
     t1 = os.path.getmtime(f1)
     assert lib.specialize(cfg, d) == f1 and os.path.getmtime(f1) == t1  # second call: found, not rebuilt
     want = {"p25jit_k1_cf32_lin", "p25jit_k1_u8_lin", "p25jit_k1_cf32_pl", "p25jit_k1_u8_pl", "p25jit_chunk_cf32", "p25jit_chunk_u8"}
-    for f in (f1, f64, fa):
+    for f in (f1, f64, fa, f5):
         k = _hsaco_kernels(f)
         assert set(k) == want, set(k) ^ want
         assert all(s_ == 0 for _, s_ in k.values()), k                 # ScratchSize 0 everywhere
@@ -139,7 +152,7 @@ def test_specialize_compiles_without_a_gpu_and_caches(lib, tmp_path):
             lib.specialize(lib.make_config(**bad), d)
         assert e.value.status == lib.ERR_ARG
     old = lib.default_config()
-    old.abi_version = 3
+    old.abi_version = 4
     with pytest.raises(lib.P25feError):
         lib.specialize(old, d)
 

@@ -231,3 +231,89 @@ def test_auto_mode_is_the_production_default_and_degrades_loudly(lib, tmp_path):
     assert d["bb"] and d["dib"]
     if os.geteuid() != 0:                                           # (root writes through a 0500 directory)
         assert d["variant"] == lib.VARIANT_SPECIALIZED and "used from memory" in d["log"] and os.listdir(ro) == []
+
+
+def _abi5_cases(spec):
+    rng = np.random.default_rng(2024)
+    r = lambda n: (rng.standard_normal(n) / 8).astype(np.float32).tolist()
+    return {
+        # name: (config keywords, which kernels may run it)
+        "rc41_phase2": (dict(avg_taps=spec["rc_avg_taps"], decim_phase=2), ("spec", "generic")),        # LDS window, raised cosine
+        "rand21_phase0": (dict(avg_taps=r(21), decim_phase=0), ("spec", "generic")),
+        "boxcar7_phase3": (dict(avg_taps=[float(np.float32(1.0 / 7.0))] * 7, decim_phase=3), ("spec", "generic")),   # registers, uniform
+        "rand11_phase1": (dict(avg_taps=r(11), decim_phase=1), ("spec", "generic")),                    # registers, fma chain
+        "one_tap": (dict(avg_taps=[1.0]), ("spec", "generic")),
+        "rand64_long_tables": (dict(avg_taps=r(64), decim_taps=rand_taps(rng, 64), chan_taps=rand_taps(rng, 64), decim_phase=2),
+                               ("spec", "generic")),                                                # 160-output segment halo
+        "default_avg_phase1": (dict(decim_phase=1), ("builtin",)),                                     # the phase is the host's: built-in kernels
+        "default_avg_as_a_table": (dict(avg_taps=spec["avg_taps"], decim_phase=4), ("builtin",)),
+    }
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("case", ["rc41_phase2", "rand21_phase0", "boxcar7_phase3", "rand11_phase1", "one_tap", "rand64_long_tables",
+                                  "default_avg_phase1", "default_avg_as_a_table"])
+def test_abi5_post_discriminator_filter_and_decimator_phase(O, FE, lib, case, c4fm_1s):
+    """ABI 5: MovingAverage::new(10) as a table (src/demod.rs:52, 114) and Decimator::new(5)'s phase (src/demod.rs:50, 87-90) --
+    the last two constructor numbers -- through every kernel shape (linear, planar, one-launch chunk), cf32 and u8, in the
+    kernels specialised for the numbers AND in the generic ones, bit for bit against the oracle configured the same way.
+    Ten equal taps of 0.1 and phase 4 are the build's own numbers and run the built-in kernels."""
+    spec = O.load_spec()
+    kw, runs = _abi5_cases(spec)[case]
+    iq = c4fm_1s[0][:120000]
+    for run in runs:
+        fe_kw = dict(kw)
+        if run == "spec":
+            fe_kw["specialize"] = lib.SPECIALIZE_REQUIRE
+            want = lib.VARIANT_SPECIALIZED
+        elif run == "generic":
+            fe_kw["specialize"] = lib.SPECIALIZE_OFF
+            want = lib.VARIANT_GENERIC
+        else:
+            want = lib.VARIANT_BUILTIN
+        fe = all_paths(O, FE, lib, iq, kw, fe_kw, want)
+        # a device range that starts mid-stream, its history in memory: the output count follows the handle's phase
+        import torch
+        t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+        a0, h = 40003 // 2 * 2, fe.shard_halo()
+        ref = O.Demod(O.make_config(spec, **kw)).feed_cf32(iq)
+        fe.reset()
+        bb, nb = fe.demod_dev(t[a0 - h:], n_hist=h, abs0=a0, offset=h)
+        assert nb == fe.n_baseband(a0, len(iq) - a0) and np.array_equal(bits(bb[0, :nb].cpu().numpy()), bits(ref[len(ref) - nb:]))
+
+
+def test_abi5_time_shards_with_a_decimator_phase_and_a_long_filter(O, FE, lib):
+    """Time shards with the ABI 5 numbers: the shards' baseband ranges follow the handle's decimator phase (p25fe_n_baseband_h) and
+    the halo (2 560 samples) covers a 41-tap post-discriminator filter behind the 41-tap channel filter: == one pass == oracle."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    spec = O.load_spec()
+    kw = dict(avg_taps=spec["rc_avg_taps"], decim_phase=1)
+    iq = c4fm.synth(2.0, seed=34, snr_db=22.0, frame_dibits=900)[0]
+    ocfg = O.make_config(spec, **kw)
+    ref = O.Recv(ocfg).feed(O.Demod(ocfg).feed_cf32(iq))[0]
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    for sp in (lib.SPECIALIZE_REQUIRE, lib.SPECIALIZE_OFF):
+        fes = [FE(specialize=sp, **kw) for _ in range(3)]
+        halo = fes[0].shard_halo()
+        assert halo == 2560
+        cuts = [0, 150000, 150008 + 8000, len(iq) // 8 * 8]
+        summ, bb0, bbn = [], [], []
+        for r in range(3):
+            a, b = cuts[r], cuts[r + 1]
+            h = min(a, halo)
+            fes[r].shard_pass1_main(t[a - h:b], offset=h, n_hist=h, abs0=a)
+            res = fes[r].shard_pass1_finish(t[a - h:b], offset=h, n_hist=h, abs0=a)
+            summ.append(parse_results(res)[0])
+            bb0.append(fes[r].n_baseband(0, a))
+            bbn.append(fes[r].n_baseband(a, b - a))
+        summ_t = torch.from_numpy(np.frombuffer(np.array(summ).tobytes(), dtype=np.uint8).copy()).view(3, -1).cuda()
+        d_bb0, d_bbn = torch.tensor(bb0, dtype=torch.int64, device="cuda"), torch.tensor(bbn, dtype=torch.int64, device="cuda")
+        out = []
+        for r in range(3):
+            dib, res, _, off = fes[r].shard_pass2_dev(summ_t, d_bb0, d_bbn, r, bbn[r])
+            out.append(dib[0, :int(parse_results(res)[0]["n_dibits"])].cpu().numpy())
+        got = np.concatenate(out)
+        nref = O.Recv(ocfg).feed(O.Demod(ocfg).feed_cf32(iq[:cuts[-1]]))[0]
+        assert np.array_equal(got, nref) and int(off[-1]) == len(nref)

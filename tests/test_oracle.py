@@ -375,6 +375,35 @@ def test_demod_against_an_independent_batch_model(spec, c4fm_1s, fmt):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[0]) > 1000
 
 
+@pytest.mark.parametrize("case", ["rc41_phase2", "ramp21_phase0", "boxcar7_phase3", "default_table", "one_tap"])
+def test_demod_constructor_numbers_against_the_independent_model(spec, c4fm_1s, case):
+    """ABI 5: the last two constructor numbers of DemodTask::new as data -- Decimator::new(5)'s phase (src/demod.rs:50, 87-90) and
+    MovingAverage::new(10) as a table (src/demod.rs:52, 114) -- in the oracle (streaming objects, ragged chunks) against the
+    whole-array model of the same SPEC text (3.2, 3.5): bit for bit, cf32 and u8; the default table IS the old boxcar."""
+    import spec_model
+    from p25rx_amd import c4fm
+    rng = np.random.default_rng(3)
+    kw = {"rc41_phase2": dict(avg_taps=spec["rc_avg_taps"], decim_phase=2),
+          "ramp21_phase0": dict(avg_taps=(rng.standard_normal(21) / 8).astype(np.float32).tolist(), decim_phase=0),
+          "boxcar7_phase3": dict(avg_taps=[float(np.float32(1.0 / 7.0))] * 7, decim_phase=3),
+          "default_table": dict(avg_taps=spec["avg_taps"], decim_phase=4),
+          "one_tap": dict(avg_taps=[1.0], decim_phase=1)}[case]
+    iq = c4fm_1s[0][:50003]
+    raw = c4fm.to_u8(iq)
+    d = O.Demod(O.make_config(spec, **kw))
+    got = np.concatenate([d.feed_cf32(iq[o:o + 7001]) for o in range(0, len(iq), 7001)])
+    ref = spec_model.demod(spec, iq=iq, **kw)
+    assert len(got) == len(ref) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    d8 = O.Demod(O.make_config(spec, **kw))
+    got8 = np.concatenate([d8.feed_u8(raw[o:o + 2 * 4099]) for o in range(0, len(raw), 2 * 4099)])
+    ref8 = spec_model.demod(spec, u8=raw, **kw)
+    assert np.array_equal(got8.view(np.uint32), ref8.view(np.uint32))
+    if case == "default_table":
+        assert np.array_equal(got.view(np.uint32), O.Demod().feed_cf32(iq).view(np.uint32))
+    # the number of outputs follows the phase: input 5 m + phase must exist
+    assert len(got) == (len(iq) - kw["decim_phase"] + 4) // 5
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_tracking_receiver_against_an_independent_batch_model(spec, seed):
     """SPEC 3.8b (the tracking symbol clock: period from sync word to sync word, interpolated instants, lookahead 2) the

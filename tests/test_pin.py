@@ -39,8 +39,8 @@ def compare_with_dump(d, gpu):
     kw = lp.config_kwargs(c)
     rep = {"standin": c["standin"], "decim_phase": c["decim_phase"], "n_decim": len(c["decim_taps"]), "n_chan": len(c["chan_taps"]),
            "boxcar": (c["boxcar_len"], c["boxcar_scale"]), "fm_gain": c["fm_gain"], "fm_probe_max_err": c["fm_probe_max_err"]}
-    assert c["decim_phase"] == 4, "the reference's decimator emits its first output from input %d, docs/SPEC.md 3.2 assumes 4" % c["decim_phase"]
-    assert c["boxcar_len"] == 10
+    # (ABI 5: whatever phase the reference's decimator has and whatever its MovingAverage's impulse response is travel as DATA --
+    # p25fe_config_t.decim_phase / avg_taps -- instead of being asserted equal to docs/SPEC.md's 4 and ten taps of 0.1)
     ocfg = O.make_config(None, **kw)
     # the discriminator, value by value, on the dumped pairs
     if len(c["fm_pairs"]):
@@ -101,7 +101,9 @@ def test_pin_harness_recovers_what_is_in_a_dump(standin):
     assert np.array_equal(c["chan_taps"].view(np.uint32), want_c.view(np.uint32))
     assert np.array_equal(c["u8_lut"].view(np.uint32), ((np.arange(256, dtype=np.float64) - 127.5) / 127.5).astype(np.float32).view(np.uint32))
     g = np.float32(np.float32(48000.0) / (np.float32(2.0) * np.float32(np.pi) * np.float32(5000.0)))
-    assert np.float32(c["fm_gain"]) == g and c["decim_phase"] == 4 and c["boxcar_len"] == 10
+    want_a = (np.hanning(23)[1:-1] / np.hanning(23)[1:-1].sum()).astype(np.float32)
+    assert np.float32(c["fm_gain"]) == g and c["decim_phase"] == 2 and c["boxcar_len"] == 21
+    assert np.array_equal(np.asarray(c["avg_taps"], dtype=np.float32).view(np.uint32), want_a.view(np.uint32))
     rep = compare_with_dump(standin, gpu=False)
     assert rep["baseband_bit_exact"] and rep["fm_pairs_max_err"] == 0.0
     assert rep["nid_mine"] == rep["nid_theirs"] and len(rep["nid_mine"]) >= 10 and all(x == (0x293, 0x3) for x in rep["nid_mine"])

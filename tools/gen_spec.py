@@ -125,6 +125,21 @@ def check_nid_code():
     return rows
 
 
+def rc_taps(alpha=0.2, span_symbols=4, sps=SPS):
+    """Raised-cosine pulse (roll-off alpha) over span_symbols symbols at sps samples per symbol, unity DC gain: the NON-default
+    example of a post-discriminator filter (p25fe_config_t.avg_taps) -- the 'raised-cosine matched filter' BASELINE.json's
+    north_star names.  (The reference's own receive filter is the 10-sample moving average: with C4FM's transmit shaping
+    that integrate-and-dump filter is what makes the cascade Nyquist; this table is a configuration example, not a better
+    receiver.)"""
+    n = span_symbols * sps + 1
+    t = (np.arange(n, dtype=np.float64) - (n - 1) / 2.0) / sps
+    den = 1.0 - (2.0 * alpha * t) ** 2
+    h = np.where(np.abs(den) < 1e-12, np.pi / 4.0 * np.sinc(1.0 / (2.0 * alpha)), np.sinc(t) * np.cos(np.pi * alpha * t) / np.where(np.abs(den) < 1e-12, 1.0, den))
+    h = h / h.sum()
+    h = 0.5 * (h + h[::-1])
+    return h.astype(np.float32)
+
+
 def hexf(x):
     return float(np.float32(x)).hex() + "f"
 
@@ -155,6 +170,9 @@ def main():
         "u8_scale": float(np.float32(2.0 / 255.0)), "u8_offset": -1.0,
         "fm_deviation_hz": 5000, "fm_sample_rate_hz": int(FS_BB),
         "boxcar_len": 10, "boxcar_scale": float(np.float32(0.1)),
+        # the post-discriminator filter as a TABLE (p25fe_config_t.avg_taps, ABI 5): ten equal taps = MovingAverage::new(10)
+        "avg_taps": [float(np.float32(0.1))] * 10, "decim_phase": 4,
+        "rc_avg_taps": [float(x) for x in rc_taps()],
         "sync_symbols": syms, "sync_sign_mask": sync_sign_mask,
         "sync_npos": npos, "sync_nneg": nneg,
         "sync_inv_npos": float(np.float32(1.0 / npos)),
@@ -212,6 +230,7 @@ def main():
     h.append("#define P25FE_FM_DEVIATION_HZ %d       /* src/demod.rs:54 */\n#define P25FE_FM_SAMPLE_RATE_HZ %d   /* src/consts.rs:13 */\n"
              % (spec["fm_deviation_hz"], spec["fm_sample_rate_hz"]))
     h.append("#define P25FE_BOXCAR_SCALE %s  /* 1/10 */\n" % hexf(spec["boxcar_scale"]))
+    h.append("#define P25FE_DECIM_PHASE %d     /* output m of the 5:1 decimator is produced by input 5 m + 4 (docs/SPEC.md 3.2) */\n" % spec["decim_phase"])
     h.append("#define P25FE_PI %s\n#define P25FE_HALF_PI %s\n" % (hexf(spec["pi"]), hexf(spec["half_pi"])))
     h.append("#define P25FE_NID_GEN_POLY 0x%xULL   /* octal 6331141367235453: BCH(63,16,23), TIA-102.BAAA */\n" % NID_GEN_POLY)
     h.append("#define P25FE_NID_T 11                /* correctable bit errors */\n")
@@ -224,6 +243,11 @@ def main():
     h.append(arr("P25FE_DEFAULT_CHAN_TAPS", list(chan)))
     h.append("\n")
     h.append(arr("P25FE_DEFAULT_PRE_TAPS", list(pre)))
+    h.append("\n/* post-discriminator filter (docs/SPEC.md 3.5): MovingAverage::new(10) as a table of ten equal taps */\n")
+    h.append(arr("P25FE_DEFAULT_AVG_TAPS", spec["avg_taps"]))
+    h.append("\n/* a NON-default example for p25fe_config_t.avg_taps: raised cosine, roll-off 0.2, 4 symbols at 10 samples per symbol */\n")
+    h.append("#define P25FE_RC_AVG_N %d\n" % len(spec["rc_avg_taps"]))
+    h.append(arr("P25FE_RC_AVG_TAPS", spec["rc_avg_taps"]))
     h.append("\n")
     h.append(arr("P25FE_ATAN_COEFFS", list(atc)))
     h.append("\n/* channeliser (SPEC 3.11): e^{+j 2 pi k / 192} as (cos, sin) pairs, k = 0..191 */\n")

@@ -61,6 +61,7 @@ def load_consts(path):
     nz = np.nonzero(av)[0]
     out["boxcar_len"] = int(nz[-1] + 1)
     out["boxcar_scale"] = float(av[0])
+    out["avg_taps"] = av[:nz[-1] + 1].copy()                       # the impulse response IS the table (p25fe_config_t.avg_taps, ABI 5)
     # ---- discriminator: output = angle * gain; choose the float32 gain that explains the probes best
     pr = np.asarray(raw["fm_probe"], dtype=np.int64)
     k = pr[:, 0]
@@ -81,7 +82,8 @@ def load_consts(path):
 def config_kwargs(consts):
     """keyword arguments for _lib.make_config / FrontEnd / oracle.make_config"""
     return dict(decim_taps=[float(x) for x in consts["decim_taps"]], chan_taps=[float(x) for x in consts["chan_taps"]],
-                u8_lut=np.asarray(consts["u8_lut"], dtype=np.float32), fm_gain=float(consts["fm_gain"]))
+                u8_lut=np.asarray(consts["u8_lut"], dtype=np.float32), fm_gain=float(consts["fm_gain"]),
+                decim_phase=int(consts["decim_phase"]), avg_taps=[float(x) for x in consts["avg_taps"]])
 
 
 DUID = {"VoiceHeader": 0x0, "VoiceSimpleTerminator": 0x3, "VoiceLCFrameGroup": 0x5, "TrunkingSignaling": 0x7,

@@ -39,7 +39,9 @@ def main():
         kw = dict(decim_taps=sps.firwin(37, 11000.0, window=("kaiser", 6.0), fs=240000.0).astype(np.float32).tolist(),
                   chan_taps=sps.firwin(48, 6500.0, window=("kaiser", 4.5), fs=48000.0).astype(np.float32).tolist(),
                   u8_lut=((np.arange(256, dtype=np.float64) - 127.5) / 127.5).astype(np.float32),
-                  fm_gain=float(np.float32(np.float32(48000.0) / (np.float32(2.0) * np.float32(np.pi) * np.float32(5000.0)))))
+                  fm_gain=float(np.float32(np.float32(48000.0) / (np.float32(2.0) * np.float32(np.pi) * np.float32(5000.0)))),
+                  # ABI 5: another decimator phase and a post-discriminator filter that is no moving average
+                  decim_phase=2, avg_taps=(np.hanning(23)[1:-1] / np.hanning(23)[1:-1].sum()).astype(np.float32).tolist())
     cfg = O.make_config(spec, **kw)
     lut = np.array([cfg.u8_lut[b] if cfg.u8_lut_valid else np.float32(np.float64(np.float32(b)) * np.float64(np.float32(cfg.u8_scale)) + np.float64(cfg.u8_offset))
                     for b in range(256)], dtype=np.float32)
@@ -49,14 +51,14 @@ def main():
     for p in range(10):
         x = np.zeros(640, dtype=np.complex64)
         x[p] = 1.0
-        ch, fm, bb = O.Demod(O.make_config(spec, decim_taps=kw.get("decim_taps"), chan_taps=[1.0])).feed_cf32_stages(x)
+        ch, fm, bb = O.Demod(O.make_config(spec, decim_taps=kw.get("decim_taps"), chan_taps=[1.0], decim_phase=kw.get("decim_phase"))).feed_cf32_stages(x)
         decim_imp.append(bits(ch.real))                          # channel filter = identity: the decimator's outputs
     x = np.zeros(5 * 256, dtype=np.complex64)
     x[4] = 1.0                                                   # one decimator output of exactly 1 needs a one-tap decimator
     ch, _, _ = O.Demod(O.make_config(spec, decim_taps=[1.0], chan_taps=kw.get("chan_taps"))).feed_cf32_stages(x)
     chan_imp = bits(ch.real[:256])
-    avg = np.zeros(32, dtype=np.float32)
-    avg[:spec["boxcar_len"]] = np.float32(spec["boxcar_scale"])
+    avg = np.zeros(96, dtype=np.float32)                         # the post-discriminator filter's impulse response
+    avg[:cfg.n_avg] = np.array([cfg.avg_taps[k] for k in range(cfg.n_avg)], dtype=np.float32)
     probes, pairs = [], []
     for k in range(360):
         a = 2.0 * np.pi * k / 360.0

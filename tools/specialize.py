@@ -6,7 +6,7 @@ and store the code object where a deployment's p25fe_create will find it ($P25FE
     make -C p25rx_amd/csrc spec SPEC=numbers.json [SPEC_DIR=DIR]
 
 numbers.json: any of the p25fe_config_t fields by name -- decim_taps, chan_taps (lists), fm_deviation_hz, fm_sample_rate_hz,
-fm_gain, u8_scale, u8_offset, u8_lut (256 values) -- or the consts.json of tools/pin/dump_consts.rs (recognised by its
+fm_gain, u8_scale, u8_offset, u8_lut (256 values), avg_taps (list), decim_phase -- or the consts.json of tools/pin/dump_consts.rs (recognised by its
 "chan_impulse" key: the reference's own tables, LUT and discriminator scale).
 """
 import argparse
@@ -30,7 +30,8 @@ def main():
         import load_pin
         kw = load_pin.config_kwargs(load_pin.load_consts(a.numbers))
     else:
-        allowed = ("decim_taps", "chan_taps", "fm_deviation_hz", "fm_sample_rate_hz", "fm_gain", "u8_scale", "u8_offset", "u8_lut")
+        allowed = ("decim_taps", "chan_taps", "fm_deviation_hz", "fm_sample_rate_hz", "fm_gain", "u8_scale", "u8_offset", "u8_lut", "avg_taps",
+                   "decim_phase")
         unknown = set(raw) - set(allowed)
         if unknown:
             sys.exit("unknown keys: %s (allowed: %s)" % (sorted(unknown), ", ".join(allowed)))
