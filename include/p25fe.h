@@ -244,7 +244,10 @@ int p25fe_run_cf32(p25fe_t *h, const float *iq, size_t n_samples, uint8_t *dibit
  * gives the same concatenated dibits) and leaves it ready for more.
  * iq: [C][n] channel-major.  Pinned memory (hipHostMalloc / hipHostRegister) is copied from directly; pageable memory is
  * staged through two pinned windows of the library by the calling thread.  dibits: [C][cap]; capacity as for p25fe_run_*.
- * stats (nullable): where the time went. */
+ * stats (nullable): where the time went.
+ * On an error (P25FE_ERR_CAPACITY from a window's count, P25FE_ERR_HIP) the handle's stream state has not moved -- the call
+ * can be repeated -- and nothing of the call is in flight any more, but `dibits` may already hold the dibits of earlier
+ * windows and n_dibits reads 0: treat the output buffers as undefined. */
 typedef struct p25fe_windows_stats {
     uint64_t n_windows;
     double ms_total;                     /* wall time of the call */

@@ -1741,9 +1741,15 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         for (auto& slot : h->win_ev) for (hipEvent_t& e : slot) HIPCHK(h, hipEventCreate(&e));
     }
     hipStream_t st = h->stream, cs = h->win_cs, os = h->win_os;
-    const size_t n_win = (n + window - 1) / window;
-    const size_t stride = SHARD_HALO + window + 8;                  // samples per channel row of a device window: [halo | window]
-    const size_t nb_win = window / DEC + 2;
+    // A remainder of fewer than 8 samples (it may not even yield a baseband sample) rides with the window in front of it -- every
+    // window of the pipeline then produces baseband, and the tail handed to a later p25fe_slice is always the last window's.
+    size_t n_win = (n + window - 1) / window;
+    const size_t rem = n - (n_win - 1) * window;                    // samples of the last window, 1 .. window
+    const bool fold = n_win >= 2 && rem < 8;
+    if (fold) --n_win;
+    // (the last window is then `window + rem` samples long: the + 8 of the strides below)
+    const size_t stride = SHARD_HALO + window + 8;                  // samples per channel row of a device window: [halo | window (+ < 8)]
+    const size_t nb_win = (window + 8) / DEC + 2;
     const size_t dstride = round_up(nb_win / (W + 1) + 2, 64);      // hard ceiling of a window's dibits (p25fe_slice's rule)
     int rc = ensure_slice_scratch(h, nb_win);
     if (rc) return rc;
@@ -1773,7 +1779,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         else (void)hipGetLastError();
     }
     if (!pinned)
-        for (int b = 0; b < 2; ++b) HIPCHK(h, h->win_stage[b].ensure(C * (SHARD_HALO + window) * eb));
+        for (int b = 0; b < 2; ++b) HIPCHK(h, h->win_stage[b].ensure(C * (SHARD_HALO + window + 8) * eb));
     memcpy(h_anc, h->anchor.data(), C * sizeof(p25fe_anchor_t));
     for (size_t c = 0; c < C; ++c) memcpy(h_hist + c * SHARD_HALO * eb, h->hist_iq.data() + c * SHARD_HALO * 8, SHARD_HALO * eb);
     p25fe_anchor_t* d_anc = h->win_anc.as<p25fe_anchor_t>();        // [2][C]: the carry-in of window k lives in half k & 1
@@ -1797,8 +1803,10 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         return P25FE_OK;
     };
     size_t nb_done = 0;
+// (inside the window loop an error must not return at once: copies that read the caller's capture are in flight)
+#define WINCHK(expr) if (const hipError_t e__ = (expr); e__ != hipSuccess) { h->last_hip = (int)e__; status = P25FE_ERR_HIP; break; } else (void)0
     for (size_t k = 0; k < n_win && status == P25FE_OK; ++k) {
-        const size_t off = k * window, wn = n - off < window ? n - off : window;
+        const size_t off = k * window, wn = k + 1 == n_win ? n - off : window;
         const uint64_t abs0 = h->abs_iq + off;
         const size_t n_hist = k == 0 ? (h->abs_iq < SHARD_HALO ? (size_t)h->abs_iq : SHARD_HALO) : SHARD_HALO;
         const int b = (int)(k & 1);
@@ -1807,27 +1815,27 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         // ---- copy stream: [halo | window] in ONE copy.  The halo of window k >= 1 is simply the SHARD_HALO samples in front of
         // it in the caller's capture (16 KB more per window); only window 0 takes it from the handle's history.  (A device-to-
         // device copy of the previous window's tail put a second operation between every two H2D copies: 7 - 9 % of the call.)
-        if (k >= 2) HIPCHK(h, hipStreamWaitEvent(cs, h->win_ev[(k - 2) % R][3], 0));      // the kernels of window k - 2 have read this buffer
+        if (k >= 2) { WINCHK(hipStreamWaitEvent(cs, h->win_ev[(k - 2) % R][3], 0)); }      // the kernels of window k - 2 have read this buffer
         const size_t lead = k == 0 ? 0 : SHARD_HALO;                // samples in front of the window that travel with it
-        if (k == 0) HIPCHK(h, hipMemcpy2DAsync(dev, stride * eb, h_hist, SHARD_HALO * eb, SHARD_HALO * eb, C, hipMemcpyHostToDevice, cs));
+        if (k == 0) { WINCHK(hipMemcpy2DAsync(dev, stride * eb, h_hist, SHARD_HALO * eb, SHARD_HALO * eb, C, hipMemcpyHostToDevice, cs)); }
         const char* src = static_cast<const char*>(iq) + (off - lead) * eb;
         size_t spitch = n * eb;
         if (!pinned) {
-            if (k >= 2) HIPCHK(h, hipEventSynchronize(h->win_ev[(k - 2) % R][1]));       // the copy engine is done with this staging window
+            if (k >= 2) { WINCHK(hipEventSynchronize(h->win_ev[(k - 2) % R][1])); }       // the copy engine is done with this staging window
             char* sg = static_cast<char*>(h->win_stage[b].p);
             for (size_t c = 0; c < C; ++c) memcpy(sg + c * (lead + wn) * eb, src + c * n * eb, (lead + wn) * eb);
             src = sg; spitch = (lead + wn) * eb;
         }
         char* dst = dev + (SHARD_HALO - lead) * eb;
-        HIPCHK(h, hipEventRecord(ev[0], cs));
-        if (C == 1) HIPCHK(h, hipMemcpyAsync(dst, src, (lead + wn) * eb, hipMemcpyHostToDevice, cs));
-        else HIPCHK(h, hipMemcpy2DAsync(dst, stride * eb, src, spitch, (lead + wn) * eb, C, hipMemcpyHostToDevice, cs));
-        HIPCHK(h, hipEventRecord(ev[1], cs));
+        WINCHK(hipEventRecord(ev[0], cs));
+        if (C == 1) { WINCHK(hipMemcpyAsync(dst, src, (lead + wn) * eb, hipMemcpyHostToDevice, cs)); }
+        else { WINCHK(hipMemcpy2DAsync(dst, stride * eb, src, spitch, (lead + wn) * eb, C, hipMemcpyHostToDevice, cs)); }
+        WINCHK(hipEventRecord(ev[1], cs));
         // ---- compute stream
-        HIPCHK(h, hipStreamWaitEvent(st, ev[1], 0));
-        if (k >= 2) HIPCHK(h, hipStreamWaitEvent(st, h->win_ev[(k - 2) % R][4], 0));      // window k - 2's dibit rows have left this device row block
-        if (k == 0) HIPCHK(h, hipMemcpyAsync(d_anc, h_anc, C * sizeof(p25fe_anchor_t), hipMemcpyHostToDevice, st));
-        HIPCHK(h, hipEventRecord(ev[2], st));
+        WINCHK(hipStreamWaitEvent(st, ev[1], 0));
+        if (k >= 2) { WINCHK(hipStreamWaitEvent(st, h->win_ev[(k - 2) % R][4], 0)); }      // window k - 2's dibit rows have left this device row block
+        if (k == 0) { WINCHK(hipMemcpyAsync(d_anc, h_anc, C * sizeof(p25fe_anchor_t), hipMemcpyHostToDevice, st)); }
+        WINCHK(hipEventRecord(ev[2], st));
         const size_t nb = p25fe_n_baseband_h(h, abs0, wn);
         const long view0 = (long)(h->abs_bb + nb_done) - h->look;
         p25fe_result_t* d_res = h->win_res.as<p25fe_result_t>() + (k % R) * C;
@@ -1846,18 +1854,22 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
             cr.pl = planar_view(h, g); cr.n = (long)nb; cr.look = (int)h->look; cr.tail = d_tail;
             hipLaunchKernelGGL(k_tail_extract, dim3((unsigned)C), dim3(WV), 0, st, cr);
         }
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipEventRecord(ev[3], st));
+        WINCHK(hipGetLastError());
+        WINCHK(hipEventRecord(ev[3], st));
         // ---- results leave on their own stream
-        HIPCHK(h, hipStreamWaitEvent(os, ev[3], 0));
-        HIPCHK(h, hipMemcpyAsync(h_res[k % R], d_res, C * sizeof(p25fe_result_t), hipMemcpyDeviceToHost, os));
-        HIPCHK(h, hipMemcpyAsync(h_dib[b], d_dib, C * dstride, hipMemcpyDeviceToHost, os));
-        HIPCHK(h, hipEventRecord(ev[4], os));
+        WINCHK(hipStreamWaitEvent(os, ev[3], 0));
+        WINCHK(hipMemcpyAsync(h_res[k % R], d_res, C * sizeof(p25fe_result_t), hipMemcpyDeviceToHost, os));
+        WINCHK(hipMemcpyAsync(h_dib[b], d_dib, C * dstride, hipMemcpyDeviceToHost, os));
+        WINCHK(hipEventRecord(ev[4], os));
         nb_done += nb;
         if (k >= 1) status = drain(k - 1);
     }
+#undef WINCHK
     if (status == P25FE_OK) status = drain(n_win - 1);
-    if (status != P25FE_OK) {                                        // nothing of the stream state has moved
+    if (status != P25FE_OK) {
+        // Nothing of the handle's STREAM STATE has moved (history, anchors, counters: the call can be repeated), and no copy or
+        // kernel of this call is still in flight when it returns: they read the caller's capture and the handle's windows.
+        // The caller's dibit buffer may already hold the dibits of earlier windows and n_dibits reads 0: treat both as undefined.
         (void)hipStreamSynchronize(cs); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(os);
         return status;
     }
@@ -1874,7 +1886,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         const char* srcc = static_cast<const char*>(iq) + c * n * eb;
         if (n >= SHARD_HALO) memcpy(hist, srcc + (n - SHARD_HALO) * eb, SHARD_HALO * eb);
         else { memmove(hist, hist + n * eb, (SHARD_HALO - n) * eb); memcpy(hist + (SHARD_HALO - n) * eb, srcc, n * eb); }
-        const size_t nb_last = p25fe_n_baseband_h(h, h->abs_iq + (n_win - 1) * window, n - (n_win - 1) * window);
+        const size_t nb_last = p25fe_n_baseband_h(h, h->abs_iq + (n_win - 1) * window, n - (n_win - 1) * window);   // (> 0: a window is at least 8 192 samples)
         float* t = h->tail_bb.data() + c * BBPAD;
         if (nb_last) {
             float merged[BBPAD];

@@ -118,10 +118,14 @@ static int bulk(Handle& h, const std::string& mode, std::ifstream& in, const cha
     std::mutex mu;
     std::condition_variable cv;
     size_t filled[2] = {0, 0};
-    bool full[2] = {false, false}, eof = false;
+    bool full[2] = {false, false}, eof = false, stop = false;      // stop: the consumer gave up (an error): the reader must not block
     std::thread reader([&] {
         for (int b = 0;; b ^= 1) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !full[b]; }); }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !full[b] || stop; });
+                if (stop) return;
+            }
             in.read(buf[b], (std::streamsize)(block * eb));
             const size_t got = (size_t)in.gcount() / eb;
             std::lock_guard<std::mutex> lk(mu);
@@ -135,21 +139,33 @@ static int bulk(Handle& h, const std::string& mode, std::ifstream& in, const cha
     size_t total = 0, samples = 0, windows = 0;
     double ms_h2d = 0.0, ms_comp = 0.0;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int b = 0;; b ^= 1) {
+    int failed = 0;                                                  // an error ends the loop, never the process: the reader thread is joinable
+    if (!out) { std::fprintf(stderr, "unable to open %s\n", out_path); failed = 1; }
+    for (int b = 0; !failed; b ^= 1) {
         size_t n;
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return full[b]; }); n = filled[b]; }
         size_t nd = 0;
         p25fe_windows_stats_t st;
-        expect(p25fe_run_host_windows(h.get(), buf[b], fmt, n, window, dib.data(), dib.size(), &nd, &st), "unable to run the capture");
+        const int rc = p25fe_run_host_windows(h.get(), buf[b], fmt, n, window, dib.data(), dib.size(), &nd, &st);
+        if (rc != P25FE_OK) {
+            std::fprintf(stderr, "p25fe_replay: unable to run the capture: %s (%d)\n", p25fe_strerror(rc), rc);
+            failed = 1;
+            break;
+        }
         out.write(reinterpret_cast<const char*>(dib.data()), (std::streamsize)nd);
+        if (!out.good()) { std::fprintf(stderr, "p25fe_replay: write error on %s (disk full?)\n", out_path); failed = 1; break; }
         total += nd; samples += n; windows += st.n_windows; ms_h2d += st.ms_h2d; ms_comp += st.ms_compute;
         bool last;
         { std::lock_guard<std::mutex> lk(mu); full[b] = false; last = eof && n < block; cv.notify_all(); }
         if (last || n < block) break;
     }
+    { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); }
     reader.join();
+    out.close();
+    if (!failed && out.fail()) { std::fprintf(stderr, "p25fe_replay: write error on %s at close\n", out_path); failed = 1; }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int b = 0; b < 2; ++b) (void)hipHostFree(buf[b]);
+    if (failed) return 1;
     std::fprintf(stderr, "p25fe_replay: %zu dibits from %zu samples in %zu windows, %.1f ms (%.1f Msamples/s, %.2f GB/s; H2D copies %.1f ms, "
                          "kernels %.1f ms)\n", total, samples, windows, ms, samples / ms / 1e3, samples * eb / ms / 1e6, ms_h2d, ms_comp);
     return 0;

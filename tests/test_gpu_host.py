@@ -307,6 +307,17 @@ def test_run_host_windows_equals_one_pass(mode, tmp_path):
     bb_rest = O.Demod().feed_cf32(iq)[len(O.Demod().feed_cf32(iq[:b])):]
     d2 = fe.slice(bb_rest)[0]
     assert np.array_equal(np.concatenate([d1, d2]), ref)
+    # a remainder too short for a baseband sample of its own (n = 2 windows + 3): it rides with the window in front of it, and the
+    # tail the call leaves is still the capture's last 256 baseband samples (it used to keep the tail from BEFORE the call)
+    w = 300000 // 8 * 8
+    for extra in (3, 7, 8, 9):
+        m = 2 * w + extra
+        fe = FrontEnd(symbol_clock=mode)
+        d1, st = fe.run_host_windows(iq[:m], window=w)
+        assert st["n_windows"] == (2 if extra < 8 else 3), (extra, st)
+        bb_rest = O.Demod().feed_cf32(iq)[len(O.Demod().feed_cf32(iq[:m])):]
+        d2 = fe.slice(bb_rest)[0]
+        assert np.array_equal(np.concatenate([d1, d2]), ref), extra
     # lock drops INSIDE the capture (p25fe_resync_at_dev: absolute baseband indices): every window sees the list
     bb_all = O.Demod().feed_cf32(iq)
     drops = np.array([len(bb_all) // 5, len(bb_all) // 2 + 3, len(bb_all) - 4000], dtype=np.int64)
@@ -596,3 +607,17 @@ def test_c_abi_shard_step_rccl_and_two_processes(tmp_path):
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         got = np.fromfile(out, dtype=np.uint8)
         assert len(got) == len(ref2) and np.array_equal(got, ref2), args
+
+
+@pytest.mark.timeout(120)
+def test_cpp_replay_bulk_mode_fails_cleanly(tmp_path):
+    """p25fe_replay -W (reader thread + pinned blocks + p25fe_run_host_windows): an output that cannot be written ends in a clean
+    non-zero exit with a message -- the reader thread joined, no std::terminate / abort -- not in a silently short dibit file."""
+    from p25rx_amd import c4fm
+    exe = os.path.join(ROOT, "build", "p25fe_replay")
+    src = tmp_path / "cap.cf32"
+    c4fm.synth(1.0, seed=5, snr_db=25.0)[0].tofile(src)
+    r = subprocess.run([exe, "-W", "256k", "cf32", str(src), "/dev/full"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 1 and "write error" in r.stderr, (r.returncode, r.stderr[-500:])
+    r = subprocess.run([exe, "-W", "256k", "cf32", str(src), str(tmp_path / "no_such_dir" / "x")], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 1 and "unable to open" in r.stderr, (r.returncode, r.stderr[-500:])

@@ -17,9 +17,9 @@ r = json.loads(sys.argv[2])
 print("%-14s ms/step %.4f  K1 %.4f frac %.4f  serial %s  gate %s" % (sys.argv[1], r["ms_per_step"], r["roofline"]["kernel_ms"], r["roofline"]["frac"],
       r["config"].get("serial_ms_per_step"), r["config"]["parity_gate"][-5:]))
 for e in r.get("extra", []):
-    n = e.get("name", "")
-    if "256" in n or "3 600" in n or "3600" in n or "u8" in n[:24]:
-        print("      %-100s ms %.4f  kernel_ms %s  frac %s  ok %s" % (n[:100], e.get("ms_per_step", 0), e.get("kernel_ms"), (e.get("roofline") or {}).get("frac"), e.get("ok")))
+    n = e.get("config", "")
+    if n.startswith("configs[3]") or n.startswith("configs[4]") or n.startswith("configs[2]") or n.startswith("configs[1] as u8 I/Q pairs (the"):
+        print("      %-70s ms %.4f  kernel_ms %s  frac %s  gate %s" % (n[:70], e.get("ms_per_step", 0), e.get("kernel_ms"), e.get("frac"), e.get("parity_gate")))
 PY
   done
 done
