@@ -94,7 +94,10 @@ constexpr int SEG_HALO = 80;                 // ... with post-discriminator filt
 // the halo a segment recomputes, for a post-discriminator filter of t3 taps behind a channel filter evaluated at t2 taps
 __host__ __device__ constexpr int seg_halo_for(int t3, int t2) { return t3 + t2 - 1 <= 80 ? 80 : 160; }
 static_assert(SEG_HALO == seg_halo_for(BOX, TMAX) && seg_halo_for(TMAX, TMAX) >= TMAX + TMAX - 1, "segment halo covers the filter memory and is byte-aligned per plane");
-__host__ __device__ constexpr bool seg_prologue(int fmt) { return fmt == P25FE_FMT_U8; }
+#ifndef P25FE_K1_PRO_CF32
+#define P25FE_K1_PRO_CF32 0
+#endif
+__host__ __device__ constexpr bool seg_prologue(int fmt) { return fmt == P25FE_FMT_U8 || P25FE_K1_PRO_CF32 != 0; }
 
 // Polyphase ("planar") baseband layout of the fused path: with p = m + PLPAD (m = range-local baseband index, the
 // 240 history samples of the receiver at m = -240..-1), sample p belongs to plane r = p % 10 at symbol index i = p / 10.
@@ -782,10 +785,16 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     // one HBM round trip for the prologue window and the first sub-tile's window (both may start before the descriptor's base
     // at the start of a stream: load_first sends those lanes out of range = zeros)
     lp.load_first(pfirst, tid);
-    ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
-    if constexpr (PF == 2) {
-        ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
-        ld1.load_first((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
+    // cf32 (16-byte vectors: 52 registers per window): the first sub-tile's window is requested only once the prologue window
+    // has been staged and its registers are free again -- otherwise the two in flight together set the kernel's register count
+    // (174: two waves per SIMD); the prologue's arithmetic runs under the second request instead of under both.
+    constexpr bool LATE_LD0 = FMT == P25FE_FMT_CF32;
+    if constexpr (!LATE_LD0) {
+        ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+        if constexpr (PF == 2) {
+            ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
+            ld1.load_first((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
+        }
     }
     {
         // ---- prologue: d[m_seg0 - ND .. m_seg0) on lanes 0 .. ND-1, y[m_seg0 - 10 .. m_seg0) and the discriminator values
@@ -794,6 +803,13 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         float2* const PD_ = XIN + PBASE;
         lp.template store<LUTM>(XIN, pfirst, a.n_hist, a.n_new, tid, LUT);
         lp.fixup(XIN, pfirst, a.n_hist, a.n_new, tid);
+        if constexpr (LATE_LD0) {
+            ld0.load_first((long)a.o0 + DEC * dlo - (T1 - 1), tid);
+            if constexpr (PF == 2) {
+                ld1.rs = ld0.rs; ld1.base_idx = ld0.base_idx;
+                ld1.load_first((long)a.o0 + DEC * (dlo + SUB) - (T1 - 1), tid);
+            }
+        }
         phase_sync();
         const int pxsh = (int)(pfirst & 1);
         v2f dacc[NDL];
@@ -945,6 +961,9 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         K1_STAMP(1);                                                // previous outputs stored, next window requested
 
 #if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
+#if defined(P25FE_ABLATE_STORES)                    // ... but keep the OUTPUT stream: the next iteration stores this sub-tile's (zero) planes --
+        out_rel = (int)(dlo - m_seg0);              // K1's whole HBM traffic (window reads + baseband / sign-plane writes) without its arithmetic
+#endif
 #if defined(P25FE_DRIFT)                            // ... with pseudo-random idle phases (units of 64 cycles) in place of the arithmetic
         {
             unsigned hsh = (unsigned)blockIdx.x * 2654435761u + (unsigned)(dlo & 0xffff) * 40503u;
