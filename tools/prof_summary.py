@@ -88,11 +88,19 @@ for sub in sorted(glob.glob(os.path.join(d, "kb_*"))):
     except OSError:
         pass
     print("== rocprofv3 --kernel-trace -- python3 tools/kbench.py : %s" % note)
+    timed = None                                            # kbench's pre-warm launches are part of the trace: keep the timed rounds
+    try:
+        m = re.search(r"kbench timed_rounds=(\d+)", open(sub + ".log").read())
+        timed = int(m.group(1)) if m else None
+    except OSError:
+        pass
     by = collections.defaultdict(list)
     for _, dur, k in rows:
         by[k].append(dur)
+    if timed:
+        print("  (the last %d launches of every kernel: the timed rounds behind kbench's >= 150 ms pre-warm)" % timed)
     for k in sorted(by):
-        v = by[k][3 * 0:]                                   # (kbench's three warm-up rounds are part of the trace: medians)
+        v = by[k][-timed:] if timed else by[k]
         st = stats(v)
         print("  %-44s calls %5d  median %9.1f us  p10 %9.1f  p90 %9.1f  mean %9.1f"
               % (k[:44], st["calls"], st["median"] / 1e3, st["p10"] / 1e3, st["p90"] / 1e3, st["mean"] / 1e3))
