@@ -46,7 +46,7 @@ BYTES_PER_SAMPLE_K1_U8 = 2.0 + 0.8
 # 41 x 2 / 5, discriminator (4 + division + 8-term Horner + selects ~ 30) / 5, boxcar 10 / 5, u8 -> f32 2 x 2
 FLOPS_PER_SAMPLE = (2 * 2 * 31 + 2 * 2 * 41 + 30 + 10) / 5.0
 FLOPS_PER_SAMPLE_U8 = FLOPS_PER_SAMPLE + 4.0
-PMC_FILES = [os.path.join("profiles", "r04_k1_pmc.json"), os.path.join("profiles", "r03_k1_pmc.json")]
+PMC_FILES = [os.path.join("profiles", "r05_k1_pmc.json"), os.path.join("profiles", "r04_k1_pmc.json")]
 PREWARM_MS = 150.0               # untimed steps before the W warm-up steps: the chip reaches its steady clock / power state
 GATHER_WORDS = {"root_exact": "point-to-point to rank 0, exactly the valid bytes, received at their offsets", "root": "point-to-point "
                 "gather of whole rows to rank 0 + compaction", "all": "all_gather of rows", "none": "nothing"}

@@ -308,7 +308,7 @@ static std::vector<std::string> jit_dirs()
     return d;
 }
 
-// P25FE_SPECIALIZE_AUTO fell back to the generic kernels (1.2 - 2.3 x slower): say so once per process, on stderr -- a caller
+// P25FE_SPECIALIZE_AUTO fell back to the generic kernels (1.3 - 2.4 x slower): say so once per process, on stderr -- a caller
 // that never polls p25fe_kernel_variant would otherwise not know.  P25FE_QUIET=1 silences it.
 static void fallback_notice()
 {
@@ -318,7 +318,7 @@ static void fallback_notice()
     const char* q = getenv("P25FE_QUIET");
     if (q && atoi(q) != 0) return;
     fprintf(stderr, "p25fe: no specialised kernels for this configuration's numbers (no usable cached code object and hipRTC did not "
-                    "deliver one): running the GENERIC kernels, 1.2 - 2.3 x slower.  p25fe_specialize_log() has the details; "
+                    "deliver one): running the GENERIC kernels, 1.3 - 2.4 x slower.  p25fe_specialize_log() has the details; "
                     "p25fe_specialize() / $P25FE_SPEC_DIR is the ahead-of-time form.\n");
 }
 

@@ -253,7 +253,7 @@ def test_cache_verifies_content_against_the_numbers(lib, tmp_path):
 
 
 def test_auto_fallback_to_the_generic_kernels_is_announced(lib, tmp_path):
-    """P25FE_SPECIALIZE_AUTO without hipRTC and without an ahead-of-time object ends on kernels 1.2 - 2.3 x slower: said once on
+    """P25FE_SPECIALIZE_AUTO without hipRTC and without an ahead-of-time object ends on kernels 1.3 - 2.4 x slower: said once on
     stderr (not only to callers that poll p25fe_kernel_variant); REQUIRE fails instead; the build's own numbers say nothing."""
     env = {"P25FE_HIPRTC": "/nonexistent/libhiprtc.so", "P25FE_CACHE_DIR": str(tmp_path / "c")}
     r = _spec_run("print(_lib.probe_variant(cfg)); print(_lib.probe_variant(cfg))", env)
