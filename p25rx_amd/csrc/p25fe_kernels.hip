@@ -151,10 +151,13 @@ struct Taps {
     float pad_;
     float avg[TMAX];
 };
+#ifndef P25FE_K1_AVG_LDS_CF32
+#define P25FE_K1_AVG_LDS_CF32 0            /* measurement builds: the LDS window also for short filters in the cf32 kernels (frees 12 SGPR carries) */
+#endif
 // dynamic LDS of a K1 workgroup (host and kernel agree through this one formula)
 template <class G> __host__ __device__ constexpr size_t k1_lds_bytes(bool ct, bool lut, int t3)
 {
-    return G::LDS_BASE + sizeof(float) * (size_t)((ct ? 0 : G::TAPS_N) + (lut ? 256 : 0) + (t3 > AVG_DPP_MAX || !ct ? t3 - 1 + G::SUB : 0));
+    return G::LDS_BASE + sizeof(float) * (size_t)((ct ? 0 : G::TAPS_N) + (lut ? 256 : 0) + (t3 > AVG_DPP_MAX || !ct || P25FE_K1_AVG_LDS_CF32 ? t3 - 1 + G::SUB : 0));
 }
 
 // SPEC 3.4: polynomial atan2, identical operation sequence to the oracle's restatement.
@@ -676,7 +679,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     // handle's own for the immediate-coefficient kernels, the ABI's ceiling for the generic ones (n_avg at run time).  Up to
     // AVG_DPP_MAX taps it runs in registers (DPP, SGPR carries); longer filters through an LDS window of fm values.
     constexpr int T3 = CT ? K1_CT_AVG_N : TMAX;
-    constexpr bool AVG_DPP = CT && T3 <= AVG_DPP_MAX;
+    constexpr bool AVG_DPP = CT && T3 <= AVG_DPP_MAX && !(P25FE_K1_AVG_LDS_CF32 != 0 && FMT == P25FE_FMT_CF32);
     constexpr int HY = T3;                                          // channel outputs needed in front of a segment's first output
     constexpr int NBACK = AVG_DPP ? ((T3 - 1 + PK - 1) / PK > 0 ? (T3 - 1 + PK - 1) / PK : 1) : 1;   // lanes to the left whose fm values the filter needs
     static_assert(T3 >= 1 && T3 <= TMAX && NBACK <= 3, "post-discriminator filter length");
