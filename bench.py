@@ -679,8 +679,13 @@ def main():
         ss = rccl.ShardStep(fe, rank, world, n, None if staged else boot[0])
         dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device=dev)
 
+        # steps one behind the other, like the N = 1 line: only K1's main launch on this stream, everything behind it (detection,
+        # scan, summary all-gather, slicer, dibit gather, compaction) on the handle's receive stream beside the NEXT step's K1
+        # (p25fe_shard_step_pipelined; all of it completes inside the timed region: join + synchronise).  --no-pipeline: the plain step.
+        shard_pipe = not args.no_pipeline and not staged
+
         def step():
-            ss.step(buf, dibits, result, gather=args.gather)
+            ss.step(buf, dibits, result, gather=args.gather, pipelined=shard_pipe)
 
     # untimed pre-warm (not part of W or K): the chip needs ~100 ms of this load to settle at its power-limited clock; the
     # driver's `--steps 20 --warmup 5` is a 6 ms timed region behind 1.5 ms of warm-up and otherwise times the clock ramp
@@ -890,6 +895,11 @@ def main():
                                      "K1 of step i + 1; join + device synchronize inside the timed region")
             if serial_ms is not None:
                 out["config"]["serial_ms_per_step"] = round(serial_ms, 4)
+        if world > 1:
+            out["config"]["step"] = ("p25fe_shard_step_pipelined: K1's main launch on the caller's stream, halo + head on the side stream, "
+                                     "detection / scan / all-gather / slicer / gather / compaction on the handle's receive stream beside "
+                                     "the next step's K1; join + device synchronize inside the timed region" if shard_pipe else
+                                     "p25fe_shard_step: every launch of a step behind its K1 on one stream")
         if comm_ms is not None:
             out["config"]["comm_ms_per_step"] = dict(comm_ms, note="rank 0, p25fe_shard_comm_ms: HIP events of the library around each "
                                                      "exchange on its stream (the halo exchange runs beside K1's main launch), on every "

@@ -188,6 +188,10 @@ extern "C" {
                                     abs0: u64, d_result: *mut ResultRec, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass1_head(h: *mut Handle, d_iq: *const c_void, fmt: c_int, ch_stride: usize, n_hist: usize, n: usize,
                                   abs0: u64, stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_pipe_begin(h: *mut Handle, stream: *mut c_void, rx_stream: *mut *mut c_void) -> c_int;
+    pub fn p25fe_shard_pipe_end(h: *mut Handle, last_stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_pass1_k1(h: *mut Handle, d_iq: *const c_void, fmt: c_int, ch_stride: usize, n_hist: usize, n: usize,
+                                abs0: u64, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass2(h: *mut Handle, d_anchor_in: *const Anchor, d_dibits: *mut u8, dibit_stride: usize,
                              d_result: *mut ResultRec, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass2_dev(h: *mut Handle, d_summaries: *const ResultRec, d_shard_bb0: *const u64, d_shard_bb_n: *const u64,
@@ -226,6 +230,9 @@ extern "C" {
     pub fn p25fe_shard_dibit_cap(s: *const Shard) -> usize;
     pub fn p25fe_shard_step(s: *mut Shard, d_buf: *mut c_void, fmt: c_int, d_dibits: *mut u8, d_result: *mut ResultRec, gather: c_int,
                             stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_step_pipelined(s: *mut Shard, d_buf: *mut c_void, fmt: c_int, d_dibits: *mut u8, d_result: *mut ResultRec,
+                                      gather: c_int, stream: *mut c_void) -> c_int;
+    pub fn p25fe_shard_join(s: *mut Shard, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_offsets(s: *mut Shard, offsets: *mut u64) -> c_int;
     pub fn p25fe_shard_stream_dev(s: *const Shard) -> *const u8;
     pub fn p25fe_shard_comm_ms(s: *mut Shard, ms: *mut f64, n_steps: *mut u64) -> c_int;

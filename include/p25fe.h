@@ -361,6 +361,19 @@ int p25fe_shard_pass1_finish(p25fe_t *h, const void *d_iq, int fmt, size_t ch_st
  * _finish launches the head itself. */
 int p25fe_shard_pass1_head(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, void *stream);
+/* The whole front end of pass 1 in ONE launch (main + head: the halo must be in memory), nothing else; p25fe_shard_pass1_finish
+ * then only enqueues the sync detection and the scan.  p25fe_shard_pass1 == _k1 + _finish. */
+int p25fe_shard_pass1_k1(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
+                         void *stream);
+/* Steps one behind the other (p25fe_shard_step_pipelined): between _begin and _end the shard passes work on the next of up to four
+ * scratch sets (p25fe_run_dev_pipelined rotates through two of them) and do not wait for the handle's receive stream -- they are
+ * its work.  _begin makes `stream` (where pass 1's front end is about to overwrite that set's planes) wait for the passes that read
+ * it four steps back and returns the receive stream in *rx_stream; p25fe_shard_pass1_k1 / _main(..., stream) then makes the receive
+ * stream wait for its launch; every later pass of the step (_finish, pass 2, the exchanges between them) is enqueued on the receive
+ * stream or on streams that wait for it.  _end(h, last) records "this step's passes are done" on `last` (NULL: the receive stream)
+ * and marks it as pending: p25fe_join_dev makes a stream wait for it, every non-pipelined entry point does so by itself. */
+int p25fe_shard_pipe_begin(p25fe_t *h, void *stream, void **rx_stream);
+int p25fe_shard_pipe_end(p25fe_t *h, void *last_stream);
 
 /* Host-side combine: summaries[r] for r = 0..n_shards-1 in time order (one channel) ->
  * anchor_in[r] (n_shards entries) and dibit_offset[r] (n_shards + 1 entries: shard r's dibits occupy

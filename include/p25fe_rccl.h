@@ -68,6 +68,21 @@ size_t p25fe_shard_dibit_cap(const p25fe_shard_t *s);
 int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,
                      void *stream);
 
+/* The same step for a host that feeds one capture after the other (p25fe_run_dev_pipelined's contract, applied to shards): only
+ * K1's main launch is enqueued on `stream`; the halo / head run on the side stream as before and EVERYTHING behind K1 (sync
+ * detection, scan, summary all-gather, slicer, dibit gather, compaction) on the handle's receive stream, so that the next call's
+ * K1 starts while this call's ~80 us chain of short kernels and exchanges is still running.  Outputs (d_dibits, d_result, the
+ * ordered stream, the offsets) are complete once a stream has been made to wait with p25fe_shard_join (or the device has been
+ * synchronised).  Consecutive calls may name the same output buffers (the chains run in call order on one stream); the ordered
+ * stream alternates between two buffers, p25fe_shard_stream_dev() names the LAST call's, and the previous call's stays untouched
+ * until the call after this one; d_buf must stay unchanged until `stream` and the step's exchanges have passed it (join).
+ * P25FE_GATHER_ROOT_EXACT keeps its one host wait per step, which ends the overlap for that mode; the shared-memory test hook runs
+ * the plain step. */
+int p25fe_shard_step_pipelined(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,
+                               void *stream);
+/* make `stream` wait for everything p25fe_shard_step_pipelined has enqueued so far */
+int p25fe_shard_join(p25fe_shard_t *s, void *stream);
+
 /* HIP events around the three exchanges (p25fe_shard_comm_ms) ride on every `every`-th step only (default 16; 0: never;
  * 1: every step): the four around the all-gather and the gather are packets between the kernels of the step's critical
  * path, ~4 us each. */

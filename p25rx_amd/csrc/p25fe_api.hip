@@ -105,6 +105,8 @@ inline size_t fmt_bytes(int fmt) { return fmt == P25FE_FMT_CF32 ? 8 : 2; }
 
 static_assert(BBPAD == (size_t)TAILN && BBPAD >= (size_t)HIST_BB + CLK_L, "baseband tail kept between calls");
 
+constexpr int MAX_LANES = 4;
+
 struct p25fe {
     p25fe_config_t cfg;
     int C = 1;
@@ -134,13 +136,18 @@ struct p25fe {
     // p25fe_run_dev_pipelined: a second set of the receiver's scratch (the member names above always are the set of the
     // current call; the sets are swapped per call), the stream the receive kernels run on, and the events that order
     // K1 (caller's stream) -> K2..K4 (rx_stream) -> next K1 into the same set two calls later
-    DevBuf alt_pl_f, alt_pl_bits, alt_evl, alt_evthr, alt_recs, alt_tsum, alt_outs, alt_gsum, alt_gouts, alt_evg;
+    // (p25fe_run_dev_pipelined rotates through two sets; the pipelined shard step through up to MAX_LANES: its chain behind K1
+    // holds exchanges that only find room on the chip when a K1 launch drains, so it spans more than one K1.)  A set keeps its id
+    // (`lane` = the current one's); the events and the pending flags are indexed by it.
+    struct RxSet { DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, gsum, gouts, evg; int id = 0; };
+    RxSet spare[MAX_LANES - 1];
     hipStream_t rx_stream = nullptr;
-    hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_rx[2] = {nullptr, nullptr};
-    bool rx_pending[2] = {false, false};
-    hipStream_t rx_joined[2] = {nullptr, nullptr};   // stream that has already been made to wait for ev_rx[l] (valid while rx_pending[l])
-    bool rx_joined_any[2] = {false, false};
+    hipEvent_t ev_k1[MAX_LANES] = {}, ev_rx[MAX_LANES] = {};
+    bool rx_pending[MAX_LANES] = {};
+    hipStream_t rx_joined[MAX_LANES] = {};           // stream that has already been made to wait for ev_rx[l] (valid while rx_pending[l])
+    bool rx_joined_any[MAX_LANES] = {};
     int lane = 0;
+    int sh_depth = MAX_LANES;              // sets the pipelined shard step rotates through (P25FE_SHARD_PIPE_DEPTH)
     // p25fe_run_host_windows: two device windows, dibit rows and result records in a ring, the copy streams and their events
     DevBuf win_buf[2], win_dib[2], win_res, win_anc;
     PinBuf win_stage[2], win_out;
@@ -178,6 +185,7 @@ struct p25fe {
     size_t sh_nbb = 0;
     long sh_abs_bb0 = 0;
     bool sh_gen = false;                   // pass 1 ran the general receiver (pass 2 reads its summaries)
+    bool sh_pipe = false;                  // between p25fe_shard_pipe_begin and _end: the shard passes do not join the receive stream (they ARE its work)
     bool sh_scan_fresh = false;            // the per-tile carry-ins in `outs` are still pass 1's (no carry-in): p25fe_shard_pass2 rewrites them
 };
 
@@ -508,6 +516,9 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
         h->ext_events = !(ee && atoi(ee) == 0);
         const char* rc_ = getenv("P25FE_RX_CUS");
         h->rx_cus = rc_ ? atoi(rc_) : 0;
+        for (int k = 0; k < MAX_LANES - 1; ++k) h->spare[k].id = k + 1;
+        const char* pd = getenv("P25FE_SHARD_PIPE_DEPTH");            // (measurement knob: 2 .. MAX_LANES)
+        if (pd && atoi(pd) >= 2 && atoi(pd) <= MAX_LANES) h->sh_depth = atoi(pd);
     }
     if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
@@ -569,13 +580,15 @@ void p25fe_destroy(p25fe_t* h)
     for (auto& slot : h->win_ev) for (hipEvent_t e : slot) if (e) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) { h->win_buf[b].release(); h->win_dib[b].release(); h->win_stage[b].release(); }
     h->win_res.release(); h->win_anc.release(); h->win_out.release();
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < MAX_LANES; ++l) {
         if (h->ev_k1[l]) (void)hipEventDestroy(h->ev_k1[l]);
         if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
     }
-    DevBuf* alt[] = {&h->alt_pl_f, &h->alt_pl_bits, &h->alt_evl, &h->alt_evthr, &h->alt_recs, &h->alt_tsum, &h->alt_outs,
-                     &h->alt_gsum, &h->alt_gouts, &h->alt_evg, &h->gsum, &h->gouts, &h->evg};
-    for (DevBuf* b : alt) b->release();
+    for (auto& a : h->spare) {
+        DevBuf* alt[] = {&a.pl_f, &a.pl_bits, &a.evl, &a.evthr, &a.recs, &a.tsum, &a.outs, &a.gsum, &a.gouts, &a.evg};
+        for (DevBuf* b : alt) b->release();
+    }
+    h->gsum.release(); h->gouts.release(); h->evg.release();
     DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps, &h->sh_flag};
     for (DevBuf* b : bufs) b->release();
     h->hin.release(); h->hbb.release(); h->hout.release();
@@ -1034,7 +1047,7 @@ static int pipe_join(p25fe_t* h, hipStream_t st)
 {
     // The events stay pending until the lane is reused: a later call on ANOTHER stream must wait too (the receive
     // kernels may still be running and share the scratch with whatever that call launches).
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < MAX_LANES; ++l)
         if (h->rx_pending[l] && !(h->rx_joined_any[l] && h->rx_joined[l] == st)) {
             HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[l], 0));
             h->rx_joined[l] = st; h->rx_joined_any[l] = true;
@@ -1049,13 +1062,10 @@ int p25fe_join_dev(p25fe_t* h, void* stream)
     return pipe_join(h, (hipStream_t)stream);
 }
 
-int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
-                            size_t dibit_stride, p25fe_result_t* d_result, void* stream)
+// The preamble of a pipelined call: the receive stream and its events exist, the OTHER scratch set becomes the current one, and
+// `st` (where K1 is about to overwrite that set's planes) waits for the receive kernels that last read it, two calls back.
+static int pipe_open(p25fe_t* h, hipStream_t st, int depth = 2)
 {
-    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband_h(h, 0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = (hipStream_t)stream;
-    shard_invalidate(h);
     if (!h->rx_stream) {
         if (h->rx_cus > 0) {
             // The receive kernels are a few thousand short one-wave workgroups and one single-workgroup scan.  Left free they
@@ -1081,17 +1091,22 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
             }
         }
     }
-    for (int l = 0; l < 2; ++l) {                                    // (per event: a failed creation is retried by the next call)
+    for (int l = 0; l < MAX_LANES; ++l) {                            // (per event: a failed creation is retried by the next call)
         if (!h->ev_k1[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
         if (!h->ev_rx[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
     }
     // the other scratch set becomes the current one; it was last read by the receive kernels of the call before the
     // previous one, which this call's K1 (it overwrites the planes) has to wait for
-    std::swap(h->pl_f, h->alt_pl_f); std::swap(h->pl_bits, h->alt_pl_bits); std::swap(h->evl, h->alt_evl);
-    std::swap(h->evthr, h->alt_evthr); std::swap(h->recs, h->alt_recs); std::swap(h->tsum, h->alt_tsum);
-    std::swap(h->outs, h->alt_outs);
-    std::swap(h->gsum, h->alt_gsum); std::swap(h->gouts, h->alt_gouts); std::swap(h->evg, h->alt_evg);
-    h->lane ^= 1;
+    {
+        p25fe::RxSet& a = h->spare[0];
+        std::swap(h->pl_f, a.pl_f); std::swap(h->pl_bits, a.pl_bits); std::swap(h->evl, a.evl);
+        std::swap(h->evthr, a.evthr); std::swap(h->recs, a.recs); std::swap(h->tsum, a.tsum);
+        std::swap(h->outs, a.outs);
+        std::swap(h->gsum, a.gsum); std::swap(h->gouts, a.gouts); std::swap(h->evg, a.evg);
+        std::swap(h->lane, a.id);
+        // the set just retired goes behind the other spare ones of this depth (depth 2: a plain swap)
+        for (int k = 0; k + 2 < depth && k + 1 < MAX_LANES - 1; ++k) std::swap(h->spare[k], h->spare[k + 1]);
+    }
     const int lane = h->lane;
     if (h->rx_pending[lane]) {
 #ifdef P25FE_MEASURE_UNSAFE
@@ -1105,6 +1120,18 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
         h->rx_pending[lane] = false;
     }
     h->rx_joined_any[lane] = false;
+    return P25FE_OK;
+}
+
+int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n, uint8_t* d_dibits,
+                            size_t dibit_stride, p25fe_result_t* d_result, void* stream)
+{
+    if (!h || !d_iq || !d_dibits || !d_result || p25fe_n_baseband_h(h, 0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    shard_invalidate(h);
+    if (int orc = pipe_open(h, st)) return orc;
+    const int lane = h->lane;
     const size_t n_bb = p25fe_n_baseband_h(h, 0, n);
     int rc = P25FE_OK;
     const PlanarGeo g(n_bb);
@@ -1191,7 +1218,8 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (do_main) shard_invalidate(h);
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (int jrc = pipe_join(h, st)) return jrc;
+    if (!h->sh_pipe)
+        if (int jrc = pipe_join(h, st)) return jrc;
     const size_t n_bb = p25fe_n_baseband_h(h, abs0, n);
     const long abs_bb0 = (long)p25fe_n_baseband_h(h, 0, (size_t)abs0) - h->look;      // first processed baseband index of this shard
     int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
@@ -1201,14 +1229,28 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (do_main) {
         prof_begin(h);
         prof_mark(h, 0, st);
+        hipEvent_t k1_done = h->sh_pipe ? h->ev_k1[h->lane] : nullptr;
+        bool k1_done_attached = false;
         if (n_bb) {
             // K1's event pair rides on THIS launch: with the split form it times the main launch alone (the head segment
             // that follows the halo wait is one workgroup), so an RCCL wait between the two is not in K1's figure
             hipEvent_t e0, e1;
             prof_k1_events(h, &e0, &e1);
+            if (h->sh_pipe && h->ext_events) {
+                if (e1) k1_done = e1;                               // a sampled call: the profiling stop event doubles as "K1 done"
+                else e1 = k1_done;
+                k1_done_attached = true;
+            }
             rc = launch_frontend(h, d_iq, fmt, ch_stride, n_hist, n, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g,
                                  do_head ? 0 : 1, e0, e1);
             if (rc) return rc;
+        }
+        if (h->sh_pipe) {
+            // pipelined step: everything behind this launch runs on the receive stream, which waits for it here
+            // (K1 on a CU-masked stream of its own, to keep a few CUs free for the exchanges that run beside it, was tried: the
+            // masked launch itself ran 30 - 60 % slower -- profiles/r05_shard_pipelined.txt)
+            if (!k1_done_attached) HIPCHK(h, hipEventRecord(k1_done, st));
+            HIPCHK(h, hipStreamWaitEvent(h->rx_stream, k1_done, 0));
         }
         h->sh_main_nbb = n_bb; h->sh_main_abs0 = abs0;
         h->sh_head_done = do_head;
@@ -1279,10 +1321,39 @@ int p25fe_shard_pass1_head(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stri
     return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, nullptr, (hipStream_t)stream, SH_HEAD);
 }
 
+int p25fe_shard_pass1_k1(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0, void* stream)
+{
+    return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, nullptr, (hipStream_t)stream, SH_MAIN | SH_HEAD);
+}
+
 int p25fe_shard_pass1_finish(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
                              p25fe_result_t* d_result, void* stream)
 {
     return shard_pass1_part(h, d_iq, fmt, ch_stride, n_hist, n, abs0, d_result, (hipStream_t)stream, SH_RECV);
+}
+
+// The pipelined step of p25fe_rccl.cpp (p25fe_shard_step_pipelined): between _begin and _end the shard passes use the scratch set
+// p25fe_run_dev_pipelined would use next; p25fe_shard_pass1_main stays on the caller's stream and makes the receive stream wait for
+// it, every later pass is given the receive stream.  _end marks that stream's work as pending (p25fe_join_dev waits for it).
+int p25fe_shard_pipe_begin(p25fe_t* h, void* stream, void** rx_stream)
+{
+    if (!h || !rx_stream || h->sh_pipe) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    shard_invalidate(h);
+    if (int orc = pipe_open(h, (hipStream_t)stream, h->sh_depth)) return orc;
+    h->sh_pipe = true;
+    *rx_stream = h->rx_stream;
+    return P25FE_OK;
+}
+
+int p25fe_shard_pipe_end(p25fe_t* h, void* last_stream)
+{
+    if (!h || !h->sh_pipe) return P25FE_ERR_ARG;
+    h->sh_pipe = false;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipEventRecord(h->ev_rx[h->lane], last_stream ? (hipStream_t)last_stream : h->rx_stream));
+    h->rx_pending[h->lane] = true;
+    return P25FE_OK;
 }
 
 int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_dibits, size_t dibit_stride,

@@ -59,6 +59,9 @@ struct p25fe_shard {
     size_t n = 0, halo = 0, cap = 0;
     bool staged = false;
     ncclComm_t comm = nullptr;
+    ncclComm_t comm_halo = nullptr;       // pipelined steps: the halo travels on a communicator of its own (ncclCommSplit), on K1's stream
+    hipEvent_t e_stage = nullptr;         // pipelined steps: summaries gathered (receive stream) -> pass 2 and the dibit gather (side stream)
+    int pipe_layout = 2;                  // measurement knob P25FE_SHARD_PIPE_LAYOUT: 1 = the step's own order on the receive stream
     Shm shm;
     hipStream_t cs = nullptr;             // the halo exchange and the shard's head segment run beside K1's main launch
     hipEvent_t e_fork = nullptr, e_head = nullptr;
@@ -71,6 +74,7 @@ struct p25fe_shard {
     uint64_t *d_bb0 = nullptr, *d_bbn = nullptr, *d_off = nullptr, *d_off_x = nullptr;
     p25fe_anchor_t *d_anc = nullptr, *d_anc_x = nullptr;
     uint8_t *d_gathered = nullptr, *d_stream = nullptr;
+    uint8_t* d_stream2 = nullptr;         // pipelined steps alternate between the two ordered-stream buffers (d_stream is always the LAST step's)
     char* d_loop = nullptr;               // one-rank RCCL group (tests on a 1-GPU box): where the halo loops back to
     uint64_t* h_off = nullptr;            // pinned: the world + 1 offsets of the current step (P25FE_GATHER_ROOT_EXACT)
     hipEvent_t e_res = nullptr, e_off = nullptr;
@@ -105,14 +109,16 @@ void p25fe_shard_destroy(p25fe_shard_t* s)
     if (!s) return;
     if (s->h) (void)hipSetDevice(p25fe_device(s->h));
     if (s->cs) { (void)hipStreamSynchronize(s->cs); (void)hipStreamDestroy(s->cs); }
+    if (s->comm_halo) (void)ncclCommDestroy(s->comm_halo);
     if (s->comm) (void)ncclCommDestroy(s->comm);
+    if (s->e_stage) (void)hipEventDestroy(s->e_stage);
     if (s->e_fork) (void)hipEventDestroy(s->e_fork);
     if (s->e_head) (void)hipEventDestroy(s->e_head);
     if (s->e_res) (void)hipEventDestroy(s->e_res);
     if (s->e_off) (void)hipEventDestroy(s->e_off);
     if (s->h_off) (void)hipHostFree(s->h_off);
     for (auto& row : s->ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
-    void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_off_x, s->d_anc, s->d_anc_x, s->d_gathered, s->d_stream, s->d_loop};
+    void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_off_x, s->d_anc, s->d_anc_x, s->d_gathered, s->d_stream, s->d_stream2, s->d_loop};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->shm.base) munmap(s->shm.base, s->shm.bytes);
     delete s;
@@ -156,6 +162,7 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
             if (hipStreamCreateWithFlags(&s->cs, hipStreamNonBlocking) != hipSuccess) return fail(P25FE_ERR_HIP);
         }
     }
+    if (hipEventCreateWithFlags(&s->e_stage, hipEventDisableTiming) != hipSuccess) return fail(P25FE_ERR_HIP);
     if (hipEventCreateWithFlags(&s->e_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->e_head, hipEventDisableTiming) != hipSuccess) return fail(P25FE_ERR_HIP);
     for (auto& row : s->ev) for (hipEvent_t& e : row) if (hipEventCreate(&e) != hipSuccess) return fail(P25FE_ERR_HIP);
@@ -168,13 +175,15 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
         hipMalloc(&s->d_bbn, W * 8) != hipSuccess || hipMalloc(&s->d_off, (W + 1) * 8) != hipSuccess ||
         hipMalloc(&s->d_off_x, (W + 1) * 8) != hipSuccess || hipMalloc(&s->d_anc_x, W * sizeof(p25fe_anchor_t)) != hipSuccess ||
         hipMalloc(&s->d_anc, W * sizeof(p25fe_anchor_t)) != hipSuccess || hipMalloc(&s->d_gathered, W * s->cap) != hipSuccess ||
-        hipMalloc(&s->d_stream, W * s->cap) != hipSuccess)
+        hipMalloc(&s->d_stream, W * s->cap) != hipSuccess || hipMalloc(&s->d_stream2, W * s->cap) != hipSuccess)
         return fail(P25FE_ERR_NOMEM);
     {
         const char* te = getenv("P25FE_SHARD_TIMING");                // (measurement knob; p25fe_shard_comm_timing is the API)
         if (te && *te) s->timing_every = atoi(te) < 0 ? 0 : atoi(te);
         const char* hw = getenv("P25FE_SHARD_HEAD_WAIT");
         s->head_event_wait = hw && !strcmp(hw, "event");
+        const char* pl = getenv("P25FE_SHARD_PIPE_LAYOUT");
+        if (pl && atoi(pl) == 1) s->pipe_layout = 1;
     }
     if (hipMemcpy(s->d_bb0, s->bb0.data(), W * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(s->d_bbn, s->bbn.data(), W * 8, hipMemcpyHostToDevice) != hipSuccess)
@@ -185,6 +194,9 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
             memcpy(&id, id128, sizeof id);
             if (ncclCommInitRank(&s->comm, world, id, rank) != ncclSuccess) return fail(P25FE_ERR_HIP);
             if (world == 1 && hipMalloc(&s->d_loop, s->halo * 8) != hipSuccess) return fail(P25FE_ERR_NOMEM);
+            // (every rank makes this call: a collective on the parent communicator.  A failure leaves the pipelined step on its
+            // one-communicator layout.)
+            if (ncclCommSplit(s->comm, 0, rank, &s->comm_halo, nullptr) != ncclSuccess) s->comm_halo = nullptr;
         } else {
             const char* name = getenv("P25FE_SHARD_SHM");
             if (!name || s->halo * 8 > SHM_HALO_MAX) return fail(P25FE_ERR_ARG);
@@ -236,14 +248,25 @@ static int exact_offsets_wait(p25fe_shard_t* s)
     return P25FE_OK;
 }
 
-int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
+} // extern "C"
+
+// Where the launches of one step go.
+//   plain step:       everything on the caller's stream; halo + head on the side stream beside K1's main launch.
+//   pipelined, 1:     K1's main launch on the caller's stream, everything behind it on the handle's receive stream (rx = rx2).
+//   pipelined, 2:     the halo (its own communicator) and then the WHOLE front end on the caller's stream -- an RCCL kernel is one
+//                     256-thread workgroup with 132 VGPRs and 20 KB of LDS, which finds no room on a chip K1's one-wave workgroups keep
+//                     full (measured: it starts when K1 drains), so the exchange is put where the chip IS drained: between two K1s;
+//                     detection, scan and the summary all-gather on the receive stream (rx), pass 2, the dibit gather and the
+//                     compaction on the side stream (rx2): two stages, each one step long, so that the exchange that ends a stage
+//                     finds its K1 boundary without holding up the next step's first stage.
+struct StepStreams { hipStream_t st, rx, rx2; bool halo_on_st; };
+static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather,
+                           const StepStreams& ss)
 {
+    const hipStream_t st = ss.st, rx = ss.rx;
     if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) || gather < P25FE_GATHER_NONE ||
         gather > P25FE_GATHER_ROOT_EXACT)
         return P25FE_ERR_ARG;
-    if (s->broken) return P25FE_ERR_HIP;
-    hipStream_t st = (hipStream_t)stream;
-    HCHK(hipSetDevice(p25fe_device(s->h)));
     const size_t eb = fmt == P25FE_FMT_CF32 ? 8 : 2;
     char* buf = static_cast<char*>(d_buf);
     char* owned = buf + s->halo * eb;
@@ -268,18 +291,28 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
             if (rc) return rc;
         } else {
-            HCHK(hipEventRecord(s->e_fork, st));                 // the exchange may not overtake earlier users of the buffers
-            HCHK(hipStreamWaitEvent(s->cs, s->e_fork, 0));
-            if (timed) HCHK(hipEventRecord(ev[0], s->cs));
+            const hipStream_t hs = ss.halo_on_st ? st : s->cs;
+            const ncclComm_t hc = ss.halo_on_st ? s->comm_halo : s->comm;
+            if (!ss.halo_on_st) {
+                HCHK(hipEventRecord(s->e_fork, st));             // the exchange may not overtake earlier users of the buffers
+                HCHK(hipStreamWaitEvent(s->cs, s->e_fork, 0));
+            }
+            if (timed) HCHK(hipEventRecord(ev[0], hs));
             NCHK(ncclGroupStart());
-            if (s->rank + 1 < s->world) NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, s->comm, s->cs));
-            if (s->rank > 0) NCHK_G(s, ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, s->comm, s->cs));
+            if (s->rank + 1 < s->world) NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, hc, hs));
+            if (s->rank > 0) NCHK_G(s, ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, hc, hs));
             if (loopback) {                                      // loop the halo back
-                NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
-                NCHK_G(s, ncclRecv(s->d_loop, s->halo * eb, ncclUint8, 0, s->comm, s->cs));
+                NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, 0, hc, hs));
+                NCHK_G(s, ncclRecv(s->d_loop, s->halo * eb, ncclUint8, 0, hc, hs));
             }
             if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
-            if (timed) HCHK(hipEventRecord(ev[1], s->cs));
+            if (timed) HCHK(hipEventRecord(ev[1], hs));
+            if (ss.halo_on_st) {
+                rc = p25fe_shard_pass1_k1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);       // the halo is in: one launch, head included
+                if (rc) return rc;
+                rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, rx);
+                if (rc) return rc;
+            } else {
             rc = p25fe_shard_pass1_main(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);
             if (rc) return rc;
             // the head segment (the one workgroup whose input reaches into the halo) follows the halo on ITS stream, beside
@@ -291,39 +324,46 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             // it costs ~10 us of idle GPU between K1 and the detection).
             if (s->head_event_wait) {
                 HCHK(hipEventRecord(s->e_head, s->cs));
-                HCHK(hipStreamWaitEvent(st, s->e_head, 0));
+                HCHK(hipStreamWaitEvent(rx, s->e_head, 0));
             }
-            rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
+            rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, rx);
             if (rc) return rc;
+            }
         }
         // ---- 2. one summary per rank to every rank
         if (s->staged) {
-            HCHK(hipStreamSynchronize(st));
+            HCHK(hipStreamSynchronize(rx));
             HCHK(hipMemcpy(s->shm.summ(s->rank), d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToHost));
             s->shm.barrier();
             HCHK(hipMemcpy(s->d_summ, s->shm.summ(0), (size_t)s->world * sizeof(p25fe_result_t), hipMemcpyHostToDevice));
             s->shm.barrier();
         } else {
-            if (timed) HCHK(hipEventRecord(ev[2], st));
-            NCHK(ncclAllGather(d_result, s->d_summ, sizeof(p25fe_result_t), ncclUint8, s->comm, st));
-            if (timed) HCHK(hipEventRecord(ev[3], st));
+            if (timed) HCHK(hipEventRecord(ev[2], rx));
+            NCHK(ncclAllGather(d_result, s->d_summ, sizeof(p25fe_result_t), ncclUint8, s->comm, rx));
+            if (timed) HCHK(hipEventRecord(ev[3], rx));
         }
     } else {
-        rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
+        rc = p25fe_shard_pass1_k1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);              // (no halo to wait for: one launch)
         if (rc) return rc;
-        HCHK(hipMemcpyAsync(s->d_summ, d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToDevice, st));
+        rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, rx);
+        if (rc) return rc;
+        HCHK(hipMemcpyAsync(s->d_summ, d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToDevice, rx));
     }
     const bool exact = gather == P25FE_GATHER_ROOT_EXACT && multi;
     if (exact) {
-        rc = exact_offsets_begin(s, st);
+        rc = exact_offsets_begin(s, rx);
         if (rc) return rc;
+    }
+    if (ss.rx2 != ss.rx) {                                           // second stage: its stream takes over behind the summaries
+        HCHK(hipEventRecord(s->e_stage, ss.rx));
+        HCHK(hipStreamWaitEvent(ss.rx2, s->e_stage, 0));
     }
     // ---- 3. pass 2 with the combine inside it (carry-in anchor, dibit offsets).  Rank 0's shard starts at offset 0 of the
     // ordered stream: it slices straight into it as well (the loopback test ranks send to themselves instead)
     const bool to_root = gather == P25FE_GATHER_ROOT || gather == P25FE_GATHER_ROOT_EXACT;
     uint8_t* dup = (s->rank == 0 && !loopback && (to_root || !multi) && gather != P25FE_GATHER_NONE) ? s->d_stream : nullptr;
     rc = p25fe_shard_pass2_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, (size_t)s->rank, s->d_anc, s->d_off, d_dibits, s->cap,
-                               dup, d_result, st);
+                               dup, d_result, ss.rx2);
     if (rc) return rc;
     s->gather_ran = multi ? gather : (gather == P25FE_GATHER_NONE ? P25FE_GATHER_NONE : P25FE_GATHER_ROOT);
     // ---- 4. the reduced dibit stream
@@ -338,7 +378,7 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             if (rc) return rc;
             const uint64_t* off = s->h_off;
             if (s->staged) {
-                HCHK(hipStreamSynchronize(st));
+                HCHK(hipStreamSynchronize(ss.rx2));
                 const size_t mine = (size_t)(off[s->rank + 1] - off[s->rank]);
                 if (s->rank > 0 && mine) HCHK(hipMemcpy(s->shm.row(s->rank), d_dibits, mine, hipMemcpyDeviceToHost));
                 s->shm.barrier();
@@ -347,19 +387,19 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
                         if (off[r + 1] > off[r]) HCHK(hipMemcpy(s->d_stream + off[r], s->shm.row(r), (size_t)(off[r + 1] - off[r]), hipMemcpyHostToDevice));
                 s->shm.barrier();
             } else {
-                if (timed) HCHK(hipEventRecord(ev[4], st));
+                if (timed) HCHK(hipEventRecord(ev[4], ss.rx2));
                 NCHK(ncclGroupStart());
                 if (s->rank == 0) {
                     for (int r = loopback ? 0 : 1; r < s->world; ++r)
-                        if (off[r + 1] > off[r]) NCHK_G(s, ncclRecv(s->d_stream + off[r], (size_t)(off[r + 1] - off[r]), ncclUint8, r, s->comm, st));
+                        if (off[r + 1] > off[r]) NCHK_G(s, ncclRecv(s->d_stream + off[r], (size_t)(off[r + 1] - off[r]), ncclUint8, r, s->comm, ss.rx2));
                 }
                 if ((s->rank > 0 || loopback) && off[s->rank + 1] > off[s->rank])
-                    NCHK_G(s, ncclSend(d_dibits, (size_t)(off[s->rank + 1] - off[s->rank]), ncclUint8, 0, s->comm, st));
+                    NCHK_G(s, ncclSend(d_dibits, (size_t)(off[s->rank + 1] - off[s->rank]), ncclUint8, 0, s->comm, ss.rx2));
                 if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
-                if (timed) HCHK(hipEventRecord(ev[5], st));
+                if (timed) HCHK(hipEventRecord(ev[5], ss.rx2));
             }
         } else if (s->staged) {
-            HCHK(hipStreamSynchronize(st));
+            HCHK(hipStreamSynchronize(ss.rx2));
             HCHK(hipMemcpy(s->shm.row(s->rank), d_dibits, s->cap, hipMemcpyDeviceToHost));
             s->shm.barrier();
             if (s->rank == 0 || gather == P25FE_GATHER_ALL) {
@@ -370,9 +410,9 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
             }
             s->shm.barrier();
         } else {
-            if (timed) HCHK(hipEventRecord(ev[4], st));
+            if (timed) HCHK(hipEventRecord(ev[4], ss.rx2));
             if (gather == P25FE_GATHER_ALL) {
-                NCHK(ncclAllGather(d_dibits, s->d_gathered, s->cap, ncclUint8, s->comm, st));
+                NCHK(ncclAllGather(d_dibits, s->d_gathered, s->cap, ncclUint8, s->comm, ss.rx2));
                 first_row = 0;
                 compact = true;
             } else {
@@ -380,22 +420,62 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
                 // all-gather would move `world` times the bytes the one consumer needs around a per-link-bound ring)
                 NCHK(ncclGroupStart());
                 if (s->rank == 0)
-                    for (int r = loopback ? 0 : 1; r < s->world; ++r) NCHK_G(s, ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, st));
-                if (s->rank > 0 || loopback) NCHK_G(s, ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, st));
+                    for (int r = loopback ? 0 : 1; r < s->world; ++r) NCHK_G(s, ncclRecv(s->d_gathered + (size_t)r * s->cap, s->cap, ncclUint8, r, s->comm, ss.rx2));
+                if (s->rank > 0 || loopback) NCHK_G(s, ncclSend(d_dibits, s->cap, ncclUint8, 0, s->comm, ss.rx2));
                 if (ncclGroupEnd() != ncclSuccess) { s->broken = true; return P25FE_ERR_HIP; }
                 if (s->rank == 0) { first_row = loopback ? 0 : 1; compact = true; }
             }
-            if (timed) HCHK(hipEventRecord(ev[5], st));
+            if (timed) HCHK(hipEventRecord(ev[5], ss.rx2));
         }
         if (compact) {
             rc = p25fe_shard_compact_from_dev(s->h, s->d_gathered, s->cap, s->d_off, first_row, (size_t)s->world, s->d_stream,
-                                              (size_t)s->world * s->cap, st);
+                                              (size_t)s->world * s->cap, ss.rx2);
             if (rc) return rc;
         }
     }
     if (timed) ++s->timed;
     ++s->steps;
     return P25FE_OK;
+}
+
+extern "C" {
+
+int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
+{
+    if (!s) return P25FE_ERR_ARG;
+    if (s->broken) return P25FE_ERR_HIP;
+    HCHK(hipSetDevice(p25fe_device(s->h)));
+    const StepStreams ss = {(hipStream_t)stream, (hipStream_t)stream, (hipStream_t)stream, false};
+    return shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
+}
+
+int p25fe_shard_step_pipelined(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
+{
+    if (!s) return P25FE_ERR_ARG;
+    if (s->broken) return P25FE_ERR_HIP;
+    HCHK(hipSetDevice(p25fe_device(s->h)));
+    if (s->staged) {                                                 // the test hook synchronises the host between its phases: nothing to overlap
+        const StepStreams ss = {(hipStream_t)stream, (hipStream_t)stream, (hipStream_t)stream, false};
+        return shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
+    }
+    void* rx = nullptr;
+    int rc = p25fe_shard_pipe_begin(s->h, stream, &rx);
+    if (rc) return rc;
+    // the ordered stream of the PREVIOUS step stays readable (by work enqueued on `stream` before this call) while this step's
+    // slicer / gather write the other buffer
+    uint8_t* t = s->d_stream; s->d_stream = s->d_stream2; s->d_stream2 = t;
+    // layout 2 needs the halo's own communicator (or no exchange at all); otherwise the step's own order on the receive stream
+    const bool two_stage = s->pipe_layout == 2 && (s->comm_halo || !s->comm);
+    const StepStreams ss = {(hipStream_t)stream, (hipStream_t)rx, two_stage ? s->cs : (hipStream_t)rx, two_stage};
+    rc = shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
+    const int erc = p25fe_shard_pipe_end(s->h, ss.rx2);              // (also after a failure: the work enqueued so far stays joinable)
+    return rc ? rc : erc;
+}
+
+int p25fe_shard_join(p25fe_shard_t* s, void* stream)
+{
+    if (!s) return P25FE_ERR_ARG;
+    return p25fe_join_dev(s->h, stream);
 }
 
 int p25fe_shard_offsets(p25fe_shard_t* s, uint64_t* offsets)

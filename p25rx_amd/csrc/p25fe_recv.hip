@@ -583,7 +583,7 @@ template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 2 : 4) void k_detect(
     if (a.head_flag && (int)blockIdx.x <= a.head_tile_max) {       // uniform
         // every head workgroup released its stores (agent scope) before it took its ticket; the acquire after seeing the
         // flag keeps this wave from reading lines its caches held before that
-        while (__hip_atomic_load(a.head_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.head_seq) __builtin_amdgcn_s_sleep(16);
+        while ((int)(__hip_atomic_load(a.head_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.head_seq) < 0) __builtin_amdgcn_s_sleep(16);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     detect_tile<GEN>(a, (int)blockIdx.x, (int)blockIdx.y);

@@ -386,6 +386,24 @@ class FrontEnd:
         self._chk(self.L.p25fe_shard_pass1_head(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0,
                                                 self._stream()))
 
+    def shard_pipe_begin(self):
+        """p25fe_shard_pipe_begin on torch's current stream -> the handle's receive stream as a torch stream: shard_pass1_main stays
+        on the current stream, every later pass of the step is enqueued under `with torch.cuda.stream(rx)`; then shard_pipe_end()."""
+        import torch
+        rx = C.c_void_p()
+        self._chk(self.L.p25fe_shard_pipe_begin(self.h, self._stream(), C.byref(rx)))
+        return torch.cuda.ExternalStream(rx.value)
+
+    def shard_pipe_end(self, last=None):
+        """last: the torch stream the step's final pass was enqueued on (default: the receive stream)"""
+        self._chk(self.L.p25fe_shard_pipe_end(self.h, C.c_void_p(last.cuda_stream) if last is not None else None))
+
+    def shard_pass1_k1(self, iq, offset, n_hist, abs0):
+        """The whole front end of pass 1 (main + head) in one launch; shard_pass1_finish then runs detection + scan only."""
+        fmt, n_total, stride = self._iq_view(iq)
+        ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
+        self._chk(self.L.p25fe_shard_pass1_k1(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0, self._stream()))
+
     def shard_pass2_dev(self, summ_all, d_bb0, d_bbn, rank, n_bb, dibits=None, dup=None, result=None):
         """Pass 2 with the combine inside it (p25fe_shard_pass2_dev): summ_all uint8 [n_shards, sizeof(result)] on the device.
         Returns (dibits, result, anchors uint8 [n_shards, sizeof(anchor)], offsets int64 [n_shards + 1])."""

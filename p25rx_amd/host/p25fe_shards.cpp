@@ -3,7 +3,7 @@
 // drives include/p25fe_rccl.h (halo by ncclSend / ncclRecv behind K1, summaries by ncclAllGather, device resolve, dibit
 // rows to rank 0 + compaction) and rank 0 writes the ORDERED dibit stream -- byte for byte what `p25fe_replay cf32` writes.
 //
-//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [-t EVERY] [--shm] <in.cf32> <dibits.out>
+//   p25fe_shards [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [-t EVERY] [-p] [-s] [--shm] <in.cf32> <dibits.out>
 //
 //   -g      how the dibits reach rank 0 (include/p25fe_rccl.h): rows = whole rows + a compaction pass (default;
 //           P25FE_GATHER_ROOT, no host wait in the step), exact = each shard's valid bytes, received at their offsets
@@ -35,7 +35,7 @@ static void die(const char* what, int rc)
     std::_Exit(1);
 }
 
-static int child(int rank, int world, int steps, bool shm, int clock, int gather, int timing, const char* in_path, const char* out_path, const std::string& key)
+static int child(int rank, int world, int steps, bool shm, int clock, int gather, int timing, bool pipelined, bool own_stream, const char* in_path, const char* out_path, const std::string& key)
 {
     FILE* f = std::fopen(in_path, "rb");
     if (!f) { std::fprintf(stderr, "unable to open %s\n", in_path); return 1; }
@@ -85,25 +85,32 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
     float* d_buf = nullptr;
     uint8_t* d_dib = nullptr;
     p25fe_result_t* d_res = nullptr;
-    hipStream_t st;
+    // The step goes to the NULL stream unless -s asks for a stream of this program's own.  Measured (profiles/r05_shard_pipelined.txt):
+    // HIP multiplexes streams onto a few hardware queues, and with one more user stream in the process the step's three streams no
+    // longer get queues of their own -- the same step costs 0.36 ms instead of 0.28 (pipelined) / 0.355 instead of 0.337 (plain).
+    hipStream_t st = nullptr;
     if (hipMalloc(&d_buf, (halo + n) * 8) != hipSuccess || hipMalloc(&d_dib, cap) != hipSuccess || hipMalloc(&d_res, sizeof *d_res) != hipSuccess ||
-        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+        (own_stream && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess))
         die("device buffers", P25FE_ERR_NOMEM);
     (void)hipMemset(d_buf, 0, halo * 8);
     (void)hipMemcpy(d_buf + 2 * halo, host.data(), n * 8, hipMemcpyHostToDevice);
+    // -p: p25fe_shard_step_pipelined -- only K1 on `st`, the rest of a step behind the next step's K1
+    auto step = pipelined ? p25fe_shard_step_pipelined : p25fe_shard_step;
     for (int k = 0; k < 2; ++k) {                                     // warm-up (communicator set-up, scratch allocation)
-        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
+        rc = step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
         if (rc) die("step", rc);
     }
+    if ((rc = p25fe_shard_join(s, st)) != 0) die("join", rc);
     (void)hipStreamSynchronize(st);
     double cms[3];
     uint64_t cn = 0;
     (void)p25fe_shard_comm_ms(s, cms, &cn);
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < steps; ++k) {
-        rc = p25fe_shard_step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
+        rc = step(s, d_buf, P25FE_FMT_CF32, d_dib, d_res, gather, st);
         if (rc) die("step", rc);
     }
+    if ((rc = p25fe_shard_join(s, st)) != 0) die("join", rc);
     const double enq_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;   // host time to ENQUEUE a step
     (void)hipStreamSynchronize(st);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
@@ -120,9 +127,9 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
         std::fclose(g);
         std::printf("{\"ranks\":%d,\"samples_per_rank\":%zu,\"dibits\":%" PRIu64 ",\"steps\":%d,\"ms_per_step\":%.4f,\"host_enqueue_ms_per_step\":%.4f,"
                     "\"comm_ms_per_step\":{\"halo\":%.4f,\"summaries\":%.4f,\"dibit_gather\":%.4f,\"steps_averaged\":%" PRIu64 "},"
-                    "\"exchange\":\"%s\",\"gather\":\"%s\"}\n",
+                    "\"exchange\":\"%s\",\"gather\":\"%s\",\"pipelined\":%s}\n",
                     world, n, off[(size_t)world], steps, ms, enq_ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL",
-                    ran == P25FE_GATHER_ROOT_EXACT ? "exact" : (ran == P25FE_GATHER_ROOT ? "rows" : "other"));
+                    ran == P25FE_GATHER_ROOT_EXACT ? "exact" : (ran == P25FE_GATHER_ROOT ? "rows" : "other"), pipelined ? "true" : "false");
         std::remove(idfile.c_str());
         std::fflush(stdout);                                          // the child leaves through _Exit
     }
@@ -134,7 +141,7 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
 int main(int argc, char** argv)
 {
     int ranks = 1, steps = 3, clock = 0, a = 1, gather = P25FE_GATHER_ROOT, timing = -1;
-    bool shm = false;
+    bool shm = false, pipelined = false, own_stream = false;
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!std::strcmp(argv[a], "-n") && a + 1 < argc) ranks = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "-k") && a + 1 < argc) steps = std::atoi(argv[++a]);
@@ -142,10 +149,12 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[a], "-g") && a + 1 < argc) gather = !std::strcmp(argv[++a], "exact") ? P25FE_GATHER_ROOT_EXACT : P25FE_GATHER_ROOT;
         else if (!std::strcmp(argv[a], "-t") && a + 1 < argc) timing = std::atoi(argv[++a]);
         else if (!std::strcmp(argv[a], "--shm")) shm = true;
+        else if (!std::strcmp(argv[a], "-p")) pipelined = true;
+        else if (!std::strcmp(argv[a], "-s")) own_stream = true;
         else break;
     }
     if (argc - a != 2 || ranks < 1 || steps < 1 || (clock != 0 && clock != 1)) {
-        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [-t EVERY] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s [-n RANKS] [-k STEPS] [-c 0|1] [-g exact|rows] [-t EVERY] [-p] [-s] [--shm] <in.cf32> <dibits.out>\n", argv[0]);
         return 2;
     }
     const std::string key = "/p25fe_shards_" + std::to_string((long)getpid());
@@ -154,7 +163,7 @@ int main(int argc, char** argv)
     std::vector<pid_t> kids;
     for (int r = 0; r < ranks; ++r) {
         const pid_t p = fork();
-        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, gather, timing, argv[a], argv[a + 1], key));
+        if (p == 0) std::_Exit(child(r, ranks, steps, shm, clock, gather, timing, pipelined, own_stream, argv[a], argv[a + 1], key));
         kids.push_back(p);
     }
     int bad = 0;

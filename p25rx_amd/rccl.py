@@ -16,7 +16,8 @@ ID_BYTES = 128
 GATHER = {"none": 0, "root": 1, "all": 2, "root_exact": 3}
 
 SYMBOLS = ["p25fe_rccl_unique_id", "p25fe_shard_create", "p25fe_shard_destroy", "p25fe_shard_dibit_cap", "p25fe_shard_step",
-           "p25fe_shard_offsets", "p25fe_shard_stream_dev", "p25fe_shard_comm_ms", "p25fe_shard_comm_timing", "p25fe_shard_gather_ran"]
+           "p25fe_shard_offsets", "p25fe_shard_stream_dev", "p25fe_shard_comm_ms", "p25fe_shard_comm_timing", "p25fe_shard_gather_ran",
+           "p25fe_shard_step_pipelined", "p25fe_shard_join"]
 
 _LIB = None
 
@@ -37,6 +38,8 @@ def load():
     L.p25fe_shard_dibit_cap.argtypes = [vp]
     L.p25fe_shard_dibit_cap.restype = sz
     L.p25fe_shard_step.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.p25fe_shard_step_pipelined.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.p25fe_shard_join.argtypes = [vp, vp]
     L.p25fe_shard_offsets.argtypes = [vp, vp]
     L.p25fe_shard_stream_dev.argtypes = [vp]
     L.p25fe_shard_stream_dev.restype = vp
@@ -79,15 +82,24 @@ class ShardStep:
 
     __del__ = close
 
-    def step(self, buf, dibits, result, gather="root", fmt=_lib.FMT_CF32):
+    def step(self, buf, dibits, result, gather="root", fmt=_lib.FMT_CF32, pipelined=False):
         """buf: device tensor [halo + n_per_rank, 2] (the halo part is overwritten); dibits: uint8 device row of dibit_cap bytes;
-        result: uint8 device tensor of one p25fe_result_t.  Enqueues on torch's current stream."""
+        result: uint8 device tensor of one p25fe_result_t.  Enqueues on torch's current stream.  pipelined: p25fe_shard_step_pipelined
+        (only K1 on the current stream, the rest on the handle's receive stream; join() before reading the outputs)."""
         import torch
         st = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
-        rc = self.L.p25fe_shard_step(self.h, C.c_void_p(buf.data_ptr()), fmt, C.c_void_p(dibits.data_ptr()),
-                                     C.c_void_p(result.data_ptr()), GATHER[gather], st)
+        fn = self.L.p25fe_shard_step_pipelined if pipelined else self.L.p25fe_shard_step
+        rc = fn(self.h, C.c_void_p(buf.data_ptr()), fmt, C.c_void_p(dibits.data_ptr()), C.c_void_p(result.data_ptr()), GATHER[gather], st)
         if rc:
-            raise _lib.P25feError(rc, "p25fe_shard_step: " + _lib.load().p25fe_strerror(rc).decode())
+            raise _lib.P25feError(rc, "p25fe_shard_step%s: " % ("_pipelined" if pipelined else "") + _lib.load().p25fe_strerror(rc).decode())
+
+    def join(self, device=None):
+        """torch's current stream waits for everything pipelined steps have enqueued"""
+        import torch
+        st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        rc = self.L.p25fe_shard_join(self.h, st)
+        if rc:
+            raise _lib.P25feError(rc, "p25fe_shard_join")
 
     def offsets(self):
         """after a synchronise: the world + 1 dibit offsets of the capture"""

@@ -422,6 +422,70 @@ def test_c_abi_shard_step_through_ctypes_rccl_world1():
     assert res == [True, True, True, True, True, True]
 
 
+def _rccl_cabi_pipelined_worker(q):
+    import torch
+    from p25rx_amd import c4fm, rccl
+    from p25rx_amd._lib import RESULT_DTYPE
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    torch.cuda.set_device(0)
+    oks = []
+    caps = [c4fm.synth(2.0, seed=78, snr_db=22.0, frame_dibits=400)[0], c4fm.synth(2.0, seed=79, snr_db=22.0, frame_dibits=900)[0]]
+    n = min(len(c) for c in caps) // 8 * 8
+    for comm_id in (rccl.unique_id(), None):                        # a one-rank RCCL communicator; no communicator at all
+        fe = FrontEnd()
+        ss = rccl.ShardStep(fe, 0, 1, n, comm_id)
+        halo = fe.shard_halo()
+        bufs, refs = [], []
+        for iq in caps:
+            b = torch.zeros((halo + n, 2), dtype=torch.float32, device="cuda")
+            b[halo:] = torch.from_numpy(iq[:n].view(np.float32).reshape(-1, 2)).cuda()
+            bufs.append(b)
+            ref, rres = FrontEnd().run_dev(b[halo:])
+            refs.append(ref[0, :int(parse_results(rres)[0]["n_dibits"])].clone())
+        order = [0, 1, 1, 0, 1, 0, 0, 1, 0]
+        outs = [(torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device="cuda"),
+                 torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")) for _ in order]
+        for gather in ("root", "all", "root_exact", "none"):
+            for k, w in enumerate(order):                            # all enqueued back to back: step k + 1's K1 beside step k's chain
+                ss.step(bufs[w], outs[k][0], outs[k][1], gather=gather, pipelined=True)
+            ss.join()
+            torch.cuda.synchronize()
+            ok = True
+            for k, w in enumerate(order):
+                nd = int(parse_results(outs[k][1])[0]["n_dibits"])
+                ok = ok and nd == len(refs[w]) and bool(torch.equal(outs[k][0][0, :nd], refs[w]))
+            if gather != "none":
+                off = ss.offsets()
+                ok = ok and int(off[-1]) == len(refs[order[-1]]) and bool(torch.equal(ss.stream(torch, "cuda", int(off[-1])), refs[order[-1]]))
+            oks.append(ok)
+        # a plain step straight behind a pipelined one (no join): it waits for the receive stream by itself
+        ss.step(bufs[1], outs[0][0], outs[0][1], gather="root", pipelined=True)
+        ss.step(bufs[0], outs[1][0], outs[1][1], gather="root")
+        torch.cuda.synchronize()
+        off = ss.offsets()
+        n1 = int(parse_results(outs[0][1])[0]["n_dibits"])
+        oks.append(n1 == len(refs[1]) and bool(torch.equal(outs[0][0][0, :n1], refs[1])) and int(off[-1]) == len(refs[0])
+                   and bool(torch.equal(ss.stream(torch, "cuda", int(off[-1])), refs[0])))
+        ss.close()
+    q.put(oks)
+
+
+@pytest.mark.timeout(300)
+def test_c_abi_shard_step_pipelined():
+    """p25fe_shard_step_pipelined: nine steps over two alternating captures enqueued back to back (every gather mode; with a one-rank
+    RCCL communicator and without one) leave, per step, the single-pass dibits of THAT step's capture, and the ordered stream of
+    the last one; a plain step behind a pipelined one needs no join."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_cabi_pipelined_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res == [True] * 10
+
+
 @pytest.mark.timeout(300)
 def test_bench_two_ranks_channel_blocks_host_staged():
     """config 4 over N GPUs (ChannelShard): bench.py --workload channels with two ranks on one GPU.  5 channels -> blocks

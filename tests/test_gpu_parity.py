@@ -303,6 +303,96 @@ def test_time_shards_equal_single_pass(O, FE):
         assert np.array_equal(dib[0, :len(out2[r])].cpu().numpy(), out2[r])
 
 
+def test_time_shard_steps_pipelined(O, FE):
+    """p25fe_shard_pipe_begin / _end (what p25fe_shard_step_pipelined drives): steps over ALTERNATING captures enqueued back to back
+    -- K1's main launch on the caller's stream, the head on a side stream (the detection's first tiles poll its flag), detection /
+    scan / combine + slicer on the handle's receive stream two scratch sets deep -- give, step for step, the bytes of the same
+    shard procedure run one call at a time."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results, n_baseband
+    caps, refs = [], []
+    for seed, fd in ((41, 1500), (42, 700)):
+        iq, _, _ = c4fm.synth(2.0, seed=seed, snr_db=20.0, frame_dibits=fd)
+        caps.append(torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda())
+        refs.append(O.run_cf32(iq))
+    n_all = caps[0].shape[0]
+    cut = 200008
+    halo = FE().shard_halo()
+    bb0 = [n_baseband(0, 0), n_baseband(0, cut)]
+    bbn = [n_baseband(0, cut), n_baseband(cut, n_all - cut)]
+    d_bb0 = torch.tensor(bb0, dtype=torch.int64, device="cuda")
+    d_bbn = torch.tensor(bbn, dtype=torch.int64, device="cuda")
+    # shard 0's summary per capture (a plain pass 1 on its own handle); shard 1 is the pipelined one
+    fe0, summ0 = FE(), []
+    for t in caps:
+        summ0.append(fe0.shard_pass1(t[:cut], offset=0, n_hist=0, abs0=0).clone())
+    torch.cuda.synchronize()
+
+    def plain(fe, t):
+        res = fe.shard_pass1(t[cut - halo:], offset=halo, n_hist=halo, abs0=cut)
+        return res
+
+    # the one-call-at-a-time answer of shard 1 for both captures
+    want = []
+    fe1 = FE()
+    for w, t in enumerate(caps):
+        res = plain(fe1, t)
+        summ_t = torch.cat([summ0[w], res])
+        dib, res2, _, off = fe1.shard_pass2_dev(summ_t, d_bb0, d_bbn, 1, bbn[1])
+        r = parse_results(res2)[0]
+        off = off.cpu().numpy()
+        assert int(off[2]) == len(refs[w])
+        want.append((r.tobytes(), dib[0, :int(r["n_dibits"])].cpu().numpy().copy()))
+        assert np.array_equal(want[-1][1], refs[w][int(off[1]):])
+    # pipelined: every step enqueued before the first one has finished
+    fe = FE()
+    side = torch.cuda.Stream()
+    st = torch.cuda.current_stream()
+    order = [0, 1, 1, 0, 1, 0, 0, 1]
+    cap = (bbn[1] // 10 + 64 + 15) // 16 * 16
+    outs = [(torch.zeros((1, cap), dtype=torch.uint8, device="cuda"), torch.zeros_like(summ0[0])) for _ in order]
+    for k, w in enumerate(order):
+        t = caps[w][cut - halo:]
+        rx = fe.shard_pipe_begin()
+        fork = st.record_event()                                  # the side stream may not overtake the wait _begin put on `st`
+        fe.shard_pass1_main(t, offset=halo, n_hist=halo, abs0=cut)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            fe.shard_pass1_head(t, offset=halo, n_hist=halo, abs0=cut)
+        with torch.cuda.stream(rx):
+            res = fe.shard_pass1_finish(t, offset=halo, n_hist=halo, abs0=cut)
+            summ_t = torch.cat([summ0[w], res])
+            fe.shard_pass2_dev(summ_t, d_bb0, d_bbn, 1, bbn[1], dibits=outs[k][0], result=outs[k][1])
+        fe.shard_pipe_end()
+    fe.join_dev()
+    torch.cuda.synchronize()
+    for k, w in enumerate(order):
+        r = parse_results(outs[k][1])[0]
+        assert r.tobytes() == want[w][0], (k, w)
+        assert np.array_equal(outs[k][0][0, :int(r["n_dibits"])].cpu().numpy(), want[w][1]), (k, w)
+    # a plain call right behind a pipelined step joins the receive stream by itself
+    rx = fe.shard_pipe_begin()
+    fe.shard_pass1_main(caps[1][cut - halo:], offset=halo, n_hist=halo, abs0=cut)
+    with torch.cuda.stream(rx):
+        res = fe.shard_pass1_finish(caps[1][cut - halo:], offset=halo, n_hist=halo, abs0=cut)
+        summ_t = torch.cat([summ0[1], res])
+        fe.shard_pass2_dev(summ_t, d_bb0, d_bbn, 1, bbn[1], dibits=outs[0][0], result=outs[0][1])
+    fe.shard_pipe_end()
+    dib, res = fe.run_dev(caps[0])
+    torch.cuda.synchronize()
+    assert np.array_equal(dib[0, :len(refs[0])].cpu().numpy(), refs[0])
+    assert parse_results(outs[0][1])[0].tobytes() == want[1][0]
+    # protocol errors: a second _begin, an _end without _begin
+    from p25rx_amd._lib import P25feError
+    fe.shard_pipe_begin()
+    with pytest.raises(P25feError):
+        fe.shard_pipe_begin()
+    fe.shard_pipe_end()
+    with pytest.raises(P25feError):
+        fe.shard_pipe_end()
+
+
 def test_custom_taps_zero_padded(O, FE, c4fm_1s):
     """Shorter filters are accepted (zero-padded at the old end) and still match the oracle bit for bit."""
     spec = O.load_spec()

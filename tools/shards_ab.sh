@@ -21,7 +21,11 @@ for r in $(seq 1 $ROUNDS); do
   echo -n "new rows, head by event wait : "; P25FE_SHARD_HEAD_WAIT=event ./build/p25fe_shards -n 1 -k $STEPS -g rows /tmp/shards_cap.cf32 /tmp/shards_dib3.out | tail -1
   echo -n "new rows, side stream at high priority : "; P25FE_SHARD_CS_PRIO=1 ./build/p25fe_shards -n 1 -k $STEPS -g rows /tmp/shards_cap.cf32 /tmp/shards_dib3.out | tail -1
   echo -n "new rows, events on every step : "; ./build/p25fe_shards -n 1 -k $STEPS -g rows -t 1 /tmp/shards_cap.cf32 /tmp/shards_dib.out | tail -1
+  echo -n "new rows, pipelined (-p) : "; ./build/p25fe_shards -n 1 -k $STEPS -g rows -p /tmp/shards_cap.cf32 /tmp/shards_dib4.out | tail -1
+  echo -n "new rows, pipelined, the step's own order on the receive stream (layout 1) : "; P25FE_SHARD_PIPE_LAYOUT=1 ./build/p25fe_shards -n 1 -k $STEPS -g rows -p /tmp/shards_cap.cf32 /tmp/shards_dib3.out | tail -1
+  echo -n "new rows, a stream of the program's own (-s) : "; ./build/p25fe_shards -n 1 -k $STEPS -g rows -s /tmp/shards_cap.cf32 /tmp/shards_dib3.out | tail -1
+  echo -n "new rows, pipelined, a stream of the program's own (-p -s) : "; ./build/p25fe_shards -n 1 -k $STEPS -g rows -p -s /tmp/shards_cap.cf32 /tmp/shards_dib3.out | tail -1
   echo -n "new exact: "; ./build/p25fe_shards -n 1 -k $STEPS -g exact /tmp/shards_cap.cf32 /tmp/shards_dib2.out | tail -1
-  cmp /tmp/shards_dib.out /tmp/shards_dib2.out && cmp /tmp/shards_dib.out /tmp/shards_dib3.out && { [ ! -f /tmp/shards_dib_old.out ] || cmp /tmp/shards_dib.out /tmp/shards_dib_old.out; } && echo "streams identical"
+  cmp /tmp/shards_dib.out /tmp/shards_dib2.out && cmp /tmp/shards_dib.out /tmp/shards_dib3.out && cmp /tmp/shards_dib.out /tmp/shards_dib4.out && { [ ! -f /tmp/shards_dib_old.out ] || cmp /tmp/shards_dib.out /tmp/shards_dib_old.out; } && echo "streams identical"
 done
-rm -f /tmp/shards_cap.cf32 /tmp/shards_dib.out /tmp/shards_dib2.out /tmp/shards_dib3.out /tmp/shards_dib_old.out
+rm -f /tmp/shards_cap.cf32 /tmp/shards_dib.out /tmp/shards_dib2.out /tmp/shards_dib3.out /tmp/shards_dib4.out /tmp/shards_dib_old.out

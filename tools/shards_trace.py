@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The sharded step in ONE process (one-rank RCCL communicator through p25rx_amd/rccl.py), for a kernel trace:
-    rocprofv3 --kernel-trace --output-format csv -d OUT -o tr -- python3 tools/shards_trace.py [gather=root]
+    rocprofv3 --kernel-trace --output-format csv -d OUT -o tr -- python3 tools/shards_trace.py [gather=root] [pipelined]
 then   python3 tools/shards_trace.py --summarise OUT   prints the timeline of one steady-state step."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +38,11 @@ c4fm.synth_torch(n, seed=3, device=torch.device("cuda", 0), out=buf[halo:])
 result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
 dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device="cuda")
 ss.comm_timing(int(os.environ.get("SHARDS_TRACE_TIMING", "0")))   # no event packets between the kernels of the traced steps
-for _ in range(300):
-    ss.step(buf, dibits, result, gather=gather)
+pipelined = len(sys.argv) > 2 and sys.argv[2] == "pipelined"   # p25fe_shard_step_pipelined: the chain behind K1 runs beside the next step's K1
+own = torch.cuda.Stream() if os.environ.get("SHARDS_TRACE_OWN_STREAM") else None      # a user stream instead of the NULL stream
+with torch.cuda.stream(own if own is not None else torch.cuda.current_stream()):
+    for _ in range(300):
+        ss.step(buf, dibits, result, gather=gather, pipelined=pipelined)
+    ss.join()
 torch.cuda.synchronize()
 print("done", ss.comm_ms())
