@@ -18,6 +18,9 @@
  *     4. the other shards' dibit rows go to rank 0 point-to-point (xGMI is a full mesh) and are compacted there behind
  *        rank 0's own -- ONE ordered stream, what RecvTask feeds into MessageReceiver (src/recv.rs:148-150).
  *   Dependent launches behind K1 on rank 0: detection, scan, all-gather, slicer, receive, compaction.
+ *   p25fe_shard_step_pipelined runs the same passes with the exchanges placed at the boundaries between consecutive steps' K1
+ *   launches (the halo on a communicator of its own directly in front of K1; 2 and 3 beside the next step's K1, 4 beside the one
+ *   after): see its declaration below.
  *
  * Bootstrap: rank 0 obtains a 128-byte id (p25fe_rccl_unique_id) and gives it to the other ranks by any means (file,
  * pipe, socket); every rank calls p25fe_shard_create with it.
@@ -77,7 +80,10 @@ int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, 
  * stream alternates between two buffers, p25fe_shard_stream_dev() names the LAST call's, and the previous call's stays untouched
  * until the call after this one; d_buf must stay unchanged until `stream` and the step's exchanges have passed it (join).
  * P25FE_GATHER_ROOT_EXACT keeps its one host wait per step, which ends the overlap for that mode; the shared-memory test hook runs
- * the plain step. */
+ * the plain step.  p25fe_shard_create makes a second communicator for the halo (ncclCommSplit, a collective every rank takes part in);
+ * if that fails the step keeps everything behind K1 in step order on the receive stream.
+ * STREAM: pass the NULL stream unless you have checked that yours does not share a hardware queue with the step's side streams
+ * ("Which stream to pass"). */
 int p25fe_shard_step_pipelined(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,
                                void *stream);
 /* make `stream` wait for everything p25fe_shard_step_pipelined has enqueued so far */

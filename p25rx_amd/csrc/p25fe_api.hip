@@ -148,6 +148,7 @@ struct p25fe {
     bool rx_joined_any[MAX_LANES] = {};
     int lane = 0;
     int sh_depth = MAX_LANES;              // sets the pipelined shard step rotates through (P25FE_SHARD_PIPE_DEPTH)
+    int run_depth = 2;                     // sets p25fe_run_dev_pipelined rotates through (P25FE_PIPE_DEPTH)
     // p25fe_run_host_windows: two device windows, dibit rows and result records in a ring, the copy streams and their events
     DevBuf win_buf[2], win_dib[2], win_res, win_anc;
     PinBuf win_stage[2], win_out;
@@ -519,6 +520,8 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
         for (int k = 0; k < MAX_LANES - 1; ++k) h->spare[k].id = k + 1;
         const char* pd = getenv("P25FE_SHARD_PIPE_DEPTH");            // (measurement knob: 2 .. MAX_LANES)
         if (pd && atoi(pd) >= 2 && atoi(pd) <= MAX_LANES) h->sh_depth = atoi(pd);
+        const char* rd = getenv("P25FE_PIPE_DEPTH");
+        if (rd && atoi(rd) >= 2 && atoi(rd) <= MAX_LANES) h->run_depth = atoi(rd);
     }
     if (e == hipSuccess) e = h->d_taps.ensure(sizeof(Taps));
     if (e == hipSuccess) e = hipMemcpy(h->d_taps.p, &h->taps, sizeof(Taps), hipMemcpyHostToDevice);
@@ -1130,7 +1133,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     shard_invalidate(h);
-    if (int orc = pipe_open(h, st)) return orc;
+    if (int orc = pipe_open(h, st, h->run_depth)) return orc;
     const int lane = h->lane;
     const size_t n_bb = p25fe_n_baseband_h(h, 0, n);
     int rc = P25FE_OK;
