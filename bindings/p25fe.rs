@@ -21,6 +21,9 @@ pub const FMT_CF32: c_int = 0;
 pub const FMT_U8: c_int = 1;
 pub const CLOCK_FIXED: i32 = 0;
 pub const CLOCK_TRACKING: i32 = 1;
+/// CLOCK_TRACKING, and the calls that hold a whole range (run_dev, run_dev_pipelined, slice_dev) re-slice the first frame of a lock
+/// run with the period the next sync word confirms (docs/SPEC.md 3.8c); streaming calls and shard passes keep CLOCK_TRACKING's rule
+pub const CLOCK_TRACKING_RESLICE: i32 = 2;
 pub const SPECIALIZE_AUTO: i32 = 0;
 pub const SPECIALIZE_OFF: i32 = -1;
 pub const SPECIALIZE_REQUIRE: i32 = 1;

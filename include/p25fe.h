@@ -102,7 +102,8 @@ typedef struct p25fe_config {
                                             sync word, the receiver structure of the reference; P25FE_CLOCK_TRACKING (1): docs/SPEC.md
                                             3.8b -- the stride is the measured interval between the last two sync words over its
                                             symbol count, instants are read by 4-tap interpolation, the receiver runs 2 samples
-                                            behind the baseband */
+                                            behind the baseband; P25FE_CLOCK_TRACKING_RESLICE (2): the same, and the calls that hold
+                                            a whole range re-slice the first frame of a lock run (SPEC 3.8c, see the define) */
     int32_t specialize;                  /* P25FE_SPECIALIZE_AUTO (0): non-default numbers get immediate-coefficient kernels (cache, then
                                             hipRTC), the generic kernels if that fails; _OFF (-1): always the generic kernels for
                                             non-default numbers; _REQUIRE (1): p25fe_create fails with P25FE_ERR_JIT instead of
@@ -136,6 +137,14 @@ typedef struct p25fe_config {
 
 #define P25FE_CLOCK_FIXED 0
 #define P25FE_CLOCK_TRACKING 1
+/* P25FE_CLOCK_TRACKING plus docs/SPEC.md 3.8c in the calls that hold a whole range in device memory (p25fe_run_dev,
+ * p25fe_run_dev_pipelined, p25fe_slice_dev): a detection without a period of its own -- the first of a lock run -- is sliced with
+ * the period of the interval that STARTS at it, once the next sync word of the range confirms one (the first frame no longer walks
+ * off the eye: 0 symbol errors at 150 and 250 ppm where P25FE_CLOCK_TRACKING leaves 4 and 37 in 28 768).  That is not causal, so
+ * the calls that see the stream in pieces -- every host-buffer streaming call, p25fe_run_host_windows, the time-shard passes --
+ * keep P25FE_CLOCK_TRACKING's rule in this mode ("any chunking gives the same output", src/demod.rs:25-40): a resident call and a
+ * streaming call then differ in the first frame of every lock run, by design. */
+#define P25FE_CLOCK_TRACKING_RESLICE 2
 #define P25FE_SPECIALIZE_AUTO 0
 #define P25FE_SPECIALIZE_OFF (-1)
 #define P25FE_SPECIALIZE_REQUIRE 1

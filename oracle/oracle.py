@@ -131,6 +131,11 @@ def _bind(lib):
     lib.p25o_recv_feed.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), vp, vp, sz, C.POINTER(sz)]
     lib.p25o_recv_state.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_float * 3), C.POINTER(C.c_uint64)]
+    lib.p25o_recv_record.argtypes = [vp, vp, sz]
+    lib.p25o_recv_override.argtypes = [vp, vp, sz]
+    lib.p25o_recv_n_det.restype = C.c_uint64
+    lib.p25o_recv_n_det.argtypes = [vp]
+    lib.p25o_reslice_table.argtypes = [vp, sz, C.c_int, vp]
     lib.p25o_predecim_create.restype = vp
     lib.p25o_predecim_create.argtypes = [vp, C.c_int, C.c_int]
     lib.p25o_predecim_destroy.argtypes = [vp]
@@ -279,6 +284,48 @@ class Recv:
         thr = (C.c_float * 3)()
         self.L.p25o_recv_state(self.h, C.byref(t), C.byref(v), C.byref(s), C.byref(thr), C.byref(nd))
         return dict(t=t.value, valid=bool(v.value), s=s.value, hi=thr[0], mid=thr[1], lo=thr[2], n_dibits=nd.value)
+
+
+CLK_DTYPE = np.dtype([("d", "<i8"), ("n", "<i8"), ("usable", "<i4"), ("pad", "<i4")])
+
+
+def recv_range(bb, cfg=None, resync_at=(), libpath=None):
+    """One RESIDENT range through the receiver: bb from a fresh stream, lock dropped before every sample index of `resync_at`
+    (ascending; p25fe_resync_at_dev).  symbol_clock 0 / 1: one pass of Recv.  symbol_clock 2 (SPEC 3.8c): pass 1 records every
+    detection's backward clock, the table gives a detection without a usable one the clock of the interval that STARTS at it, pass
+    2 slices with the table.  Returns (dibits, sync_pos, sync_dibit)."""
+    cfg = cfg or make_config()
+    bb = np.ascontiguousarray(bb, dtype=np.float32)
+    cuts = [0] + [min(max(int(q), 0), bb.size) for q in sorted(resync_at)] + [bb.size]
+
+    def one_pass(rec=None, ovr=None):
+        r = Recv(cfg, libpath)
+        keep = []
+        if rec is not None:
+            r.L.p25o_recv_record(r.h, _ptr(rec), rec.size)
+        if ovr is not None:
+            r.L.p25o_recv_override(r.h, _ptr(ovr), ovr.size)
+            keep.append(ovr)
+        outs = []
+        for i in range(len(cuts) - 1):
+            if i:
+                r.resync()
+            outs.append(r.feed(bb[cuts[i]:cuts[i + 1]]))
+        nd = int(r.L.p25o_recv_n_det(r.h))
+        base = np.cumsum([0] + [len(o[0]) for o in outs[:-1]])
+        return (np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]),
+                np.concatenate([o[2] for o in outs]) if outs else np.zeros(0, np.uint64), nd)
+
+    if cfg.symbol_clock != 2:
+        d, sp, sd, _ = one_pass()
+        return d, sp, sd
+    rec = np.zeros(bb.size // (cfg.peak_w + 1) + 2, dtype=CLK_DTYPE)
+    _, _, _, nd = one_pass(rec=rec)
+    tab = np.zeros(nd, dtype=CLK_DTYPE)
+    lib(libpath).p25o_reslice_table(_ptr(rec), nd, cfg.sps, _ptr(tab))
+    d, sp, sd, nd2 = one_pass(ovr=tab)
+    assert nd2 == nd
+    return d, sp, sd
 
 
 NID_DTYPE = np.dtype([("raw", "<u8"), ("sync_pos", "<i8"), ("nac", "<u2"), ("duid", "u1"), ("n_errors", "u1"),

@@ -427,6 +427,7 @@ float p25o_atan2f(const p25o_config *c, float y, float x) { return spec_atan2f(c
  *   dibits have no lag.
  * ---------------------------------------------------------------------------------------- */
 #define RING 512
+typedef struct { int64_t d, n; int32_t usable, pad_; } p25o_clk;       /* a clock D / N; usable: it came from a sync-to-sync interval that passed 3.8b's test */
 typedef struct {
     p25o_config cfg;
     int64_t t;                  /* samples fed so far */
@@ -442,6 +443,11 @@ typedef struct {
     int64_t prev_s;
     int prev_f;                 /* ... and its position's fraction in quarter samples (SPEC 3.8b) */
     uint64_t n_dibits;
+    /* SPEC 3.8c (symbol_clock = 2, resident ranges): the clock of detection k, counted from the creation of the receiver,
+     * can be RECORDED (pass 1) and REPLACED (pass 2) -- see p25o_reslice_table */
+    uint64_t n_det;
+    p25o_clk *rec; size_t rec_cap;
+    const p25o_clk *ovr; size_t ovr_len;
 } p25o_recv;
 
 p25o_recv *p25o_recv_create(const p25o_config *cfg)
@@ -453,6 +459,25 @@ p25o_recv *p25o_recv_create(const p25o_config *cfg)
 }
 
 void p25o_recv_destroy(p25o_recv *r) { free(r); }
+
+/* SPEC 3.8c.  The streaming receiver gives a detection the period of the interval that ENDS at it, so the first frame of a lock
+ * run (first detection, after a resync, after an implausible interval) is sliced at the nominal 10 / 1 and walks off the eye when the
+ * sample clock is off.  A call that has the whole range in memory can do better: such a detection takes the period of the interval
+ * that STARTS at it -- the backward clock of the NEXT detection -- if that one is usable.  Restated here as two passes of the
+ * same receiver: pass 1 records (backward clock, usable) of every detection, p25o_reslice_table forms the table, pass 2 (a fresh
+ * receiver fed the same samples and the same resyncs) takes its clocks from the table.  Detections do not depend on the clock,
+ * so the k-th detection of both passes is the same sync word. */
+void p25o_recv_record(p25o_recv *r, p25o_clk *rec, size_t cap) { r->rec = rec; r->rec_cap = cap; }
+void p25o_recv_override(p25o_recv *r, const p25o_clk *tab, size_t len) { r->ovr = tab; r->ovr_len = len; }
+uint64_t p25o_recv_n_det(const p25o_recv *r) { return r->n_det; }
+void p25o_reslice_table(const p25o_clk *rec, size_t n, int sps, p25o_clk *out)
+{
+    for (size_t k = 0; k < n; k++) {
+        if (rec[k].usable) out[k] = rec[k];
+        else if (k + 1 < n && rec[k + 1].usable) { out[k] = rec[k + 1]; out[k].usable = 0; }
+        else { out[k].d = sps; out[k].n = 1; out[k].usable = 0; out[k].pad_ = 0; }
+    }
+}
 
 /* MessageReceiver::resync (src/recv.rs:136, 179): drop lock (and with it the clock estimate). */
 void p25o_recv_resync(p25o_recv *r) { r->anchor_valid = 0; r->prev_valid = 0; }
@@ -550,14 +575,19 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
                     }
                 }
                 r->per_d = S; r->per_n = 1;
+                int usable = 0;
                 if (track && r->prev_valid) {
                     const int64_t dd = m - r->prev_s, nn = (dd + S / 2) / S;
                     const int64_t err = dd > S * nn ? dd - S * nn : S * nn - dd;
                     if (nn >= 1 && dd <= ((int64_t)1 << g->clk_dmax_log2) && (err << g->clk_tol_shift) <= S * nn) {
                         const int64_t d4 = 4 * dd + (fq - r->prev_f);
+                        usable = 1;
                         if (d4 != 4 * S * nn) { r->per_d = d4; r->per_n = 4 * nn; }     /* (exactly nominal: written 10 / 1, the same instants) */
                     }
                 }
+                if (r->rec && r->n_det < r->rec_cap) { p25o_clk k = {r->per_d, r->per_n, usable, 0}; r->rec[r->n_det] = k; }
+                if (r->ovr && r->n_det < r->ovr_len) { r->per_d = r->ovr[r->n_det].d; r->per_n = r->ovr[r->n_det].n; }   /* SPEC 3.8c, pass 2 */
+                r->n_det++;
                 r->prev_s = m; r->prev_f = fq; r->prev_valid = 1;
                 r->anchor_s = m;
                 r->anchor_valid = 1;

@@ -133,6 +133,8 @@ struct p25fe {
     DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, chunk_cnt;
     PinBuf hin, hbb, hout;                 // streaming entry points: staged input ([history | new] IQ, [tail | new] baseband), results
     DevBuf gsum, gouts, evg;               // general receiver only (tracking clock / lock drops): allocated on first use
+    DevBuf evrec, evnext, evoff;           // SPEC 3.8c (symbol_clock = 2, resident ranges): the list of detections, allocated on first use
+    unsigned long long ev_seq = 0;         // ... and the sequence number that marks an EvNext entry as this call's
     // p25fe_run_dev_pipelined: a second set of the receiver's scratch (the member names above always are the set of the
     // current call; the sets are swapped per call), the stream the receive kernels run on, and the events that order
     // K1 (caller's stream) -> K2..K4 (rx_stream) -> next K1 into the same set two calls later
@@ -234,7 +236,7 @@ static bool lut_is_affine(const float* lut, float sc, float of)
 static int resolve_config(const p25fe_config_t* cfg, Resolved* r)
 {
     if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_decim_taps < 1 || cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 ||
-        cfg->n_chan_taps > P25FE_MAX_TAPS || (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING) ||
+        cfg->n_chan_taps > P25FE_MAX_TAPS || (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING && cfg->symbol_clock != P25FE_CLOCK_TRACKING_RESLICE) ||
         cfg->specialize < P25FE_SPECIALIZE_OFF || cfg->specialize > P25FE_SPECIALIZE_FORCE || cfg->decim_phase < 0 || cfg->decim_phase >= DEC ||
         cfg->n_avg_taps < 1 || cfg->n_avg_taps > P25FE_MAX_TAPS)
         return P25FE_ERR_ARG;
@@ -592,6 +594,7 @@ void p25fe_destroy(p25fe_t* h)
         for (DevBuf* b : alt) b->release();
     }
     h->gsum.release(); h->gouts.release(); h->evg.release();
+    h->evrec.release(); h->evnext.release(); h->evoff.release();
     DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps, &h->sh_flag};
     for (DevBuf* b : bufs) b->release();
     h->hin.release(); h->hbb.release(); h->hout.release();
@@ -830,6 +833,7 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
 // sync detection; a shard keeps its copy for pass 2.
 struct RecvCall {
     bool gen = false;
+    bool reslice = false;       // SPEC 3.8c: set by the entry points that hold the whole range (p25fe_run_dev*, p25fe_slice_dev)
     RecvOpt opt;
 };
 static RecvCall recv_call(const p25fe_t* h)
@@ -903,6 +907,40 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         HIPCHK(h, hipGetLastError());
         prof_mark(h, 3, st);
         if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
+        if (rc.reslice) {
+            // SPEC 3.8c: the slicer by detection (k_ev_collect / k_ev_clock / k_ev_slice) on k_scan_g's carry-ins
+            const size_t C = (size_t)h->C;
+            size_t cap_ev = (size_t)n_tiles * EVCAP;
+            const size_t bound = n_bb / (size_t)(W + 1) + (size_t)n_tiles + 8;
+            if (bound < cap_ev) cap_ev = bound;
+            const size_t stride = cap_ev + 2;
+            HIPCHK(h, h->evrec.ensure(C * stride * sizeof(EvRec)));
+            HIPCHK(h, h->evoff.ensure(C * (stride + 1) * sizeof(unsigned long long)));
+            {
+                const void* before = h->evnext.p;
+                HIPCHK(h, h->evnext.ensure(C * stride * sizeof(EvNext)));
+                if (h->evnext.p != before) HIPCHK(h, hipMemsetAsync(h->evnext.p, 0, h->evnext.cap, st));   // sequence numbers start above 0
+            }
+            EvArgs e;
+            e.pl = planar_view(h, g); e.n = (long)n_bb; e.abs0 = abs_bb0; e.n_tiles = n_tiles;
+            e.outs = h->gouts.as<ScanOutG>(); e.gsum = h->gsum.as<TileSumG>(); e.evl = h->evl.as<uint16_t>(); e.evg = h->evg.as<uint32_t>();
+            e.evthr = h->evthr.as<float>(); e.anchor_in = d_anchor_in;
+            e.rec = h->evrec.as<EvRec>(); e.nxt = h->evnext.as<EvNext>(); e.off = h->evoff.as<unsigned long long>();
+            e.ev_stride = (long)stride; e.seq = ++h->ev_seq; e.result = d_result;
+            e.dibits = d_dibits; e.dibit_stride = (long)dibit_stride;
+            e.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; e.sync_dibit = d_sync_dibit; e.sync_stride = (long)sync_stride;
+            hipLaunchKernelGGL(k_ev_collect, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, e);
+            HIPCHK(h, hipGetLastError());
+            hipLaunchKernelGGL(k_ev_clock, dim3((unsigned)h->C), dim3(NT3), 0, st, e);
+            HIPCHK(h, hipGetLastError());
+            // (a tracked period is within 1 / 1024 of the nominal one over long intervals and at least 9 samples over the shortest)
+            const size_t max_dibits = n_bb / (SPS - 1) + (size_t)n_tiles + 64;
+            const size_t lim = dibit_stride < max_dibits ? dibit_stride : max_dibits;
+            launch_ev(k_ev_slice, dim3((unsigned)((lim + WV * 4 - 1) / (WV * 4)), (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, e);
+            HIPCHK(h, hipGetLastError());
+            prof_mark(h, 4, st);
+            return P25FE_OK;
+        }
         SliceArgsG l;
         l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = abs_bb0; l.n_tiles = n_tiles;
         l.outs = h->gouts.as<ScanOutG>(); l.gsum = h->gsum.as<TileSumG>(); l.recs = h->recs.as<TileRec>();
@@ -962,7 +1000,8 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
     const long view0 = (long)abs_bb0 - h->look;          // first processed index: the tracking clock runs h->look samples late
     int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
-    const RecvCall rcall = recv_call(h);
+    RecvCall rcall = recv_call(h);
+    rcall.reslice = h->track == P25FE_CLOCK_TRACKING_RESLICE;      // the whole range is in memory: SPEC 3.8c applies
     h->rs_n = 0;                                         // the lock drops belong to this call
     if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
         return launch_scan_slice(h, 0, view0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
@@ -1142,7 +1181,8 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     bool k1_done_attached = false;
     rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);   // (growing a buffer frees the old one: hipFree synchronises the device)
     if (rc) return rc;
-    const RecvCall rcall = recv_call(h);
+    RecvCall rcall = recv_call(h);
+    rcall.reslice = h->track == P25FE_CLOCK_TRACKING_RESLICE;      // the whole range is in memory: SPEC 3.8c applies
     h->rs_n = 0;
     if (n_bb) {
         prof_begin(h);
@@ -1185,7 +1225,8 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     const size_t n_bb = p25fe_n_baseband_h(h, 0, n);
     int rc = ensure_slice_scratch(h, n_bb ? n_bb : 1);
     if (rc) return rc;
-    const RecvCall rcall = recv_call(h);
+    RecvCall rcall = recv_call(h);
+    rcall.reslice = h->track == P25FE_CLOCK_TRACKING_RESLICE;      // the whole range is in memory: SPEC 3.8c applies
     h->rs_n = 0;
     if (n_bb == 0)
         return launch_scan_slice(h, 0, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st, rcall);

@@ -118,13 +118,17 @@ __host__ __device__ inline int sync_frac(float cl, float c0, float cr)
 // the fraction travels in three bits (two's complement) of records that have them to spare
 __host__ __device__ inline int frac3(unsigned v) { return (int)((v & 7u) ^ 4u) - 4; }
 
-__host__ __device__ inline void clock_period(bool track, bool prev_valid, long s_prev, int f_prev, long s_new, int f_new, int& D, int& N)
+// usable: the interval passed the test, i.e. (D, N) IS a period estimate (also when it came out exactly nominal) -- SPEC 3.8c
+__host__ __device__ inline void clock_period(bool track, bool prev_valid, long s_prev, int f_prev, long s_new, int f_new, int& D, int& N,
+                                             bool* usable = nullptr)
 {
     D = SPS; N = 1;
+    if (usable) *usable = false;
     if (track && prev_valid) {
         const long dd = s_new - s_prev, nn = (dd + SPS / 2) / SPS;
         const long err = dd > SPS * nn ? dd - SPS * nn : SPS * nn - dd;
         if (nn >= 1 && dd <= (1L << P25FE_CLK_DMAX_LOG2) && (err << P25FE_CLK_TOL_SHIFT) <= SPS * nn) {
+            if (usable) *usable = true;
             const long d4 = 4 * dd + (f_new - f_prev);
             // (an interval of exactly 10 N samples IS the nominal clock: kept as 10 / 1, the same instants, so that the
             // division-free paths below apply)
@@ -1457,6 +1461,240 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
             a.sync_dibit[(size_t)ch * a.sync_stride + so.event_off + k] = so.dibit_off + (unsigned long long)rank;
         }
         rank += emit(sk, D, N, ek + 1, T0 + (long)(eg & 0x7fffu), h, m, l, rank);
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
+// SPEC 3.8c (symbol_clock = 2), resident ranges: the slicer by DETECTION instead of by tile.
+//
+// A detection without a usable clock of its own (the first of a lock run) takes the clock of the interval that STARTS at it: the
+// backward clock of the next detection.  That look-ahead crosses tiles, and the clock changes how many instants the detection
+// governs, i.e. every later dibit's offset -- the tile-local bookkeeping of k_scan_g / k_slice_g has no place for it.  The list of
+// detections has: K2 and k_scan_g (unchanged) give every tile its carry-in and its first detection's index in the range;
+//   k_ev_collect  one wave per tile: its detections -> EvRec[1 + index] (position, backward clock + usable, where the governed
+//                 interval ends inside the tile, thresholds); the tile that ends an interval left OPEN by an earlier tile records
+//                 where (EvNext of that detection: position + the call's sequence number, so that nothing has to be cleared);
+//                 entry 0 is the range's carry-in anchor;
+//   k_ev_clock    one workgroup per channel: final clock (one step of look-ahead), instants per detection in closed form, prefix
+//                 sum -> offsets, the range's record, the sync lists;
+//   k_ev_slice    one wave per 256 dibits: binary search of the offsets, instant position, 4-tap interpolation, thresholds.
+// ------------------------------------------------------------------------------------------
+struct EvRec {
+    long s;                     // sync position
+    long g_lo, g_hi;            // governed interval [g_lo, g_hi): g_hi as known inside the detection's tile (valid unless EV_OPEN)
+    int Db, Nb;                 // backward clock (SPEC 3.8b)
+    int D2, N2;                 // final clock (k_ev_clock)
+    unsigned flags;             // EV_*
+    float hi, mid, lo;
+    int pad_;
+};
+static_assert(sizeof(EvRec) == 64, "EvRec layout");
+struct EvNext { long pos; unsigned long long seq; };
+constexpr unsigned EV_USABLE = 1u, EV_OPEN = 2u, EV_VALID = 4u;
+
+struct EvArgs {
+    Planar pl;
+    long n, abs0;
+    int n_tiles;
+    const ScanOutG* outs;
+    const TileSumG* gsum;
+    const uint16_t* evl;
+    const uint32_t* evg;
+    const float* evthr;
+    const p25fe_anchor_t* anchor_in;     // nullable, [ch]
+    EvRec* rec;                          // [ch][ev_stride]
+    EvNext* nxt;                         // [ch][ev_stride]
+    unsigned long long* off;             // [ch][ev_stride + 1]
+    long ev_stride;
+    unsigned long long seq;
+    p25fe_result_t* result;              // [ch] (k_scan_g's; n_sync is read, the counts are rewritten)
+    uint8_t* dibits;
+    long dibit_stride;
+    int64_t* sync_pos;                   // nullable
+    uint64_t* sync_dibit;
+    long sync_stride;
+};
+
+#ifndef P25FE_JIT
+__global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a)
+{
+    __shared__ uint16_t EV[EVCAP];
+    __shared__ uint32_t EG[EVCAP];
+    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const long t0 = (long)tile * TS;
+    const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
+    const ScanOutG so = a.outs[(size_t)ch * a.n_tiles + tile];
+    const TileSumG g = a.gsum[(size_t)ch * a.n_tiles + tile];
+    const int n_ev = (int)(g.n_det_flags & 0xffffu);
+    const long T0 = a.abs0 + t0;
+    EvRec* rec = a.rec + (size_t)ch * a.ev_stride;
+    EvNext* nxt = a.nxt + (size_t)ch * a.ev_stride;
+    p25fe_anchor_t Ain;
+    Ain.valid = 0; Ain.s = 0; Ain.hi = Ain.mid = Ain.lo = 0.f; Ain.period_d = SPS; Ain.period_n = 1;
+    if (a.anchor_in) Ain = a.anchor_in[ch];
+    const bool carry_valid = so.src >= 0 || (so.src == -1 && Ain.valid != 0);
+    if (tile == 0 && lane == 0) {                                   // entry 0: the range's carry-in anchor (its clock is what it is)
+        EvRec r;
+        r.s = Ain.s; r.g_lo = a.abs0; r.g_hi = a.abs0 + a.n;
+        const bool ok = clock_plausible(Ain.period_d, Ain.period_n);
+        r.Db = ok ? Ain.period_d : SPS; r.Nb = ok ? Ain.period_n : 1; r.D2 = r.Db; r.N2 = r.Nb;
+        r.flags = EV_USABLE | EV_OPEN | (Ain.valid ? EV_VALID : 0u);
+        r.hi = Ain.hi; r.mid = Ain.mid; r.lo = Ain.lo; r.pad_ = 0;
+        rec[0] = r;
+    }
+    if (!g.pre_end1) return;                                        // no event of any kind
+    // this tile's first event ends the interval the carry-in's detection left open
+    if (lane == 0 && carry_valid) {
+        EvNext x; x.pos = T0 + (long)g.pre_end1 - 1; x.seq = a.seq;
+        nxt[so.event_off] = x;                                      // (entry of detection event_off - 1; 0 = the carry-in anchor)
+    }
+    if (n_ev == 0) return;
+    const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+    const uint32_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+    for (int k = lane; k < n_ev; k += WV) { EV[k] = evl[k]; EG[k] = evg[k]; }
+    phase_sync();
+    const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
+    const float* eth = a.evthr + ((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3);
+    for (int k0 = 0; k0 < n_ev; k0 += WV) {
+        const int k = k0 + lane;
+        if (k < n_ev) {
+            const unsigned eg = EG[k];
+            const long ek = T0 + EV[k], sk = ek - W;
+            EvRec r;
+            bool us;
+            if (k == 0) clock_period(true, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && carry_valid, so.s, so.f, sk, frac3(eg >> 16), r.Db, r.Nb, &us);
+            else clock_period(true, ((eg >> 15) & 1u) != 0, T0 + EV[k - 1] - W, frac3(EG[k - 1] >> 16), sk, frac3(eg >> 16), r.Db, r.Nb, &us);
+            r.s = sk; r.g_lo = ek + 1; r.g_hi = T0 + (long)(eg & 0x7fffu);
+            r.D2 = r.Db; r.N2 = r.Nb;
+            r.flags = EV_VALID | (us ? EV_USABLE : 0u) | ((k == n_ev - 1 && (int)(eg & 0x7fffu) == tn) ? EV_OPEN : 0u);
+            r.hi = r.mid = r.lo = 0.f; r.pad_ = 0;
+            if (k < EVTHR_N) { r.hi = eth[3 * k]; r.mid = eth[3 * k + 1]; r.lo = eth[3 * k + 2]; }
+            rec[1 + so.event_off + k] = r;
+        }
+    }
+    // thresholds beyond the ones K2 handed over: recomputed from the sync word, one detection at a time (every lane, same window)
+    for (int k = EVTHR_N; k < n_ev; ++k) {
+        float v[NSYN], h, m, l;
+        sync_gather(f, t0 + EV[k] - W + PLPAD, v);
+        sync_thresholds(v, h, m, l);
+        if (lane == 0) { EvRec* r = rec + 1 + so.event_off + k; r->hi = h; r->mid = m; r->lo = l; }
+    }
+}
+
+__global__ __launch_bounds__(NT3) void k_ev_clock(EvArgs a)
+{
+    __shared__ unsigned long long shu[NT3 / 64];
+    __shared__ unsigned long long c_base;
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    EvRec* rec = a.rec + (size_t)ch * a.ev_stride;
+    const EvNext* nxt = a.nxt + (size_t)ch * a.ev_stride;
+    unsigned long long* off = a.off + (size_t)ch * (a.ev_stride + 1);
+    const long n_e = (long)a.result[ch].n_sync + 1;                  // entries 0 .. n_e - 1 (0 = the carry-in anchor)
+    const long range_end = a.abs0 + a.n;
+    if (tid == 0) c_base = 0ull;
+    __syncthreads();
+    for (long c0 = 0; c0 < n_e; c0 += (long)NT3 * 4) {
+        unsigned long long cnt[4];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long e = c0 + (long)tid * 4 + q;
+            cnt[q] = 0;
+            if (e < n_e) {
+                EvRec r = rec[e];
+                if (r.flags & EV_VALID) {
+                    int D = r.Db, N = r.Nb;
+                    if (!(r.flags & EV_USABLE) && e + 1 < n_e) {
+                        // the next detection's backward clock is the interval that starts here -- if lock was held and it is plausible
+                        // (fields k_ev_collect wrote; that entry's owner writes D2 / N2 / g_hi only)
+                        if (rec[e + 1].flags & EV_USABLE) { D = rec[e + 1].Db; N = rec[e + 1].Nb; }
+                    }
+                    long ghi = r.g_hi;
+                    if (r.flags & EV_OPEN) {
+                        const EvNext x = nxt[e];
+                        ghi = x.seq == a.seq ? x.pos : range_end;
+                    }
+                    const long c = clock_count(r.s, D, N, r.g_lo, ghi);
+                    cnt[q] = (unsigned long long)(c < 0 ? 0 : c);
+                    rec[e].D2 = D; rec[e].N2 = N; rec[e].g_hi = ghi;
+                }
+                mine += cnt[q];
+            }
+        }
+        unsigned long long tot;
+        const unsigned long long incl = block_incl_sum(mine, shu, tid, tot);
+        unsigned long long o = c_base + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long e = c0 + (long)tid * 4 + q;
+            if (e < n_e) {
+                off[e] = o;
+                if (e >= 1 && a.sync_pos && e - 1 < a.sync_stride) {
+                    a.sync_pos[(size_t)ch * a.sync_stride + e - 1] = rec[e].s;
+                    a.sync_dibit[(size_t)ch * a.sync_stride + e - 1] = o;
+                }
+                o += cnt[q];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) c_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        off[n_e] = c_base;
+        p25fe_result_t r = a.result[ch];
+        r.n_dibits = c_base;
+        r.n_dibits_after_first = n_e >= 2 ? c_base - off[1] : 0;
+        a.result[ch] = r;
+    }
+}
+
+__global__ __launch_bounds__(WV, 4) void k_ev_slice(EvArgs a)
+{
+    __shared__ float CI[P25FE_CLK_PHASES * 4];
+    const int lane = threadIdx.x, ch = blockIdx.y;
+    const EvRec* rec = a.rec + (size_t)ch * a.ev_stride;
+    const unsigned long long* off = a.off + (size_t)ch * (a.ev_stride + 1);
+    const long n_e = (long)a.result[ch].n_sync + 1;
+    const unsigned long long total = off[n_e];
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * (WV * 4);
+    if (g0 >= total) return;
+    for (int k = lane; k < P25FE_CLK_PHASES * 4; k += WV) CI[k] = P25FE_CLK_INTERP[k];
+    phase_sync();
+    const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
+    uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned long long gi = g0 + (unsigned long long)(q * WV + lane);
+        if (gi < total && (long)gi < a.dibit_stride) {
+            long lo_ = 0, hi_ = n_e;                                 // largest e with off[e] <= gi
+            while (hi_ - lo_ > 1) {
+                const long mid_ = (lo_ + hi_) >> 1;
+                if (off[mid_] <= gi) lo_ = mid_; else hi_ = mid_;
+            }
+            const EvRec r = rec[lo_];
+            long glo = r.g_lo < r.s + W + 1 ? r.s + W + 1 : r.g_lo;
+            const long j = clock_J(glo - r.s, r.D2, r.N2) + 1 + (long)(gi - off[lo_]);
+            const long num = j * (long)r.D2;
+            long i; int ph = 0;
+            if (r.N2 == 1) { i = r.s + num; }
+            else { const long qu = num / r.N2; i = r.s + qu; ph = (int)(((num - qu * r.N2) * P25FE_CLK_PHASES) / r.N2); }
+            const long p = i - a.abs0 + PLPAD;
+            float b[4];
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const long pp = p - 1 + tq;
+                const long sy = pp / SPS;
+                b[tq] = f[planar_index(sy, (int)(pp - sy * SPS))];
+            }
+            const float* w = CI + 4 * ph;
+            float v = w[0] * b[0];
+            v = __builtin_fmaf(w[1], b[1], v);
+            v = __builtin_fmaf(w[2], b[2], v);
+            v = __builtin_fmaf(w[3], b[3], v);
+            out[gi] = slice_dibit(v, r.hi, r.mid, r.lo);
+        }
     }
 }
 #endif

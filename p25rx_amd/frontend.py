@@ -24,7 +24,7 @@ class FrontEnd:
         u8_offset, u8_lut, decim_phase, avg_taps) -- the run-time arguments of the reference's constructors
         (src/demod.rs:50, 52, 54, 83)."""
         self.L = _lib.load()
-        # symbol_clock 0: fixed stride (the reference's receiver), 1: SPEC 3.8b
+        # symbol_clock 0: fixed stride (the reference's receiver), 1: SPEC 3.8b, 2: 3.8b + 3.8c in run_dev / run_dev_pipelined / slice_dev
         cfg = _lib.make_config(n_channels=n_channels, device=device, decim_taps=decim_taps, chan_taps=chan_taps,
                                symbol_clock=symbol_clock, **spec)
         self.symbol_clock = symbol_clock

@@ -87,10 +87,12 @@ class Model:
         r = np.abs(c[m] * c[m] - float(self.rho2_n) * e[m]) / np.maximum(c[m] * c[m], 1e-30)
         return float(min(a.min(), r.min()))
 
-    def receive_tracking(self, b, spec, resync=()):
+    def receive_tracking(self, b, spec, resync=(), reslice=False):
         """SPEC 3.8b (symbol_clock = 1): every detection carries a clock D / N measured from the previous sync word, instants
         s + (j D) div N are read by the 4-tap interpolation of their phase; the receiver runs L samples behind the
-        baseband (it processes index u when sample u + L exists), a drop before sample q removes instants >= q - L."""
+        baseband (it processes index u when sample u + L exists), a drop before sample q removes instants >= q - L.
+        reslice (SPEC 3.8c, symbol_clock = 2, one resident range): a detection whose own interval gave no clock takes the clock of
+        the interval that starts at it, if the next detection's is usable."""
         b = np.ascontiguousarray(b, dtype=F)
         n = len(b)
         L = int(spec["clk_lookahead"])
@@ -112,6 +114,32 @@ class Model:
         ev = [(s + self.W + 1, 0, k) for k, (s, _, _, _) in enumerate(dets)] + [(min(max(int(q) - L, -L), n), 1, -1) for q in resync]
         ev.sort()
         bp = np.concatenate([np.zeros(2, dtype=F), b, np.zeros(4, dtype=F)])       # b[i] sits at bp[i + 2]
+        # the backward clock of every detection, and whether its interval was usable (3.8b's test passed)
+        back = {}
+        prev = None
+        for t, kind, k in ev:
+            if kind == 0:
+                s = dets[k][0]
+                D, N, ok = self.sps, 1, False
+                if prev is not None:
+                    delta = s - prev[0]
+                    Nn = (delta + 5) // 10
+                    if Nn >= 1 and delta <= dmax and abs(delta - 10 * Nn) * tol <= 10 * Nn:
+                        ok = True
+                        d4 = 4 * delta + (fr[k] - prev[1])
+                        if d4 != 40 * Nn:
+                            D, N = d4, 4 * Nn
+                back[k] = (D, N, ok)
+                prev = (s, fr[k])
+            else:
+                prev = None
+        order = [k for _, kind, k in ev if kind == 0]
+        clock = {}
+        for i, k in enumerate(order):
+            D, N, ok = back[k]
+            if reslice and not ok and i + 1 < len(order) and back[order[i + 1]][2]:
+                D, N = back[order[i + 1]][0], back[order[i + 1]][1]
+            clock[k] = (D, N)
         dib, spos, sdib = [], [], []
         anchor, start = None, -L
         for t, kind, k in ev + [(n - L, 2, -1)]:
@@ -139,14 +167,7 @@ class Model:
             start = max(start, t)
             if kind == 0:
                 s, hi, mid, lo = dets[k]
-                D, N = self.sps, 1
-                if anchor is not None:                               # lock was held from the previous sync word to this one
-                    delta = s - anchor[0]
-                    Nn = (delta + 5) // 10
-                    if Nn >= 1 and delta <= dmax and abs(delta - 10 * Nn) * tol <= 10 * Nn:
-                        d4 = 4 * delta + (fr[k] - anchor[6])
-                        if d4 != 40 * Nn:
-                            D, N = d4, 4 * Nn
+                D, N = clock[k]
                 anchor = (s, hi, mid, lo, D, N, fr[k])
                 spos.append(s)
                 sdib.append(sum(len(x) for x in dib))

@@ -99,6 +99,66 @@ def test_tracking_clock_device_matches_oracle(O, FE, ppm, frame):
     assert np.array_equal(got3, ref[0])
 
 
+@pytest.mark.parametrize("ppm,frame", [(150.0, 864), (-250.0, 864), (100.0, 3000), (0.0, 864)])
+def test_reslice_device_matches_oracle(O, FE, ppm, frame):
+    """SPEC 3.8c (symbol_clock = 2): the calls that hold the whole range -- p25fe_slice_dev on a linear baseband, p25fe_run_dev and
+    p25fe_run_dev_pipelined from IQ -- equal the oracle's two-pass restatement bit for bit, and EVERY frame, the first of the lock run
+    included, decodes to the modulator's dibits; the streaming calls keep mode 1's causal rule in this mode."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    iq, truth, _ = c4fm.synth(5 * frame / 4800.0 + 0.3, seed=23, snr_db=30.0, frame_dibits=frame, clock_ppm=ppm)
+    iq = iq[:len(iq) // 8 * 8]
+    bb = O.Demod().feed_cf32(iq)
+    ref = O.recv_range(bb, O.make_config(symbol_clock=2))
+    one = oracle_recv(O, bb, 1)
+    assert len(ref[1]) >= 5 and np.array_equal(ref[1], one[1])
+    for k in range(0, len(ref[2]) - 1):                              # every frame between two sync words is error free, the first too
+        assert np.array_equal(ref[0][int(ref[2][k]):int(ref[2][k + 1])], truth[frame * k + 24:frame * (k + 1) + 24]), k
+    if abs(ppm) >= 150:
+        assert not np.array_equal(one[0][:int(one[2][1])], truth[24:24 + int(one[2][1])])     # mode 1 does lose symbols there
+    fe = FE(symbol_clock=2)
+    got = dev_slice(fe, bb)
+    same(got, ref, "slice_dev")
+    assert int(got[3]["n_sync"]) == len(ref[1])
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    dib, res = fe.run_dev(t)
+    nd = int(parse_results(res)[0]["n_dibits"])
+    assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
+    for _ in range(3):
+        dib, res = fe.run_dev_pipelined(t, dibits=dib, result=res)
+    fe.join_dev()
+    nd = int(parse_results(res)[0]["n_dibits"])
+    assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
+    # the streaming calls in this mode: mode 1's answer
+    fe3 = FE(symbol_clock=2)
+    got3 = np.concatenate([fe3.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)])
+    assert np.array_equal(got3, one[0])
+
+
+def test_reslice_dense_events_and_lock_drops(O, FE):
+    """Mode 2 where the list of detections is long and ragged: dozens of detections per tile, lock drops at decision indices, between
+    detections, many in one tile -- lock runs of one detection (nothing to look ahead to), of two, intervals that fail 3.8b's test."""
+    from p25rx_amd import c4fm
+    rng = np.random.default_rng(79)
+    pieces = []
+    for fd, snr, amp, toff, ppm in ((26, 25.0, 0.5, 0, 0.0), (140, 14.0, 0.25, 3, 200.0), (31, 30.0, 0.1, 41, -90.0), (1200, 25.0, 0.4, 7, 250.0)):
+        pieces.append(c4fm.synth(0.6, seed=400 + fd, snr_db=snr, frame_dibits=fd, amplitude=amp, timing_offset=toff, clock_ppm=ppm)[0])
+        pieces.append((0.3 * (rng.standard_normal(5003) + 1j * rng.standard_normal(5003))).astype(np.complex64))
+    bb = O.Demod().feed_cf32(np.concatenate(pieces))
+    cfg = O.make_config(symbol_clock=2)
+    ref0 = O.recv_range(bb, cfg)
+    assert len(ref0[1]) > 200
+    same(dev_slice(FE(symbol_clock=2), bb, sync_cap=8192), ref0, "no drops")
+    sp = ref0[1]
+    drops = [int(sp[10]) + 7, int(sp[10]) + 8, int(sp[11]) + 6, int(sp[40]) + 9, int(sp[41]) + 10, int(sp[41]) + 10, int(sp[90]) + 100,
+             0, 1, len(bb) - 1, len(bb) + 7] + [int(x) for x in rng.integers(0, len(bb), size=80)]
+    ref = O.recv_range(bb, cfg, drops)
+    got = dev_slice(FE(symbol_clock=2), bb, resync=drops, sync_cap=8192)
+    same(got, ref, "91 drops")
+    assert np.array_equal(oracle_recv(O, bb, 1, drops)[1], ref[1])            # the same sync words as the streaming rule finds
+
+
 def test_tracking_clock_on_a_nominal_clock_equals_the_fixed_stride(O, FE, c4fm_1s):
     bb = O.Demod().feed_cf32(c4fm_1s[0])
     fix, trk = dev_slice(FE(), bb), dev_slice(FE(symbol_clock=1), bb)

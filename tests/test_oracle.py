@@ -434,6 +434,46 @@ def test_tracking_receiver_against_an_independent_batch_model(spec, seed):
         assert len(got[k]) == len(ref[k]) and np.array_equal(got[k], ref[k].astype(got[k].dtype)), (seed, snr, frame, ppm, k)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_reslice_receiver_against_an_independent_batch_model(spec, seed):
+    """SPEC 3.8c (symbol_clock = 2, one resident range): the oracle's two passes -- record every detection's backward clock, give a
+    detection without a usable one the clock of the interval that STARTS at it, slice again with the table -- against
+    spec_model.Model.receive_tracking(reslice=True), which forms the same clocks from its own list of detections; lock drops inside
+    the range, clock errors up to 250 ppm."""
+    import spec_model
+    from p25rx_amd import c4fm
+    rng = np.random.default_rng(8100 + seed)
+    snr = float(rng.choice([30.0, 12.0, 6.0]))
+    frame = int(rng.choice([24, 48, 100, 864, 3000]))
+    ppm = float(rng.choice([0.0, 60.0, -150.0, 250.0]))
+    iq, _, _ = c4fm.synth(float(rng.choice([0.3, 0.7, 1.5])), seed=seed, snr_db=snr, frame_dibits=frame,
+                          timing_offset=int(rng.integers(0, 50)), clock_ppm=ppm)
+    bb = O.Demod().feed_cf32(iq)
+    drops = sorted(set(int(x) for x in rng.integers(1, len(bb), size=int(rng.choice([0, 0, 2, 9])))))
+    got = O.recv_range(bb, O.make_config(symbol_clock=2), drops)
+    ref = spec_model.Model(spec).receive_tracking(bb, spec, drops, reslice=True)
+    for k in range(3):
+        assert len(got[k]) == len(ref[k]) and np.array_equal(got[k], ref[k].astype(got[k].dtype)), (seed, snr, frame, ppm, k)
+    # and it is not the streaming rule in disguise: with a clock error and frames long enough to drift, some scene differs from mode 1
+    one = O.recv_range(bb, O.make_config(symbol_clock=1), drops)
+    assert len(one[1]) == len(got[1]) and np.array_equal(one[1], got[1])          # the same sync words either way
+
+
+def test_reslice_removes_the_first_frame_errors(spec):
+    """What 3.8c is for: P25's 0.18 s between sync words, sample clock 150 and 250 ppm off -- the streaming rule (mode 1) loses a few
+    symbols at the end of the first frame of the lock run, which has no period yet; the resident rule (mode 2) loses none."""
+    from p25rx_amd import c4fm
+    for ppm, min_err1 in ((150.0, 1), (250.0, 10), (-150.0, 1)):
+        iq, truth, _ = c4fm.synth(3.0, seed=5, snr_db=30.0, frame_dibits=864, clock_ppm=ppm)
+        errs = {}
+        for mode in (1, 2):
+            cfg = O.make_config(symbol_clock=mode)
+            d, _, _ = O.recv_range(O.Demod(cfg).feed_cf32(iq), cfg)
+            k = min(len(d), len(truth) - 24)
+            errs[mode] = int(np.count_nonzero(d[:k] != truth[24:24 + k]))
+        assert errs[2] == 0 and errs[1] >= min_err1, (ppm, errs)
+
+
 def test_nid_against_the_published_generator_polynomial(spec):
     """SPEC 3.9 independently: all 65 536 code words by polynomial division with the published octal generator (not the
     matrix rows of spec.json): minimum weight 23, the spec's systematic rows are among them, and the oracle's decoder agrees
