@@ -163,11 +163,14 @@ def align_dibits(decoded, truth, max_skip=64):
 # torch back end: generate long captures directly in HBM (bench.py, full-size tests)
 # ---------------------------------------------------------------------------------------------
 def synth_torch(n_iq, seed, device, snr_db=30.0, frame_dibits=864, amplitude=0.5, chunk_symbols=1 << 18,
-                out=None, out_u8=None):
+                out=None, out_u8=None, clock_ppm=0.0):
     """Generate n_iq cf32 samples of C4FM on `device`.  Returns (iq[n_iq, 2] float32, dibits uint8 cpu).
 
     Generated in chunks of symbols with phase continuity carried in float64; each chunk is
     shaped by a polyphase matrix product over +-span symbols of context.
+    clock_ppm: as in synth() -- the receiver's sample clock runs that many ppm fast: the phase trajectory is read at the instants
+    m / (1 + ppm 1e-6) (linear interpolation of the float64 phase, whose curvature over one 240 kHz sample is < 1e-3 rad) before
+    the noise is added.
     """
     import torch
 
@@ -205,6 +208,9 @@ def synth_torch(n_iq, seed, device, snr_db=30.0, frame_dibits=864, amplitude=0.5
     padded = torch.zeros(total_sym + 2 * span, dtype=torch.float32)
     padded[span + lead: span + lead + nsym] = sym_all
     pos = 0
+    kclk = 1.0 + float(clock_ppm) * 1e-6
+    nom0 = 0                                                  # nominal index of the chunk's first sample
+    carry = None                                              # the previous chunk's last phase sample (nominal index nom0 - 1)
     for s0 in range(0, total_sym, chunk_symbols):
         s1 = min(total_sym, s0 + chunk_symbols)
         seg = padded[s0: s1 + 2 * span].to(device)            # symbols s0-span .. s1+span
@@ -212,6 +218,19 @@ def synth_torch(n_iq, seed, device, snr_db=30.0, frame_dibits=864, amplitude=0.5
         freq = y.double() * (DEV_HZ_PER_UNIT / SPS_IQ)
         ph = torch.cumsum(freq, 0) * (2.0 * np.pi / FS_IQ) + phase0
         phase0 = torch.remainder(ph[-1], 2.0 * np.pi)
+        if clock_ppm:
+            ext = ph if carry is None else torch.cat([carry.reshape(1), ph])
+            base = nom0 if carry is None else nom0 - 1
+            m_hi = int(np.floor((nom0 + len(ph) - 1) * kclk))         # last output index whose instant lies inside this chunk
+            nom0 += len(ph)
+            carry = phase0.clone()                               # (the next chunk continues from the wrapped value)
+            if m_hi < pos:
+                continue
+            tau = torch.arange(pos, m_hi + 1, dtype=torch.float64, device=device) / kclk - base
+            i0 = torch.clamp(torch.floor(tau).long(), 0, len(ext) - 1)
+            fr = tau - i0.double()
+            i1 = torch.clamp(i0 + 1, max=len(ext) - 1)
+            ph = ext[i0] * (1.0 - fr) + ext[i1] * fr
         ph = torch.remainder(ph, 2.0 * np.pi).float()
         n = min(len(ph), n_iq - pos)
         if n <= 0:

@@ -908,7 +908,7 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         prof_mark(h, 3, st);
         if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
         if (rc.reslice) {
-            // SPEC 3.8c: the slicer by detection (k_ev_collect / k_ev_clock / k_ev_slice) on k_scan_g's carry-ins
+            // SPEC 3.8c: the slicer by detection (k_ev_collect / k_ev_count / k_ev_scan / k_ev_slice) on k_scan_g's carry-ins
             const size_t C = (size_t)h->C;
             size_t cap_ev = (size_t)n_tiles * EVCAP;
             const size_t bound = n_bb / (size_t)(W + 1) + (size_t)n_tiles + 8;
@@ -931,7 +931,9 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
             e.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; e.sync_dibit = d_sync_dibit; e.sync_stride = (long)sync_stride;
             hipLaunchKernelGGL(k_ev_collect, dim3((unsigned)n_tiles, (unsigned)h->C), dim3(WV), 0, st, e);
             HIPCHK(h, hipGetLastError());
-            hipLaunchKernelGGL(k_ev_clock, dim3((unsigned)h->C), dim3(NT3), 0, st, e);
+            hipLaunchKernelGGL(k_ev_count, dim3((unsigned)(n_tiles < 1024 ? n_tiles : 1024), (unsigned)h->C), dim3(WV), 0, st, e);
+            HIPCHK(h, hipGetLastError());
+            hipLaunchKernelGGL(k_ev_scan, dim3((unsigned)h->C), dim3(WV), 0, st, e);
             HIPCHK(h, hipGetLastError());
             // (a tracked period is within 1 / 1024 of the nominal one over long intervals and at least 9 samples over the shortest)
             const size_t max_dibits = n_bb / (SPS - 1) + (size_t)n_tiles + 64;

@@ -1476,15 +1476,15 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
 //                 interval ends inside the tile, thresholds); the tile that ends an interval left OPEN by an earlier tile records
 //                 where (EvNext of that detection: position + the call's sequence number, so that nothing has to be cleared);
 //                 entry 0 is the range's carry-in anchor;
-//   k_ev_clock    one workgroup per channel: final clock (one step of look-ahead), instants per detection in closed form, prefix
-//                 sum -> offsets, the range's record, the sync lists;
+//   k_ev_count    one lane per detection: final clock (one step of look-ahead), its instants in closed form;
+//   k_ev_scan     one wave per channel: prefix sum -> offsets, the range's record, the sync lists;
 //   k_ev_slice    one wave per 256 dibits: binary search of the offsets, instant position, 4-tap interpolation, thresholds.
 // ------------------------------------------------------------------------------------------
 struct EvRec {
     long s;                     // sync position
     long g_lo, g_hi;            // governed interval [g_lo, g_hi): g_hi as known inside the detection's tile (valid unless EV_OPEN)
     int Db, Nb;                 // backward clock (SPEC 3.8b)
-    int D2, N2;                 // final clock (k_ev_clock)
+    int D2, N2;                 // final clock (k_ev_count)
     unsigned flags;             // EV_*
     float hi, mid, lo;
     int pad_;
@@ -1582,52 +1582,66 @@ __global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a)
     }
 }
 
-__global__ __launch_bounds__(NT3) void k_ev_clock(EvArgs a)
+// k_ev_count: one lane per detection (grid-stride), the divisions of clock_count in parallel; k_ev_scan: ONE wave (it runs beside the
+// next call's K1, whose one-wave workgroups leave room for exactly that -- a 512-thread workgroup waits for K1 to drain, as k_scan_g
+// in front of it already does), prefix sum of the counts, the range's record and the sync lists.
+__global__ __launch_bounds__(WV, 4) void k_ev_count(EvArgs a)
 {
-    __shared__ unsigned long long shu[NT3 / 64];
-    __shared__ unsigned long long c_base;
-    const int tid = threadIdx.x, ch = blockIdx.x;
+    const int lane = threadIdx.x, ch = blockIdx.y;
     EvRec* rec = a.rec + (size_t)ch * a.ev_stride;
     const EvNext* nxt = a.nxt + (size_t)ch * a.ev_stride;
-    unsigned long long* off = a.off + (size_t)ch * (a.ev_stride + 1);
     const long n_e = (long)a.result[ch].n_sync + 1;                  // entries 0 .. n_e - 1 (0 = the carry-in anchor)
     const long range_end = a.abs0 + a.n;
-    if (tid == 0) c_base = 0ull;
-    __syncthreads();
-    for (long c0 = 0; c0 < n_e; c0 += (long)NT3 * 4) {
-        unsigned long long cnt[4];
+    for (long e = (long)blockIdx.x * WV + lane; e < n_e; e += (long)gridDim.x * WV) {
+        const EvRec r = rec[e];
+        unsigned cnt = 0u;
+        long jlo = 1;
+        if (r.flags & EV_VALID) {
+            int D = r.Db, N = r.Nb;
+            if (!(r.flags & EV_USABLE) && e + 1 < n_e) {
+                // the next detection's backward clock is the interval that starts here -- if lock was held and it is plausible
+                // (fields k_ev_collect wrote; that entry's owner writes D2 / N2 / g_lo / g_hi / pad_ only)
+                if (rec[e + 1].flags & EV_USABLE) { D = rec[e + 1].Db; N = rec[e + 1].Nb; }
+            }
+            long ghi = r.g_hi;
+            if (r.flags & EV_OPEN) {
+                const EvNext x = nxt[e];
+                ghi = x.seq == a.seq ? x.pos : range_end;
+            }
+            long glo = r.g_lo < r.s + W + 1 ? r.s + W + 1 : r.g_lo;
+            const long j0 = clock_J(glo - r.s, D, N);
+            long c = ghi > glo ? clock_J(ghi - r.s, D, N) - j0 : 0;
+            cnt = (unsigned)(c < 0 ? 0 : (c > 0x7fffffffL ? 0x7fffffffL : c));
+            jlo = j0 + 1;
+            rec[e].D2 = D; rec[e].N2 = N; rec[e].g_hi = ghi;
+        }
+        rec[e].g_lo = jlo;                                           // from here on: the index j of the first instant this detection governs
+        rec[e].pad_ = (int)cnt;
+    }
+}
+
+constexpr int EVC_PER = 16;
+__global__ __launch_bounds__(WV) void k_ev_scan(EvArgs a)
+{
+    const int lane = threadIdx.x, ch = blockIdx.x;
+    const EvRec* rec = a.rec + (size_t)ch * a.ev_stride;
+    unsigned long long* off = a.off + (size_t)ch * (a.ev_stride + 1);
+    const long n_e = (long)a.result[ch].n_sync + 1;
+    unsigned long long c_base = 0ull;                                // uniform
+    for (long c0 = 0; c0 < n_e; c0 += (long)WV * EVC_PER) {
+        unsigned cnt[EVC_PER];
         unsigned long long mine = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long e = c0 + (long)tid * 4 + q;
-            cnt[q] = 0;
-            if (e < n_e) {
-                EvRec r = rec[e];
-                if (r.flags & EV_VALID) {
-                    int D = r.Db, N = r.Nb;
-                    if (!(r.flags & EV_USABLE) && e + 1 < n_e) {
-                        // the next detection's backward clock is the interval that starts here -- if lock was held and it is plausible
-                        // (fields k_ev_collect wrote; that entry's owner writes D2 / N2 / g_hi only)
-                        if (rec[e + 1].flags & EV_USABLE) { D = rec[e + 1].Db; N = rec[e + 1].Nb; }
-                    }
-                    long ghi = r.g_hi;
-                    if (r.flags & EV_OPEN) {
-                        const EvNext x = nxt[e];
-                        ghi = x.seq == a.seq ? x.pos : range_end;
-                    }
-                    const long c = clock_count(r.s, D, N, r.g_lo, ghi);
-                    cnt[q] = (unsigned long long)(c < 0 ? 0 : c);
-                    rec[e].D2 = D; rec[e].N2 = N; rec[e].g_hi = ghi;
-                }
-                mine += cnt[q];
-            }
+        for (int q = 0; q < EVC_PER; ++q) {
+            const long e = c0 + (long)lane * EVC_PER + q;
+            cnt[q] = e < n_e ? (unsigned)rec[e].pad_ : 0u;
+            mine += cnt[q];
         }
-        unsigned long long tot;
-        const unsigned long long incl = block_incl_sum(mine, shu, tid, tot);
+        const unsigned long long incl = wave_incl_sum64(mine, lane);
         unsigned long long o = c_base + incl - mine;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long e = c0 + (long)tid * 4 + q;
+        for (int q = 0; q < EVC_PER; ++q) {
+            const long e = c0 + (long)lane * EVC_PER + q;
             if (e < n_e) {
                 off[e] = o;
                 if (e >= 1 && a.sync_pos && e - 1 < a.sync_stride) {
@@ -1637,11 +1651,9 @@ __global__ __launch_bounds__(NT3) void k_ev_clock(EvArgs a)
                 o += cnt[q];
             }
         }
-        __syncthreads();
-        if (tid == 0) c_base += tot;
-        __syncthreads();
+        c_base += __shfl(incl, WV - 1, 64);
     }
-    if (tid == 0) {
+    if (lane == 0) {
         off[n_e] = c_base;
         p25fe_result_t r = a.result[ch];
         r.n_dibits = c_base;
@@ -1664,18 +1676,23 @@ __global__ __launch_bounds__(WV, 4) void k_ev_slice(EvArgs a)
     phase_sync();
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride;
+    // the detection of the wave's first dibit: one binary search with uniform indices (scalar loads); lanes then walk forward
+    long e0 = 0;
+    {
+        long hi_ = n_e;                                             // largest e with off[e] <= g0
+        while (hi_ - e0 > 1) {
+            const long mid_ = (e0 + hi_) >> 1;
+            if (off[mid_] <= g0) e0 = mid_; else hi_ = mid_;
+        }
+    }
+    long lo_ = e0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const unsigned long long gi = g0 + (unsigned long long)(q * WV + lane);
         if (gi < total && (long)gi < a.dibit_stride) {
-            long lo_ = 0, hi_ = n_e;                                 // largest e with off[e] <= gi
-            while (hi_ - lo_ > 1) {
-                const long mid_ = (lo_ + hi_) >> 1;
-                if (off[mid_] <= gi) lo_ = mid_; else hi_ = mid_;
-            }
+            while (lo_ + 1 < n_e && off[lo_ + 1] <= gi) ++lo_;      // (864 dibits per detection on a P25 channel: zero or one step)
             const EvRec r = rec[lo_];
-            long glo = r.g_lo < r.s + W + 1 ? r.s + W + 1 : r.g_lo;
-            const long j = clock_J(glo - r.s, r.D2, r.N2) + 1 + (long)(gi - off[lo_]);
+            const long j = r.g_lo + (long)(gi - off[lo_]);           // (k_ev_count left the first governed instant's index in g_lo)
             const long num = j * (long)r.D2;
             long i; int ph = 0;
             if (r.N2 == 1) { i = r.s + num; }
