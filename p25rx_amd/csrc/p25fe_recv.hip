@@ -319,7 +319,13 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
     __shared__ uint16_t DETE[K2_DCAP];                           // per detection: decision offset ...
     __shared__ float DETT[K2_DCAP][3];                           // ... and thresholds
     __shared__ unsigned DETN;
-    __shared__ uint8_t FRO[GEN ? TS : 4];                         // GEN: per decision offset, the detection's position fraction (3 bits)
+    // GEN: per decision offset, the detection's position fraction (3 bits) -- one NIBBLE per offset: detections are more than W samples
+    // apart, so the two offsets of a byte never both hold one, and a byte is written whole (no clearing pass, no read-modify-write).
+    // (With the byte-per-offset table and a separate TRK array the workgroup needed 21 KB of LDS: more than ONE retiring K1 workgroup
+    // frees beside a running front end -- 6.9 KB spare + 13 KB -- so the general detection waited for K1 to drain: 250 us instead of 28.)
+    __shared__ uint8_t FRO[GEN ? TS / 2 : 4];
+    auto fro_set = [&](int off, int v) { FRO[off >> 1] = (uint8_t)((v & 7) << ((off & 1) * 4)); };
+    auto fro_get = [&](int off) -> unsigned { return ((unsigned)FRO[off >> 1] >> ((off & 1) * 4)) & 7u; };
 
     const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
@@ -410,7 +416,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
 #pragma unroll
                     for (int i = 1; i <= W; ++i) det = det && (c0 > CN[q][W - i]) && (c0 >= CN[q][W + i]);
                     if (det) {
-                        if constexpr (GEN) FRO[ec] = (uint8_t)(sync_frac(CN[q][W - 1], c0, CN[q][W + 1]) & 7);
+                        if constexpr (GEN) fro_set(ec, sync_frac(CN[q][W - 1], c0, CN[q][W + 1]));
                         atomicOr(&EVB[ec >> 5], 1u << (ec & 31));
                         const unsigned di = atomicAdd(&DETN, 1u);
                         if (di < (unsigned)K2_DCAP) {
@@ -500,25 +506,25 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         // per detection k: where its governed interval ends (the next detection's decision index + 1, the next lock drop or
         // the tile's end) and whether detection k + 1 may take its period from the interval s_k -> s_{k+1} (no drop between)
         __shared__ uint16_t ENDO[EVCAP];
-        __shared__ uint8_t TRK[EVCAP];
         const long T0 = a.abs0 + t0, TE = T0 + tn;
         for (int k = lane; k < n_ev; k += WV) {
             const long ek = T0 + EVS[k];
             const long f = first_kill(a.opt, ch, ek + 1);
             const long nxt = k + 1 < n_ev ? T0 + EVS[k + 1] + 1 : TE;
             ENDO[k] = (uint16_t)((f < nxt ? f : nxt) - T0);
-            if (k + 1 < n_ev) TRK[k + 1] = f >= nxt ? 1 : 0;
         }
-        if (lane == 0) TRK[0] = kill0 > T0 + first_off ? 1 : 0;
         phase_sync();
+        // detection k may take its period from the interval s_{k-1} -> s_k when no lock drop ended k - 1's governed interval before
+        // k's decision, i.e. when that interval ends AT k's decision index + 1 (k = 0: no drop between the tile's start and it)
+        auto trk = [&](int k) -> bool { return k == 0 ? (kill0 > T0 + first_off) : ((int)ENDO[k - 1] == (int)EVS[k] + 1); };
         uint32_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
         long rest = 0;
         for (int k = lane; k < n_ev; k += WV) {
-            evg[k] = (uint32_t)ENDO[k] | ((uint32_t)TRK[k] << 15) | ((uint32_t)FRO[EVS[k]] << 16);
+            evg[k] = (uint32_t)ENDO[k] | ((uint32_t)(trk(k) ? 1u : 0u) << 15) | ((uint32_t)fro_get(EVS[k]) << 16);
             if (k >= 1) {
                 const long sk = T0 + EVS[k] - W, sp = T0 + EVS[k - 1] - W;
                 int D, N;
-                clock_period(a.opt.track != 0, TRK[k] != 0, sp, frac3(FRO[EVS[k - 1]]), sk, frac3(FRO[EVS[k]]), D, N);
+                clock_period(a.opt.track != 0, trk(k), sp, frac3(fro_get(EVS[k - 1])), sk, frac3(fro_get(EVS[k])), D, N);
                 rest += clock_count(sk, D, N, sk + W + 1, T0 + ENDO[k]);
             }
         }
@@ -527,17 +533,17 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
             TileSumG g;
             const long pe = kill0 < T0 + first_off + 1 ? kill0 : T0 + first_off + 1;
             g.pre_end1 = (unsigned)(pe - T0) + 1u;
-            g.first1 = ((unsigned)first_off + 1u) | ((unsigned)FRO[first_off] << 16);
+            g.first1 = ((unsigned)first_off + 1u) | ((unsigned)fro_get(first_off) << 16);
             g.end0 = ENDO[0];
             g.last1 = (unsigned)last_off + 1u;
-            unsigned fl = TRK[0] ? G_FIRST_TRACKS : 0u;
+            unsigned fl = trk(0) ? G_FIRST_TRACKS : 0u;
             if ((int)ENDO[n_ev - 1] == tn) fl |= G_OUT_VALID;
             g.out_D = SPS; g.out_N = 1;
             if (n_ev >= 2) {
                 fl |= G_OUT_PERIOD_KNOWN;
-                clock_period(a.opt.track != 0, TRK[n_ev - 1] != 0, T0 + EVS[n_ev - 2] - W, frac3(FRO[EVS[n_ev - 2]]), T0 + last_off - W,
-                             frac3(FRO[last_off]), g.out_D, g.out_N);
-            } else if (!a.opt.track || !TRK[0]) {
+                clock_period(a.opt.track != 0, trk(n_ev - 1), T0 + EVS[n_ev - 2] - W, frac3(fro_get(EVS[n_ev - 2])), T0 + last_off - W,
+                             frac3(fro_get(last_off)), g.out_D, g.out_N);
+            } else if (!a.opt.track || !trk(0)) {
                 fl |= G_OUT_PERIOD_KNOWN;                          // nominal period: nothing to take it from
             }
             g.n_det_flags = (unsigned)n_ev | (fl << 16);
@@ -575,7 +581,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         rc.n_events = n_ev;
         rc.post_count = post;
         rc.last_f = 0; rc.pad_ = 0;
-        if constexpr (GEN) rc.last_f = frac3(FRO[last_off]);
+        if constexpr (GEN) rc.last_f = frac3(fro_get(last_off));
         a.recs[(size_t)ch * a.n_tiles + tile] = rc;
         a.tsum[(size_t)ch * a.n_tiles + tile] = pack_tsum(first_off, last_off, n_ev, post);
     }
