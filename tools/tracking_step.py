@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Wall time per pipelined call (p25fe_run_dev_pipelined) of configs[1] generated with a 150 ppm sample clock, under a tracking symbol
+clock.  usage: tracking_step.py [symbol_clock=2]   (P25FE_PIPE_DEPTH = scratch sets; profiles/r05_tracking_pipeline.txt)"""
 import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from p25rx_amd import c4fm
