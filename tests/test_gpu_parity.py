@@ -371,6 +371,28 @@ def test_time_shard_steps_pipelined(O, FE):
         r = parse_results(outs[k][1])[0]
         assert r.tobytes() == want[w][0], (k, w)
         assert np.array_equal(outs[k][0][0, :int(r["n_dibits"])].cpu().numpy(), want[w][1]), (k, w)
+    # the same steps with the WHOLE front end in one launch on the caller's stream (p25fe_shard_pass1_k1: what the pipelined RCCL step
+    # runs once the halo has arrived in front of K1), detection + scan on the receive stream, pass 2 on a third stream behind an event
+    outs2 = [(torch.zeros((1, cap), dtype=torch.uint8, device="cuda"), torch.zeros_like(summ0[0])) for _ in order]
+    for k, w in enumerate(order):
+        t = caps[w][cut - halo:]
+        rx = fe.shard_pipe_begin()
+        fe.shard_pass1_k1(t, offset=halo, n_hist=halo, abs0=cut)
+        with torch.cuda.stream(rx):
+            res = fe.shard_pass1_finish(t, offset=halo, n_hist=halo, abs0=cut)
+            summ_t = torch.cat([summ0[w], res])
+            stage = rx.record_event()
+        with torch.cuda.stream(side):
+            side.wait_event(stage)
+            fe.shard_pass2_dev(summ_t, d_bb0, d_bbn, 1, bbn[1], dibits=outs2[k][0], result=outs2[k][1])
+            summ_t.record_stream(side)
+        fe.shard_pipe_end(last=side)
+    fe.join_dev()
+    torch.cuda.synchronize()
+    for k, w in enumerate(order):
+        r = parse_results(outs2[k][1])[0]
+        assert r.tobytes() == want[w][0], ("k1", k, w)
+        assert np.array_equal(outs2[k][0][0, :int(r["n_dibits"])].cpu().numpy(), want[w][1]), ("k1", k, w)
     # a plain call right behind a pipelined step joins the receive stream by itself
     rx = fe.shard_pipe_begin()
     fe.shard_pass1_main(caps[1][cut - halo:], offset=halo, n_hist=halo, abs0=cut)
