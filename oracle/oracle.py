@@ -286,7 +286,7 @@ class Recv:
         return dict(t=t.value, valid=bool(v.value), s=s.value, hi=thr[0], mid=thr[1], lo=thr[2], n_dibits=nd.value)
 
 
-CLK_DTYPE = np.dtype([("d", "<i8"), ("n", "<i8"), ("usable", "<i4"), ("pad", "<i4")])
+CLK_DTYPE = np.dtype([("d", "<i8"), ("n", "<i8"), ("usable", "<i4"), ("f", "<i4")])
 
 
 def recv_range(bb, cfg=None, resync_at=(), libpath=None):

@@ -427,7 +427,8 @@ float p25o_atan2f(const p25o_config *c, float y, float x) { return spec_atan2f(c
  *   dibits have no lag.
  * ---------------------------------------------------------------------------------------- */
 #define RING 512
-typedef struct { int64_t d, n; int32_t usable, pad_; } p25o_clk;       /* a clock D / N; usable: it came from a sync-to-sync interval that passed 3.8b's test */
+typedef struct { int64_t d, n; int32_t usable, f; } p25o_clk;          /* a clock D / N; usable: it came from a sync-to-sync interval that passed 3.8b's test;
+                                                                           f: pass 1 -- the sync position's fraction (quarter samples); table -- the anchor's offset in 1 / N samples */
 typedef struct {
     p25o_config cfg;
     int64_t t;                  /* samples fed so far */
@@ -437,7 +438,7 @@ typedef struct {
     int64_t anchor_s;
     float hi, mid, lo;
     /* symbol clock of the anchor in force: instants at anchor_s + j * per_d / per_n, j = 1, 2, ...  (10 / 1 in mode 0) */
-    int64_t per_d, per_n, next_j, next_i;
+    int64_t per_d, per_n, per_off, next_j, next_i;     /* per_off: SPEC 3.8c's fractional anchor (0 in modes 0 / 1): instants at anchor_s + (j per_d + per_off) / per_n */
     int next_q;
     int prev_valid;             /* a detection since the last lock drop: the next sync-to-sync interval is a period estimate */
     int64_t prev_s;
@@ -475,7 +476,11 @@ void p25o_reslice_table(const p25o_clk *rec, size_t n, int sps, p25o_clk *out)
     for (size_t k = 0; k < n; k++) {
         if (rec[k].usable) out[k] = rec[k];
         else if (k + 1 < n && rec[k + 1].usable) { out[k] = rec[k + 1]; out[k].usable = 0; }
-        else { out[k].d = sps; out[k].n = 1; out[k].usable = 0; out[k].pad_ = 0; }
+        else { out[k].d = sps; out[k].n = 1; out[k].usable = 0; }
+        /* the fractional anchor: the instants start from s + f / 4 instead of s.  Clocks are D / (4 N_sym) (3.8b); the nominal 10 / 1
+         * is written 40 / 4 so that the quarter fits; the offset is f N_sym = f n / 4 in units of 1 / n samples */
+        if (out[k].n == 1) { out[k].d *= 4; out[k].n = 4; }
+        out[k].f = (int32_t)(rec[k].f * (out[k].n / 4));
     }
 }
 
@@ -488,7 +493,7 @@ static inline float cget(const p25o_recv *r, int64_t n) { return n < 0 ? 0.0f : 
 /* position of instant next_j of the current anchor: integer part and interpolation phase (SPEC 3.8b) */
 static inline void clock_advance(p25o_recv *r)
 {
-    const int64_t num = r->next_j * r->per_d;
+    const int64_t num = r->next_j * r->per_d + r->per_off;      /* (> 0: |per_off| <= per_n / 2 < per_d) */
     r->next_i = r->anchor_s + num / r->per_n;
     r->next_q = (int)(((num % r->per_n) * 64) / r->per_n);
 }
@@ -585,8 +590,11 @@ int p25o_recv_feed(p25o_recv *r, const float *bb, size_t n, uint8_t *dibits, siz
                         if (d4 != 4 * S * nn) { r->per_d = d4; r->per_n = 4 * nn; }     /* (exactly nominal: written 10 / 1, the same instants) */
                     }
                 }
-                if (r->rec && r->n_det < r->rec_cap) { p25o_clk k = {r->per_d, r->per_n, usable, 0}; r->rec[r->n_det] = k; }
-                if (r->ovr && r->n_det < r->ovr_len) { r->per_d = r->ovr[r->n_det].d; r->per_n = r->ovr[r->n_det].n; }   /* SPEC 3.8c, pass 2 */
+                r->per_off = 0;
+                if (r->rec && r->n_det < r->rec_cap) { p25o_clk k = {r->per_d, r->per_n, usable, fq}; r->rec[r->n_det] = k; }
+                if (r->ovr && r->n_det < r->ovr_len) {                       /* SPEC 3.8c, pass 2 */
+                    r->per_d = r->ovr[r->n_det].d; r->per_n = r->ovr[r->n_det].n; r->per_off = r->ovr[r->n_det].f;
+                }
                 r->n_det++;
                 r->prev_s = m; r->prev_f = fq; r->prev_valid = 1;
                 r->anchor_s = m;

@@ -1497,7 +1497,14 @@ struct EvRec {
 };
 static_assert(sizeof(EvRec) == 64, "EvRec layout");
 struct EvNext { long pos; unsigned long long seq; };
-constexpr unsigned EV_USABLE = 1u, EV_OPEN = 2u, EV_VALID = 4u;
+constexpr unsigned EV_USABLE = 1u, EV_OPEN = 2u, EV_VALID = 4u;     // bits 8..10: the sync position's fraction (quarter samples, two's complement)
+// SPEC 3.8c's fractional anchor: the instants of a detection (s, f) under the clock D / N (N a multiple of 4) are s + (j D + f N / 4) div N.
+// number of instants j >= 1 with position < x  (x relative to s): j D + off < x N
+__host__ __device__ inline long clock_J_off(long x, int D, int N, int off)
+{
+    const long num = x * (long)N - (long)off - 1;
+    return num < 0 ? 0 : num / (long)D;
+}
 
 struct EvArgs {
     Planar pl;
@@ -1573,7 +1580,7 @@ __global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a)
             else clock_period(true, ((eg >> 15) & 1u) != 0, T0 + EV[k - 1] - W, frac3(EG[k - 1] >> 16), sk, frac3(eg >> 16), r.Db, r.Nb, &us);
             r.s = sk; r.g_lo = ek + 1; r.g_hi = T0 + (long)(eg & 0x7fffu);
             r.D2 = r.Db; r.N2 = r.Nb;
-            r.flags = EV_VALID | (us ? EV_USABLE : 0u) | ((k == n_ev - 1 && (int)(eg & 0x7fffu) == tn) ? EV_OPEN : 0u);
+            r.flags = EV_VALID | (us ? EV_USABLE : 0u) | ((k == n_ev - 1 && (int)(eg & 0x7fffu) == tn) ? EV_OPEN : 0u) | (((eg >> 16) & 7u) << 8);
             r.hi = r.mid = r.lo = 0.f; r.pad_ = 0;
             if (k < EVTHR_N) { r.hi = eth[3 * k]; r.mid = eth[3 * k + 1]; r.lo = eth[3 * k + 2]; }
             rec[1 + so.event_off + k] = r;
@@ -1614,9 +1621,12 @@ __global__ __launch_bounds__(WV, 4) void k_ev_count(EvArgs a)
                 const EvNext x = nxt[e];
                 ghi = x.seq == a.seq ? x.pos : range_end;
             }
+            // the fractional anchor (entry 0, the carry-in, arrives without a fraction: bits 8..10 are 0); 10 / 1 is written 40 / 4
+            if (N == 1) { D *= 4; N = 4; }
+            const int off = frac3(r.flags >> 8) * (N / 4);
             long glo = r.g_lo < r.s + W + 1 ? r.s + W + 1 : r.g_lo;
-            const long j0 = clock_J(glo - r.s, D, N);
-            long c = ghi > glo ? clock_J(ghi - r.s, D, N) - j0 : 0;
+            const long j0 = clock_J_off(glo - r.s, D, N, off);
+            long c = ghi > glo ? clock_J_off(ghi - r.s, D, N, off) - j0 : 0;
             cnt = (unsigned)(c < 0 ? 0 : (c > 0x7fffffffL ? 0x7fffffffL : c));
             jlo = j0 + 1;
             rec[e].D2 = D; rec[e].N2 = N; rec[e].g_hi = ghi;
@@ -1699,10 +1709,10 @@ __global__ __launch_bounds__(WV, 4) void k_ev_slice(EvArgs a)
             while (lo_ + 1 < n_e && off[lo_ + 1] <= gi) ++lo_;      // (864 dibits per detection on a P25 channel: zero or one step)
             const EvRec r = rec[lo_];
             const long j = r.g_lo + (long)(gi - off[lo_]);           // (k_ev_count left the first governed instant's index in g_lo)
-            const long num = j * (long)r.D2;
-            long i; int ph = 0;
-            if (r.N2 == 1) { i = r.s + num; }
-            else { const long qu = num / r.N2; i = r.s + qu; ph = (int)(((num - qu * r.N2) * P25FE_CLK_PHASES) / r.N2); }
+            const long num = j * (long)r.D2 + (long)(frac3(r.flags >> 8) * (r.N2 / 4));    // (> 0: j >= 1 and |offset| <= N / 2 < D)
+            const long qu = num / r.N2;
+            const long i = r.s + qu;
+            const int ph = (int)(((num - qu * r.N2) * P25FE_CLK_PHASES) / r.N2);
             const long p = i - a.abs0 + PLPAD;
             float b[4];
 #pragma unroll

@@ -92,7 +92,8 @@ class Model:
         s + (j D) div N are read by the 4-tap interpolation of their phase; the receiver runs L samples behind the
         baseband (it processes index u when sample u + L exists), a drop before sample q removes instants >= q - L.
         reslice (SPEC 3.8c, symbol_clock = 2, one resident range): a detection whose own interval gave no clock takes the clock of
-        the interval that starts at it, if the next detection's is usable."""
+        the interval that starts at it, if the next detection's is usable; and every detection's instants start from its REFINED
+        position s + f / 4 (the fraction that so far entered the period only)."""
         b = np.ascontiguousarray(b, dtype=F)
         n = len(b)
         L = int(spec["clk_lookahead"])
@@ -139,23 +140,28 @@ class Model:
             D, N, ok = back[k]
             if reslice and not ok and i + 1 < len(order) and back[order[i + 1]][2]:
                 D, N = back[order[i + 1]][0], back[order[i + 1]][1]
-            clock[k] = (D, N)
+            off = 0
+            if reslice:                                              # the fractional anchor: clocks are D / (4 N_sym), 10 / 1 is written 40 / 4
+                if N == 1:
+                    D, N = 4 * D, 4
+                off = fr[k] * (N // 4)
+            clock[k] = (D, N, off)
         dib, spos, sdib = [], [], []
         anchor, start = None, -L
         for t, kind, k in ev + [(n - L, 2, -1)]:
             t = min(t, n - L)
             if anchor is not None and t > start:
-                s, hi, mid, lo, D, N, _ = anchor
-                # j with start <= s + (j D) div N < t, j >= 1
-                j = max(1, ((start - s) * N + D - 1) // D)
-                while s + (j * D) // N < start:
+                s, hi, mid, lo, D, N, _, off = anchor
+                # j with start <= s + (j D + off) div N < t, j >= 1
+                j = max(1, ((start - s) * N - off + D - 1) // D - 1)
+                while s + (j * D + off) // N < start:
                     j += 1
                 js = []
-                while s + (j * D) // N < t:
+                while s + (j * D + off) // N < t:
                     js.append(j); j += 1
                 if js:
                     js = np.array(js, dtype=np.int64)
-                    num = js * D
+                    num = js * D + off
                     i = s + num // N
                     q = ((num % N) * phases) // N
                     w = Ci[q]
@@ -167,8 +173,8 @@ class Model:
             start = max(start, t)
             if kind == 0:
                 s, hi, mid, lo = dets[k]
-                D, N = clock[k]
-                anchor = (s, hi, mid, lo, D, N, fr[k])
+                D, N, off = clock[k]
+                anchor = (s, hi, mid, lo, D, N, fr[k], off)
                 spos.append(s)
                 sdib.append(sum(len(x) for x in dib))
             elif kind == 1:
