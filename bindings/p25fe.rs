@@ -195,6 +195,7 @@ extern "C" {
     pub fn p25fe_shard_pipe_end(h: *mut Handle, last_stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass1_k1(h: *mut Handle, d_iq: *const c_void, fmt: c_int, ch_stride: usize, n_hist: usize, n: usize,
                                 abs0: u64, stream: *mut c_void) -> c_int;
+    pub fn p25fe_streams_share_queue(h: *mut Handle, stream_a: *mut c_void, stream_b: *mut c_void, shared: *mut c_int) -> c_int;
     pub fn p25fe_shard_pass2(h: *mut Handle, d_anchor_in: *const Anchor, d_dibits: *mut u8, dibit_stride: usize,
                              d_result: *mut ResultRec, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pass2_dev(h: *mut Handle, d_summaries: *const ResultRec, d_shard_bb0: *const u64, d_shard_bb_n: *const u64,

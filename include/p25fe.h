@@ -423,6 +423,12 @@ int p25fe_shard_compact_dev(p25fe_t *h, const uint8_t *d_gathered, size_t cap, c
 int p25fe_shard_compact_from_dev(p25fe_t *h, const uint8_t *d_gathered, size_t cap, const uint64_t *d_dibit_offset,
                                  size_t first_shard, size_t n_shards, uint8_t *d_out, size_t out_cap, void *stream);
 
+/* Do two streams of this process share a HARDWARE queue (*shared = 1) -- i.e. do their kernels run one after the other whatever the
+ * streams say?  HIP multiplexes the streams of one priority level onto four queues in creation order; the pipelined calls of this
+ * library only overlap what they promise when their streams sit on different queues ("Which stream to pass").
+ * Synchronises both streams and runs a 1-thread probe on each (< 1 ms); p25fe_shard_create's side stream is chosen with it. */
+int p25fe_streams_share_queue(p25fe_t *h, void *stream_a, void *stream_b, int *shared);
+
 /* Network identifier that follows each frame sync (next row after the dibits, SURVEY.md section 8f: what
  * p25::MessageReceiver reports as MessageEvent::PacketNID, src/recv.rs:216-222, consumed by
  * ReceiverPolicy::handle_nid, src/policy.rs:92).  64 bits = BCH(63,16,23) code word (NAC 12 bits, DUID 4 bits)

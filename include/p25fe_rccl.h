@@ -82,8 +82,8 @@ int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, 
  * P25FE_GATHER_ROOT_EXACT keeps its one host wait per step, which ends the overlap for that mode; the shared-memory test hook runs
  * the plain step.  p25fe_shard_create makes a second communicator for the halo (ncclCommSplit, a collective every rank takes part in);
  * if that fails the step keeps everything behind K1 in step order on the receive stream.
- * STREAM: pass the NULL stream unless you have checked that yours does not share a hardware queue with the step's side streams
- * ("Which stream to pass"). */
+ * STREAM: any.  The first step that sees a caller's stream checks that the side stream does not share its hardware queue
+ * (p25fe_streams_share_queue: synchronises both streams once) and replaces it if it does ("Which stream to pass"). */
 int p25fe_shard_step_pipelined(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,
                                void *stream);
 /* make `stream` wait for everything p25fe_shard_step_pipelined has enqueued so far */

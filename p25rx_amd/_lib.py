@@ -70,7 +70,7 @@ SYMBOLS = [
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
     "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
     "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log", "p25fe_run_host_windows",
-    "p25fe_shard_pass1_head", "p25fe_shard_pipe_begin", "p25fe_shard_pipe_end", "p25fe_shard_pass1_k1", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant", "p25fe_n_baseband_h",
+    "p25fe_shard_pass1_head", "p25fe_shard_pipe_begin", "p25fe_shard_pipe_end", "p25fe_shard_pass1_k1", "p25fe_streams_share_queue", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant", "p25fe_n_baseband_h",
 ]
 
 
@@ -142,6 +142,7 @@ def load():
     L.p25fe_shard_pipe_begin.argtypes = [vp, vp, C.POINTER(C.c_void_p)]
     L.p25fe_shard_pipe_end.argtypes = [vp, vp]
     L.p25fe_shard_pass1_k1.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp]
+    L.p25fe_streams_share_queue.argtypes = [vp, vp, vp, C.POINTER(C.c_int)]
     L.p25fe_shard_pass2_dev.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp, vp, sz, vp, vp, vp]
     L.p25fe_shard_compact_from_dev.argtypes = [vp, vp, sz, vp, sz, sz, vp, sz, vp]
     L.p25fe_shard_pass2.argtypes = [vp, vp, vp, sz, vp, vp]

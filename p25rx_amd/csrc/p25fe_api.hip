@@ -1319,8 +1319,8 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
                 // the launch's last workgroup publishes "the head is in memory"; the detection's first tiles wait for that
                 // word instead of the whole stream waiting for an event
                 if (!h->sh_flag.p) {
-                    HIPCHK(h, h->sh_flag.ensure(2 * sizeof(unsigned)));
-                    HIPCHK(h, hipMemsetAsync(h->sh_flag.p, 0, 2 * sizeof(unsigned), st));
+                    HIPCHK(h, h->sh_flag.ensure(4 * sizeof(unsigned)));
+                    HIPCHK(h, hipMemsetAsync(h->sh_flag.p, 0, 4 * sizeof(unsigned), st));
                 }
                 ++h->sh_seq;
                 if (h->sh_seq == 0u) ++h->sh_seq;
@@ -1484,6 +1484,36 @@ int p25fe_shard_resolve_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const
     hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, (hipStream_t)stream, d_summaries, d_shard_bb0, d_shard_bb_n,
                        (int)n_shards, h->track, d_anchor_in, d_dibit_offset);
     HIPCHK(h, hipGetLastError());
+    return P25FE_OK;
+}
+
+int p25fe_streams_share_queue(p25fe_t* h, void* stream_a, void* stream_b, int* shared)
+{
+    if (!h || !shared) return P25FE_ERR_ARG;
+    *shared = 0;
+    if (stream_a == stream_b) { *shared = 1; return P25FE_OK; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->sh_flag.p) {
+        HIPCHK(h, h->sh_flag.ensure(4 * sizeof(unsigned)));
+        HIPCHK(h, hipMemset(h->sh_flag.p, 0, 4 * sizeof(unsigned)));
+    }
+    HIPCHK(h, h->sh_flag.ensure(4 * sizeof(unsigned)));
+    unsigned* w = h->sh_flag.as<unsigned>() + 2;                     // (words 0 / 1 are the head segment's flag and ticket)
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_a));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_b));
+    int votes = 0;
+    for (int rep = 0; rep < 3; ++rep) {                              // (three rounds: a busy chip can delay the setter once)
+        HIPCHK(h, hipMemset(w, 0, 2 * sizeof(unsigned)));
+        hipLaunchKernelGGL(k_queue_probe_wait, dim3(1), dim3(1), 0, (hipStream_t)stream_a, w, 20000ull);      // 200 us at 100 MHz
+        hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(1), 0, (hipStream_t)stream_b, w);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_a));
+        HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_b));
+        unsigned r[2] = {0u, 0u};
+        HIPCHK(h, hipMemcpy(r, w, sizeof r, hipMemcpyDeviceToHost));
+        if (r[1] == 2u) ++votes;
+    }
+    *shared = votes == 3;
     return P25FE_OK;
 }
 

@@ -1884,6 +1884,20 @@ __global__ __launch_bounds__(256) void k_shard_compact(const uint8_t* gathered, 
 #endif
 
 #ifndef P25FE_JIT
+// Do two streams share a hardware queue?  HIP multiplexes the streams of one priority level onto four queues; streams on one queue
+// run their kernels strictly one after the other.  k_queue_probe_wait (stream A) waits for a word k_queue_probe_set (stream B, launched
+// after it) writes -- for at most `ticks` of the 100 MHz wall clock: on one queue the setter cannot start before the waiter has given up.
+__global__ void k_queue_probe_wait(unsigned* word, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned seen = 0u;
+    while (!(seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    word[1] = seen ? 1u : 2u;                                        // 1: the other stream ran beside this one; 2: it did not
+}
+__global__ void k_queue_probe_set(unsigned* word) { __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
+#ifndef P25FE_JIT
 // anchor_out of C result records -> a contiguous anchor array (the carry-in of the next window of p25fe_run_host_windows)
 __global__ void k_anchors_from_results(const p25fe_result_t* results, p25fe_anchor_t* anchors, int n_ch)
 {

@@ -61,6 +61,8 @@ struct p25fe_shard {
     ncclComm_t comm = nullptr;
     ncclComm_t comm_halo = nullptr;       // pipelined steps: the halo travels on a communicator of its own (ncclCommSplit), on K1's stream
     hipEvent_t e_stage = nullptr;         // pipelined steps: summaries gathered (receive stream) -> pass 2 and the dibit gather (side stream)
+    bool probed = false;                  // the side stream has been checked against `probed_st` (p25fe_streams_share_queue)
+    hipStream_t probed_st = nullptr;
     int pipe_layout = 2;                  // measurement knob P25FE_SHARD_PIPE_LAYOUT: 1 = the step's own order on the receive stream
     Shm shm;
     hipStream_t cs = nullptr;             // the halo exchange and the shard's head segment run beside K1's main launch
@@ -249,6 +251,31 @@ static int exact_offsets_wait(p25fe_shard_t* s)
 }
 
 } // extern "C"
+
+// The side stream must not sit on the hardware queue of the caller's stream: HIP hands the streams of one priority level four queues
+// to share, in creation order, and two streams on one queue run their kernels one after the other -- the halo would no longer hide
+// behind K1, the pipelined step's second stage would hold up the next K1 (measured: 0.35 - 0.36 ms per step instead of 0.28 / 0.33).
+// Checked once per caller's stream (the probe synchronises both streams, < 1 ms): a side stream that shares is replaced by a fresh one.
+static int pick_side_stream(p25fe_shard_t* s, hipStream_t st)
+{
+    if (s->probed && s->probed_st == st) return P25FE_OK;
+    s->probed = true; s->probed_st = st;
+    const char* e = getenv("P25FE_SHARD_QUEUE_PROBE");
+    if (e && atoi(e) == 0) return P25FE_OK;
+    std::vector<hipStream_t> rejected;
+    try {
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            int shared = 0;
+            if (p25fe_streams_share_queue(s->h, st, s->cs, &shared) != P25FE_OK || !shared) break;
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+            rejected.push_back(s->cs);                              // kept alive until the search ends: its queue slot stays taken
+            s->cs = fresh;
+        }
+    } catch (...) {}
+    for (hipStream_t r : rejected) { (void)hipStreamSynchronize(r); (void)hipStreamDestroy(r); }
+    return P25FE_OK;
+}
 
 // Where the launches of one step go.
 //   plain step:       everything on the caller's stream; halo + head on the side stream beside K1's main launch.
@@ -445,6 +472,7 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
     if (!s) return P25FE_ERR_ARG;
     if (s->broken) return P25FE_ERR_HIP;
     HCHK(hipSetDevice(p25fe_device(s->h)));
+    if (!s->staged) (void)pick_side_stream(s, (hipStream_t)stream);
     const StepStreams ss = {(hipStream_t)stream, (hipStream_t)stream, (hipStream_t)stream, false};
     return shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
 }
@@ -458,6 +486,7 @@ int p25fe_shard_step_pipelined(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* 
         const StepStreams ss = {(hipStream_t)stream, (hipStream_t)stream, (hipStream_t)stream, false};
         return shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
     }
+    (void)pick_side_stream(s, (hipStream_t)stream);
     void* rx = nullptr;
     int rc = p25fe_shard_pipe_begin(s->h, stream, &rx);
     if (rc) return rc;

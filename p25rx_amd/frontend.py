@@ -404,6 +404,14 @@ class FrontEnd:
         ptr = iq.data_ptr() + offset * (8 if fmt == FMT_CF32 else 2)
         self._chk(self.L.p25fe_shard_pass1_k1(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0, self._stream()))
 
+    def streams_share_queue(self, a, b):
+        """do the torch streams a and b (None: the NULL stream) sit on one hardware queue?  (p25fe_streams_share_queue; synchronises both)"""
+        sh = C.c_int(0)
+        pa = C.c_void_p(a.cuda_stream) if a is not None else None
+        pb = C.c_void_p(b.cuda_stream) if b is not None else None
+        self._chk(self.L.p25fe_streams_share_queue(self.h, pa, pb, C.byref(sh)))
+        return bool(sh.value)
+
     def shard_pass2_dev(self, summ_all, d_bb0, d_bbn, rank, n_bb, dibits=None, dup=None, result=None):
         """Pass 2 with the combine inside it (p25fe_shard_pass2_dev): summ_all uint8 [n_shards, sizeof(result)] on the device.
         Returns (dibits, result, anchors uint8 [n_shards, sizeof(anchor)], offsets int64 [n_shards + 1])."""

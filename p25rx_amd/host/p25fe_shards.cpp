@@ -85,9 +85,9 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
     float* d_buf = nullptr;
     uint8_t* d_dib = nullptr;
     p25fe_result_t* d_res = nullptr;
-    // The step goes to the NULL stream unless -s asks for a stream of this program's own.  Measured (profiles/r05_shard_pipelined.txt):
-    // HIP multiplexes streams onto a few hardware queues, and with one more user stream in the process the step's three streams no
-    // longer get queues of their own -- the same step costs 0.36 ms instead of 0.28 (pipelined) / 0.355 instead of 0.337 (plain).
+    // The step goes to the NULL stream unless -s asks for a stream of this program's own.  (HIP multiplexes streams onto a few hardware
+    // queues; before the library checked for it, one more user stream in the process put the step's side stream on K1's queue: 0.36 ms
+    // instead of 0.28 pipelined / 0.355 instead of 0.337 plain -- profiles/r05_shard_pipelined.txt.  Now -s costs what the NULL stream costs.)
     hipStream_t st = nullptr;
     if (hipMalloc(&d_buf, (halo + n) * 8) != hipSuccess || hipMalloc(&d_dib, cap) != hipSuccess || hipMalloc(&d_res, sizeof *d_res) != hipSuccess ||
         (own_stream && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess))

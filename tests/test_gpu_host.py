@@ -422,6 +422,23 @@ def test_c_abi_shard_step_through_ctypes_rccl_world1():
     assert res == [True, True, True, True, True, True]
 
 
+def test_streams_share_queue_probe():
+    """p25fe_streams_share_queue: a stream shares with itself; HIP gives the streams of one priority level four hardware queues, so of
+    six normal-priority streams some pair shares one; a high-priority stream never shares with a normal-priority one.  (What
+    p25fe_shard_step uses to keep its side stream off the caller's queue.)"""
+    import torch
+    from p25rx_amd.frontend import FrontEnd
+    fe = FrontEnd()
+    ss = [torch.cuda.Stream() for _ in range(6)]
+    assert fe.streams_share_queue(ss[0], ss[0])
+    pairs = [(i, j) for i in range(6) for j in range(i + 1, 6) if fe.streams_share_queue(ss[i], ss[j])]
+    assert pairs, "six streams on four queues and no pair shares one?"
+    assert len(pairs) <= 6
+    hi = torch.cuda.Stream(priority=-1)
+    assert not any(fe.streams_share_queue(hi, x) for x in ss)
+    fe.streams_share_queue(None, ss[0])                              # the NULL stream is a legal argument
+
+
 def _rccl_cabi_pipelined_worker(q):
     import torch
     from p25rx_amd import c4fm, rccl
