@@ -76,7 +76,8 @@ int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, 
  * detection, scan, summary all-gather, slicer, dibit gather, compaction) on the handle's receive stream, so that the next call's
  * K1 starts while this call's ~80 us chain of short kernels and exchanges is still running.  Outputs (d_dibits, d_result, the
  * ordered stream, the offsets) are complete once a stream has been made to wait with p25fe_shard_join (or the device has been
- * synchronised).  Consecutive calls may name the same output buffers (the chains run in call order on one stream); the ordered
+ * synchronised).  Consecutive calls may name the same output buffers (d_dibits and d_result are written by pass 2 only, and the pass 2s
+ * run in call order on one stream; pass 1's summaries live in the shard object, one slot per step in flight); the ordered
  * stream alternates between two buffers, p25fe_shard_stream_dev() names the LAST call's, and the previous call's stays untouched
  * until the call after this one; d_buf must stay unchanged until `stream` and the step's exchanges have passed it (join).
  * P25FE_GATHER_ROOT_EXACT keeps its one host wait per step, which ends the overlap for that mode; the shared-memory test hook runs

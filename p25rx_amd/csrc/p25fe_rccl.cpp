@@ -17,6 +17,7 @@
 
 namespace {
 
+constexpr int SLOTS = 4;                  // >= the scratch sets the pipelined step rotates through
 constexpr int RING = 64;                  // steps whose exchange events are kept for p25fe_shard_comm_ms
 constexpr size_t SHM_HALO_MAX = 4096 * 8; // bytes of one halo slot in the test hook's shared segment
 
@@ -72,7 +73,11 @@ struct p25fe_shard {
                                           // the step's critical path and cost ~4 us each there
     uint64_t steps = 0, timed = 0, read_from = 0;
     std::vector<uint64_t> bb0, bbn;
-    p25fe_result_t* d_summ = nullptr;
+    // Pass 1's summary and the gathered summaries live in rings of SLOTS entries indexed by the step: in the pipelined step stage 1 of
+    // step j + 1 (receive stream) runs beside stage 2 of step j (side stream), which still reads step j's summaries and writes the
+    // caller's result record -- pass 1 therefore never writes that record, and never the summaries of the step before.
+    p25fe_result_t* d_summ = nullptr;     // [SLOTS][world]
+    p25fe_result_t* d_res1 = nullptr;     // [SLOTS]
     uint64_t *d_bb0 = nullptr, *d_bbn = nullptr, *d_off = nullptr, *d_off_x = nullptr;
     p25fe_anchor_t *d_anc = nullptr, *d_anc_x = nullptr;
     uint8_t *d_gathered = nullptr, *d_stream = nullptr;
@@ -120,7 +125,7 @@ void p25fe_shard_destroy(p25fe_shard_t* s)
     if (s->e_off) (void)hipEventDestroy(s->e_off);
     if (s->h_off) (void)hipHostFree(s->h_off);
     for (auto& row : s->ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
-    void* bufs[] = {s->d_summ, s->d_bb0, s->d_bbn, s->d_off, s->d_off_x, s->d_anc, s->d_anc_x, s->d_gathered, s->d_stream, s->d_stream2, s->d_loop};
+    void* bufs[] = {s->d_summ, s->d_res1, s->d_bb0, s->d_bbn, s->d_off, s->d_off_x, s->d_anc, s->d_anc_x, s->d_gathered, s->d_stream, s->d_stream2, s->d_loop};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->shm.base) munmap(s->shm.base, s->shm.bytes);
     delete s;
@@ -173,7 +178,8 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
         hipHostMalloc(reinterpret_cast<void**>(&s->h_off), ((size_t)world + 1) * 8, hipHostMallocDefault) != hipSuccess)
         return fail(P25FE_ERR_HIP);
     const size_t W = (size_t)world;
-    if (hipMalloc(&s->d_summ, W * sizeof(p25fe_result_t)) != hipSuccess || hipMalloc(&s->d_bb0, W * 8) != hipSuccess ||
+    if (hipMalloc(&s->d_summ, SLOTS * W * sizeof(p25fe_result_t)) != hipSuccess || hipMalloc(&s->d_res1, SLOTS * sizeof(p25fe_result_t)) != hipSuccess ||
+        hipMalloc(&s->d_bb0, W * 8) != hipSuccess ||
         hipMalloc(&s->d_bbn, W * 8) != hipSuccess || hipMalloc(&s->d_off, (W + 1) * 8) != hipSuccess ||
         hipMalloc(&s->d_off_x, (W + 1) * 8) != hipSuccess || hipMalloc(&s->d_anc_x, W * sizeof(p25fe_anchor_t)) != hipSuccess ||
         hipMalloc(&s->d_anc, W * sizeof(p25fe_anchor_t)) != hipSuccess || hipMalloc(&s->d_gathered, W * s->cap) != hipSuccess ||
@@ -230,11 +236,11 @@ int p25fe_shard_gather_ran(const p25fe_shard_t* s) { return s ? s->gather_ran : 
 
 // The world + 1 offsets of this step on the HOST (P25FE_GATHER_ROOT_EXACT: the counts are host arguments of the sends and
 // receives): a one-thread resolve beside pass 2, into buffers of its own, then one small copy to pinned memory.
-static int exact_offsets_begin(p25fe_shard_t* s, hipStream_t st)
+static int exact_offsets_begin(p25fe_shard_t* s, const p25fe_result_t* summ, hipStream_t st)
 {
     HCHK(hipEventRecord(s->e_res, st));                              // the summaries are in d_summ
     HCHK(hipStreamWaitEvent(s->cs, s->e_res, 0));
-    const int rc = p25fe_shard_resolve_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, s->d_anc_x, s->d_off_x, s->cs);
+    const int rc = p25fe_shard_resolve_dev(s->h, summ, s->d_bb0, s->d_bbn, (size_t)s->world, s->d_anc_x, s->d_off_x, s->cs);
     if (rc) return rc;
     HCHK(hipMemcpyAsync(s->h_off, s->d_off_x, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost, s->cs));
     HCHK(hipEventRecord(s->e_off, s->cs));
@@ -306,6 +312,8 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
     // kernels of the step's critical path
     const bool timed = rccl && s->timing_every > 0 && (s->steps % (uint64_t)s->timing_every) == 0;
     hipEvent_t* ev = s->ev[s->timed % RING];
+    p25fe_result_t* const res1 = s->d_res1 + (s->steps % SLOTS);                       // pass 1's summary of THIS step
+    p25fe_result_t* const summ = s->d_summ + (s->steps % SLOTS) * (size_t)s->world;    // every rank's, gathered
     int rc;
     if (multi) {
         // ---- 1. halo: my last `halo` samples -> rank + 1, rank - 1's -> the front of my buffer, beside K1's main launch
@@ -315,7 +323,7 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
             s->shm.barrier();
             if (s->rank > 0) HCHK(hipMemcpy(buf, s->shm.halo(s->rank - 1), s->halo * eb, hipMemcpyHostToDevice));
             s->shm.barrier();
-            rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, st);
+            rc = p25fe_shard_pass1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, res1, st);
             if (rc) return rc;
         } else {
             const hipStream_t hs = ss.halo_on_st ? st : s->cs;
@@ -337,7 +345,7 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
             if (ss.halo_on_st) {
                 rc = p25fe_shard_pass1_k1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);       // the halo is in: one launch, head included
                 if (rc) return rc;
-                rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, rx);
+                rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, res1, rx);
                 if (rc) return rc;
             } else {
             rc = p25fe_shard_pass1_main(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);
@@ -353,32 +361,32 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
                 HCHK(hipEventRecord(s->e_head, s->cs));
                 HCHK(hipStreamWaitEvent(rx, s->e_head, 0));
             }
-            rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, rx);
+            rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, res1, rx);
             if (rc) return rc;
             }
         }
         // ---- 2. one summary per rank to every rank
         if (s->staged) {
             HCHK(hipStreamSynchronize(rx));
-            HCHK(hipMemcpy(s->shm.summ(s->rank), d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToHost));
+            HCHK(hipMemcpy(s->shm.summ(s->rank), res1, sizeof(p25fe_result_t), hipMemcpyDeviceToHost));
             s->shm.barrier();
-            HCHK(hipMemcpy(s->d_summ, s->shm.summ(0), (size_t)s->world * sizeof(p25fe_result_t), hipMemcpyHostToDevice));
+            HCHK(hipMemcpy(summ, s->shm.summ(0), (size_t)s->world * sizeof(p25fe_result_t), hipMemcpyHostToDevice));
             s->shm.barrier();
         } else {
             if (timed) HCHK(hipEventRecord(ev[2], rx));
-            NCHK(ncclAllGather(d_result, s->d_summ, sizeof(p25fe_result_t), ncclUint8, s->comm, rx));
+            NCHK(ncclAllGather(res1, summ, sizeof(p25fe_result_t), ncclUint8, s->comm, rx));
             if (timed) HCHK(hipEventRecord(ev[3], rx));
         }
     } else {
         rc = p25fe_shard_pass1_k1(s->h, owned, fmt, s->n, n_hist, s->n, abs0, st);              // (no halo to wait for: one launch)
         if (rc) return rc;
-        rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, d_result, rx);
+        rc = p25fe_shard_pass1_finish(s->h, owned, fmt, s->n, n_hist, s->n, abs0, res1, rx);
         if (rc) return rc;
-        HCHK(hipMemcpyAsync(s->d_summ, d_result, sizeof(p25fe_result_t), hipMemcpyDeviceToDevice, rx));
+        HCHK(hipMemcpyAsync(summ, res1, sizeof(p25fe_result_t), hipMemcpyDeviceToDevice, rx));
     }
     const bool exact = gather == P25FE_GATHER_ROOT_EXACT && multi;
     if (exact) {
-        rc = exact_offsets_begin(s, rx);
+        rc = exact_offsets_begin(s, summ, rx);
         if (rc) return rc;
     }
     if (ss.rx2 != ss.rx) {                                           // second stage: its stream takes over behind the summaries
@@ -389,7 +397,7 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
     // ordered stream: it slices straight into it as well (the loopback test ranks send to themselves instead)
     const bool to_root = gather == P25FE_GATHER_ROOT || gather == P25FE_GATHER_ROOT_EXACT;
     uint8_t* dup = (s->rank == 0 && !loopback && (to_root || !multi) && gather != P25FE_GATHER_NONE) ? s->d_stream : nullptr;
-    rc = p25fe_shard_pass2_dev(s->h, s->d_summ, s->d_bb0, s->d_bbn, (size_t)s->world, (size_t)s->rank, s->d_anc, s->d_off, d_dibits, s->cap,
+    rc = p25fe_shard_pass2_dev(s->h, summ, s->d_bb0, s->d_bbn, (size_t)s->world, (size_t)s->rank, s->d_anc, s->d_off, d_dibits, s->cap,
                                dup, d_result, ss.rx2);
     if (rc) return rc;
     s->gather_ran = multi ? gather : (gather == P25FE_GATHER_NONE ? P25FE_GATHER_NONE : P25FE_GATHER_ROOT);
