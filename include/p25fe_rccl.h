@@ -81,8 +81,9 @@ int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, 
  * stream alternates between two buffers, p25fe_shard_stream_dev() names the LAST call's, and the previous call's stays untouched
  * until the call after this one; d_buf must stay unchanged until `stream` and the step's exchanges have passed it (join).
  * P25FE_GATHER_ROOT_EXACT keeps its one host wait per step, which ends the overlap for that mode; the shared-memory test hook runs
- * the plain step.  p25fe_shard_create makes a second communicator for the halo (ncclCommSplit, a collective every rank takes part in);
- * if that fails the step keeps everything behind K1 in step order on the receive stream.
+ * the plain step.  p25fe_shard_create makes two more communicators, for the halo and for the summaries (ncclCommSplit, a collective every
+ * rank takes part in: RCCL serialises the operations of one communicator across streams); if that fails the step keeps everything behind
+ * K1 in step order on the receive stream.
  * STREAM: any.  The first step that sees a caller's stream checks that the side stream does not share its hardware queue
  * (p25fe_streams_share_queue: synchronises both streams once) and replaces it if it does ("Which stream to pass"). */
 int p25fe_shard_step_pipelined(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,

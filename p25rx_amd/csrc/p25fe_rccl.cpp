@@ -61,6 +61,9 @@ struct p25fe_shard {
     bool staged = false;
     ncclComm_t comm = nullptr;
     ncclComm_t comm_halo = nullptr;       // pipelined steps: the halo travels on a communicator of its own (ncclCommSplit), on K1's stream
+    ncclComm_t comm_summ = nullptr;       // ... and so do the summaries: RCCL runs the operations of ONE communicator in issue order, whatever
+                                          // their streams -- step j + 1's all-gather (receive stream) would wait for step j's dibit gather (side
+                                          // stream, megabytes at N = 8) and miss the K1 boundary both were meant to share
     hipEvent_t e_stage = nullptr;         // pipelined steps: summaries gathered (receive stream) -> pass 2 and the dibit gather (side stream)
     bool probed = false;                  // the side stream has been checked against `probed_st` (p25fe_streams_share_queue)
     hipStream_t probed_st = nullptr;
@@ -117,6 +120,7 @@ void p25fe_shard_destroy(p25fe_shard_t* s)
     if (s->h) (void)hipSetDevice(p25fe_device(s->h));
     if (s->cs) { (void)hipStreamSynchronize(s->cs); (void)hipStreamDestroy(s->cs); }
     if (s->comm_halo) (void)ncclCommDestroy(s->comm_halo);
+    if (s->comm_summ) (void)ncclCommDestroy(s->comm_summ);
     if (s->comm) (void)ncclCommDestroy(s->comm);
     if (s->e_stage) (void)hipEventDestroy(s->e_stage);
     if (s->e_fork) (void)hipEventDestroy(s->e_fork);
@@ -205,6 +209,7 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
             // (every rank makes this call: a collective on the parent communicator.  A failure leaves the pipelined step on its
             // one-communicator layout.)
             if (ncclCommSplit(s->comm, 0, rank, &s->comm_halo, nullptr) != ncclSuccess) s->comm_halo = nullptr;
+            if (s->comm_halo && ncclCommSplit(s->comm, 0, rank, &s->comm_summ, nullptr) != ncclSuccess) s->comm_summ = nullptr;
         } else {
             const char* name = getenv("P25FE_SHARD_SHM");
             if (!name || s->halo * 8 > SHM_HALO_MAX) return fail(P25FE_ERR_ARG);
@@ -374,7 +379,7 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
             s->shm.barrier();
         } else {
             if (timed) HCHK(hipEventRecord(ev[2], rx));
-            NCHK(ncclAllGather(res1, summ, sizeof(p25fe_result_t), ncclUint8, s->comm, rx));
+            NCHK(ncclAllGather(res1, summ, sizeof(p25fe_result_t), ncclUint8, (ss.halo_on_st && s->comm_summ) ? s->comm_summ : s->comm, rx));
             if (timed) HCHK(hipEventRecord(ev[3], rx));
         }
     } else {
