@@ -1419,7 +1419,11 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
                 else { const long qu = num / N; i = s + qu; q = (int)(((num - qu * N) * P25FE_CLK_PHASES) / N); }
                 const long p = i - a.abs0 + PLPAD;                 // planar position of the instant's integer sample
                 float v;
-                if (track) {
+                if (i < lo_ || i >= hi_) {
+                    // cannot happen for a clock and a position the library produced; a foreign anchor whose position is so far away
+                    // that j D wrapped 64 bits (p25fe_slice_dev's d_anchor_in) must not become a load outside the planes
+                    v = 0.f;
+                } else if (track) {
                     float b[4];
 #pragma unroll
                     for (int tq = 0; tq < 4; ++tq) {
@@ -1713,6 +1717,9 @@ __global__ __launch_bounds__(WV, 4) void k_ev_slice(EvArgs a)
             const long qu = num / r.N2;
             const long i = r.s + qu;
             const int ph = (int)(((num - qu * r.N2) * P25FE_CLK_PHASES) / r.N2);
+            // an instant lies inside the range by construction; a foreign carry-in anchor whose position is so far away that j D
+            // wrapped (anchors also arrive from outside: p25fe_slice_dev's d_anchor_in) must not turn into a load outside the planes
+            if (i < a.abs0 || i >= a.abs0 + a.n) { out[gi] = 0; continue; }
             const long p = i - a.abs0 + PLPAD;
             float b[4];
 #pragma unroll

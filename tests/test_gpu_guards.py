@@ -193,7 +193,7 @@ def test_shard_and_wideband_outputs_stay_inside_their_buffers(scene):
     gc.check("channelise_dev")
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_foreign_anchors_cannot_drive_the_slicer_out_of_bounds(mode):
     """Anchors also arrive from outside -- a caller's d_anchor_in, a state blob -- and their clock (period_d / period_n) sizes the
     slicer's loops: a period such as 1 / 2^30 would mean 2^43 instants per tile.  A clock the library could not
@@ -223,10 +223,22 @@ def test_foreign_anchors_cannot_drive_the_slicer_out_of_bounds(mode):
         g.check("slice_dev with the clock %d / %d" % (d, n))
         # an implausible clock reads as 10 / 1: the same dibits as the nominal anchor
         assert int(parse_results(res)[0]["n_dibits"]) == nref and torch.equal(g.t[:nref], ref[0, :nref]), (d, n)
+    # an anchor position absurdly far in the past with a plausible tracked clock: j D / N wraps 64 bits -- whatever comes out stays inside
+    # the row and nothing is read outside the planes (no fault)
+    for s_far in (-(1 << 40), -(1 << 52), -(1 << 61)):
+        cap = (n_bb // 10 + 64 + 15) // 16 * 16
+        g = Guarded(cap)
+        res = torch.empty((1, _lib.RESULT_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        a_in = torch.from_numpy(np.frombuffer(np.array([(s_far, 0.24, 0.0, -0.24, 1, 4 * 8641, 4 * 864)], dtype=_lib.ANCHOR_DTYPE).tobytes(),
+                                              dtype=np.uint8).copy()).cuda()
+        fe._chk(fe.L.p25fe_slice_dev(fe.h, C.c_void_p(t.data_ptr()), n_bb, 0, n_bb, 0, C.c_void_p(a_in.data_ptr()),
+                                     C.c_void_p(g.t.data_ptr()), cap, None, None, 0, C.c_void_p(res.data_ptr()), None))
+        torch.cuda.synchronize()
+        g.check("slice_dev with an anchor at %d" % s_far)
     # the state blob: every anchor's clock is checked before anything is taken over
     blob = fe.state_export()
     off = len(blob) - 8 - _lib.ANCHOR_DTYPE.itemsize                  # [... | anchors (C = 1) | totals]
-    for d, n, ok in ((10, 1, True), (0, 0, True), (1, 1 << 30, False), (10, -1, False), (41, 4, mode == 1), (10 * 4 * 864 + 3, 4 * 864, mode == 1),
+    for d, n, ok in ((10, 1, True), (0, 0, True), (1, 1 << 30, False), (10, -1, False), (41, 4, mode >= 1), (10 * 4 * 864 + 3, 4 * 864, mode >= 1),
                      (10 * 4 * 864 + 90, 4 * 864, False)):
         bad = blob.copy()
         a = np.zeros(1, dtype=_lib.ANCHOR_DTYPE)
