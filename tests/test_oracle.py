@@ -459,6 +459,24 @@ def test_reslice_receiver_against_an_independent_batch_model(spec, seed):
     assert len(one[1]) == len(got[1]) and np.array_equal(one[1], got[1])          # the same sync words either way
 
 
+def test_reslice_table_rule():
+    """p25o_reslice_table on a hand-made list of detections: usable clocks are kept; a detection without one takes the NEXT one's when that is
+    usable, else the nominal clock; 10 / 1 is written 40 / 4; the anchor offset is f N / 4."""
+    import ctypes as C
+    rec = np.zeros(6, dtype=O.CLK_DTYPE)
+    #            d      n    usable  f        what
+    rec[0] = (10,     1,    0,      2)      # first of a lock run, successor usable      -> takes rec[1]'s clock, offset 2 * 864
+    rec[1] = (34565,  3456, 1,     -1)      # usable                                      -> kept, offset -1 * 864
+    rec[2] = (10,     1,    1,      1)      # usable and exactly nominal                  -> 40 / 4, offset 1
+    rec[3] = (10,     1,    0,     -2)      # after a lock drop, successor NOT usable     -> 40 / 4, offset -2
+    rec[4] = (10,     1,    0,      0)      # again none, successor usable                -> rec[5]'s clock, offset 0
+    rec[5] = (34555,  3456, 1,      2)      # usable, last of the range                   -> kept
+    out = np.zeros(6, dtype=O.CLK_DTYPE)
+    O.lib().p25o_reslice_table(O._ptr(rec), 6, 10, O._ptr(out))
+    got = [(int(r["d"]), int(r["n"]), int(r["f"])) for r in out]
+    assert got == [(34565, 3456, 2 * 864), (34565, 3456, -864), (40, 4, 1), (40, 4, -2), (34555, 3456, 0), (34555, 3456, 2 * 864)]
+
+
 def test_reslice_removes_the_first_frame_errors(spec):
     """What 3.8c is for: P25's 0.18 s between sync words, sample clock 150 and 250 ppm off -- the streaming rule (mode 1) loses a few
     symbols at the end of the first frame of the lock run, which has no period yet; the resident rule (mode 2) loses none."""
