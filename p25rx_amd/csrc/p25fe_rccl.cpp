@@ -65,8 +65,7 @@ struct p25fe_shard {
                                           // their streams -- step j + 1's all-gather (receive stream) would wait for step j's dibit gather (side
                                           // stream, megabytes at N = 8) and miss the K1 boundary both were meant to share
     hipEvent_t e_stage = nullptr;         // pipelined steps: summaries gathered (receive stream) -> pass 2 and the dibit gather (side stream)
-    bool probed = false;                  // the side stream has been checked against `probed_st` (p25fe_streams_share_queue)
-    hipStream_t probed_st = nullptr;
+    std::vector<hipStream_t> probed;      // caller's streams the CURRENT side stream has been checked against (p25fe_streams_share_queue)
     int pipe_layout = 2;                  // measurement knob P25FE_SHARD_PIPE_LAYOUT: 1 = the step's own order on the receive stream
     Shm shm;
     hipStream_t cs = nullptr;             // the halo exchange and the shard's head segment run beside K1's main launch
@@ -269,12 +268,13 @@ static int exact_offsets_wait(p25fe_shard_t* s)
 // Checked once per caller's stream (the probe synchronises both streams, < 1 ms): a side stream that shares is replaced by a fresh one.
 static int pick_side_stream(p25fe_shard_t* s, hipStream_t st)
 {
-    if (s->probed && s->probed_st == st) return P25FE_OK;
-    s->probed = true; s->probed_st = st;
-    const char* e = getenv("P25FE_SHARD_QUEUE_PROBE");
-    if (e && atoi(e) == 0) return P25FE_OK;
+    for (hipStream_t p : s->probed) if (p == st) return P25FE_OK;    // (a host that alternates between a few streams is probed once per stream)
     std::vector<hipStream_t> rejected;
     try {
+        if (s->probed.size() >= 8) s->probed.clear();
+        s->probed.push_back(st);
+        const char* e = getenv("P25FE_SHARD_QUEUE_PROBE");
+        if (e && atoi(e) == 0) return P25FE_OK;
         for (int attempt = 0; attempt < 8; ++attempt) {
             int shared = 0;
             if (p25fe_streams_share_queue(s->h, st, s->cs, &shared) != P25FE_OK || !shared) break;
@@ -282,6 +282,7 @@ static int pick_side_stream(p25fe_shard_t* s, hipStream_t st)
             if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
             rejected.push_back(s->cs);                              // kept alive until the search ends: its queue slot stays taken
             s->cs = fresh;
+            s->probed.assign(1, st);                                // the new side stream has been checked against this stream only
         }
     } catch (...) {}
     for (hipStream_t r : rejected) { (void)hipStreamSynchronize(r); (void)hipStreamDestroy(r); }
