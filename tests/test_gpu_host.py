@@ -448,8 +448,8 @@ def _rccl_cabi_pipelined_worker(q):
     oks = []
     caps = [c4fm.synth(2.0, seed=78, snr_db=22.0, frame_dibits=400)[0], c4fm.synth(2.0, seed=79, snr_db=22.0, frame_dibits=900)[0]]
     n = min(len(c) for c in caps) // 8 * 8
-    for comm_id in (rccl.unique_id(), None):                        # a one-rank RCCL communicator; no communicator at all
-        fe = FrontEnd()
+    for comm_id, clock in ((rccl.unique_id(), 0), (None, 0), (rccl.unique_id(), 1)):   # a one-rank RCCL communicator; no communicator at all;
+        fe = FrontEnd(symbol_clock=clock)                           # ... and the tracking clock (pass 2 = resolve kernel + general scan + slicer)
         ss = rccl.ShardStep(fe, 0, 1, n, comm_id)
         halo = fe.shard_halo()
         bufs, refs = [], []
@@ -457,7 +457,7 @@ def _rccl_cabi_pipelined_worker(q):
             b = torch.zeros((halo + n, 2), dtype=torch.float32, device="cuda")
             b[halo:] = torch.from_numpy(iq[:n].view(np.float32).reshape(-1, 2)).cuda()
             bufs.append(b)
-            ref, rres = FrontEnd().run_dev(b[halo:])
+            ref, rres = FrontEnd(symbol_clock=clock).run_dev(b[halo:])
             refs.append(ref[0, :int(parse_results(rres)[0]["n_dibits"])].clone())
         order = [0, 1, 1, 0, 1, 0, 0, 1, 0]
         outs = [(torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device="cuda"),
@@ -500,7 +500,7 @@ def test_c_abi_shard_step_pipelined():
     res = q.get(timeout=240)
     p.join(60)
     assert p.exitcode == 0
-    assert res == [True] * 10
+    assert res == [True] * 15
 
 
 @pytest.mark.timeout(300)
