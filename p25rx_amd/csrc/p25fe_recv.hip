@@ -1586,8 +1586,15 @@ __global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a)
             r.D2 = r.Db; r.N2 = r.Nb;
             r.flags = EV_VALID | (us ? EV_USABLE : 0u) | ((k == n_ev - 1 && (int)(eg & 0x7fffu) == tn) ? EV_OPEN : 0u) | (((eg >> 16) & 7u) << 8);
             r.hi = r.mid = r.lo = 0.f; r.pad_ = 0;
-            if (k < EVTHR_N) { r.hi = eth[3 * k]; r.mid = eth[3 * k + 1]; r.lo = eth[3 * k + 2]; }
-            rec[1 + so.event_off + k] = r;
+            EvRec* dst = rec + 1 + so.event_off + k;
+            if (k < EVTHR_N) {
+                r.hi = eth[3 * k]; r.mid = eth[3 * k + 1]; r.lo = eth[3 * k + 2];
+                *dst = r;
+            } else {
+                // (the thresholds of these are written by the loop below: no second store to the same words from this wave)
+                dst->s = r.s; dst->g_lo = r.g_lo; dst->g_hi = r.g_hi; dst->Db = r.Db; dst->Nb = r.Nb; dst->D2 = r.D2; dst->N2 = r.N2;
+                dst->flags = r.flags; dst->pad_ = 0;
+            }
         }
     }
     // thresholds beyond the ones K2 handed over: recomputed from the sync word, one detection at a time (every lane, same window)
