@@ -1723,7 +1723,8 @@ __global__ __launch_bounds__(WV, 4) void k_ev_slice(EvArgs a)
             const long num = j * (long)r.D2 + (long)(frac3(r.flags >> 8) * (r.N2 / 4));    // (> 0: j >= 1 and |offset| <= N / 2 < D)
             const long qu = num / r.N2;
             const long i = r.s + qu;
-            const int ph = (int)(((num - qu * r.N2) * P25FE_CLK_PHASES) / r.N2);
+            // (the remainder is < N2 <= 2^26 -- clock_plausible -- so the phase is a 32-bit division)
+            const int ph = (int)((((unsigned)(num - qu * r.N2) * (unsigned)P25FE_CLK_PHASES) / (unsigned)r.N2) & (unsigned)(P25FE_CLK_PHASES - 1));   // (the mask: a no-op for any clock the library makes)
             // an instant lies inside the range by construction; a foreign carry-in anchor whose position is so far away that j D
             // wrapped (anchors also arrive from outside: p25fe_slice_dev's d_anchor_in) must not turn into a load outside the planes
             if (i < a.abs0 || i >= a.abs0 + a.n) { out[gi] = 0; continue; }
