@@ -907,7 +907,12 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         c.gsum = h->gsum.as<TileSumG>(); c.recs = h->recs.as<TileRec>(); c.outs = h->gouts.as<ScanOutG>();
         c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
         c.n_baseband = n_bb; c.track = h->track;
-        launch_ev(k_scan_g, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
+        // (measurement knob P25FE_SCAN_G_WAVES=1: the one-wave form, which fits beside a running K1 instead of waiting for it to drain --
+        // and then walks 3 750 tiles alone: 0.414 / 0.440 ms per pipelined step against 0.284 / 0.338, profiles/r05_tracking_pipeline.txt)
+        static const int scan_waves = [] { const char* e = getenv("P25FE_SCAN_G_WAVES"); return e ? atoi(e) : 0; }();
+        const bool one_wave = scan_waves == 1;
+        if (one_wave) launch_ev(k_scan_g_t<WV, 256>, dim3((unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
+        else launch_ev(k_scan_g_t<NT3, KG_CHUNK>, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
         HIPCHK(h, hipGetLastError());
         prof_mark(h, 3, st);
         if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }

@@ -648,6 +648,7 @@ __device__ __forceinline__ int block_incl_max(int v, int* sh, int tid, int& tota
     total = tot;
     return inc > carry ? inc : carry;
 }
+template <int NT = NT3>
 __device__ __forceinline__ unsigned long long block_incl_sum(unsigned long long v, unsigned long long* sh, int tid,
                                                                   unsigned long long& total)
 {
@@ -657,7 +658,7 @@ __device__ __forceinline__ unsigned long long block_incl_sum(unsigned long long 
     __syncthreads();
     unsigned long long carry = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < NT3 / 64; ++k) {
+    for (int k = 0; k < NT / 64; ++k) {
         const unsigned long long t = sh[k];
         if (k < wv) carry += t;
         tot += t;
@@ -1141,17 +1142,21 @@ __device__ __forceinline__ Top2 top2_shfl_up(Top2 v, int d)
 struct CState { int valid; long s; int D, N; int src; int f; };
 
 #ifndef P25FE_JIT
-__global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
+// NT threads, KC tiles staged per chunk.  <512, 1024> (48 KB of LDS) is the product's; <64, 256> (13 KB, ONE wave) is a measured
+// alternative for the place behind a pipelined call: there the 512-thread workgroup waits until the K1 beside it drains (170 us of
+// the receive stream's time per call), a one-wave workgroup gets the slot of the next K1 workgroup that retires -- and is then so
+// much slower at walking the tiles alone that the step loses 45 % (profiles/r05_tracking_pipeline.txt, P25FE_SCAN_G_WAVES).
+template <int NT, int KC> __global__ __launch_bounds__(NT) void k_scan_g_t(ScanArgsG a)
 {
     // a chunk of summaries (and of the tiles' last detection positions) is staged in LDS: the per-tile work below is a chain
     // of dependent reads (summary -> latest event tile's summary -> the one before) that cost a memory round trip each
     // when they went to global memory (k_scan_g 45 us for config 2; 3 750 tiles)
-    __shared__ TileSumG GS[KG_CHUNK];
-    __shared__ long LS[KG_CHUNK];
-    __shared__ int LF[KG_CHUNK];
-    __shared__ unsigned CNT[KG_CHUNK], PRE[KG_CHUNK];
-    __shared__ Top2 sh2[NT3 / 64];
-    __shared__ unsigned long long shu[NT3 / 64];
+    __shared__ TileSumG GS[KC];
+    __shared__ long LS[KC];
+    __shared__ int LF[KC];
+    __shared__ unsigned CNT[KC], PRE[KC];
+    __shared__ Top2 sh2[NT / 64];
+    __shared__ unsigned long long shu[NT / 64];
     __shared__ Top2 c_top;                                         // latest two event tiles before the chunk (global indices)
     __shared__ unsigned long long c_cnt, c_ev, c_base_first;
     __shared__ long c_first_event, c_carry_end, c_first_seg_end, c_first_seg_next;
@@ -1198,13 +1203,13 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         return rem < TS ? (int)rem : TS;
     };
 
-    for (int c0 = 0; c0 < a.n_tiles; c0 += KG_CHUNK) {
-        const int cn = (a.n_tiles - c0 < KG_CHUNK) ? a.n_tiles - c0 : KG_CHUNK;
+    for (int c0 = 0; c0 < a.n_tiles; c0 += KC) {
+        const int cn = (a.n_tiles - c0 < KC) ? a.n_tiles - c0 : KC;
         __syncthreads();                                            // the previous chunk's readers are done with GS / LS
-        for (int k = tid; k < cn; k += NT3) { GS[k] = gsum[c0 + k]; LS[k] = recs[c0 + k].last_s; LF[k] = recs[c0 + k].last_f; }
+        for (int k = tid; k < cn; k += NT) { GS[k] = gsum[c0 + k]; LS[k] = recs[c0 + k].last_s; LF[k] = recs[c0 + k].last_f; }
         cc0 = c0; ccn = cn;
         __syncthreads();
-        const int per = (cn + NT3 - 1) / NT3;
+        const int per = (cn + NT - 1) / NT;
         const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
         // ---- latest two event tiles of my run -> exclusive scan
         Top2 mine; mine.a = mine.b = -1;
@@ -1224,7 +1229,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
         if (lane == 0) { exc.a = exc.b = -1; }
         exc = top2_merge(carry, exc);                              // latest two event tiles before my run
         Top2 tot = c_top;
-        for (int k = 0; k < NT3 / 64; ++k) tot = top2_merge(tot, sh2[k]);
+        for (int k = 0; k < NT / 64; ++k) tot = top2_merge(tot, sh2[k]);
         __syncthreads();
 
         // ---- dibits / detections of every tile of my run
@@ -1250,7 +1255,7 @@ __global__ __launch_bounds__(NT3) void k_scan_g(ScanArgsG a)
             }
         }
         unsigned long long tot_pk;
-        const unsigned long long ipk = block_incl_sum(my_cnt | (my_ev << 40), shu, tid, tot_pk);
+        const unsigned long long ipk = block_incl_sum<NT>(my_cnt | (my_ev << 40), shu, tid, tot_pk);
         // ---- carry-ins
         {
             unsigned long long dc = c_cnt + (ipk & ((1ull << 40) - 1)) - my_cnt, ec = c_ev + (ipk >> 40) - my_ev;
