@@ -46,7 +46,7 @@ BYTES_PER_SAMPLE_K1_U8 = 2.0 + 0.8
 # 41 x 2 / 5, discriminator (4 + division + 8-term Horner + selects ~ 30) / 5, boxcar 10 / 5, u8 -> f32 2 x 2
 FLOPS_PER_SAMPLE = (2 * 2 * 31 + 2 * 2 * 41 + 30 + 10) / 5.0
 FLOPS_PER_SAMPLE_U8 = FLOPS_PER_SAMPLE + 4.0
-PMC_FILES = [os.path.join("profiles", "r05_k1_pmc.json"), os.path.join("profiles", "r04_k1_pmc.json")]
+PMC_FILES = [os.path.join("profiles", "r06_k1_pmc.json"), os.path.join("profiles", "r05_k1_pmc.json"), os.path.join("profiles", "r04_k1_pmc.json")]
 PREWARM_MS = 150.0               # untimed steps before the W warm-up steps: the chip reaches its steady clock / power state
 GATHER_WORDS = {"root_exact": "point-to-point to rank 0, exactly the valid bytes, received at their offsets", "root": "point-to-point "
                 "gather of whole rows to rank 0 + compaction", "all": "all_gather of rows", "none": "nothing"}
@@ -386,14 +386,28 @@ def run_extras(torch, dev, args, iq2, truth2):
     torch.cuda.synchronize()
     err_fixed, k_fixed = sym_errors(d0, r0)
     del fe0, d0, r0
-    fe1 = FrontEnd(device=dev.index, symbol_clock=1)             # the causal rule (what the streaming calls run), for the error count only
-    d1, r1 = fe1.run_dev(iq_ppm)
-    torch.cuda.synchronize()
-    bad_causal, _ = sym_errors(d1, r1, where=True)
+    # symbol_clock = 1, the causal rule -- what EVERY entry point can run (streaming chunks, host windows, time shards): timed on the same
+    # capture, its own line, so that the mode-2 line below has its comparable beside it
+    fe1 = FrontEnd(device=dev.index, symbol_clock=1)
+    d1 = r1 = None
+    def step_causal():
+        nonlocal d1, r1
+        d1, r1 = run(fe1, iq_ppm, d1, r1)
+    k = steps_for(0.30)
+    dt1 = timed(torch, step_causal, k, 5, finish=fe1.join_dev)
+    k1c, _, kmsc = k1_frac(fe1, torch, lambda: fe1.run_dev(iq_ppm, dibits=d1, result=r1), n, BYTES_PER_SAMPLE)
+    bad_causal, k_causal = sym_errors(d1, r1, where=True)
     err_causal = int(len(bad_causal))
+    entry("configs[1] with a 150 ppm sample clock and symbol_clock = 1 (tracking, CAUSAL: period from the last two sync words, 4-tap "
+          "interpolated instants; SPEC 3.8b) -- the rule every entry point runs, streaming / windows / time shards included",
+          n, dt1 / k * 1e3, "k_frontend<cf32>", k1c, BYTES_PER_SAMPLE,
+          k_causal > 2800000 and err_causal <= k_causal // 10000 and err_causal < err_fixed, steps=k,
+          receiver_ms={"k_detect<general> (+ K3 in its tail)": round(kmsc[1], 4), "k_scan_g_groups": round(kmsc[2], 4), "k_slice_g": round(kmsc[3], 4)},
+          symbol_errors={"tracking_causal (symbol_clock 1, timed)": err_causal, "fixed_stride_same_capture": err_fixed, "of": k_causal},
+          gate="symbol errors vs the modulator over the whole capture: <= 0.01 % and fewer than the fixed stride's")
     del fe1, d1, r1
     # timed: symbol_clock = 2 -- the tracking clock, and the resident call slices the first frame of a lock run with the period the NEXT
-    # sync word confirms and starts every detection's instants from its refined position s + f / 4 (SPEC 3.8c: the slicer by detection, k_ev_collect / k_ev_count / k_ev_scan / k_ev_slice behind k_scan_g)
+    # sync word confirms and starts every detection's instants from its refined position s + f / 4 (SPEC 3.8c: the slicer by detection, k_ev_collect / k_ev_count / k_ev_scan / k_ev_slice behind the general receiver's scan)
     fe = FrontEnd(device=dev.index, symbol_clock=2)
     dib = res = None
     def step_trk():
@@ -409,7 +423,10 @@ def run_extras(torch, dev, args, iq2, truth2):
     entry("configs[1] with a 150 ppm sample clock and symbol_clock = tracking + first-frame re-slice (period from sync word to sync word, "
           "4-tap interpolated instants; SPEC 3.8b / 3.8c)", n_ppm, dt / k * 1e3, "k_frontend<cf32>", k1, BYTES_PER_SAMPLE,
           k_trk > 2800000 and err_trk == 0 and first_causal >= 1 and err_causal <= k_trk // 10000 and err_causal < err_fixed, steps=k,
-          receiver_ms={"k_detect<general>": round(kms[1], 4), "k_scan_g": round(kms[2], 4), "k_ev_collect + k_ev_count + k_ev_scan + k_ev_slice": round(kms[3], 4)},
+          receiver_ms={"k_detect<general> (+ K3 in its tail)": round(kms[1], 4), "k_scan_g_groups": round(kms[2], 4), "k_ev_collect + k_ev_count + k_ev_scan + k_ev_slice": round(kms[3], 4)},
+          entry_points_with_3_8c="p25fe_run_dev, p25fe_run_dev_pipelined (timed here), p25fe_slice_dev -- the calls that hold the whole range; p25fe_slice, "
+                                 "p25fe_run_u8 / _cf32, p25fe_run_host_windows and the time-shard passes cannot run it and return P25FE_ERR_ARG on such a handle "
+                                 "unless it was created with P25FE_CLOCK_CAUSAL_OK (then: the symbol_clock = 1 line above)",
           last_period="%d / %d" % (int(a_out["period_d"]), int(a_out["period_n"])),
           symbol_errors={"tracking_reslice (symbol_clock 2, timed)": err_trk, "tracking_causal (symbol_clock 1)": err_causal,
                          "in_the_first_frame": {"reslice": first_trk, "causal": first_causal},
@@ -564,6 +581,102 @@ def bench_channels(args, torch, dist, world, rank, local, dev, staged):
         sys.exit(3)
 
 
+def shard_evidence(ss, dist, world):
+    """What the LIBRARY says about the job, from every rank (p25fe_shard_info gathered over gloo): did RCCL see N ranks, on N different
+    GPUs, which communicator layout does the pipelined step run.  None of it comes from the launcher's environment."""
+    mine = ss.info()
+    infos = [None] * world
+    dist.all_gather_object(infos, mine)
+    buses = [i["pci_bus_id"] for i in infos]
+    return {"rccl_ranks": [i["rccl_ranks"] for i in infos], "rccl_rank_of_rank": [i["rccl_rank"] for i in infos],
+            "device_of_rank": [i["device"] for i in infos], "pci_bus_id_of_rank": buses, "distinct_gpus": len(set(buses)),
+            "communicators": sorted(set(i["comms"] for i in infos)), "pipe_layout": sorted(set(i["pipe_layout"] for i in infos)),
+            "layout_words": {3: "three communicators: halo / summaries / dibit rows each their own (two stages at K1 boundaries)",
+                             1: "one communicator: everything behind K1 in step order on the receive stream",
+                             0: "no communicator (TEST HOOK: shared memory)"}.get(mine["comms"], "?"),
+            "staged_test_hook": bool(mine["staged"]), "broken": any(i["broken"] for i in infos),
+            "source": "p25fe_shard_info on every rank: ncclCommCount / ncclCommUserRank of the step's communicator, hipDeviceGetPCIBusId "
+                      "of the handle's device, the layout agreed by all-reduce in p25fe_shard_create"}
+
+
+def strong_row(torch, dist, args, world, rank, local, dev, staged, steps, total_s):
+    """BASELINE.json configs[4] AS WORDED, as one more timed region of an N > 1 run: ONE 3 600 s capture cut into N contiguous time
+    shards (--scaling strong), the same pipelined step, its own gates.  Every rank runs it (the steps hold collectives); rank 0 gets the row."""
+    from p25rx_amd import c4fm, rccl
+    from p25rx_amd.frontend import FrontEnd, parse_results
+    from p25rx_amd._lib import RESULT_DTYPE
+    n = int(round(total_s * 240000)) // world
+    n -= n % 8
+    fe = FrontEnd(device=local)
+    halo = fe.shard_halo()
+    buf = torch.zeros((halo + n, 2), dtype=torch.float32, device=dev)
+    _, truth = c4fm.synth_torch(n, seed=2000 + rank, device=dev, snr_db=30.0, out=buf[halo:])
+    result = torch.empty((1, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    boot = [None]
+    if rank == 0:
+        boot[0] = ("/p25fe_bench_s_%d" % os.getpid()) if staged else rccl.unique_id()
+    dist.broadcast_object_list(boot, src=0)
+    if staged:
+        os.environ["P25FE_SHARD_SHM"] = boot[0]
+    ss = rccl.ShardStep(fe, rank, world, n, None if staged else boot[0])
+    ss.prepare(dev)
+    dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device=dev)
+    pipe = not args.no_pipeline and not staged
+
+    def step():
+        ss.step(buf, dibits, result, gather=args.gather, pipelined=pipe)
+    dt = timed(torch, step, steps, 8 if not staged else 1, dist, finish=fe.join_dev)
+    tt = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    r = parse_results(result)[0]
+    nd = int(r["n_dibits"])
+    got = dibits[0, :nd].cpu().numpy()
+    ok = False
+    if int(r["first_event"]) >= 0:
+        first = nd - int(r["n_dibits_after_first"])
+        for j in (24, 24 + 864, 24 + 2 * 864):
+            k = min(nd - first, len(truth) - j)
+            if k > 0 and np.array_equal(got[first:first + k], truth[j:j + k]):
+                ok = True
+                break
+    gather_ok = None
+    if args.gather != "none":
+        off = ss.offsets()
+        d_stream = ss.stream(torch, dev, int(off[world])) if (rank == 0 or args.gather == "all") else None
+        w = torch.arange(1, nd + 1, dtype=torch.int64, device=dev) % 65521
+        mine = dibits[0, :nd].to(torch.int64)
+        sig = torch.stack([torch.tensor(nd, dtype=torch.int64, device=dev), mine.sum(), (mine * w).sum()]).cpu()
+        sigs = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        gather_ok = True
+        if rank == 0 or args.gather == "all":
+            for r_ in range(world):
+                seg = d_stream[int(off[r_]):int(off[r_ + 1])].to(torch.int64)
+                wr = torch.arange(1, seg.numel() + 1, dtype=torch.int64, device=dev) % 65521
+                gather_ok = gather_ok and [seg.numel(), int(seg.sum().item()), int((seg * wr).sum().item())] == [int(x) for x in sigs[r_].tolist()]
+    okt = torch.tensor([1 if ok else 0, 1 if gather_ok in (None, True) else 0])
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    ok, gather_ok = bool(okt[0].item()), (None if args.gather == "none" else bool(okt[1].item()))
+    ev = shard_evidence(ss, dist, world)
+    comm = None if staged else {k_: (round(v_, 4) if isinstance(v_, float) else v_) for k_, v_ in ss.comm_ms().items()}
+    row = None
+    if rank == 0:
+        row = {"config": "configs[4] as worded: ONE %.0f s capture (%d samples, %.3f GB) cut into %d contiguous time shards of %.1f s "
+                         "(--scaling strong), pipelined shard step, gather %s" % (total_s, n * world, n * world * 8 / 1e9, world, n / 240000.0, ss.gather_ran()),
+               "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+               "value": round(float(n) * world * steps / dt / 1e6, 1), "unit": "Msamples/s",
+               "parity_gate": "every shard's dibits from its first own sync word on == the modulator's symbols: %s" % ok,
+               "gather_gate": (None if gather_ok is None else "gathered stream holds every shard at its resolved offset: %s" % gather_ok),
+               "rccl": ev, "comm_ms_per_step": comm,
+               "whole_step": {"algorithmic_bytes_per_sample": 8.02, "achieved_GBps": round(8.02 * n * world * steps / dt / 1e9, 1),
+                              "frac_of_peak_x_gpus": round(8.02 * n * steps / dt / 1e9 / HBM_PEAK_GBPS, 4)}}
+    ss.close()
+    del buf, dibits
+    torch.cuda.empty_cache()
+    return row, (ok and gather_ok is not False)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): start the N ranks as CHILD processes -- one per GPU,
     through torch.distributed.run exactly as the driver does -- before this process has touched HIP (it never does), relay
@@ -611,7 +724,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N = 1: strictly serial steps (K1 -> K2 -> K3 -> K4 on one stream) instead of p25fe_run_dev_pipelined")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU configurations")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations (N = 1: the other single-GPU configs; N > 1 weak: the strong row)")
+    ap.add_argument("--strong-seconds", type=float, default=3600.0,
+                    help="N > 1, --scaling weak: total length of the capture of the extra configs[4]-as-worded (strong) row")
     ap.add_argument("--cpu-seconds", type=float, default=600.0, help="length of the capture prefix timed on the CPU")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -688,6 +803,7 @@ def main():
         if staged:
             os.environ["P25FE_SHARD_SHM"] = boot[0]
         ss = rccl.ShardStep(fe, rank, world, n, None if staged else boot[0])
+        ss.prepare(dev)                                            # once per stream: the side stream off this stream's hardware queue
         dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device=dev)
 
         # steps one behind the other, like the N = 1 line: only K1's main launch on this stream, everything behind it (detection,
@@ -827,13 +943,22 @@ def main():
         ok, gather_ok = bool(okt[0].item()), (None if args.gather == "none" else bool(okt[1].item()))
 
     gather_ran = ss.gather_ran() if world > 1 else "none"           # the mode the library EXECUTED (p25fe_shard_gather_ran)
+    rccl_evidence = shard_evidence(ss, dist, world) if world > 1 else None
+    strong_extra, strong_ok = None, True
+    if world > 1 and not strong and not args.no_extra:
+        # configs[4] AS WORDED rides along as an extra row of the default (weak) line: one 3 600 s capture cut N ways
+        try:
+            strong_extra, strong_ok = strong_row(torch, dist, args, world, rank, local, dev, staged, max(3, min(args.steps, 100)),
+                                                 args.strong_seconds)
+        except Exception as e:
+            strong_extra, strong_ok = {"config": "configs[4] as worded (strong)", "error": "%s: %s" % (type(e).__name__, e)}, False
     if rank == 0:
         total_samples = float(n) * world * args.steps
         value = total_samples / dt / 1e6
         k1_ms = kms[0] / max(ncalls, 1)
         achieved = BYTES_PER_SAMPLE * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         achieved_k1_alone = BYTES_PER_SAMPLE_K1 * n / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_warning = None, None, None
         if world == 1 and abs(total_s - 600.0) < 1e-9:
             for pmc_file in PMC_FILES:
                 try:
@@ -841,6 +966,16 @@ def main():
                         traffic = json.load(f).get("hbm_bytes_per_launch")
                     traffic_source = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, collected in "
                                       "a SEPARATE run (tools/prof.sh), not by this process" % pmc_file)
+                    # the counters were read from SOME build of K1: say so when it was not the source this run's library was built from
+                    import hashlib
+                    with open(os.path.join(ROOT, "p25rx_amd", "csrc", "p25fe_kernels.hip"), "rb") as kf:
+                        sha = hashlib.sha256(kf.read()).hexdigest()[:16]
+                    with open(os.path.join(ROOT, pmc_file)) as f:
+                        was = json.load(f).get("k1_source_sha16")
+                    if was != sha:
+                        traffic_warning = ("STALE: %s was collected on %s, this run's p25fe_kernels.hip is %s -- `traffic` describes another build "
+                                           "of K1; a traffic regression since then is NOT visible in this line (re-run tools/prof.sh)"
+                                           % (pmc_file, ("K1 source " + was) if was else "an unrecorded K1 source", sha))
                     break
                 except Exception:
                     traffic = None
@@ -872,6 +1007,7 @@ def main():
                        "parity_gate": "dibits == modulator symbols: %s" % ok},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_warning": traffic_warning,
                          "traffic_ratio": (round(traffic / (BYTES_PER_SAMPLE * n), 4) if traffic else None),
                          "kernel": "k_frontend<cf32>", "kernel_ms": round(k1_ms, 4), "kernel_ms_samples": int(ncalls),
                          "algorithmic_bytes_per_sample": BYTES_PER_SAMPLE,
@@ -891,10 +1027,10 @@ def main():
                                         "achieved": round(8.02 * n * world * args.steps / dt / 1e9, 1),
                                         "frac_of_peak_x_gpus": round(8.02 * n * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)},
                          "other_kernels_ms": {"k_detect": round(kms_all[1] / n_extra_steps, 4),
-                                              "k_scan": round(kms_all[2] / n_extra_steps, 4),
+                                              "k_scan_tiles": round(kms_all[2] / n_extra_steps, 4),
                                               "k_slice": round(kms_all[3] / n_extra_steps, 4),
                                               "note": "from extra SERIAL steps after the timed region, HIP events around every kernel"
-                                                      + ("; N > 1: k_scan = pass 1 + pass 2 scans, RCCL time is in neither" if world > 1 else "")}},
+                                                      + ("; N > 1: RCCL time is in none of them" if world > 1 else "")}},
         }
         if world == 1:
             out["config"]["prewarm"] = "%d untimed steps (>= %.0f ms) before the W warm-up steps" % (n_prewarm, PREWARM_MS)
@@ -916,6 +1052,10 @@ def main():
                                                      "exchange on its stream (the halo exchange runs beside K1's main launch), on every "
                                                      "16th step of the timed region only (p25fe_shard_comm_timing: four of these "
                                                      "events are packets between the kernels of the step's critical path)")
+        if rccl_evidence is not None:
+            out["config"]["rccl"] = rccl_evidence
+        if strong_extra is not None:
+            out["extra"] = [strong_extra]
         if gather_ok is not None:
             out["config"]["gather_gate"] = ("gathered stream holds every shard at its resolved offset (length, sum and "
                                             "position-weighted sum of every rank's dibits): %s" % gather_ok)
@@ -943,7 +1083,7 @@ def main():
             except OSError:
                 pass
         dist.destroy_process_group()
-    if not ok or gather_ok is False:
+    if not ok or gather_ok is False or not strong_ok:
         sys.exit(3)                        # a wrong result is a failed bench at every N (the gates are in the JSON line as well)
 
 

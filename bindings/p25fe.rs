@@ -1,4 +1,4 @@
-//! bindings/p25fe.rs -- Rust side of the C ABI of `include/p25fe.h` / `include/p25fe_rccl.h` (ABI version 4).
+//! bindings/p25fe.rs -- Rust side of the C ABI of `include/p25fe.h` / `include/p25fe_rccl.h` (ABI version 6).
 //!
 //! NOT COMPILED IN THIS REPOSITORY: the build image has no Rust toolchain.  This is the file a
 //! maintainer of kchmck/p25rx drops in as `src/p25fe.rs` (`mod p25fe;` in `src/main.rs:55-64`); the layouts below are the
@@ -15,15 +15,20 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const ABI_VERSION: i32 = 5;
+pub const ABI_VERSION: i32 = 6;
 pub const MAX_TAPS: usize = 64;
 pub const FMT_CF32: c_int = 0;
 pub const FMT_U8: c_int = 1;
 pub const CLOCK_FIXED: i32 = 0;
 pub const CLOCK_TRACKING: i32 = 1;
 /// CLOCK_TRACKING, and the calls that hold a whole range (run_dev, run_dev_pipelined, slice_dev) re-slice the first frame of a lock
-/// run with the period the next sync word confirms (docs/SPEC.md 3.8c); streaming calls and shard passes keep CLOCK_TRACKING's rule
+/// run with the period the next sync word confirms (docs/SPEC.md 3.8c).  The calls that see the stream in pieces (slice, run_u8 / run_cf32,
+/// run_host_windows, the time-shard passes) cannot: on such a handle they return ERR_ARG (ABI 6) unless CLOCK_CAUSAL_OK was or-ed into
+/// `symbol_clock`, which lets them run CLOCK_TRACKING's causal rule instead
 pub const CLOCK_TRACKING_RESLICE: i32 = 2;
+pub const CLOCK_CAUSAL_OK: i32 = 0x100;
+/// a device-side wait gave up (p25fe_shard_head_check: the head segment of a time shard never arrived)
+pub const ERR_TIMEOUT: c_int = -8;
 pub const SPECIALIZE_AUTO: i32 = 0;
 pub const SPECIALIZE_OFF: i32 = -1;
 pub const SPECIALIZE_REQUIRE: i32 = 1;
@@ -193,6 +198,8 @@ extern "C" {
                                   abs0: u64, stream: *mut c_void) -> c_int;
     pub fn p25fe_shard_pipe_begin(h: *mut Handle, stream: *mut c_void, rx_stream: *mut *mut c_void) -> c_int;
     pub fn p25fe_shard_pipe_end(h: *mut Handle, last_stream: *mut c_void) -> c_int;
+    pub fn p25fe_rx_stream(h: *mut Handle, rx_stream: *mut *mut c_void) -> c_int;
+    pub fn p25fe_shard_head_check(h: *mut Handle) -> c_int;
     pub fn p25fe_shard_pass1_k1(h: *mut Handle, d_iq: *const c_void, fmt: c_int, ch_stride: usize, n_hist: usize, n: usize,
                                 abs0: u64, stream: *mut c_void) -> c_int;
     pub fn p25fe_streams_share_queue(h: *mut Handle, stream_a: *mut c_void, stream_b: *mut c_void, shared: *mut c_int) -> c_int;
@@ -242,6 +249,28 @@ extern "C" {
     pub fn p25fe_shard_comm_ms(s: *mut Shard, ms: *mut f64, n_steps: *mut u64) -> c_int;
     pub fn p25fe_shard_comm_timing(s: *mut Shard, every: c_int) -> c_int;
     pub fn p25fe_shard_gather_ran(s: *const Shard) -> c_int;
+    pub fn p25fe_shard_info(s: *const Shard, out: *mut ShardInfo) -> c_int;
+    pub fn p25fe_shard_prepare(s: *mut Shard, stream: *mut c_void) -> c_int;
+}
+
+/// `p25fe_shard_info_t`: what the shard object itself knows about the job (RCCL's own rank count, this rank's GPU, the agreed layout)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct ShardInfo {
+    pub rank: i32,
+    pub world: i32,
+    pub rccl_ranks: i32,
+    pub rccl_rank: i32,
+    pub device: i32,
+    pub comms: i32,
+    pub pipe_layout: i32,
+    pub gather_ran: i32,
+    pub staged: i32,
+    pub head_wait: i32,
+    pub broken: i32,
+    pub reserved: i32,
+    pub steps: u64,
+    pub pci_bus_id: [c_char; 32],
 }
 
 /// Owning wrapper of one handle.  One per thread, like the tasks of the reference (src/main.rs:270-287).

@@ -53,7 +53,7 @@ extern "C" {
 #endif
 
 #define P25FE_MAX_TAPS 64
-#define P25FE_ABI_VERSION 5        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
+#define P25FE_ABI_VERSION 6        /* 3: symbol_clock in the config, clock period in p25fe_anchor_t, carry_end / first_seg_end /
                                       flags in p25fe_result_t, p25fe_resync_at_dev, symbol_clock argument of p25fe_shard_resolve
                                       4: the run-time arguments of the reference's constructors in the config (FM deviation / rate,
                                       the u8 -> float LUT), `specialize`, p25fe_specialize / p25fe_kernel_variant,
@@ -61,7 +61,11 @@ extern "C" {
                                       5: the LAST constructor numbers: the post-discriminator filter as a table (avg_taps:
                                       MovingAverage::new(10)) and the decimator's phase (decim_phase: Decimator::new(5));
                                       p25fe_n_baseband_h; p25fe_shard_halo() is 2 560; p25fe_shard_pass1_head / _pass2_dev /
-                                      _compact_from_dev; p25fe_probe_variant */
+                                      _compact_from_dev; p25fe_probe_variant
+                                      6: symbol_clock = 2 is refused by the calls that cannot run SPEC 3.8c unless P25FE_CLOCK_CAUSAL_OK
+                                      is or-ed in; P25FE_ERR_TIMEOUT, p25fe_shard_head_check (the detection's wait for a shard's head is
+                                      bounded); p25fe_rx_stream; p25fe_rccl.h: p25fe_shard_info, p25fe_shard_prepare (no step probes or
+                                      synchronises streams any more), the communicator layout agreed by all ranks */
 
 typedef enum p25fe_status {
     P25FE_OK = 0,
@@ -71,7 +75,8 @@ typedef enum p25fe_status {
     P25FE_ERR_CAPACITY = -4,   /* output buffer too small; nothing consumed */
     P25FE_ERR_FORMAT = -5,     /* u8 / cf32 mixed within one stream */
     P25FE_ERR_NOMEM = -6,
-    P25FE_ERR_JIT = -7         /* specialising the kernels failed (p25fe_specialize_log has the compiler's words) */
+    P25FE_ERR_JIT = -7,        /* specialising the kernels failed (p25fe_specialize_log has the compiler's words) */
+    P25FE_ERR_TIMEOUT = -8     /* a device-side wait gave up (the head segment of a time shard never arrived: p25fe_shard_head_check) */
 } p25fe_status;
 
 typedef enum p25fe_format {
@@ -103,7 +108,8 @@ typedef struct p25fe_config {
                                             3.8b -- the stride is the measured interval between the last two sync words over its
                                             symbol count, instants are read by 4-tap interpolation, the receiver runs 2 samples
                                             behind the baseband; P25FE_CLOCK_TRACKING_RESLICE (2): the same, and the calls that hold
-                                            a whole range re-slice the first frame of a lock run (SPEC 3.8c, see the define) */
+                                            a whole range re-slice the first frame of a lock run (SPEC 3.8c, see the define; the calls
+                                            that cannot are refused unless P25FE_CLOCK_CAUSAL_OK is or-ed in) */
     int32_t specialize;                  /* P25FE_SPECIALIZE_AUTO (0): non-default numbers get immediate-coefficient kernels (cache, then
                                             hipRTC), the generic kernels if that fails; _OFF (-1): always the generic kernels for
                                             non-default numbers; _REQUIRE (1): p25fe_create fails with P25FE_ERR_JIT instead of
@@ -142,9 +148,13 @@ typedef struct p25fe_config {
  * the period of the interval that STARTS at it, once the next sync word of the range confirms one, and every detection's instants
  * start from its refined position s + f / 4 instead of the whole sample s (0 symbol errors of 2.88 M at 150 ppm where
  * P25FE_CLOCK_TRACKING leaves 29 and the fixed stride 16 502).  That is not causal, so the calls that see the stream in pieces --
- * every host-buffer streaming call, p25fe_run_host_windows, the time-shard passes -- keep P25FE_CLOCK_TRACKING's rule in this mode
- * ("any chunking gives the same output", src/demod.rs:25-40): a resident call and a streaming call then differ, by design. */
+ * p25fe_slice, p25fe_run_u8 / _cf32, p25fe_run_host_windows, the time-shard passes (and with them p25fe_shard_step) -- cannot run it: they
+ * have P25FE_CLOCK_TRACKING's rule only ("any chunking gives the same output", src/demod.rs:25-40).  ABI 6: on a handle created with
+ * symbol_clock = 2 those calls return P25FE_ERR_ARG -- a request for one receiver is not answered with another's dibits -- unless the
+ * handle was created with symbol_clock = P25FE_CLOCK_TRACKING_RESLICE | P25FE_CLOCK_CAUSAL_OK: 3.8c where a call holds the range, 3.8b
+ * everywhere else, and a resident call and a streaming call then differ, by design (what ABI 5's mode 2 did without being asked). */
 #define P25FE_CLOCK_TRACKING_RESLICE 2
+#define P25FE_CLOCK_CAUSAL_OK 0x100
 #define P25FE_SPECIALIZE_AUTO 0
 #define P25FE_SPECIALIZE_OFF (-1)
 #define P25FE_SPECIALIZE_REQUIRE 1
@@ -366,10 +376,17 @@ int p25fe_shard_pass1_finish(p25fe_t *h, const void *d_iq, int fmt, size_t ch_st
                              uint64_t abs0, p25fe_result_t *d_result, void *stream);
 /* The head alone (same arguments, after the halo has arrived), so that it can run on ANOTHER stream beside the main launch
  * -- the stream the halo arrives on: the two launches share no byte of their outputs.  p25fe_shard_pass1_finish then only
- * enqueues the sync detection and the scan; its stream must have been made to wait for the head's.  Optional: without it
- * _finish launches the head itself. */
+ * enqueues the sync detection and the scan, and needs NO stream-level wait for the head: the head launch's last workgroup
+ * publishes a flag word, and the detection workgroups whose tiles read the head's planes poll it (a cross-stream event wait
+ * costs 10 - 20 us of idle GPU) -- for at most 2 s of device wall clock, after which they give up and p25fe_shard_head_check
+ * reports P25FE_ERR_TIMEOUT (a stalled peer must not hang the queue).  Making _finish's stream wait for the head's with an
+ * event as well is harmless.  Optional: without this call _finish launches the head itself. */
 int p25fe_shard_pass1_head(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n,
                            uint64_t abs0, void *stream);
+/* After the stream(s) of a step whose head ran through p25fe_shard_pass1_head have been synchronised: P25FE_OK, or P25FE_ERR_TIMEOUT if a
+ * detection workgroup gave up waiting for the head's flag (2 s of device wall clock: the stream the head was on never delivered it, e.g. a
+ * halo exchange whose peer died) -- the results of that step, and of every later one on this handle, are not to be used. */
+int p25fe_shard_head_check(p25fe_t *h);
 /* The whole front end of pass 1 in ONE launch (main + head: the halo must be in memory), nothing else; p25fe_shard_pass1_finish
  * then only enqueues the sync detection and the scan.  p25fe_shard_pass1 == _k1 + _finish. */
 int p25fe_shard_pass1_k1(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride, size_t n_hist, size_t n, uint64_t abs0,
@@ -383,6 +400,9 @@ int p25fe_shard_pass1_k1(p25fe_t *h, const void *d_iq, int fmt, size_t ch_stride
  * and marks it as pending: p25fe_join_dev makes a stream wait for it, every non-pipelined entry point does so by itself. */
 int p25fe_shard_pipe_begin(p25fe_t *h, void *stream, void **rx_stream);
 int p25fe_shard_pipe_end(p25fe_t *h, void *last_stream);
+/* the handle's receive stream (created on first use), without starting a step: for a host that wants to check its own streams against it
+ * (p25fe_streams_share_queue; libp25fe_rccl.so's p25fe_shard_create / p25fe_shard_prepare do) */
+int p25fe_rx_stream(p25fe_t *h, void **rx_stream);
 
 /* Host-side combine: summaries[r] for r = 0..n_shards-1 in time order (one channel) ->
  * anchor_in[r] (n_shards entries) and dibit_offset[r] (n_shards + 1 entries: shard r's dibits occupy

@@ -62,6 +62,33 @@ int p25fe_rccl_unique_id(void *id128);
 int p25fe_shard_create(p25fe_t *h, int rank, int world, const void *id128, size_t n_per_rank, p25fe_shard_t **out);
 void p25fe_shard_destroy(p25fe_shard_t *s);
 
+/* What the shard object itself knows about the job it is part of -- the evidence a record of an N > 1 run needs: did RCCL see N ranks, on
+ * which GPU does this rank sit, which layout does the pipelined step run.  Every field is read from the library's own state (the
+ * communicator's ncclCommCount / ncclCommUserRank, hipDeviceGetPCIBusId of the handle's device), none from the launcher's environment. */
+typedef struct p25fe_shard_info {
+    int32_t rank, world;                 /* as given to p25fe_shard_create */
+    int32_t rccl_ranks, rccl_rank;       /* ncclCommCount / ncclCommUserRank of the communicator; 0 / -1: no communicator (world 1 without an id, the test hook) */
+    int32_t device;                      /* HIP device ordinal of the handle */
+    int32_t comms;                       /* communicators the steps use: 0 none; 1 one for everything; 3 halo / summaries / dibit rows each their own */
+    int32_t pipe_layout;                 /* p25fe_shard_step_pipelined as AGREED by all ranks in p25fe_shard_create: 2 = two stages placed at K1
+                                            boundaries (needs comms == 3 or 0), 1 = the step's own order on the receive stream */
+    int32_t gather_ran;                  /* P25FE_GATHER_* of the last step */
+    int32_t staged;                      /* 1: the shared-memory test hook, not RCCL */
+    int32_t head_wait;                   /* plain step, how the detection waits for the head segment: 0 flag word (bounded spin), 1 stream event */
+    int32_t broken;                      /* 1: a collective failed half-way; every later step fails */
+    int32_t reserved;
+    uint64_t steps;                      /* steps enqueued so far */
+    char pci_bus_id[32];                 /* "0000:05:00.0" */
+} p25fe_shard_info_t;
+int p25fe_shard_info(const p25fe_shard_t *s, p25fe_shard_info_t *out);
+
+/* Once per stream the steps will be given (optional, recommended for p25fe_shard_step_pipelined): makes sure the shard's side stream does not
+ * share a HARDWARE queue with `stream` or with the handle's receive stream (p25fe_streams_share_queue; a side stream that does is
+ * replaced).  SYNCHRONISES those streams (< 1 ms each) -- which is why it is a call of its own and no step does it: a step never
+ * blocks the host (ROOT gather) and may be given a capturing stream.  p25fe_shard_create has already checked the side stream against
+ * the handle's receive stream. */
+int p25fe_shard_prepare(p25fe_shard_t *s, void *stream);
+
 /* bytes of a per-rank dibit row (the gather granule): n / 50 plus proportional slack for the transmitter's symbol clock */
 size_t p25fe_shard_dibit_cap(const p25fe_shard_t *s);
 
@@ -81,11 +108,11 @@ int p25fe_shard_step(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, 
  * stream alternates between two buffers, p25fe_shard_stream_dev() names the LAST call's, and the previous call's stays untouched
  * until the call after this one; d_buf must stay unchanged until `stream` and the step's exchanges have passed it (join).
  * P25FE_GATHER_ROOT_EXACT keeps its one host wait per step, which ends the overlap for that mode; the shared-memory test hook runs
- * the plain step.  p25fe_shard_create makes two more communicators, for the halo and for the summaries (ncclCommSplit, a collective every
- * rank takes part in: RCCL serialises the operations of one communicator across streams); if that fails the step keeps everything behind
- * K1 in step order on the receive stream.
- * STREAM: any.  The first step that sees a caller's stream checks that the side stream does not share its hardware queue
- * (p25fe_streams_share_queue: synchronises both streams once) and replaces it if it does ("Which stream to pass"). */
+ * the plain step.  The halo and the summaries travel on communicators of their own (ncclCommSplit: RCCL serialises the operations of one
+ * communicator across streams); without them the step keeps everything behind K1 in step order on the receive stream.
+ * p25fe_shard_create makes two more communicators for this step (halo, summaries) and AGREES with the other ranks on whether all of them
+ * have both (p25fe_shard_info.pipe_layout / .comms): if any rank lacks one, every rank runs the one-communicator layout.
+ * STREAM: any; call p25fe_shard_prepare(s, stream) once before the first step on it ("Which stream to pass"). */
 int p25fe_shard_step_pipelined(p25fe_shard_t *s, void *d_buf, int fmt, uint8_t *d_dibits, p25fe_result_t *d_result, int gather,
                                void *stream);
 /* make `stream` wait for everything p25fe_shard_step_pipelined has enqueued so far */

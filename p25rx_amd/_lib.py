@@ -11,10 +11,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libp25fe.so")
 MAX_TAPS = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 FMT_CF32, FMT_U8 = 0, 1
 
-OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM, ERR_JIT = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_FORMAT, ERR_NOMEM, ERR_JIT, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
+CLOCK_FIXED, CLOCK_TRACKING, CLOCK_TRACKING_RESLICE, CLOCK_CAUSAL_OK = 0, 1, 2, 0x100
 SPECIALIZE_AUTO, SPECIALIZE_OFF, SPECIALIZE_REQUIRE, SPECIALIZE_FORCE = 0, -1, 1, 2
 VARIANT_BUILTIN, VARIANT_SPECIALIZED, VARIANT_GENERIC = 0, 1, 2
 
@@ -70,7 +71,7 @@ SYMBOLS = [
     "p25fe_nid_batch_dev", "p25fe_chan_stats_dev", "p25fe_channelise_dev", "p25fe_nid",
     "p25fe_shard_pass1_main", "p25fe_shard_pass1_finish", "p25fe_shard_compact_dev", "p25fe_resync_at_dev",
     "p25fe_kernel_variant", "p25fe_specialize", "p25fe_specialize_log", "p25fe_run_host_windows",
-    "p25fe_shard_pass1_head", "p25fe_shard_pipe_begin", "p25fe_shard_pipe_end", "p25fe_shard_pass1_k1", "p25fe_streams_share_queue", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant", "p25fe_n_baseband_h",
+    "p25fe_shard_pass1_head", "p25fe_shard_pipe_begin", "p25fe_shard_pipe_end", "p25fe_rx_stream", "p25fe_shard_head_check", "p25fe_shard_pass1_k1", "p25fe_streams_share_queue", "p25fe_shard_pass2_dev", "p25fe_shard_compact_from_dev", "p25fe_probe_variant", "p25fe_n_baseband_h",
 ]
 
 

@@ -106,6 +106,8 @@ inline size_t fmt_bytes(int fmt) { return fmt == P25FE_FMT_CF32 ? 8 : 2; }
 static_assert(BBPAD == (size_t)TAILN && BBPAD >= (size_t)HIST_BB + CLK_L, "baseband tail kept between calls");
 
 constexpr int MAX_LANES = 4;
+// p25fe::sh_flag: words 0 / 1 the head segment's flag and ticket, 2 / 3 the queue probe's pair, 4 "a detection gave up waiting for the head"
+constexpr int SH_FLAG_WORDS = 8, SH_FLAG_ERR = 4;
 
 struct p25fe {
     p25fe_config_t cfg;
@@ -124,15 +126,17 @@ struct p25fe {
     hipFunction_t jit_fn[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     hipStream_t stream = nullptr;          // for the host-pointer calls
 
-    int track = 0;                         // p25fe_config_t.symbol_clock (docs/SPEC.md 3.8b)
+    int track = 0;                         // p25fe_config_t.symbol_clock without its flag bits (docs/SPEC.md 3.8b)
+    bool causal_ok = false;                // P25FE_CLOCK_CAUSAL_OK: mode 2 may run as mode 1 in the calls that see the stream in pieces
     long look = 0;                         // samples the receiver runs behind the baseband (2 with the tracking clock)
     // lock drops for the next receiver-running call (p25fe_resync_at_dev); consumed by it
     const long* rs_idx = nullptr;
     size_t rs_n = 0, rs_stride = 0;
     // scratch
     DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, chunk_cnt;
+    DevBuf gagg, gpre, gtick;              // K3 in K2's tail: group aggregates, group carry-ins, the arrival counters (zero between launches)
     PinBuf hin, hbb, hout;                 // streaming entry points: staged input ([history | new] IQ, [tail | new] baseband), results
-    DevBuf gsum, gouts, evg;               // general receiver only (tracking clock / lock drops): allocated on first use
+    DevBuf gsum, gouts, evg, gsg, gpg;     // general receiver only (tracking clock / lock drops): allocated on first use
     DevBuf evrec, evnext, evoff;           // SPEC 3.8c (symbol_clock = 2, resident ranges): the list of detections, allocated on first use
     unsigned long long ev_seq = 0;         // ... and the sequence number that marks an EvNext entry as this call's
     // p25fe_run_dev_pipelined: a second set of the receiver's scratch (the member names above always are the set of the
@@ -141,7 +145,7 @@ struct p25fe {
     // (p25fe_run_dev_pipelined rotates through two sets; the pipelined shard step through up to MAX_LANES: its chain behind K1
     // holds exchanges that only find room on the chip when a K1 launch drains, so it spans more than one K1.)  A set keeps its id
     // (`lane` = the current one's); the events and the pending flags are indexed by it.
-    struct RxSet { DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, gsum, gouts, evg; int id = 0; };
+    struct RxSet { DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, gsum, gouts, evg, gagg, gpre, gtick, gsg, gpg; int id = 0; };
     RxSet spare[MAX_LANES - 1];
     hipStream_t rx_stream = nullptr;
     hipEvent_t ev_k1[MAX_LANES] = {}, ev_rx[MAX_LANES] = {};
@@ -189,7 +193,7 @@ struct p25fe {
     long sh_abs_bb0 = 0;
     bool sh_gen = false;                   // pass 1 ran the general receiver (pass 2 reads its summaries)
     bool sh_pipe = false;                  // between p25fe_shard_pipe_begin and _end: the shard passes do not join the receive stream (they ARE its work)
-    bool sh_scan_fresh = false;            // the per-tile carry-ins in `outs` are still pass 1's (no carry-in): p25fe_shard_pass2 rewrites them
+    bool sh_scan_fresh = false;            // the groups' carry-ins (`gpre`) are still pass 1's (no carry-in): p25fe_shard_pass2 rewrites them
 };
 
 // geometry of the planar scratch for n_bb owned baseband samples (p25fe_recv.hip: Planar)
@@ -236,7 +240,8 @@ static bool lut_is_affine(const float* lut, float sc, float of)
 static int resolve_config(const p25fe_config_t* cfg, Resolved* r)
 {
     if (cfg->abi_version != P25FE_ABI_VERSION || cfg->n_decim_taps < 1 || cfg->n_decim_taps > P25FE_MAX_TAPS || cfg->n_chan_taps < 1 ||
-        cfg->n_chan_taps > P25FE_MAX_TAPS || (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING && cfg->symbol_clock != P25FE_CLOCK_TRACKING_RESLICE) ||
+        cfg->n_chan_taps > P25FE_MAX_TAPS || (cfg->symbol_clock != P25FE_CLOCK_FIXED && cfg->symbol_clock != P25FE_CLOCK_TRACKING && cfg->symbol_clock != P25FE_CLOCK_TRACKING_RESLICE &&
+         cfg->symbol_clock != (P25FE_CLOCK_TRACKING_RESLICE | P25FE_CLOCK_CAUSAL_OK)) ||
         cfg->specialize < P25FE_SPECIALIZE_OFF || cfg->specialize > P25FE_SPECIALIZE_FORCE || cfg->decim_phase < 0 || cfg->decim_phase >= DEC ||
         cfg->n_avg_taps < 1 || cfg->n_avg_taps > P25FE_MAX_TAPS)
         return P25FE_ERR_ARG;
@@ -399,6 +404,7 @@ const char* p25fe_strerror(int status)
     case P25FE_ERR_FORMAT: return "sample format changed within a stream";
     case P25FE_ERR_NOMEM: return "out of memory";
     case P25FE_ERR_JIT: return "kernel specialisation failed (p25fe_specialize_log)";
+    case P25FE_ERR_TIMEOUT: return "a device-side wait gave up (time shard: the head segment never arrived)";
     default: return "unknown status";
     }
 }
@@ -499,8 +505,9 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
     if (!h) return P25FE_ERR_NOMEM;
     h->cfg = *cfg;
     h->C = cfg->n_channels;
-    h->track = cfg->symbol_clock;
-    h->look = cfg->symbol_clock ? CLK_L : 0;
+    h->track = cfg->symbol_clock & 0xff;
+    h->causal_ok = (cfg->symbol_clock & P25FE_CLOCK_CAUSAL_OK) != 0;
+    h->look = h->track ? CLK_L : 0;
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->taps = rs.taps;
     h->phase = cfg->decim_phase;
@@ -594,12 +601,13 @@ void p25fe_destroy(p25fe_t* h)
         if (h->ev_rx[l]) (void)hipEventDestroy(h->ev_rx[l]);
     }
     for (auto& a : h->spare) {
-        DevBuf* alt[] = {&a.pl_f, &a.pl_bits, &a.evl, &a.evthr, &a.recs, &a.tsum, &a.outs, &a.gsum, &a.gouts, &a.evg};
+        DevBuf* alt[] = {&a.pl_f, &a.pl_bits, &a.evl, &a.evthr, &a.recs, &a.tsum, &a.outs, &a.gsum, &a.gouts, &a.evg, &a.gagg, &a.gpre, &a.gtick, &a.gsg, &a.gpg};
         for (DevBuf* b : alt) b->release();
     }
-    h->gsum.release(); h->gouts.release(); h->evg.release();
+    h->gsum.release(); h->gouts.release(); h->evg.release(); h->gsg.release(); h->gpg.release();
     h->evrec.release(); h->evnext.release(); h->evoff.release();
-    DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps, &h->sh_flag};
+    DevBuf* bufs[] = {&h->pl_f, &h->pl_bits, &h->evl, &h->evthr, &h->recs, &h->tsum, &h->outs, &h->power_partial, &h->chunk_cnt, &h->d_taps, &h->sh_flag,
+                      &h->gagg, &h->gpre, &h->gtick};
     for (DevBuf* b : bufs) b->release();
     h->hin.release(); h->hbb.release(); h->hout.release();
     for (auto& e : h->prof_ev) if (e) (void)hipEventDestroy(e);
@@ -825,10 +833,20 @@ static int ensure_slice_scratch(p25fe_t* h, size_t n_bb)
     HIPCHK(h, h->recs.ensure(C * g.n_tiles * sizeof(TileRec)));
     HIPCHK(h, h->tsum.ensure(C * g.n_tiles * sizeof(unsigned long long)));
     HIPCHK(h, h->outs.ensure(C * g.n_tiles * sizeof(ScanOut)));
+    const size_t ng = (size_t)n_groups_of((int)g.n_tiles);
+    {
+        HIPCHK(h, h->gagg.ensure(C * ng * sizeof(GroupAgg)));
+        HIPCHK(h, h->gpre.ensure(C * ng * sizeof(GroupPre)));
+        const void* before = h->gtick.p;
+        HIPCHK(h, h->gtick.ensure(C * (ng + 1) * sizeof(unsigned)));
+        if (h->gtick.p != before) HIPCHK(h, hipMemset(h->gtick.p, 0, h->gtick.cap));    // a fresh buffer: the counters start at zero and return to it
+    }
     if (h->track || h->rs_n) {                                       // the general receiver's summaries and carry-ins
         HIPCHK(h, h->gsum.ensure(C * g.n_tiles * sizeof(TileSumG)));
         HIPCHK(h, h->gouts.ensure(C * g.n_tiles * sizeof(ScanOutG)));
         HIPCHK(h, h->evg.ensure(C * g.n_tiles * EVCAP * sizeof(uint32_t)));
+        HIPCHK(h, h->gsg.ensure(C * ng * sizeof(GroupSumG)));
+        HIPCHK(h, h->gpg.ensure(C * ng * sizeof(GroupPreG)));
     }
     return P25FE_OK;
 }
@@ -873,51 +891,79 @@ static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, siz
     return P25FE_OK;
 }
 
-// K2 on the planar scratch.  abs_bb0: absolute index of the first PROCESSED sample (owned sample 0 minus h->look).
-static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc, bool wait_head_flag = false)
+// K2 on the planar scratch (abs_bb0: absolute index of the first PROCESSED sample = owned sample 0 minus h->look), and K3 in its tail
+// (ScanTail / GroupSumG in p25fe_recv.hip): d_anchor_in (nullable) is the range's carry-in, d_result receives the range's record.
+static void scan_tail_args(p25fe_t* h, size_t n_bb, const p25fe_anchor_t* d_anchor_in, p25fe_result_t* d_result, ScanTail* t)
+{
+    t->on = 1;
+    t->gsg = h->gsg.as<GroupSumG>(); t->gpg = h->gpg.as<GroupPreG>();
+    t->outs = h->outs.as<ScanOut>(); t->gagg = h->gagg.as<GroupAgg>(); t->gpre = h->gpre.as<GroupPre>();
+    t->tickets = h->gtick.as<unsigned>(); t->anchor_in = d_anchor_in; t->result = d_result;
+    t->n_baseband = n_bb;
+}
+static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc, bool wait_head_flag,
+                         const p25fe_anchor_t* d_anchor_in, p25fe_result_t* d_result)
 {
     const PlanarGeo g(n_bb);
     DetArgs d;
-    d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1;
-    if (wait_head_flag) { d.head_flag = h->sh_flag.as<unsigned>(); d.head_seq = h->sh_seq; d.head_tile_max = h->sh_head_tile_max; }
+    d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1; d.head_err = nullptr;
+    scan_tail_args(h, n_bb, d_anchor_in, d_result, &d.tail);
+    d.tail.on = rc.gen ? 1 : 0;                                      // (the fixed-stride receiver's K3 is a launch of its own: k_scan_tiles)
+    if (wait_head_flag) {
+        d.head_flag = h->sh_flag.as<unsigned>(); d.head_seq = h->sh_seq; d.head_tile_max = h->sh_head_tile_max;
+        d.head_err = h->sh_flag.as<unsigned>() + SH_FLAG_ERR;
+    }
     d.pl = planar_view(h, g); d.n = (long)n_bb; d.abs0 = abs_bb0; d.n_tiles = (int)g.n_tiles;
     d.recs = h->recs.as<TileRec>(); d.tsum = h->tsum.as<unsigned long long>(); d.evl = h->evl.as<uint16_t>(); d.evthr = h->evthr.as<float>();
     d.opt = rc.opt; d.gsum = h->gsum.as<TileSumG>(); d.evg = h->evg.as<uint32_t>();
-    if (rc.gen) hipLaunchKernelGGL(k_detect<true>, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
-    else hipLaunchKernelGGL(k_detect<false>, dim3((unsigned)g.n_tiles, (unsigned)h->C), dim3(WV), 0, st, d);
+    const dim3 grid((unsigned)g.n_tiles, (unsigned)h->C);
+    if (rc.gen) hipLaunchKernelGGL(k_detect<true>, grid, dim3(WV), 0, st, d);
+    else hipLaunchKernelGGL(k_detect<false>, grid, dim3(WV), 0, st, d);
     HIPCHK(h, hipGetLastError());
     return P25FE_OK;
 }
 
-// K3 (+ K4 when do_slice) on the summaries of launch_detect
+// What follows K2: the slicer (do_slice), in front of it whatever completes the per-tile carry-ins.
+//   scanned   K2 has just run in this call, for THIS carry-in: the general receiver's K3 ran in its tail, the fixed-stride receiver's is
+//             launched here (k_scan_tiles).  Otherwise the summaries in the scratch are re-scanned under d_anchor_in by the top step
+//             alone (k_range_scan / k_range_scan_g: a time shard's pass 2 under resolved anchors; an empty range, whose record is the
+//             carry-in handed through).
+//   ev_done   (nullable) attached to the LAST kernel this function launches (its completion = the receive side is done)
+//   d_dibits2 (nullable) second destination of the dibits
+//   fix       (nullable, fixed-stride receiver only) pass 2 of a time shard on pass 1's scan: the slicer applies the shard's carry-in in
+//             closed form (ShardFix in p25fe_recv.hip) on top of the group's
 static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_anchor_t* d_anchor_in,
                              uint8_t* d_dibits, size_t dibit_stride, int64_t* d_sync_pos, uint64_t* d_sync_dibit,
                              size_t sync_stride, p25fe_result_t* d_result, bool do_slice, hipStream_t st,
-                             const RecvCall& rc, hipEvent_t ev_done = nullptr, uint8_t* d_dibits2 = nullptr,
+                             const RecvCall& rc, bool scanned, hipEvent_t ev_done = nullptr, uint8_t* d_dibits2 = nullptr,
                              const ShardFix* fix = nullptr)
 {
-    // ev_done (nullable): attached to the LAST kernel this function launches (its completion = the receive side is done)
-    // d_dibits2 (nullable): second destination of the dibits; fix (nullable, fixed-stride receiver only): pass 2 of a time
-    // shard on pass 1's scan -- no scan launch, the slicer applies the carry-in in closed form (ShardFix in p25fe_recv.hip)
     const PlanarGeo g(n_bb);
     const int n_tiles = n_bb ? (int)g.n_tiles : 0;
     const bool slice = do_slice && n_tiles != 0;
+    bool ev_pending = ev_done != nullptr;                            // no kernel has carried ev_done yet
     if (rc.gen) {
         ScanArgsG c;
         c.gsum = h->gsum.as<TileSumG>(); c.recs = h->recs.as<TileRec>(); c.outs = h->gouts.as<ScanOutG>();
+        c.gsg = h->gsg.as<GroupSumG>(); c.gpg = h->gpg.as<GroupPreG>(); c.tickets = h->gtick.as<unsigned>();
         c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
         c.n_baseband = n_bb; c.track = h->track;
-        // (measurement knob P25FE_SCAN_G_WAVES=1: the one-wave form, which fits beside a running K1 instead of waiting for it to drain --
-        // and then walks 3 750 tiles alone: 0.414 / 0.440 ms per pipelined step against 0.284 / 0.338, profiles/r05_tracking_pipeline.txt)
-        static const int scan_waves = [] { const char* e = getenv("P25FE_SCAN_G_WAVES"); return e ? atoi(e) : 0; }();
-        const bool one_wave = scan_waves == 1;
-        if (one_wave) launch_ev(k_scan_g_t<WV, 256>, dim3((unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
-        else launch_ev(k_scan_g_t<NT3, KG_CHUNK>, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
-        HIPCHK(h, hipGetLastError());
+        if (!scanned) {
+            launch_ev(k_range_scan_g, dim3((unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
+            HIPCHK(h, hipGetLastError());
+            if (!slice) ev_pending = false;
+        }
         prof_mark(h, 3, st);
-        if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
+        if (!slice) {
+            if (ev_pending) HIPCHK(h, hipEventRecord(ev_done, st));  // (K2 was the last kernel: the event goes behind it)
+            prof_mark(h, 4, st);
+            return P25FE_OK;
+        }
+        // pass B: the tiles' carry-ins under their groups' (one wave per group)
+        hipLaunchKernelGGL(k_scan_g_groups, dim3((unsigned)n_groups_of(n_tiles), (unsigned)h->C), dim3(WV), 0, st, c);
+        HIPCHK(h, hipGetLastError());
         if (rc.reslice) {
-            // SPEC 3.8c: the slicer by detection (k_ev_collect / k_ev_count / k_ev_scan / k_ev_slice) on k_scan_g's carry-ins
+            // SPEC 3.8c: the slicer by detection (k_ev_collect / k_ev_count / k_ev_scan / k_ev_slice) on those carry-ins
             const size_t C = (size_t)h->C;
             size_t cap_ev = (size_t)n_tiles * EVCAP;
             const size_t bound = n_bb / (size_t)(W + 1) + (size_t)n_tiles + 8;
@@ -964,16 +1010,23 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         prof_mark(h, 4, st);
         return P25FE_OK;
     }
-    ScanArgs c;
-    c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>(); c.outs = h->outs.as<ScanOut>();
-    c.n_tiles = n_tiles; c.n = (long)n_bb; c.abs0 = abs_bb0; c.anchor_in = d_anchor_in; c.result = d_result;
-    c.n_baseband = n_bb;
     if (!fix) {
-        launch_ev(k_scan, dim3((unsigned)h->C), dim3(NT3), 0, st, nullptr, slice ? nullptr : ev_done, c);
+        DetArgs c;
+        memset(&c, 0, sizeof c);
+        c.n = (long)n_bb; c.abs0 = abs_bb0; c.n_tiles = n_tiles; c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>();
+        scan_tail_args(h, n_bb, d_anchor_in, d_result, &c.tail);
+        // K2 has just run: the whole scan (groups, then the range); otherwise only the range's, on the group aggregates that are there
+        if (scanned && n_tiles) launch_ev(k_scan_tiles, dim3((unsigned)n_groups_of(n_tiles), (unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
+        else launch_ev(k_range_scan, dim3((unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
         HIPCHK(h, hipGetLastError());
+        if (!slice) ev_pending = false;
     }
     prof_mark(h, 3, st);
-    if (!slice) { prof_mark(h, 4, st); return P25FE_OK; }
+    if (!slice) {
+        if (ev_pending) HIPCHK(h, hipEventRecord(ev_done, st));      // (K2 was the last kernel: the event goes behind it)
+        prof_mark(h, 4, st);
+        return P25FE_OK;
+    }
     SliceArgs l;
     l.pl = planar_view(h, g); l.n = (long)n_bb; l.abs0 = abs_bb0; l.n_tiles = n_tiles;
     l.outs = h->outs.as<ScanOut>(); l.recs = h->recs.as<TileRec>(); l.tsum = h->tsum.as<unsigned long long>();
@@ -982,6 +1035,7 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
     l.sync_pos = (d_sync_pos && d_sync_dibit) ? d_sync_pos : nullptr; l.sync_dibit = d_sync_dibit;
     l.sync_stride = (long)sync_stride;
     l.dibits2 = d_dibits2;
+    l.gpre = h->gpre.as<GroupPre>();
     if (fix) l.fix = *fix; else memset(&l.fix, 0, sizeof l.fix);
     // (pass 2 of a time shard: one extra workgroup runs the combine for the record beside the slicing ones)
     launch_ev(k_slice, dim3((unsigned)n_tiles + (fix ? 1u : 0u), (unsigned)h->C), dim3(WV), 0, st, nullptr, ev_done, l);
@@ -989,6 +1043,11 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
     prof_mark(h, 4, st);
     return P25FE_OK;
 }
+
+// SPEC 3.8c needs the whole range in one call.  The calls that see the stream in pieces (host streaming chunks, host windows, the
+// passes of a time shard) can only run 3.8b's causal rule; a handle that asked for 3.8c gets that ONLY if it said so
+// (P25FE_CLOCK_CAUSAL_OK) -- otherwise the call is refused instead of quietly returning another receiver's dibits.
+static inline bool piecewise_refused(const p25fe_t* h) { return h->track == P25FE_CLOCK_TRACKING_RESLICE && !h->causal_ok; }
 
 // every entry point that overwrites the receiver's scratch: a shard's pass-1 context is gone
 static void shard_invalidate(p25fe_t* h)
@@ -1016,14 +1075,14 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
     h->rs_n = 0;                                         // the lock drops belong to this call
     if (n_bb == 0)        // empty range: only the scan runs (zero tiles) and hands the anchor through
         return launch_scan_slice(h, 0, view0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result,
-                                 false, st, rcall);
+                                 false, st, rcall, false);
     rc = launch_planarize(h, d_bb, bb_stride, n_hist_bb, n_bb, st);
     if (rc) return rc;
-    rc = launch_detect(h, n_bb, view0, st, rcall);
+    rc = launch_detect(h, n_bb, view0, st, rcall, false, d_anchor_in, d_result);
     if (rc) return rc;
     prof_mark(h, 2, st);
     return launch_scan_slice(h, n_bb, view0, d_anchor_in, d_dibits, dibit_stride, d_sync_pos, d_sync_dibit,
-                             sync_stride, d_result, true, st, rcall);
+                             sync_stride, d_result, true, st, rcall, true);
 }
 
 extern "C" {
@@ -1117,7 +1176,7 @@ int p25fe_join_dev(p25fe_t* h, void* stream)
 
 // The preamble of a pipelined call: the receive stream and its events exist, the OTHER scratch set becomes the current one, and
 // `st` (where K1 is about to overwrite that set's planes) waits for the receive kernels that last read it, two calls back.
-static int pipe_open(p25fe_t* h, hipStream_t st, int depth = 2)
+static int ensure_rx_stream(p25fe_t* h)
 {
     if (!h->rx_stream) {
         if (h->rx_cus > 0) {
@@ -1144,6 +1203,11 @@ static int pipe_open(p25fe_t* h, hipStream_t st, int depth = 2)
             }
         }
     }
+    return P25FE_OK;
+}
+static int pipe_open(p25fe_t* h, hipStream_t st, int depth = 2)
+{
+    if (int rc = ensure_rx_stream(h)) return rc;
     for (int l = 0; l < MAX_LANES; ++l) {                            // (per event: a failed creation is retried by the next call)
         if (!h->ev_k1[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_k1[l], hipEventDisableTiming));
         if (!h->ev_rx[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx[l], hipEventDisableTiming));
@@ -1155,20 +1219,16 @@ static int pipe_open(p25fe_t* h, hipStream_t st, int depth = 2)
         std::swap(h->pl_f, a.pl_f); std::swap(h->pl_bits, a.pl_bits); std::swap(h->evl, a.evl);
         std::swap(h->evthr, a.evthr); std::swap(h->recs, a.recs); std::swap(h->tsum, a.tsum);
         std::swap(h->outs, a.outs);
+        std::swap(h->gagg, a.gagg); std::swap(h->gpre, a.gpre); std::swap(h->gtick, a.gtick);
         std::swap(h->gsum, a.gsum); std::swap(h->gouts, a.gouts); std::swap(h->evg, a.evg);
+        std::swap(h->gsg, a.gsg); std::swap(h->gpg, a.gpg);
         std::swap(h->lane, a.id);
         // the set just retired goes behind the other spare ones of this depth (depth 2: a plain swap)
         for (int k = 0; k + 2 < depth && k + 1 < MAX_LANES - 1; ++k) std::swap(h->spare[k], h->spare[k + 1]);
     }
     const int lane = h->lane;
     if (h->rx_pending[lane]) {
-#ifdef P25FE_MEASURE_UNSAFE
-        // measurement builds only (-DP25FE_MEASURE_UNSAFE + P25FE_PIPE_NOWAIT=1): what this wait packet costs -- without it the
-        // planes can be overwritten under a receive kernel that is still reading them
-        static const bool nowait = [] { const char* e = getenv("P25FE_PIPE_NOWAIT"); return e && atoi(e) != 0; }();
-#else
-        constexpr bool nowait = false;
-#endif
+        const bool nowait = P25FE_M_PIPE_NOWAIT();                   // (false in the product: measurement hook, p25fe_kernels.hip)
         if (!nowait && !(h->rx_joined_any[lane] && h->rx_joined[lane] == st)) HIPCHK(h, hipStreamWaitEvent(st, h->ev_rx[lane], 0));
         h->rx_pending[lane] = false;
     }
@@ -1212,12 +1272,12 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (!k1_done_attached) HIPCHK(h, hipEventRecord(k1_done, st));
     HIPCHK(h, hipStreamWaitEvent(h->rx_stream, k1_done, 0));
     if (n_bb) {
-        rc = launch_detect(h, n_bb, -h->look, h->rx_stream, rcall);
+        rc = launch_detect(h, n_bb, -h->look, h->rx_stream, rcall, false, nullptr, d_result);
         if (rc) return rc;
         prof_mark(h, 2, h->rx_stream);
     }
     rc = launch_scan_slice(h, n_bb, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, n_bb != 0, h->rx_stream,
-                           rcall, h->ext_events ? h->ev_rx[lane] : nullptr);
+                           rcall, n_bb != 0, h->ext_events ? h->ev_rx[lane] : nullptr);
     h->prof_slot = -1;
     if (rc) return rc;
     if (!h->ext_events) HIPCHK(h, hipEventRecord(h->ev_rx[lane], h->rx_stream));
@@ -1240,7 +1300,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     rcall.reslice = h->track == P25FE_CLOCK_TRACKING_RESLICE;      // the whole range is in memory: SPEC 3.8c applies
     h->rs_n = 0;
     if (n_bb == 0)
-        return launch_scan_slice(h, 0, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st, rcall);
+        return launch_scan_slice(h, 0, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, false, st, rcall, false);
     const PlanarGeo g(n_bb);
     prof_begin(h);
     prof_mark(h, 0, st);
@@ -1251,10 +1311,10 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
     if (rc) return rc;
     prof_mark(h, 1, st);
-    rc = launch_detect(h, n_bb, -h->look, st, rcall);
+    rc = launch_detect(h, n_bb, -h->look, st, rcall, false, nullptr, d_result);
     if (rc) return rc;
     prof_mark(h, 2, st);
-    rc = launch_scan_slice(h, n_bb, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall);
+    rc = launch_scan_slice(h, n_bb, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall, true);
     h->prof_slot = -1;
     return rc;
 }
@@ -1269,7 +1329,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
 {
     const bool do_main = (what & SH_MAIN) != 0, do_finish = (what & SH_RECV) != 0;
     bool do_head = (what & SH_HEAD) != 0;
-    if (!h || !d_iq || (do_finish && !d_result) || p25fe_n_baseband_h(h, abs0, n) > MAX_RANGE_BB) return P25FE_ERR_ARG;
+    if (!h || !d_iq || (do_finish && !d_result) || p25fe_n_baseband_h(h, abs0, n) > MAX_RANGE_BB || piecewise_refused(h)) return P25FE_ERR_ARG;
     if (do_main) shard_invalidate(h);
     if (n_hist < SHARD_HALO && n_hist != abs0) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1324,8 +1384,8 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
                 // the launch's last workgroup publishes "the head is in memory"; the detection's first tiles wait for that
                 // word instead of the whole stream waiting for an event
                 if (!h->sh_flag.p) {
-                    HIPCHK(h, h->sh_flag.ensure(4 * sizeof(unsigned)));
-                    HIPCHK(h, hipMemsetAsync(h->sh_flag.p, 0, 4 * sizeof(unsigned), st));
+                    HIPCHK(h, h->sh_flag.ensure(SH_FLAG_WORDS * sizeof(unsigned)));
+                    HIPCHK(h, hipMemsetAsync(h->sh_flag.p, 0, SH_FLAG_WORDS * sizeof(unsigned), st));
                 }
                 ++h->sh_seq;
                 if (h->sh_seq == 0u) ++h->sh_seq;
@@ -1345,12 +1405,12 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     const RecvCall rcall = recv_call(h);
     h->rs_n = 0;
     if (n_bb) {
-        rc = launch_detect(h, n_bb, abs_bb0, st, rcall, h->sh_head_flagged);
+        rc = launch_detect(h, n_bb, abs_bb0, st, rcall, h->sh_head_flagged, nullptr, d_result);
         if (rc) return rc;
     }
     h->sh_head_flagged = false;
     prof_mark(h, 2, st);
-    rc = launch_scan_slice(h, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0, d_result, false, st, rcall);
+    rc = launch_scan_slice(h, n_bb, abs_bb0, nullptr, nullptr, 0, nullptr, nullptr, 0, d_result, false, st, rcall, n_bb != 0);
     h->prof_slot = -1;
     if (rc) return rc;
     h->sh_valid = true; h->sh_nbb = n_bb; h->sh_abs_bb0 = abs_bb0; h->sh_gen = rcall.gen; h->sh_scan_fresh = true;
@@ -1401,6 +1461,15 @@ int p25fe_shard_pipe_begin(p25fe_t* h, void* stream, void** rx_stream)
     return P25FE_OK;
 }
 
+int p25fe_rx_stream(p25fe_t* h, void** rx_stream)
+{
+    if (!h || !rx_stream) return P25FE_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (int rc = ensure_rx_stream(h)) return rc;
+    *rx_stream = h->rx_stream;
+    return P25FE_OK;
+}
+
 int p25fe_shard_pipe_end(p25fe_t* h, void* last_stream)
 {
     if (!h || !h->sh_pipe) return P25FE_ERR_ARG;
@@ -1420,9 +1489,9 @@ int p25fe_shard_pass2(p25fe_t* h, const p25fe_anchor_t* d_anchor_in, uint8_t* d_
     prof_mark(h, 2, (hipStream_t)stream);
     RecvCall rcall = recv_call(h);
     rcall.gen = h->sh_gen;                               // K3 / K4 read what pass 1's K2 left (the lock drops are in its summaries)
-    h->sh_scan_fresh = false;                            // the scan below rewrites the per-tile carry-ins with THIS carry-in
+    h->sh_scan_fresh = false;                            // the re-scan below rewrites the groups' carry-ins with THIS carry-in
     const int rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, d_anchor_in, d_dibits, dibit_stride, nullptr, nullptr,
-                                     0, d_result, true, (hipStream_t)stream, rcall);
+                                     0, d_result, true, (hipStream_t)stream, rcall, false);
     h->prof_slot = -1;
     return rc;
 }
@@ -1440,7 +1509,7 @@ int p25fe_shard_pass2_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const u
     rcall.gen = h->sh_gen;
     if (rcall.gen || !h->sh_scan_fresh) {
         // tracking clock / lock drops inside the shard (or a p25fe_shard_pass2 has already rewritten pass 1's scan): the combine
-        // as its own (one-thread) launch, then scan + slicer with that carry-in
+        // as its own (one-thread) launch, then the re-scan of the shard's groups + slicer with that carry-in
         h->sh_scan_fresh = false;
         hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, st, d_summaries, d_shard_bb0, d_shard_bb_n, (int)n_shards, h->track,
                            d_anchor_in, d_dibit_offset);
@@ -1448,7 +1517,7 @@ int p25fe_shard_pass2_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const u
         prof_begin(h);
         prof_mark(h, 2, st);
         const int rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, d_anchor_in + rank, d_dibits, dibit_stride, nullptr, nullptr, 0,
-                                         d_result, true, st, rcall, nullptr, d_dibits_dup);
+                                         d_result, true, st, rcall, false, nullptr, d_dibits_dup);
         h->prof_slot = -1;
         return rc;
     }
@@ -1463,10 +1532,10 @@ int p25fe_shard_pass2_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const u
         hipLaunchKernelGGL(k_shard_resolve, dim3(1), dim3(64), 0, st, d_summaries, d_shard_bb0, d_shard_bb_n, (int)n_shards, h->track,
                            d_anchor_in, d_dibit_offset);
         HIPCHK(h, hipGetLastError());
-        rc = launch_scan_slice(h, 0, h->sh_abs_bb0, d_anchor_in + rank, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall);
+        rc = launch_scan_slice(h, 0, h->sh_abs_bb0, d_anchor_in + rank, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall, false);
     } else {
         rc = launch_scan_slice(h, h->sh_nbb, h->sh_abs_bb0, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall,
-                               nullptr, d_dibits_dup, &fx);
+                               true, nullptr, d_dibits_dup, &fx);
     }
     h->prof_slot = -1;
     return rc;
@@ -1492,6 +1561,16 @@ int p25fe_shard_resolve_dev(p25fe_t* h, const p25fe_result_t* d_summaries, const
     return P25FE_OK;
 }
 
+int p25fe_shard_head_check(p25fe_t* h)
+{
+    if (!h) return P25FE_ERR_ARG;
+    if (!h->sh_flag.p) return P25FE_OK;                              // no head segment has ever run on a stream of its own
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    unsigned err = 0u;
+    HIPCHK(h, hipMemcpy(&err, h->sh_flag.as<unsigned>() + SH_FLAG_ERR, sizeof err, hipMemcpyDeviceToHost));
+    return err ? P25FE_ERR_TIMEOUT : P25FE_OK;
+}
+
 int p25fe_streams_share_queue(p25fe_t* h, void* stream_a, void* stream_b, int* shared)
 {
     if (!h || !shared) return P25FE_ERR_ARG;
@@ -1499,10 +1578,9 @@ int p25fe_streams_share_queue(p25fe_t* h, void* stream_a, void* stream_b, int* s
     if (stream_a == stream_b) { *shared = 1; return P25FE_OK; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (!h->sh_flag.p) {
-        HIPCHK(h, h->sh_flag.ensure(4 * sizeof(unsigned)));
-        HIPCHK(h, hipMemset(h->sh_flag.p, 0, 4 * sizeof(unsigned)));
+        HIPCHK(h, h->sh_flag.ensure(SH_FLAG_WORDS * sizeof(unsigned)));
+        HIPCHK(h, hipMemset(h->sh_flag.p, 0, SH_FLAG_WORDS * sizeof(unsigned)));
     }
-    HIPCHK(h, h->sh_flag.ensure(4 * sizeof(unsigned)));
     unsigned* w = h->sh_flag.as<unsigned>() + 2;                     // (words 0 / 1 are the head segment's flag and ticket)
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_a));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_b));
@@ -1720,7 +1798,7 @@ static int chunk_wait(p25fe_t* h, const RecvOut& o, const ChunkRecvArgs& c)
 int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits, int64_t* sync_pos,
                 uint64_t* sync_dibit, size_t sync_cap, size_t* n_sync)
 {
-    if (!h || (!bb && n) || !dibits || !n_dibits) return P25FE_ERR_ARG;
+    if (!h || (!bb && n) || !dibits || !n_dibits || piecewise_refused(h)) return P25FE_ERR_ARG;
     if ((sync_pos || sync_dibit) && !(sync_pos && sync_dibit)) return P25FE_ERR_ARG;
     if (!sync_pos) sync_cap = 0;
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1761,10 +1839,10 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
         const RecvCall rcall = recv_call(h);                        // (a pending p25fe_resync_at_dev list belongs to this call: cleared below, once it has succeeded)
         rc = launch_planarize(h, db + BBPAD, bb_stride, hist, n, h->stream);
         if (rc) return rc;
-        rc = launch_detect(h, n, view0, h->stream, rcall);
+        rc = launch_detect(h, n, view0, h->stream, rcall, false, o.d_anc, o.d_res);
         if (rc) return rc;
         rc = launch_scan_slice(h, n, view0, o.d_anc, o.d_dib, o.dstride, sync_cap ? o.d_spos : nullptr,
-                               sync_cap ? o.d_sdib : nullptr, o.sstride, o.d_res, true, h->stream, rcall);
+                               sync_cap ? o.d_sdib : nullptr, o.sstride, o.d_res, true, h->stream, rcall, true);
         if (rc) return rc;
     }
     rc = chunk_wait(h, o, polled);
@@ -1788,7 +1866,7 @@ static int launch_chunk(p25fe_t* h, const void* d_x, int fmt, size_t ch_stride, 
 
 static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibits, size_t cap, size_t* n_dibits)
 {
-    if (!h || (!iq && n) || !dibits || !n_dibits) return P25FE_ERR_ARG;
+    if (!h || (!iq && n) || !dibits || !n_dibits || piecewise_refused(h)) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const size_t C = (size_t)h->C;
     const size_t nb = p25fe_n_baseband_h(h, h->abs_iq, n);
@@ -1825,9 +1903,9 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
         rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)PLPAD - h->look, nullptr, 0,
                              nullptr, h->stream, &g);
         if (rc) return rc;
-        rc = launch_detect(h, nb, view0, h->stream, rcall);
+        rc = launch_detect(h, nb, view0, h->stream, rcall, false, o.d_anc, o.d_res);
         if (rc) return rc;
-        rc = launch_scan_slice(h, nb, view0, o.d_anc, o.d_dib, o.dstride, nullptr, nullptr, 0, o.d_res, true, h->stream, rcall);
+        rc = launch_scan_slice(h, nb, view0, o.d_anc, o.d_dib, o.dstride, nullptr, nullptr, 0, o.d_res, true, h->stream, rcall, true);
         if (rc) return rc;
         hipLaunchKernelGGL(k_tail_extract, dim3((unsigned)C), dim3(WV), 0, h->stream, cr);
         HIPCHK(h, hipGetLastError());
@@ -1870,7 +1948,7 @@ int p25fe_run_cf32(p25fe_t* h, const float* iq, size_t n_samples, uint8_t* dibit
 int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t window, uint8_t* dibits, size_t cap,
                            size_t* n_dibits, p25fe_windows_stats_t* stats)
 {
-    if (!h || (!iq && n) || !dibits || !n_dibits || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8)) return P25FE_ERR_ARG;
+    if (!h || (!iq && n) || !dibits || !n_dibits || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) || piecewise_refused(h)) return P25FE_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->fmt_locked >= 0 && h->fmt_locked != fmt && h->abs_iq > 0) return P25FE_ERR_FORMAT;
     const size_t C = (size_t)h->C, eb = fmt_bytes(fmt);
@@ -1999,9 +2077,9 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         const PlanarGeo g(nb ? nb : 1);
         if (nb) {
             rc = launch_frontend(h, dev + SHARD_HALO * eb, fmt, stride, n_hist, wn, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g);
-            if (!rc) rc = launch_detect(h, nb, view0, st, rcall);
+            if (!rc) rc = launch_detect(h, nb, view0, st, rcall, false, d_anc + (size_t)b * C, d_res);
         }
-        if (!rc) rc = launch_scan_slice(h, nb, view0, d_anc + (size_t)b * C, d_dib, dstride, nullptr, nullptr, 0, d_res, nb != 0, st, rcall);
+        if (!rc) rc = launch_scan_slice(h, nb, view0, d_anc + (size_t)b * C, d_dib, dstride, nullptr, nullptr, 0, d_res, nb != 0, st, rcall, nb != 0);
         if (rc) { status = rc; break; }
         hipLaunchKernelGGL(k_anchors_from_results, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, d_res, d_anc + (size_t)(b ^ 1) * C, (int)C);
         if (k + 1 == n_win && nb) {                                  // the baseband tail for a later p25fe_slice on this handle
@@ -2270,16 +2348,5 @@ int p25fe_state_import(p25fe_t* h, const void* buf, size_t n)
     return P25FE_OK;
 }
 
-#ifdef P25FE_K1_STAMP
-// measurement builds only: read (and clear) K1's per-phase cycle sums; out[7] = sub-tiles counted
-int p25fe_debug_k1_stamps(uint64_t out[16])
-{
-    std::vector<unsigned long long> z((size_t)p25k::K1_STAMP_SLOTS * 16, 0ull), v(z.size());
-    if (hipMemcpyFromSymbol(v.data(), HIP_SYMBOL(p25k::g_k1_stamp), v.size() * 8) != hipSuccess) return P25FE_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(p25k::g_k1_stamp), z.data(), z.size() * 8) != hipSuccess) return P25FE_ERR_HIP;
-    for (int i = 0; i < 16; ++i) out[i] = 0;
-    for (size_t k = 0; k < v.size(); ++k) out[k & 15] += v[k];
-    return P25FE_OK;
-}
-#endif
+P25FE_M_API_EXTRAS
 }  // extern "C"

@@ -32,6 +32,43 @@
 
 namespace p25k {
 
+// ---- measurement hooks -------------------------------------------------------------------------------------------------------------
+// The product's kernels -- and the source hipRTC compiles for a caller's numbers -- hold NO measurement code.  The builds that time
+// parts of K1 / K2 / K6 (tools/ablate.sh, tools/k1_stamps.py, tools/k6_variants.sh, the model of docs/K1_MODEL.md: `make variant
+// DEFS="-DP25FE_MEASURE ..."`) get the bodies of the hooks below from p25fe_measure.inc, which is neither part of the library's
+// embedded source nor read by the product build.  Here every hook is empty (or the constant `false`), so the product's ISA does not
+// depend on them (tests/test_isa_lint.py; the kernels' text is identical to that of the build that had the code inline).
+#ifdef P25FE_MEASURE
+#include "p25fe_measure.inc"
+#else
+#define P25FE_M_LOAD_OFFSET(product_, cached_row_) (product_)      // the window loader's byte offset
+#define P25FE_M_ENTRY do { } while (0)                              // frontend_body: entry
+#define P25FE_M_LOCALS do { } while (0)                             // ... its counters
+#define P25FE_M_ITEM do { } while (0)                               // ... top of a work item
+#define P25FE_M_SUBTILE do { } while (0)                            // ... top of a sub-tile
+#define P25FE_M_EXIT do { } while (0)                               // ... exit
+#define K1_STAMP(i) do { } while (0)                                // phase boundary i of a sub-tile
+#define K1_PIN2(a, b) do { } while (0)
+#define P25FE_M_PIN_V2(arr_, n_) do { } while (0)
+#define P25FE_M_PIN_F2(arr_, n_) do { } while (0)
+#define P25FE_M_CUT_LOADS do { } while (0)                          // truncated builds: leave the sub-tile after stage N
+#define P25FE_M_CUT(stage_) do { } while (0)
+#define P25FE_M_CUT_KEEP_F2(stage_, arr_, n_) do { } while (0)
+#define P25FE_M_CUT_KEEP_F(stage_, arr_, n_) do { } while (0)
+#define P25FE_M_KEEP1(a_) do { } while (0)
+#define P25FE_M_KEEP2(a_, b_) do { } while (0)
+#define P25FE_M_K6_STORES_ONLY do { } while (0)
+#define P25FE_M_NO_BB_STORES false                                  // parts of the output stream left out
+#define P25FE_M_NO_SIGN_PLANES false
+#define P25FE_M_NO_CH_FMA false
+#define P25FE_M_NO_OUT_STAGE false
+#define P25FE_M_DET_CUT_SCREEN do { } while (0)                     // K2 truncated after its screen / without its peak test
+#define P25FE_M_DET_NO_PEAK_TEST false
+#define P25FE_M_PIPE_NOWAIT() false                                 // host side (p25fe_api.hip)
+#define P25FE_M_API_EXTRAS
+#endif
+
+
 // (own two-line versions: hipRTC has no <type_traits>)
 template <int V> struct icst { static constexpr int value = V; };
 template <bool B, class A, class C> struct cond { using type = A; };
@@ -496,11 +533,7 @@ template <int FMT, int PK, int TX = 0, int NVX = 0> struct Loader {
         const int voff = (int)rel + VB * tid;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-#if (defined(P25FE_ABLATE) && P25FE_ABLATE == 6) || defined(P25FE_ABLATE_CACHED)     // measurement build: every window load hits one cached vector row
-            const int o = VB * tid;
-#else
-            const int o = voff + j * VB * WV;
-#endif
+            const int o = P25FE_M_LOAD_OFFSET(voff + j * VB * WV, VB * tid);
             if constexpr (FMT == P25FE_FMT_CF32) {
                 const v4u_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, P25FE_K1_LD_AUX);
                 v[j] = make_uint4(t.x, t.y, t.z, t.w);
@@ -641,24 +674,6 @@ struct K1Args {
 #ifndef P25FE_K1_PF_U8
 #define P25FE_K1_PF_U8 2
 #endif
-// Measurement builds only (-DP25FE_K1_STAMP): a wave accumulates the shader-clock time of each phase of its sub-tiles
-// and adds the sums to g_k1_stamp at its end (read through p25fe_debug_k1_stamps).  s_memtime + s_waitcnt lgkmcnt(0) per
-// stamp: the phase boundaries drain the LDS queue, which the product does not do everywhere.
-#ifdef P25FE_K1_STAMP
-constexpr int K1_STAMP_SLOTS = 8192;          // workgroup b adds into slot b % 8192: no hot address
-__device__ unsigned long long g_k1_stamp[K1_STAMP_SLOTS][16];
-#define K1_STAMP(i)                                                                   \
-    do {                                                                              \
-        unsigned long long t_;                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
-        st_acc[i] += t_ - st_last;                                                    \
-        st_last = t_;                                                                 \
-    } while (0)
-#define K1_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#else
-#define K1_STAMP(i) do { } while (0)
-#define K1_PIN2(a, b) do { } while (0)
-#endif
 template <int FMT, bool CT, int PK, int OM = OUT_LINEAR, int TX = 0>
 __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __restrict__ gtaps)
 {
@@ -667,10 +682,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     static_assert(TX == 0 || !CT, "the 64-tap geometry is for caller-supplied taps");
 #endif
     static_assert(OM == OUT_LINEAR || PK == 5, "the planar epilogue maps a 320-sample sub-tile onto 10 planes x 32 symbols");
-#ifdef P25FE_K1_STAMP
-    unsigned long long st_t0, st_r0;                                // entry: shader clock / constant 100 MHz clock
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
-#endif
+    P25FE_M_ENTRY;
     using G = Geo<PK, TX>;
     constexpr int SUB = G::SUB;
     constexpr int P = PK;
@@ -723,9 +735,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     constexpr int PBASE = 2 * WV * NVP;                             // the d's are parked behind the staged prologue window
     constexpr int NDL = (ND + WV - 1) / WV;                         // d's per lane: 1 (2)
     static_assert(PBASE + ND <= G::XIN_N && D_CARRY <= ND, "prologue scratch fits the window region");
-#ifdef P25FE_K1_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_n = 0, st_pro = 0, st_items = 0;
-#endif
+    P25FE_M_LOCALS;
     // Work items (segment, channel) are taken in a grid-stride loop: the launch holds one workgroup per resident wave
     // slot, wave b works on items b, b + G, b + 2 G, ... (consecutive items = consecutive segments of one channel, so at
     // any moment the resident waves stream one compact, advancing region of the capture -- what the dispatcher's in-order
@@ -735,12 +745,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     const bool grid2d = gridDim.x == (unsigned)a.seg_count;         // uniform: one workgroup per item, blockIdx.y = channel
     for (long item = grid2d ? (long)blockIdx.y * a.seg_count + blockIdx.x : (long)blockIdx.x; item < n_items;
          item += grid2d ? n_items : (long)gridDim.x) {
-#ifdef P25FE_K1_STAMP
-    unsigned long long st_i0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_i0)::"memory");
-    bool st_first_sub = true;
-    ++st_items;
-#endif
+    P25FE_M_ITEM;
     const int ch = grid2d ? (int)blockIdx.y : (int)((unsigned)item / (unsigned)a.seg_count);
     const long seg_rel = grid2d ? (long)blockIdx.x : item - (long)ch * a.seg_count;
     const long seg = seg_rel + a.seg_first;
@@ -912,24 +917,22 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 const int r = out_rel + SPS_ * pl_sym + pl_h5 + q;
-#if defined(P25FE_EXP) && (P25FE_EXP & 8)      // measurement build: no baseband stores at all (what the write stream costs)
-                asm volatile("" ::"v"(outv[q]), "v"(r));
-#else
+                if constexpr (P25FE_M_NO_BB_STORES) { P25FE_M_KEEP2(outv[q], r); }
+                else {
 #if P25FE_K1_NT_STORES
                 if (r >= 0 && r < seg_n) __builtin_nontemporal_store(outv[q], row + 32 * q);
 #else
                 if (r >= 0 && r < seg_n) row[32 * q] = outv[q];
 #endif
-#endif
+                }
             }
             // a byte = 8 symbols = 80 consecutive outputs of one plane; out_rel is a multiple of 80, so a byte is
             // either wholly inside the segment or wholly halo (the range's last byte may carry bits past n_out: unread)
             const int r0 = out_rel + 8 * SPS_ * (tid & 3) + (tid >> 2);
             const int ib = i_sub + 8 * (tid & 3);
-#if !(defined(P25FE_EXP) && (P25FE_EXP & 1))   // (measurement build: no sign planes)
+            if constexpr (!P25FE_M_NO_SIGN_PLANES)
             if (tid < 4 * SPS_ && r0 >= 0 && r0 < seg_n)
                 bits_ch[((size_t)(ib >> 5) * SPS_ + (tid >> 2)) * 4 + ((ib >> 3) & 3)] = (uint8_t)bitsv;
-#endif
             }
         }
     };
@@ -937,11 +940,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
     // One sub-tile.  `ld` holds its window (requested PF sub-tiles ago) and is refilled with the window PF sub-tiles ahead.
     auto sub_tile = [&](auto& ld) -> bool {
         if (dlo >= m_seg1) return false;                           // uniform
-#ifdef P25FE_K1_STAMP
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-        if (st_first_sub) { st_pro += st_last - st_i0; st_first_sub = false; }
-        ++st_n;
-#endif
+        P25FE_M_SUBTILE;
         const long first = (long)a.o0 + DEC * dlo - (T1 - 1);      // XIN[xsh + k] = x[first + k]
         const int xsh = (int)(first & 1);                           // window start relative to the aligned staging origin
 #if P25FE_K1_TURNAROUND_PRIO
@@ -963,20 +962,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #endif
         K1_STAMP(1);                                                // previous outputs stored, next window requested
 
-#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 1      // measurement builds only (tools/ablate.sh): stop after the load pipeline
-#if defined(P25FE_ABLATE_STORES)                    // ... but keep the OUTPUT stream: the next iteration stores this sub-tile's (zero) planes --
-        out_rel = (int)(dlo - m_seg0);              // K1's whole HBM traffic (window reads + baseband / sign-plane writes) without its arithmetic
-#endif
-#if defined(P25FE_DRIFT)                            // ... with pseudo-random idle phases (units of 64 cycles) in place of the arithmetic
-        {
-            unsigned hsh = (unsigned)blockIdx.x * 2654435761u + (unsigned)(dlo & 0xffff) * 40503u;
-            hsh ^= hsh >> 13;
-            const int units = P25FE_DRIFT + (int)(hsh % (unsigned)(P25FE_DRIFT_SPREAD + 1));
-            for (int u = 0; u < units; ++u) __builtin_amdgcn_s_sleep(1);
-        }
-#endif
-        return true;
-#endif
+        P25FE_M_CUT_LOADS;                                          // (measurement builds: stop after the load pipeline)
         // ---- stage 2: 5:1 decimating FIR (src/demod.rs:87). Lane: d[dlo + P tid + p], p = 0..P-1.
         // Output p needs x[first + 5(P tid + p) + (T1-1) - k], k = 0..T1-1  -> XIN[5 P tid + 5p + 30 - k].
         {
@@ -995,19 +981,14 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             // d overwrites the front of the window: every lane's window reads must be complete first.  (The compiler
             // reasons per thread and could prove a lane's own store and loads disjoint -- the fence orders the wave.)
             phase_sync();
-#ifdef P25FE_K1_STAMP
-#pragma unroll
-            for (int p = 0; p < P; ++p) K1_PIN2(acc[p].x, acc[p].y);
+            P25FE_M_PIN_V2(acc, P);
             K1_STAMP(2);                                            // decimator
-#endif
 #pragma unroll
             for (int p = 0; p < P; ++p) D[D_CARRY + P * tid + p] = make_float2(acc[p].x, acc[p].y);
         }
         phase_sync();
 
-#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 2
-        return true;
-#endif
+        P25FE_M_CUT(2);
         // ---- stage 3: channel FIR (src/demod.rs:93). Lane: y[dlo + P tid + p] from D[P tid + p + 40 - k].
         float2 y[P];
         {
@@ -1020,11 +1001,8 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const int k = p + (T2 - 1) - j;
-#if defined(P25FE_EXP) && (P25FE_EXP & 4)      // measurement build: the channel filter's FMAs gone (upper bound of moving them off the VALU)
-                    if (k == 0) yv[p] = s;
-#else
-                    if (k >= 0 && k < T2) yv[p] = cfma(tap_ch(k), s, yv[p]);
-#endif
+                    if constexpr (P25FE_M_NO_CH_FMA) { if (k == 0) yv[p] = s; }
+                    else if (k >= 0 && k < T2) yv[p] = cfma(tap_ch(k), s, yv[p]);
                 }
             });
 #pragma unroll
@@ -1040,20 +1018,13 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
                 }
             }
         }
-#ifdef P25FE_K1_STAMP
-#pragma unroll
-        for (int p = 0; p < P; ++p) K1_PIN2(y[p].x, y[p].y);
+        P25FE_M_PIN_F2(y, P);
         K1_STAMP(3);                                                // d stores + channel filter
-#endif
         phase_sync();                                               // all reads of D done before its carry is rewritten
         // carry the d history to the next sub-tile (ordered before its next use by the next phase boundaries)
         for (int k = tid; k < D_CARRY; k += WV) D[k] = D[SUB + k];
 
-#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 3
-#pragma unroll
-        for (int p = 0; p < P; ++p) asm volatile("" ::"v"(y[p].x), "v"(y[p].y));     // keep the filter alive
-        return true;
-#endif
+        P25FE_M_CUT_KEEP_F2(3, y, P);
         // ---- stage 4: FM discriminator (src/demod.rs:109-111) on the lane's own P outputs; the sample before
         // the first one comes from lane-1 (DPP), for lane 0 from the previous sub-tile (SGPR carry)
         float f[P];
@@ -1067,16 +1038,9 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             y_carry.x = lane_bcast<WV - 1>(y[P - 1].x);
             y_carry.y = lane_bcast<WV - 1>(y[P - 1].y);
         }
-#ifdef P25FE_K1_STAMP
         K1_PIN2(f[0], f[1]); K1_PIN2(f[2], f[P - 2]); K1_PIN2(f[P - 1], f[0]);
         K1_STAMP(4);                                                // d carry copy + discriminator
-#endif
-
-#if defined(P25FE_ABLATE) && P25FE_ABLATE <= 4
-#pragma unroll
-        for (int p = 0; p < P; ++p) asm volatile("" ::"v"(f[p]));
-        return true;
-#endif
+        P25FE_M_CUT_KEEP_F(4, f, P);
         // ---- stage 5: post-discriminator filter (src/demod.rs:114; docs/SPEC.md 3.5).  The reference's is MovingAverage::new(10):
         // b[m] = (fm[m] + fm[m-1] + ... + fm[m-9]) * 0.1, summed newest first -- the rule for every table whose taps are all
         // equal; any other table is a FIR like the two before it: acc = +0, acc = fma(h[k], fm[m - k], acc) in tap order.
@@ -1109,11 +1073,8 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
 #pragma unroll
                     for (int j = 0; j < T3; ++j) acc = __builtin_fmaf(K1_CT_AVG_TAPS[j], fm_back(p, j), acc);
                 }
-#if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
-                asm volatile("" ::"v"(acc));
-#else
-                OUT[P * tid + p] = acc;                             // lane stride P dwords (odd): conflict-free
-#endif
+                if constexpr (P25FE_M_NO_OUT_STAGE) { P25FE_M_KEEP1(acc); }
+                else OUT[P * tid + p] = acc;                        // lane stride P dwords (odd): conflict-free
             }
             // next sub-tile's lane 0 / 1 / ... read these: lane 63 is one lane back, lane 62 two, ...
 #pragma unroll
@@ -1187,9 +1148,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             phase_sync();                                           // every lane's window reads precede the carry's rewrite
             for (int k = tid; k < T3 - 1; k += WV) FM[k] = FM[SUB + k];
         }
-#if defined(P25FE_ABLATE) && P25FE_ABLATE == 5
-        return true;
-#endif
+        if constexpr (P25FE_M_NO_OUT_STAGE) return true;
         phase_sync();
         K1_STAMP(5);                                                // boxcar + transpose stores
         // transpose through LDS: lane-consecutive outputs -> coalesced (deferred) global stores
@@ -1206,9 +1165,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
                 outv[q] = OUT[SPS_ * pl_sym + pl_h5 + q];
                 sg[q] = __builtin_amdgcn_ballot_w64(__float_as_int(outv[q]) < 0);
             }
-#if !(defined(P25FE_EXP) && (P25FE_EXP & 1))
-            w = lanes_from_ballots(sg);                              // lane q: word of plane q, lane q + 5: plane q + 5
-#endif
+            if constexpr (!P25FE_M_NO_SIGN_PLANES) w = lanes_from_ballots(sg);        // lane q: word of plane q, lane q + 5: plane q + 5
             if constexpr (PRO) {
                 bitsv = w;
             } else {
@@ -1218,10 +1175,8 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
         }
         out_rel = (int)(dlo - m_seg0);
         phase_sync();
-#ifdef P25FE_K1_STAMP
         K1_PIN2(outv[0], outv[P - 1]);
         K1_STAMP(6);                                                // transpose reads (+ sign words)
-#endif
         return true;
     };
     if constexpr (PF == 1) {
@@ -1262,20 +1217,7 @@ __device__ __forceinline__ void frontend_body(const K1Args& a, const Taps* __res
             }
         }
     }
-#ifdef P25FE_K1_STAMP
-    if (tid == 0) {
-        unsigned long long st_t1, st_r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1), "=s"(st_r1)::"memory");
-        unsigned long long* slot = g_k1_stamp[blockIdx.x % K1_STAMP_SLOTS];
-        for (int i = 0; i < 7; ++i) atomicAdd(&slot[i], st_acc[i]);
-        atomicAdd(&slot[7], st_n);
-        atomicAdd(&slot[8], st_pro);                                // prologues: item start -> its first sub-tile
-        atomicAdd(&slot[9], st_t1 - st_t0);                         // lifetime, shader clock
-        atomicAdd(&slot[10], st_r1 - st_r0);                        // lifetime, 100 MHz clock
-        atomicAdd(&slot[11], 1ull);                                 // workgroups
-        atomicAdd(&slot[12], st_items);                             // work items
-    }
-#endif
+    P25FE_M_EXIT;
 }
 
 // (register budget of the generic u8 kernels: one wave per SIMD less than the immediate-coefficient ones -- the taps' LDS
@@ -1592,24 +1534,7 @@ __global__ __launch_bounds__(WV, P25FE_CZ_WPS) void k_channelise(ChzArgs a)
     // c1 in groups of CZ_G (a rolled loop: the c1-dependent twiddles come from CZ_TW by scalar loads): the 80 products
     // a[p] = h[p] x[n - p] are re-formed from LDS once per group (window position 79 + 10 lane - p -> phase
     // 9 - p % 10, column lane + 7 - p / 10) instead of living in 160 registers
-#if defined(P25FE_ABLATE6)                          // measurement build (tools/k6_variants.sh): the store stream alone
-    {
-        const float2 xv = lds_read_c(X + lane);
-#if P25FE_ABLATE6 == 2                              // ... as 16-byte stores: a lane pair writes two instants of two rows
-        float4* const y4 = reinterpret_cast<float4*>(yb - (lane & 1));
-#pragma unroll 1
-        for (int c = 0; c < CZ_M; c += 2) {
-            typedef float __attribute__((ext_vector_type(4))) f32x4;
-            f32x4 ov; ov.x = xv.x + (float)c; ov.y = xv.y; ov.z = xv.x; ov.w = xv.y;
-            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4*>(reinterpret_cast<float2*>(y4) + (size_t)(c + (lane & 1)) * a.y_stride));
-        }
-#else
-#pragma unroll 1
-        for (int c = 0; c < CZ_M; ++c) yb[(size_t)c * a.y_stride] = make_float2(xv.x + (float)c, xv.y);
-#endif
-        return;
-    }
-#endif
+    P25FE_M_K6_STORES_ONLY;                                         // (measurement builds: the store stream alone)
 #pragma unroll 1
     for (int c1g = 0; c1g < CZ_C1; c1g += CZ_G) {
         float2 BB[CZ_G][CZ_C2];

@@ -65,7 +65,6 @@ struct p25fe_shard {
                                           // their streams -- step j + 1's all-gather (receive stream) would wait for step j's dibit gather (side
                                           // stream, megabytes at N = 8) and miss the K1 boundary both were meant to share
     hipEvent_t e_stage = nullptr;         // pipelined steps: summaries gathered (receive stream) -> pass 2 and the dibit gather (side stream)
-    std::vector<hipStream_t> probed;      // caller's streams the CURRENT side stream has been checked against (p25fe_streams_share_queue)
     int pipe_layout = 2;                  // measurement knob P25FE_SHARD_PIPE_LAYOUT: 1 = the step's own order on the receive stream
     Shm shm;
     hipStream_t cs = nullptr;             // the halo exchange and the shard's head segment run beside K1's main launch
@@ -90,6 +89,9 @@ struct p25fe_shard {
     int gather_ran = P25FE_GATHER_NONE;   // how the last step's dibits actually travelled
     bool head_event_wait = false;         // measurement knob (P25FE_SHARD_HEAD_WAIT=event)
     bool broken = false;                  // a collective failed half-way: the communicator's state is unknown, every later step fails
+    bool coll_issued = false;             // the current step has put a collective on the wire (a failure behind it retires the object)
+    int rccl_ranks = 0, rccl_rank = -1;   // what the communicator itself says (ncclCommCount / ncclCommUserRank): p25fe_shard_info
+    char pci[32] = {0};                   // hipDeviceGetPCIBusId of the handle's device
 };
 
 #define HCHK(x) do { if ((x) != hipSuccess) return P25FE_ERR_HIP; } while (0)
@@ -97,6 +99,34 @@ struct p25fe_shard {
 // inside ncclGroupStart / ncclGroupEnd: close the group before returning (an open group would swallow every later collective
 // of this communicator) and retire the shard object
 #define NCHK_G(s, x) do { if ((x) != ncclSuccess) { (void)ncclGroupEnd(); (s)->broken = true; return P25FE_ERR_HIP; } } while (0)
+
+// The side stream must not sit on the hardware queue of a stream whose work it is meant to run BESIDE: HIP hands the streams of one
+// priority level four queues to share, in creation order, and two streams on one queue run their kernels one after the other -- the halo
+// would no longer hide behind K1, the pipelined step's second stage would hold up the next K1 (measured: 0.35 - 0.36 ms per step instead
+// of 0.28 / 0.33).  The probe synchronises the streams it compares (< 1 ms each), so it runs where that is allowed: in p25fe_shard_create
+// (against the handle's receive stream) and in p25fe_shard_prepare (against a caller's stream and the receive stream) -- never inside a
+// step (a step must not synchronise the host, and a capturing stream cannot be probed).  A side stream that shares is replaced
+// by a fresh one (the rejected ones stay alive until the search ends: their queue slots stay taken).
+static int side_stream_apart(p25fe_shard_t* s, hipStream_t a, hipStream_t b)
+{
+    const char* e = getenv("P25FE_SHARD_QUEUE_PROBE");
+    if (e && atoi(e) == 0) return P25FE_OK;
+    std::vector<hipStream_t> rejected;
+    try {
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            int sh_a = 0, sh_b = 0;
+            if (p25fe_streams_share_queue(s->h, a, s->cs, &sh_a) != P25FE_OK) break;
+            if (b && b != a && p25fe_streams_share_queue(s->h, b, s->cs, &sh_b) != P25FE_OK) break;
+            if (!sh_a && !sh_b) break;
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+            rejected.push_back(s->cs);
+            s->cs = fresh;
+        }
+    } catch (...) {}
+    for (hipStream_t r : rejected) { (void)hipStreamSynchronize(r); (void)hipStreamDestroy(r); }
+    return P25FE_OK;
+}
 
 extern "C" {
 
@@ -205,10 +235,33 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
             memcpy(&id, id128, sizeof id);
             if (ncclCommInitRank(&s->comm, world, id, rank) != ncclSuccess) return fail(P25FE_ERR_HIP);
             if (world == 1 && hipMalloc(&s->d_loop, s->halo * 8) != hipSuccess) return fail(P25FE_ERR_NOMEM);
-            // (every rank makes this call: a collective on the parent communicator.  A failure leaves the pipelined step on its
-            // one-communicator layout.)
-            if (ncclCommSplit(s->comm, 0, rank, &s->comm_halo, nullptr) != ncclSuccess) s->comm_halo = nullptr;
-            if (s->comm_halo && ncclCommSplit(s->comm, 0, rank, &s->comm_summ, nullptr) != ncclSuccess) s->comm_summ = nullptr;
+            if (ncclCommCount(s->comm, &s->rccl_ranks) != ncclSuccess || ncclCommUserRank(s->comm, &s->rccl_rank) != ncclSuccess ||
+                s->rccl_ranks != world || s->rccl_rank != rank)
+                return fail(P25FE_ERR_HIP);                              // the communicator is not the one the caller described
+            // Two more communicators for the pipelined step (halo, summaries).  ncclCommSplit is a collective on the parent: EVERY rank
+            // makes BOTH calls whatever the first one returned here (a rank that skipped the second would leave its peers inside it),
+            // and what the step may use is then AGREED: an all-reduce (min) of {halo split ok, summary split ok, layout wanted} on the
+            // parent communicator -- ranks that disagreed would issue the halo and the summaries on different communicators and
+            // streams and hang without a word.  Any rank without a split, or asking for layout 1, puts every rank on the
+            // one-communicator layout.  (Test knob P25FE_SHARD_SPLIT_FAIL = "all" or a rank number: that rank discards its splits.)
+            const bool ok_h = ncclCommSplit(s->comm, 0, rank, &s->comm_halo, nullptr) == ncclSuccess && s->comm_halo;
+            const bool ok_s = ncclCommSplit(s->comm, 0, rank, &s->comm_summ, nullptr) == ncclSuccess && s->comm_summ;
+            int agree[3] = {ok_h ? 1 : 0, ok_s ? 1 : 0, s->pipe_layout};
+            if (const char* sf = getenv("P25FE_SHARD_SPLIT_FAIL"))
+                if (!strcmp(sf, "all") || (*sf >= '0' && *sf <= '9' && atoi(sf) == rank)) agree[0] = agree[1] = 0;
+            int* d_agree = nullptr;
+            if (hipMalloc(&d_agree, sizeof agree) != hipSuccess) return fail(P25FE_ERR_NOMEM);
+            bool agreed = hipMemcpy(d_agree, agree, sizeof agree, hipMemcpyHostToDevice) == hipSuccess &&
+                          ncclAllReduce(d_agree, d_agree, 3, ncclInt32, ncclMin, s->comm, s->cs) == ncclSuccess &&
+                          hipStreamSynchronize(s->cs) == hipSuccess &&
+                          hipMemcpy(agree, d_agree, sizeof agree, hipMemcpyDeviceToHost) == hipSuccess;
+            (void)hipFree(d_agree);
+            if (!agreed) return fail(P25FE_ERR_HIP);
+            if (!(agree[0] && agree[1]) || agree[2] != 2) {
+                if (s->comm_halo) { (void)ncclCommDestroy(s->comm_halo); s->comm_halo = nullptr; }
+                if (s->comm_summ) { (void)ncclCommDestroy(s->comm_summ); s->comm_summ = nullptr; }
+                s->pipe_layout = 1;
+            }
         } else {
             const char* name = getenv("P25FE_SHARD_SHM");
             if (!name || s->halo * 8 > SHM_HALO_MAX) return fail(P25FE_ERR_ARG);
@@ -225,7 +278,42 @@ int p25fe_shard_create(p25fe_t* h, int rank, int world, const void* id128, size_
             s->shm.hd->row_bytes = s->cap;
         }
     }
+    if (hipDeviceGetPCIBusId(s->pci, (int)sizeof s->pci, p25fe_device(h)) != hipSuccess) { (void)hipGetLastError(); s->pci[0] = 0; }
+    // the handle's own streams must not share a hardware queue with the side stream (p25fe_shard_prepare does the same for a caller's)
+    if (!s->staged) {
+        void* rx = nullptr;
+        if (p25fe_rx_stream(h, &rx) == P25FE_OK) (void)side_stream_apart(s, (hipStream_t)rx, nullptr);
+    }
     *out = s;
+    return P25FE_OK;
+}
+
+int p25fe_shard_prepare(p25fe_shard_t* s, void* stream)
+{
+    if (!s) return P25FE_ERR_ARG;
+    if (s->staged) return P25FE_OK;
+    HCHK(hipSetDevice(p25fe_device(s->h)));
+    void* rx = nullptr;
+    const int rc = p25fe_rx_stream(s->h, &rx);
+    if (rc) return rc;
+    return side_stream_apart(s, (hipStream_t)stream, (hipStream_t)rx);
+}
+
+int p25fe_shard_info(const p25fe_shard_t* s, p25fe_shard_info_t* out)
+{
+    if (!s || !out) return P25FE_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    out->rank = s->rank; out->world = s->world;
+    out->rccl_ranks = s->comm ? s->rccl_ranks : 0; out->rccl_rank = s->comm ? s->rccl_rank : -1;
+    out->device = p25fe_device(s->h);
+    out->comms = !s->comm ? 0 : ((s->comm_halo && s->comm_summ) ? 3 : 1);
+    out->pipe_layout = (s->pipe_layout == 2 && (s->comm_halo || !s->comm)) ? 2 : 1;
+    out->gather_ran = s->gather_ran;
+    out->staged = s->staged ? 1 : 0;
+    out->head_wait = s->head_event_wait ? 1 : 0;
+    out->broken = s->broken ? 1 : 0;
+    out->steps = s->steps;
+    memcpy(out->pci_bus_id, s->pci, sizeof out->pci_bus_id);
     return P25FE_OK;
 }
 
@@ -262,33 +350,6 @@ static int exact_offsets_wait(p25fe_shard_t* s)
 
 } // extern "C"
 
-// The side stream must not sit on the hardware queue of the caller's stream: HIP hands the streams of one priority level four queues
-// to share, in creation order, and two streams on one queue run their kernels one after the other -- the halo would no longer hide
-// behind K1, the pipelined step's second stage would hold up the next K1 (measured: 0.35 - 0.36 ms per step instead of 0.28 / 0.33).
-// Checked once per caller's stream (the probe synchronises both streams, < 1 ms): a side stream that shares is replaced by a fresh one.
-static int pick_side_stream(p25fe_shard_t* s, hipStream_t st)
-{
-    for (hipStream_t p : s->probed) if (p == st) return P25FE_OK;    // (a host that alternates between a few streams is probed once per stream)
-    std::vector<hipStream_t> rejected;
-    try {
-        if (s->probed.size() >= 8) s->probed.clear();
-        s->probed.push_back(st);
-        const char* e = getenv("P25FE_SHARD_QUEUE_PROBE");
-        if (e && atoi(e) == 0) return P25FE_OK;
-        for (int attempt = 0; attempt < 8; ++attempt) {
-            int shared = 0;
-            if (p25fe_streams_share_queue(s->h, st, s->cs, &shared) != P25FE_OK || !shared) break;
-            hipStream_t fresh = nullptr;
-            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
-            rejected.push_back(s->cs);                              // kept alive until the search ends: its queue slot stays taken
-            s->cs = fresh;
-            s->probed.assign(1, st);                                // the new side stream has been checked against this stream only
-        }
-    } catch (...) {}
-    for (hipStream_t r : rejected) { (void)hipStreamSynchronize(r); (void)hipStreamDestroy(r); }
-    return P25FE_OK;
-}
-
 // Where the launches of one step go.
 //   plain step:       everything on the caller's stream; halo + head on the side stream beside K1's main launch.
 //   pipelined, 1:     K1's main launch on the caller's stream, everything behind it on the handle's receive stream (rx = rx2).
@@ -299,13 +360,16 @@ static int pick_side_stream(p25fe_shard_t* s, hipStream_t st)
 //                     compaction on the side stream (rx2): two stages, each one step long, so that the exchange that ends a stage
 //                     finds its K1 boundary without holding up the next step's first stage.
 struct StepStreams { hipStream_t st, rx, rx2; bool halo_on_st; };
+static bool step_args_ok(const void* d_buf, int fmt, const void* d_dibits, const void* d_result, int gather)
+{
+    return d_buf && d_dibits && d_result && (fmt == P25FE_FMT_CF32 || fmt == P25FE_FMT_U8) && gather >= P25FE_GATHER_NONE &&
+           gather <= P25FE_GATHER_ROOT_EXACT;
+}
 static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather,
                            const StepStreams& ss)
 {
     const hipStream_t st = ss.st, rx = ss.rx;
-    if (!s || !d_buf || !d_dibits || !d_result || (fmt != P25FE_FMT_CF32 && fmt != P25FE_FMT_U8) || gather < P25FE_GATHER_NONE ||
-        gather > P25FE_GATHER_ROOT_EXACT)
-        return P25FE_ERR_ARG;
+    if (!s || !step_args_ok(d_buf, fmt, d_dibits, d_result, gather)) return P25FE_ERR_ARG;
     const size_t eb = fmt == P25FE_FMT_CF32 ? 8 : 2;
     char* buf = static_cast<char*>(d_buf);
     char* owned = buf + s->halo * eb;
@@ -339,6 +403,7 @@ static int shard_step_impl(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_di
                 HCHK(hipStreamWaitEvent(s->cs, s->e_fork, 0));
             }
             if (timed) HCHK(hipEventRecord(ev[0], hs));
+            s->coll_issued = true;
             NCHK(ncclGroupStart());
             if (s->rank + 1 < s->world) NCHK_G(s, ncclSend(buf + s->n * eb, s->halo * eb, ncclUint8, s->rank + 1, hc, hs));
             if (s->rank > 0) NCHK_G(s, ncclRecv(buf, s->halo * eb, ncclUint8, s->rank - 1, hc, hs));
@@ -486,9 +551,11 @@ int p25fe_shard_step(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, 
     if (!s) return P25FE_ERR_ARG;
     if (s->broken) return P25FE_ERR_HIP;
     HCHK(hipSetDevice(p25fe_device(s->h)));
-    if (!s->staged) (void)pick_side_stream(s, (hipStream_t)stream);
     const StepStreams ss = {(hipStream_t)stream, (hipStream_t)stream, (hipStream_t)stream, false};
-    return shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
+    s->coll_issued = false;
+    const int rc = shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
+    if (rc && s->coll_issued) s->broken = true;                     // peers may already be inside an exchange this rank will not finish
+    return rc;
 }
 
 int p25fe_shard_step_pipelined(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* d_dibits, p25fe_result_t* d_result, int gather, void* stream)
@@ -496,11 +563,12 @@ int p25fe_shard_step_pipelined(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* 
     if (!s) return P25FE_ERR_ARG;
     if (s->broken) return P25FE_ERR_HIP;
     HCHK(hipSetDevice(p25fe_device(s->h)));
+    if (!step_args_ok(d_buf, fmt, d_dibits, d_result, gather)) return P25FE_ERR_ARG;      // before any state moves (scratch rotation, buffer swap)
+    s->coll_issued = false;
     if (s->staged) {                                                 // the test hook synchronises the host between its phases: nothing to overlap
         const StepStreams ss = {(hipStream_t)stream, (hipStream_t)stream, (hipStream_t)stream, false};
         return shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
     }
-    (void)pick_side_stream(s, (hipStream_t)stream);
     void* rx = nullptr;
     int rc = p25fe_shard_pipe_begin(s->h, stream, &rx);
     if (rc) return rc;
@@ -511,7 +579,13 @@ int p25fe_shard_step_pipelined(p25fe_shard_t* s, void* d_buf, int fmt, uint8_t* 
     const bool two_stage = s->pipe_layout == 2 && (s->comm_halo || !s->comm);
     const StepStreams ss = {(hipStream_t)stream, (hipStream_t)rx, two_stage ? s->cs : (hipStream_t)rx, two_stage};
     rc = shard_step_impl(s, d_buf, fmt, d_dibits, d_result, gather, ss);
-    const int erc = p25fe_shard_pipe_end(s->h, ss.rx2);              // (also after a failure: the work enqueued so far stays joinable)
+    if (rc) {
+        // a failure half-way: whatever has been enqueued stays joinable -- the stream the "done" event goes on first waits for the other
+        // stage's (the event alone would not cover detection / scan / all-gather already on the receive stream)
+        if (s->coll_issued) s->broken = true;
+        if (ss.rx2 != ss.rx && hipEventRecord(s->e_stage, ss.rx) == hipSuccess) (void)hipStreamWaitEvent(ss.rx2, s->e_stage, 0);
+    }
+    const int erc = p25fe_shard_pipe_end(s->h, ss.rx2);
     return rc ? rc : erc;
 }
 
@@ -526,6 +600,7 @@ int p25fe_shard_offsets(p25fe_shard_t* s, uint64_t* offsets)
     if (!s || !offsets) return P25FE_ERR_ARG;
     HCHK(hipSetDevice(p25fe_device(s->h)));
     HCHK(hipMemcpy(offsets, s->d_off, ((size_t)s->world + 1) * 8, hipMemcpyDeviceToHost));
+    if (const int hrc = p25fe_shard_head_check(s->h)) { s->broken = true; return hrc; }     // a detection gave up waiting for the head: nothing of this step holds
     for (int r = 0; r < s->world; ++r)
         if (offsets[r + 1] - offsets[r] > s->cap) return P25FE_ERR_CAPACITY;     // the row was filled to the brim; the count is exact
     return P25FE_OK;

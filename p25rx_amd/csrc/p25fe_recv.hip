@@ -8,7 +8,8 @@
 //                 5 integer ops per sample on 3.6 MB instead of 48 flops per sample on 115 MB; the few positions that
 //                 pass (0.08 % of random data) get the exact SPEC 3.7 arithmetic from the float planes, where a
 //                 24-symbol window is 96 contiguous bytes.  Same detections as evaluating c / e everywhere, bit for bit.
-//   K3 k_scan   : the receiver's serial state (anchor in force, dibits / events so far) as a scan over tile summaries.
+//   K3          : the receiver's serial state (anchor in force, dibits / events so far) as a hierarchical scan over tile summaries by
+//                 one-wave workgroups (k_scan_tiles; the general receiver: in K2's tail + k_scan_g_groups) -- see ScanTail below.
 //   K4 k_slice  : 4-level slicer (SPEC 3.8): a locked receiver reads ONE plane, contiguously.
 //   k_planarize : linear baseband -> planes + sign bits, for the entry points that are handed a 48 kHz float stream
 //                 (p25fe_slice / p25fe_slice_dev: the RecvEvent::Baseband hand-off of src/demod.rs:116).
@@ -69,10 +70,10 @@ __host__ __device__ inline unsigned long long pack_tsum(int first_off, int last_
            ((unsigned long long)n_events << (2 * TS_BITS)) | ((unsigned long long)post_count << (3 * TS_BITS));
 }
 
-struct ScanOut {            // per (channel, tile) carry-in written by K3
-    int src;                        // tile whose last event is in force at this tile's first sample; -1: the range's anchor_in
-    unsigned event_off;             // events of the range before this tile
-    unsigned long long dibit_off;   // dibits of the range before this tile
+struct ScanOut {            // per (channel, tile) GROUP-LOCAL carry-in written by K3's group scan (completed by the slicer: group_fix)
+    int src;                        // tile whose last event is in force at this tile's first sample; -1: the group's carry-in
+    unsigned event_off;             // events of the GROUP before this tile
+    unsigned long long dibit_off;   // dibits of the group before this tile (from its first own detection on)
 };
 
 // number of n in [lo, hi) with n > s and (n - s) % SPS == 0   (closed form)
@@ -184,7 +185,7 @@ __device__ __forceinline__ long first_kill(const RecvOpt& o, int ch, long x)
 }
 
 // Per-tile summary of the general receiver (K2 -> K3 / K4), 32 bytes
-struct TileSumG {
+struct alignas(8) TileSumG {
     unsigned pre_end1;          // (tile offset from which the carry-in anchor no longer governs) + 1; 0: the tile has no event of any kind
     unsigned first1;            // first own detection's decision offset + 1 (bits 0..15; 0: none) | its sync position's fraction (3 bits) << 16
     unsigned end0;              // tile offset (exclusive) at which the first detection's governed interval ends
@@ -275,6 +276,80 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)      // set bi
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// A record another workgroup of the SAME launch reads (K3 in K2's tail): written through (sc1: 8-byte relaxed agent-scope stores), so that
+// no release fence is needed -- a fence is `buffer_wbl2`, a write-back of the XCD's whole L2, and 3 750 of them made K2 four times slower
+// and K1 beside it 30 % slower (measured, round 6).  The writer drains (`s_waitcnt vmcnt(0)`) before it takes its ticket (last_arrival);
+// the reader's acquire drops its CU's stale L1 lines.  cdna_hip_programming.md guideline 16, recipe R1.
+template <class T> __device__ __forceinline__ void publish(T* dst, const T& v, const bool through = true)
+{
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) >= 8, "whole 8-byte words");
+    if (!through) { *dst = v; return; }                             // (the reader is a LATER launch: a plain store)
+    unsigned long long w[sizeof(T) / 8];
+    __builtin_memcpy(w, &v, sizeof(T));
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 8; ++k) __hip_atomic_store(d + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3, the receiver's serial state, as work of ONE-WAVE workgroups (round 6).  It was a scan by one workgroup of 512 threads behind K2
+// (k_scan: 33 KB of LDS; the general receiver's k_scan_g: 48 - 53 KB): beside a running front end -- twelve one-wave workgroups on every
+// CU, a freed slot refilled at once -- such a workgroup finds no CU with room until K1 DRAINS (p90 214 us in round 5's pipelined trace
+// against 9.4 us alone), so the receive chain of a pipelined call ran at the tail of the next call's K1 instead of beside it, and the
+// tracking clock's longer chain did not fit the K1 period (0.34 - 0.35 ms per step in mode 2).  Now a hierarchical scan:
+//   * tiles form groups of GT = 64 (one tile per lane).  A group is scanned with NO carry-in by one wave: per tile the group-local
+//     carry-in record (ScanOut), per group an aggregate (GroupAgg), published write-through;
+//   * the last group of a channel to arrive (a ticket) scans the aggregates -- 64 groups per step, the carried state uniform -- under
+//     the range's carry-in anchor: per group the anchor in force at its first sample and the dibits / detections in front of it
+//     (GroupPre), and the range's result record;
+//   * every slicer workgroup turns its tile's group-local record into the final one in closed form (group_fix: the rule ShardFix
+//     applies one level up): tiles in front of the group's first own detection are governed by the group's carry-in, every later
+//     tile's offset grows by the instants that carry-in governs inside the group.
+// "Latest anchor wins" and event-free stretches counted in closed form -- the same algebra as k_scan, k_scan's results bit for bit.
+// WHERE the group scans run: the fixed-stride receiver launches them as k_scan_tiles (one wave per group: 51 - 59 VGPRs, no LDS, p90
+// 17 us beside K1), the general receiver in K2's own tail (the last detection workgroup of a group scans it: GroupSumG below).  The tail
+// form was measured for the fixed stride too and lost -- every one of 3 750 detection workgroups then lives ~4 us longer (drain of its
+// write-through stores + the ticket's round trip) and K1 beside them paid 10 - 25 us (profiles/r06_rx_grid_ab.txt); the general
+// receiver's K2 is 5 - 10 x longer anyway and saves a launch by it.  k_range_scan / k_range_scan_g are the top step alone: the re-scan
+// of a time shard under a resolved carry-in (p25fe_shard_pass2), and the record of an empty range.
+// ------------------------------------------------------------------------------------------
+constexpr int GT = 64;                                           // tiles per group (one per lane)
+#ifndef P25FE_HEAD_WAIT_TICKS
+#define P25FE_HEAD_WAIT_TICKS 200000000ull                       // 2 s of the 100 MHz wall clock (tests build a short one)
+#endif
+constexpr unsigned long long HEAD_WAIT_TICKS = P25FE_HEAD_WAIT_TICKS;
+struct GroupAgg {               // per (channel, group), its tiles alone
+    long first_event;           // absolute decision index of the group's first detection, -1: none
+    long last_s;                // position of its last detection
+    unsigned long long after_first;     // instants in (first_event, group end) under the group's own detections
+    int src;                    // tile of the last detection
+    unsigned n_events;
+};
+struct GroupPre {               // per (channel, group), from the range's point of view
+    long s;                     // the anchor in force at the group's first sample ...
+    unsigned long long dibit_off;       // dibits of the range in front of the group
+    unsigned long long carry_cnt;       // instants that anchor governs inside the group ([group start, first_event] or all of it)
+    int src;                    // ... tile whose record holds its thresholds; -1: the range's anchor_in
+    int valid;                  // ... 0: not locked
+    unsigned event_off;         // detections of the range in front of the group
+    unsigned pad_;
+};
+struct GroupSumG;
+struct GroupPreG;
+struct ScanTail {
+    int on;
+    GroupSumG* gsg;             // the general receiver's group summaries / carry-ins (k_detect<true>): [ch][n_groups]
+    GroupPreG* gpg;
+    ScanOut* outs;              // [ch][n_tiles] group-local carry-ins
+    GroupAgg* gagg;             // [ch][n_groups]
+    GroupPre* gpre;             // [ch][n_groups]
+    unsigned* tickets;          // [ch][n_groups + 1], zero between launches (the last arrival resets its counter)
+    const p25fe_anchor_t* anchor_in;    // nullable, [ch]
+    p25fe_result_t* result;     // [ch]
+    unsigned long long n_baseband;
+};
+__host__ __device__ inline int n_groups_of(int n_tiles) { return (n_tiles + GT - 1) / GT; }
+
 // ------------------------------------------------------------------------------------------
 // K2: frame-sync detection.  One wave per tile of TS decision indices e = s + W (tile t owns the detections DECIDED in
 // [TS t, TS t + tn): every dependency points left).  Lane (plane r = lane / 6, block = lane % 6) screens 128 symbol
@@ -299,6 +374,8 @@ struct DetArgs {
     const unsigned* head_flag;  // nullable
     unsigned head_seq;
     int head_tile_max;
+    unsigned* head_err;         // with head_flag: receives head_seq if a wait gave up (p25fe_shard_head_check)
+    ScanTail tail;              // tail.on: K3 runs in this launch's tail (the last workgroup of every group of tiles, then of the channel)
 };
 
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
@@ -367,10 +444,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         }
     }
 
-#if defined(P25FE_ABLATE_DET) && P25FE_ABLATE_DET == 1      // measurement build: the sign-bit screen alone
-    if (lane == 0) a.tsum[(size_t)ch * a.n_tiles + tile] = (hw[0] | hw[1] | hw[2] | hw[3]) == 0x12345u ? 1ull : 0ull;
-    return;
-#endif
+    P25FE_M_DET_CUT_SCREEN;                                         // (measurement builds: the sign-bit screen alone)
     // ---- exact test of the screened positions (SPEC 3.7), candidates -> peak test against their 10 neighbours
     int nh = 0;
     auto flush_hits = [&]() {
@@ -387,11 +461,8 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
                 cand = (c > 0.0f) && (e >= P25FE_SYNC_E_MIN) && (c * c >= P25FE_SYNC_RHO2_N * e);
                 if (cand) sync_thresholds(v, th_hi, th_mid, th_lo);
             }
-#if defined(P25FE_ABLATE_DET) && P25FE_ABLATE_DET == 2      // measurement build: screen + exact test, no peak test
-            const unsigned long long cm = 0ull; if (cand) EVB[eo >> 5] = 1u;
-#else
-            const unsigned long long cm = __ballot(cand);
-#endif
+            unsigned long long cm = __ballot(cand);
+            if constexpr (P25FE_M_DET_NO_PEAK_TEST) { cm = 0ull; if (cand) EVB[eo >> 5] = 1u; }      // (measurement builds: no peak test)
             const int nc = __popcll(cm);
             if (cand) {
                 const int slot = lane_rank(cm);
@@ -468,13 +539,13 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         if (lane == 0) {
             TileRec rc;
             rc.first_event = -1; rc.last_s = -1; rc.hi = rc.mid = rc.lo = 0.f; rc.n_events = 0; rc.post_count = 0; rc.last_f = 0; rc.pad_ = 0;
-            a.recs[(size_t)ch * a.n_tiles + tile] = rc;
-            a.tsum[(size_t)ch * a.n_tiles + tile] = 0ull;
+            publish(&a.recs[(size_t)ch * a.n_tiles + tile], rc, a.tail.on != 0);
+            publish(&a.tsum[(size_t)ch * a.n_tiles + tile], 0ull, a.tail.on != 0);
             if constexpr (GEN) {
                 TileSumG g;
                 g.pre_end1 = kill0 < a.abs0 + t0 + tn ? (unsigned)(kill0 - (a.abs0 + t0)) + 1u : 0u;   // a lock drop alone ends the carry-in
                 g.first1 = 0u; g.end0 = 0u; g.last1 = 0u; g.n_det_flags = 0u; g.post_rest = 0u; g.out_D = SPS; g.out_N = 1;
-                a.gsum[(size_t)ch * a.n_tiles + tile] = g;
+                publish(&a.gsum[(size_t)ch * a.n_tiles + tile], g, a.tail.on != 0);
             }
         }
         return;
@@ -548,7 +619,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
             }
             g.n_det_flags = (unsigned)n_ev | (fl << 16);
             g.post_rest = (unsigned)rest;
-            a.gsum[(size_t)ch * a.n_tiles + tile] = g;
+            publish(&a.gsum[(size_t)ch * a.n_tiles + tile], g, a.tail.on != 0);
         }
     }
     // thresholds of the first EVTHR_N detections (for K4) and of the last one (the anchor the tile hands on): looked up in
@@ -582,262 +653,173 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         rc.post_count = post;
         rc.last_f = 0; rc.pad_ = 0;
         if constexpr (GEN) rc.last_f = frac3(fro_get(last_off));
-        a.recs[(size_t)ch * a.n_tiles + tile] = rc;
-        a.tsum[(size_t)ch * a.n_tiles + tile] = pack_tsum(first_off, last_off, n_ev, post);
+        publish(&a.recs[(size_t)ch * a.n_tiles + tile], rc, a.tail.on != 0);
+        publish(&a.tsum[(size_t)ch * a.n_tiles + tile], pack_tsum(first_off, last_off, n_ev, post), a.tail.on != 0);
     }
 }
 
-// (GEN: 21 KB of LDS per one-wave workgroup -- the per-offset fraction table -- bounds it at 7 workgroups per CU)
-template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 2 : 4) void k_detect(DetArgs a)
+// Is this workgroup the last of `expected` to arrive at `counter`?  What the arrivals PUBLISHED before (write-through stores, drained
+// here in front of the ticket) is visible to the last one behind its acquire; the last arrival leaves the counter at zero for the next launch.
+__device__ __forceinline__ bool last_arrival(unsigned* counter, unsigned expected)
 {
-    if (a.head_flag && (int)blockIdx.x <= a.head_tile_max) {       // uniform
-        // every head workgroup released its stores (agent scope) before it took its ticket; the acquire after seeing the
-        // flag keeps this wave from reading lines its caches held before that
-        while ((int)(__hip_atomic_load(a.head_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.head_seq) < 0) __builtin_amdgcn_s_sleep(16);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    detect_tile<GEN>(a, (int)blockIdx.x, (int)blockIdx.y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have left
+    unsigned ticket = 0u;
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket != expected - 1u) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+__device__ __forceinline__ long shfl_l(long v, int src) { return (long)__shfl((unsigned long long)v, src, 64); }
+// lane j's value, j uniform: v_readlane_b32 into scalar registers, no LDS crossbar
+__device__ __forceinline__ int rdl(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+__device__ __forceinline__ long rdl_l(long v, int j)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v & 0xffffffffull), j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), j);
+    return (long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int last_set_below(unsigned long long mask, int lane)      // highest set bit of mask below `lane`, -1: none
+{
+    const unsigned long long m = mask & ((1ull << lane) - 1ull);
+    return m ? 63 - __builtin_clzll(m) : -1;
 }
 
-
-// ------------------------------------------------------------------------------------------
-// K3: scan of the tile summaries.  One workgroup per channel walks the tiles in chunks of K3_CHUNK; inside a chunk
-// every thread owns a short run of tiles and two block scans (latest event tile; dibit / event counts, the counts of
-// event-free stretches in closed form through the phase (tile_start - s) mod 10) give every tile its carry-in.  The
-// state carried from chunk to chunk is the receiver's: anchor in force, dibits and events so far.
-// ------------------------------------------------------------------------------------------
-struct ScanArgs {
-    const TileRec* recs;
-    const unsigned long long* tsum;
-    ScanOut* outs;
-    int n_tiles;
-    long n;                 // owned samples per channel
-    long abs0;
-    const p25fe_anchor_t* anchor_in;    // nullable, [ch]
-    p25fe_result_t* result;             // [ch]
-    unsigned long long n_baseband;      // to report
-};
-
-constexpr int NT3 = 512;                                     // 8 waves: 256 VGPRs each (1024 threads spilled 25 of their 128)
-constexpr int K3_CHUNK = 4096;
-static_assert((long)K3_CHUNK * EVCAP < (1L << 24) && (long)K3_CHUNK * (TSYM + EVCAP) < (1L << 40), "a chunk's counts fit the packed scan");
-
-__device__ __forceinline__ int wave_incl_max_i(int v, int lane)
+// One group of tiles, no carry-in: lane = tile.
+__device__ __forceinline__ void group_scan(const DetArgs& a, const int g, const int ch)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v = o > v ? o : v;
+    const ScanTail& t = a.tail;
+    const int lane = threadIdx.x, tl = g * GT + lane;
+    const bool act = tl < a.n_tiles;
+    const unsigned long long u = act ? a.tsum[(size_t)ch * a.n_tiles + tl] : 0ull;
+    const int first1 = (int)(u & TS_MASK);
+    const bool has = first1 != 0;
+    const unsigned long long evm = __ballot(has);
+    const int pl = last_set_below(evm, lane);                       // latest tile of the group with a detection, in front of mine
+    const unsigned long long up = __shfl(u, pl < 0 ? 0 : pl, 64);
+    const long T0 = a.abs0 + (long)tl * TS;
+    const long rem = a.n - (long)tl * TS;
+    const int tn = rem < TS ? (int)rem : TS;
+    unsigned pre = 0u;                                              // instants of my tile under the anchor it starts with, if that is the group's own
+    if (act && pl >= 0) {
+        const long sp = a.abs0 + (long)(g * GT + pl) * TS + ((long)((up >> TS_BITS) & TS_MASK) - 1) - W;
+        pre = (unsigned)count_instants(sp, T0, T0 + (has ? first1 : tn));       // (the instant AT the decision index is still the old anchor's)
     }
-    return v;
+    const unsigned long long cnt = act ? (unsigned long long)pre + ((u >> (3 * TS_BITS)) & TS_MASK) : 0ull;
+    const unsigned long long ev = (u >> (2 * TS_BITS)) & TS_MASK;
+    const unsigned long long mine = cnt | (ev << 40);               // (64 tiles: < 2^18 dibits, < 2^17 detections)
+    const unsigned long long incl = wave_incl_sum64(mine, lane);
+    if (act) {
+        ScanOut o;
+        o.src = pl >= 0 ? g * GT + pl : -1;
+        o.event_off = (unsigned)((incl - mine) >> 40);
+        o.dibit_off = (incl - mine) & ((1ull << 40) - 1);
+        t.outs[(size_t)ch * a.n_tiles + tl] = o;
+    }
+    const unsigned long long tot = __shfl(incl, WV - 1, 64);
+    const int fl = evm ? __builtin_ctzll(evm) : 0, ll = evm ? 63 - __builtin_clzll(evm) : 0;
+    const unsigned long long uf = __shfl(u, fl, 64), ul = __shfl(u, ll, 64);
+    if (lane == 0) {
+        GroupAgg A;
+        A.first_event = -1; A.last_s = 0; A.src = -1;
+        if (evm) {
+            A.first_event = a.abs0 + (long)(g * GT + fl) * TS + (long)(uf & TS_MASK) - 1;
+            A.last_s = a.abs0 + (long)(g * GT + ll) * TS + ((long)((ul >> TS_BITS) & TS_MASK) - 1) - W;
+            A.src = g * GT + ll;
+        }
+        A.after_first = tot & ((1ull << 40) - 1);
+        A.n_events = (unsigned)(tot >> 40);
+        publish(&t.gagg[(size_t)ch * n_groups_of(a.n_tiles) + g], A);
+    }
 }
-__device__ __forceinline__ int block_incl_max(int v, int* sh, int tid, int& total)
+
+// The groups of one channel under the range's carry-in: lane = group, 64 groups per step, the carried state uniform.
+__device__ __forceinline__ void range_scan(const DetArgs& a, const int ch)
 {
-    const int lane = tid & 63, wv = tid >> 6;
-    int inc = wave_incl_max_i(v, lane);
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    int carry = -1, tot = -1;
-#pragma unroll
-    for (int k = 0; k < NT3 / 64; ++k) {
-        const int t = sh[k];
-        if (k < wv) carry = t > carry ? t : carry;
-        tot = t > tot ? t : tot;
+    const ScanTail& t = a.tail;
+    const int lane = threadIdx.x, n_groups = n_groups_of(a.n_tiles);
+    p25fe_anchor_t Ain;
+    Ain.valid = 0; Ain.s = 0; Ain.hi = Ain.mid = Ain.lo = 0.f; Ain.period_d = SPS; Ain.period_n = 1;
+    if (t.anchor_in) Ain = t.anchor_in[ch];
+    int cv = Ain.valid != 0 ? 1 : 0, csrc = -1;
+    long cs = Ain.s, cfirst = -1;
+    unsigned long long ccnt = 0ull, cev = 0ull, cbase = 0ull;
+    const GroupAgg* ga = t.gagg + (size_t)ch * n_groups;
+    GroupPre* gp = t.gpre + (size_t)ch * n_groups;
+    const long range_end = a.abs0 + a.n;
+    for (int c0 = 0; c0 < n_groups; c0 += WV) {
+        const int gi = c0 + lane;
+        const bool act = gi < n_groups;
+        GroupAgg A;
+        A.first_event = -1; A.last_s = 0; A.after_first = 0ull; A.src = -1; A.n_events = 0u;
+        if (act) A = ga[gi];
+        const bool has = A.first_event >= 0;
+        const unsigned long long evm = __ballot(has);
+        const int pl = last_set_below(evm, lane);
+        const long ps = shfl_l(A.last_s, pl < 0 ? 0 : pl);
+        const int psrc = __shfl(A.src, pl < 0 ? 0 : pl, 64);
+        const int v = pl >= 0 ? 1 : cv, src = pl >= 0 ? psrc : csrc;
+        const long s = pl >= 0 ? ps : cs;
+        const long G0 = a.abs0 + (long)gi * (GT * TS);
+        const long G1 = G0 + (long)GT * TS < range_end ? G0 + (long)GT * TS : range_end;
+        const unsigned long long carry = (act && v) ? (unsigned long long)count_instants(s, G0, has ? A.first_event + 1 : G1) : 0ull;
+        const unsigned long long mine = (act ? carry + A.after_first : 0ull) | ((unsigned long long)A.n_events << 40);
+        const unsigned long long incl = wave_incl_sum64(mine, lane);
+        const unsigned long long dib0 = ccnt + ((incl - mine) & ((1ull << 40) - 1));
+        if (act) {
+            GroupPre P;
+            P.s = s; P.dibit_off = dib0; P.carry_cnt = carry; P.src = src; P.valid = v;
+            P.event_off = (unsigned)(cev + ((incl - mine) >> 40)); P.pad_ = 0u;
+            gp[gi] = P;
+        }
+        const unsigned long long tot = __shfl(incl, WV - 1, 64);
+        if (evm) {                                                   // uniform
+            const int fl = __builtin_ctzll(evm), ll = 63 - __builtin_clzll(evm);
+            if (cfirst < 0) {                                        // the range's first own detection
+                cfirst = shfl_l(A.first_event, fl);
+                cbase = __shfl(dib0 + carry, fl, 64);
+            }
+            cv = 1; cs = shfl_l(A.last_s, ll); csrc = __shfl(A.src, ll, 64);
+        }
+        ccnt += tot & ((1ull << 40) - 1);
+        cev += tot >> 40;
     }
-    __syncthreads();
-    total = tot;
-    return inc > carry ? inc : carry;
-}
-template <int NT = NT3>
-__device__ __forceinline__ unsigned long long block_incl_sum(unsigned long long v, unsigned long long* sh, int tid,
-                                                                  unsigned long long& total)
-{
-    const int lane = tid & 63, wv = tid >> 6;
-    const unsigned long long inc = wave_incl_sum64(v, lane);
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    unsigned long long carry = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) {
-        const unsigned long long t = sh[k];
-        if (k < wv) carry += t;
-        tot += t;
+    if (lane == 0) {
+        p25fe_result_t r;
+        r.n_baseband = t.n_baseband;
+        r.n_dibits = ccnt;
+        r.n_sync = cev;
+        p25fe_anchor_t A = Ain;
+        if (csrc >= 0) {
+            const TileRec rc = a.recs[(size_t)ch * a.n_tiles + csrc];
+            A.valid = 1; A.s = rc.last_s; A.hi = rc.hi; A.mid = rc.mid; A.lo = rc.lo;
+        }
+        A.period_d = SPS; A.period_n = 1;                          // fixed stride
+        r.anchor_out = A;
+        r.first_event = cfirst;
+        r.n_dibits_after_first = cfirst >= 0 ? ccnt - cbase : 0ull;
+        r.carry_end = cfirst >= 0 ? cfirst + 1 : -1;
+        r.first_seg_end = -1;
+        r.flags = 0u; r.reserved = 0u;
+        t.result[ch] = r;
     }
-    __syncthreads();
-    total = tot;
-    return inc + carry;
 }
 
 #ifndef P25FE_JIT
-__global__ __launch_bounds__(NT3) void k_scan(ScanArgs a)
+// The top step alone (fixed-stride receiver): a re-scan of group aggregates that are already there under another carry-in
+// (p25fe_shard_pass2 with host-resolved anchors), and the record of an EMPTY range (no tile, no K2: the carry-in is handed through).
+__global__ __launch_bounds__(WV, 4) void k_range_scan(DetArgs a) { range_scan(a, (int)blockIdx.x); }
+// K3 of the fixed-stride receiver as its own launch of ONE-WAVE workgroups, one per group of GT tiles (grid: groups x channels): the group
+// scan, then -- the channel's last group to arrive -- the scan of the groups.  It fits beside a running K1 (no LDS, 51 VGPRs), where the
+// 512-thread k_scan of rounds 2 - 5 waited for the drain.  (K2 keeps its tail-less form here: with the scan in K2's own tail, as the
+// general receiver has it, every one of 3 750 detection workgroups lives ~4 us longer -- drain + ticket -- and K1 beside them paid 20 us.)
+__global__ __launch_bounds__(WV, 4) void k_scan_tiles(DetArgs a)
 {
-    __shared__ unsigned long long TSL[K3_CHUNK];
-    __shared__ int shl[NT3 / 64];
-    __shared__ unsigned long long shu[NT3 / 64];
-    __shared__ int excl_tmp[NT3 / 64];
-    // carried state
-    __shared__ int c_valid, c_src;
-    __shared__ long c_s, c_first_event;
-    __shared__ unsigned long long c_cnt, c_ev, c_base_first;
-    __shared__ long n_first_event;                                // found in the current chunk
-    __shared__ unsigned long long n_base_first;
-
-    const int tid = threadIdx.x, ch = blockIdx.x;
-    const unsigned long long* tsum = a.tsum + (size_t)ch * a.n_tiles;
-    ScanOut* outs = a.outs + (size_t)ch * a.n_tiles;
-    if (tid == 0) {
-        p25fe_anchor_t A;
-        A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f; A.period_d = SPS; A.period_n = 1;
-        if (a.anchor_in) A = a.anchor_in[ch];
-        c_valid = A.valid; c_s = A.s; c_src = -1;
-        c_cnt = 0; c_ev = 0; c_first_event = -1; c_base_first = 0;
-    }
-    __syncthreads();
-
-    auto count32 = [&](unsigned ph, int len) -> unsigned {        // n in [0, len): (ph + n) % 10 == 0
-        const int f = (int)((SPS - ph) % (unsigned)SPS);          // first instant offset
-        return len > f ? (unsigned)(len - f + SPS - 1) / (unsigned)SPS : 0u;
-    };
-
-    TileRec last_rec;
-    last_rec.first_event = -1; last_rec.last_s = 0; last_rec.hi = last_rec.mid = last_rec.lo = 0.f; last_rec.n_events = 0; last_rec.post_count = 0; last_rec.last_f = 0; last_rec.pad_ = 0;
-    bool have_last_rec = false;
-    for (int c0 = 0; c0 < a.n_tiles; c0 += K3_CHUNK) {
-        const int cn = (a.n_tiles - c0 < K3_CHUNK) ? a.n_tiles - c0 : K3_CHUNK;
-        for (int k = tid; k < cn; k += NT3) TSL[k] = tsum[c0 + k];
-        if (tid == 0) n_first_event = -1;
-        __syncthreads();
-        const int per = (cn + NT3 - 1) / NT3;
-        const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
-
-        // pass 1: latest event tile inside my run -> block exclusive max
-        int last = -1;
-        for (int k = k0; k < k1; ++k) if (TSL[k] & TS_MASK) last = k;
-        int tot_max;
-        const int incl = block_incl_max(last, shl, tid, tot_max);
-        int excl = __shfl_up(incl, 1, 64);
-        if ((tid & 63) == 63) excl_tmp[tid >> 6] = incl;
-        __syncthreads();
-        if ((tid & 63) == 0) excl = tid > 0 ? excl_tmp[(tid >> 6) - 1] : -1;
-        __syncthreads();
-        // the anchor the range will end on lives in the record of the (so far) last event tile: request it now, while the
-        // counting passes run, instead of as a dependent load after them
-        if (tid == 0 && tot_max >= 0) { last_rec = a.recs[(size_t)ch * a.n_tiles + c0 + tot_max]; have_last_rec = true; }
-
-        const int cv = c_valid, csrc = c_src;
-        const long cs = c_s;
-        const unsigned long long ccnt = c_cnt, cev = c_ev;
-        const long cfirst = c_first_event;
-
-        // phase of tile k's first sample under the anchor in force there: ph = (tile_start - s) mod 10
-        auto phase_at = [&](int k, int src, bool& v) -> unsigned {
-            if (src >= 0) {
-                v = true;
-                const int last_off = (int)((TSL[src] >> TS_BITS) & TS_MASK) - 1;
-                const unsigned dist = (unsigned)(k - (int)src) * (unsigned)TS - (unsigned)last_off + (unsigned)W;   // tile_start - s > 0
-                return dist % (unsigned)SPS;
-            }
-            v = cv != 0;
-            if (!v) return 0u;
-            return (unsigned)((a.abs0 + (long)(c0 + k) * TS - cs) % SPS);          // the one 64-bit modulo per thread
-        };
-        auto tile_len = [&](int k) -> int {
-            const long rem = a.n - (long)(c0 + k) * TS;
-            return rem < TS ? (int)rem : TS;
-        };
-        bool v0 = false;
-        const unsigned ph0 = k0 < k1 ? phase_at(k0, excl, v0) : 0u;
-        // pass 2: dibits / events of my run
-        unsigned long long my_cnt = 0, my_ev = 0;
-        if (k0 < k1) {
-            bool v = v0;
-            unsigned ph = ph0;
-            for (int k = k0; k < k1; ++k) {
-                const unsigned long long u = TSL[k];
-                const int first1 = (int)(u & TS_MASK);
-                const int len = first1 ? first1 : tile_len(k);    // the instant AT the decision index is still the old anchor's
-                my_cnt += (v ? count32(ph, len) : 0u) + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
-                my_ev += (u >> (2 * TS_BITS)) & TS_MASK;
-                if (first1) {
-                    v = true;
-                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
-                    ph = (unsigned)(TS - last_off + W) % (unsigned)SPS;      // next tile's start under the new anchor
-                } else {
-                    ph = (ph + (unsigned)TS) % (unsigned)SPS;
-                }
-            }
-        }
-        // one scan for both counts: dibits in the low 40 bits, detections above (a chunk holds < 2^22 / < 2^23 of them)
-        unsigned long long tot_pk;
-        const unsigned long long ipk = block_incl_sum(my_cnt | (my_ev << 40), shu, tid, tot_pk);
-        const unsigned long long icnt = ipk & ((1ull << 40) - 1), iev = ipk >> 40;
-        const unsigned long long tot_cnt = tot_pk & ((1ull << 40) - 1), tot_ev = tot_pk >> 40;
-
-        // pass 3: per-tile carry-ins
-        if (k0 < k1) {
-            int src = excl;
-            bool v = v0;
-            unsigned ph = ph0;
-            unsigned long long dc = ccnt + icnt - my_cnt, ec = cev + iev - my_ev;
-            for (int k = k0; k < k1; ++k) {
-                const unsigned long long u = TSL[k];
-                const int first1 = (int)(u & TS_MASK);
-                const int len = first1 ? first1 : tile_len(k);
-                const unsigned pre = v ? count32(ph, len) : 0u;
-                ScanOut o;
-                o.src = src >= 0 ? (int)(c0 + src) : csrc;
-                o.event_off = (unsigned)ec;
-                o.dibit_off = dc;
-                outs[c0 + k] = o;
-                if (first1 && src < 0 && cfirst < 0) {            // the range's first own detection
-                    n_first_event = a.abs0 + (long)(c0 + k) * TS + first1 - 1;
-                    n_base_first = dc + pre;
-                }
-                dc += pre + (unsigned)((u >> (3 * TS_BITS)) & TS_MASK);
-                ec += (u >> (2 * TS_BITS)) & TS_MASK;
-                if (first1) {
-                    src = k; v = true;
-                    const int last_off = (int)((u >> TS_BITS) & TS_MASK) - 1;
-                    ph = (unsigned)(TS - last_off + W) % (unsigned)SPS;
-                } else {
-                    ph = (ph + (unsigned)TS) % (unsigned)SPS;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            if (tot_max >= 0) {
-                const int last_off = (int)((TSL[tot_max] >> TS_BITS) & TS_MASK) - 1;
-                c_valid = 1;
-                c_s = a.abs0 + (long)(c0 + tot_max) * TS + last_off - W;
-                c_src = c0 + (int)tot_max;
-            }
-            c_cnt = ccnt + tot_cnt;
-            c_ev = cev + tot_ev;
-            if (cfirst < 0 && n_first_event >= 0) { c_first_event = n_first_event; c_base_first = n_base_first; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        p25fe_result_t r;
-        r.n_baseband = a.n_baseband;
-        r.n_dibits = c_cnt;
-        r.n_sync = c_ev;
-        p25fe_anchor_t A;
-        A.valid = 0; A.s = 0; A.hi = A.mid = A.lo = 0.f;
-        if (a.anchor_in) A = a.anchor_in[ch];
-        if (c_src >= 0 && have_last_rec) {
-            A.valid = 1; A.s = last_rec.last_s; A.hi = last_rec.hi; A.mid = last_rec.mid; A.lo = last_rec.lo;
-        }
-        A.period_d = SPS; A.period_n = 1;                          // fixed stride (the tracking clock runs k_scan_g)
-        r.anchor_out = A;
-        r.first_event = c_first_event;
-        r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
-        r.carry_end = c_first_event >= 0 ? c_first_event + 1 : -1;
-        r.first_seg_end = -1;                                      // only the tracking clock's resolve needs it
-        r.flags = 0u; r.reserved = 0u;
-        a.result[ch] = r;
-    }
+    const int g = blockIdx.x, ch = blockIdx.y, n_groups = n_groups_of(a.n_tiles);
+    group_scan(a, g, ch);
+    if (!last_arrival(a.tail.tickets + (size_t)ch * (n_groups + 1) + n_groups, (unsigned)n_groups)) return;
+    range_scan(a, ch);
 }
 #endif
 
@@ -931,7 +913,24 @@ struct SliceArgs {
     uint8_t* dibits2;           // nullable: a second destination of every dibit, same row layout (rank 0 of a time-sharded capture
                                 // slices straight into the ordered stream as well: its shard starts at offset 0)
     ShardFix fix;               // fix.summ != nullptr: pass 2 of a time shard, the combine done here (p25fe_shard_pass2_dev)
+    const GroupPre* gpre;       // non-null: `outs` are the group-local records of K2's tail, completed here (group_fix); null: k_scan's
 };
+
+// A tile's group-local carry-in record (group_scan) + its group's carry-in (range_scan) -> the record k_scan would have written.
+__device__ __forceinline__ ScanOut group_fix(ScanOut so, const GroupPre& P, const long abs0, const int tile, int& valid, long& s_abs)
+{
+    if (so.src < 0) {                                               // in front of the group's first own detection: the group's carry-in governs
+        valid = P.valid; s_abs = P.s;
+        so.src = P.src;
+        so.event_off = P.event_off;
+        const long G0 = abs0 + (long)(tile / GT) * ((long)GT * TS);
+        so.dibit_off = P.dibit_off + (P.valid ? (unsigned long long)count_instants(P.s, G0, abs0 + (long)tile * TS) : 0ull);
+    } else {
+        so.event_off += P.event_off;
+        so.dibit_off += P.dibit_off + P.carry_cnt;
+    }
+    return so;
+}
 
 // so: the tile's carry-in record; u: its packed summary; (valid, s_abs, hi, mid, lo): the anchor in force at its first sample
 __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, const int ch, const ScanOut so,
@@ -1020,10 +1019,8 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
     }
 }
 
-#ifndef P25FE_JIT
-__global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
+__device__ __forceinline__ void slice_item(const SliceArgs& a, const int tile, const int ch)
 {
-    const int tile = blockIdx.x, ch = blockIdx.y;
     const ShardFix& x = a.fix;
     const bool fixm = x.summ != nullptr;                            // uniform: pass 2 of a time shard (one channel), see ShardFix
     if (fixm && tile == a.n_tiles) {
@@ -1057,6 +1054,10 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
     int valid = 0;
     long s_abs = 0;
     float hi = 0.f, mid = 0.f, lo = 0.f;
+    if (a.gpre) {                                                   // uniform: K3 ran in K2's tail
+        const GroupPre P = a.gpre[(size_t)ch * n_groups_of(a.n_tiles) + tile / GT];
+        so = group_fix(so, P, a.abs0, tile, valid, s_abs);
+    }
     if (so.src >= 0) {
         const TileRec t = a.recs[(size_t)ch * a.n_tiles + so.src];
         valid = 1; s_abs = t.last_s; hi = t.hi; mid = t.mid; lo = t.lo;
@@ -1086,6 +1087,12 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a)
     }
     slice_tile(a, tile, ch, so, u, valid, s_abs, hi, mid, lo);
 }
+#ifndef P25FE_JIT
+// (One workgroup per tile.  A BOUNDED grid of persistent workgroups walking the tiles -- 1 024, i.e. 4 per CU, which leave K1 beside
+// them its 10 workgroups per CU -- was built and measured in round 6: a 400-step pipelined run cost the same as this form, the chain
+// took ~240 us instead of ~60, so that the driver's 20-step command, whose LAST chain overlaps nothing, lost 1.5 - 4 %, and the loop
+// cost 25 - 70 VGPRs per kernel (SGPR spills).  profiles/r06_rx_grid_ab.txt; not adopted.)
+__global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a) { slice_item(a, (int)blockIdx.x, (int)blockIdx.y); }
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -1109,10 +1116,105 @@ struct ScanOutG {               // per (channel, tile) carry-in written by k_sca
     int pad_;
 };
 
+struct CState { int valid; long s; int D, N; int src; int f; };
+
+// ------------------------------------------------------------------------------------------
+// The general receiver's scan, hierarchical like the fixed-stride one (ScanTail above) -- the 512-thread k_scan_g of rounds 3 - 5
+// (48 - 53 KB of LDS) is gone: beside a running K1 it waited for the drain, and the tracking clock's pipelined step paid for it.
+//   pass A   K2's tail: the last detection workgroup of a group of GT tiles scans the group with NO carry-in (scan_g_lanes: lane =
+//            tile, the "latest two event tiles" rule by two bit scans of a ballot, neighbours' fields by lane shuffles) and leaves
+//            a summary of what a carry-in would change -- the same fields a time shard's pass 1 leaves in p25fe_result_t, for the
+//            same reason (GroupSumG);
+//   top      the channel's last group walks the summaries under the range's carry-in (range_scan_g: shard_resolve_impl's rule, one
+//            level down): every group's carry-in state and offsets (GroupPreG), and the range's record;
+//   pass B   k_scan_g_groups, one wave per group: the same lane scan under the group's real carry-in -> the per-tile carry-ins
+//            (ScanOutG) that k_slice_g / k_ev_collect read, as k_scan_g wrote them.
+// A re-scan under another carry-in (a time shard's pass 2) is k_range_scan_g (the top step alone, on pass 1's summaries) + pass B.
+// ------------------------------------------------------------------------------------------
+struct GroupSumG {              // per (channel, group): the group's tiles under NO carry-in
+    long first_event;           // decision index of the group's first detection, -1: none
+    long carry_end;             // index of the group's first event of any kind (GS_HAS_EVENT)
+    long first_seg_end;         // where the first detection's governed interval ends inside the group (the group's end if GS_SEG_OPEN)
+    unsigned long long after_first;     // instants the group's own detections govern, the first one's interval counted at 10 / 1
+    long out_s;                 // the state the group ends in, if it has an event: position, fraction, tile, clock of the last detection
+    int out_valid, out_f, out_src, out_D, out_N;
+    unsigned n_sync;
+    unsigned flags;             // GS_*
+    int first_f;                // the first detection's fraction
+    int n_event_tiles;
+    int pad_;
+};
+constexpr unsigned GS_FIRST_TRACKS = 1u;      // no lock drop between the group's start and its first detection (P25FE_RES_FIRST_TRACKS_CARRY)
+constexpr unsigned GS_OUT_FROM_CARRY = 2u;    // out_D / out_N are the interval from the carry-in to the group's only detection (P25FE_RES_OUT_PERIOD_FROM_CARRY)
+constexpr unsigned GS_HAS_EVENT = 4u;
+constexpr unsigned GS_SEG_OPEN = 8u;          // the first detection's interval is still open at the group's end
+struct GroupPreG {              // per (channel, group): the state at its first sample and what lies in front of it
+    long s;
+    unsigned long long dibit_off;
+    int valid, D, N, src, f;
+    unsigned event_off;
+};
+
+struct GLanes {
+    CState st;                  // the receiver's state at my tile's first sample
+    unsigned pre;               // instants of my tile under it
+    unsigned long long excl;    // dibits (low 40 bits) | detections << 40 of the group in front of my tile
+    unsigned long long total;   // ... of the whole group
+    unsigned long long evm;     // the group's tiles with an event of any kind
+};
+// the state after event tile (lane) t1, t2 = the event tile before it, -1: the carry-in C.  Every lane calls it (shuffles).
+__device__ __forceinline__ CState state_after_lane(const int t1, const int t2, const CState& C, const bool track, const TileSumG& g,
+                                                   const long last_s, const int last_f, const int tile0)
+{
+    const int i1 = t1 < 0 ? 0 : t1, i2 = t2 < 0 ? 0 : t2;
+    const unsigned fl1 = (unsigned)__shfl((int)g.n_det_flags, i1, 64) >> 16, fl2 = (unsigned)__shfl((int)g.n_det_flags, i2, 64) >> 16;
+    const int D1 = __shfl(g.out_D, i1, 64), N1 = __shfl(g.out_N, i1, 64);
+    const long s1 = shfl_l(last_s, i1), s2 = shfl_l(last_s, i2);
+    const int f1 = __shfl(last_f, i1, 64), f2 = __shfl(last_f, i2, 64);
+    if (t1 < 0) return C;
+    CState st;
+    if (!(fl1 & G_OUT_VALID)) { st.valid = 0; st.s = 0; st.D = SPS; st.N = 1; st.src = -2; st.f = 0; return st; }
+    st.valid = 1; st.src = tile0 + t1; st.s = s1; st.f = f1;
+    if (fl1 & G_OUT_PERIOD_KNOWN) { st.D = D1; st.N = N1; return st; }
+    bool pv; long ps; int pf;
+    if (t2 >= 0) { pv = (fl2 & G_OUT_VALID) != 0; ps = pv ? s2 : 0; pf = pv ? f2 : 0; }
+    else { pv = C.valid != 0; ps = C.s; pf = C.f; }                // (what the state after ANY earlier event tile hands on: locked?, position, fraction)
+    clock_period(track, pv, ps, pf, st.s, st.f, st.D, st.N);
+    return st;
+}
+// One group under the carry-in C: lane = tile tile0 + lane (g all zero for a lane past the range), T0 / tn my tile's first index / length.
+__device__ __forceinline__ GLanes scan_g_lanes(const TileSumG& g, const long last_s, const int last_f, const CState& C, const bool track,
+                                               const long T0, const int tn, const int tile0)
+{
+    GLanes o;
+    const int lane = threadIdx.x;
+    o.evm = __ballot(g.pre_end1 != 0u);
+    const int t1 = last_set_below(o.evm, lane);
+    const int t2 = t1 >= 0 ? last_set_below(o.evm, t1) : -1;
+    o.st = state_after_lane(t1, t2, C, track, g, last_s, last_f, tile0);
+    const long pre_hi = g.pre_end1 ? T0 + (long)g.pre_end1 - 1 : T0 + tn;
+    o.pre = (tn > 0 && o.st.valid) ? (unsigned)clock_count(o.st.s, o.st.D, o.st.N, T0, pre_hi) : 0u;
+    unsigned tot = o.pre;
+    if (g.first1) {
+        const long s0 = T0 + (long)(g.first1 & 0xffffu) - 1 - W;
+        int D0, N0;
+        clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && o.st.valid, o.st.s, o.st.f, s0, frac3(g.first1 >> 16), D0, N0);
+        tot += (unsigned)clock_count(s0, D0, N0, s0 + W + 1, T0 + g.end0) + g.post_rest;
+    }
+    const unsigned long long mine = (unsigned long long)tot | ((unsigned long long)(g.n_det_flags & 0xffffu) << 40);
+    const unsigned long long incl = wave_incl_sum64(mine, lane);
+    o.excl = incl - mine;
+    o.total = __shfl(incl, WV - 1, 64);
+    return o;
+}
+
 struct ScanArgsG {
     const TileSumG* gsum;
     const TileRec* recs;
     ScanOutG* outs;
+    GroupSumG* gsg;                     // [ch][n_groups]
+    GroupPreG* gpg;                     // [ch][n_groups]
+    unsigned* tickets;                  // [ch][n_groups + 1] (K2's tail)
     int n_tiles;
     long n;
     long abs0;                          // absolute index of the first PROCESSED sample (owned sample 0 minus the lookahead)
@@ -1122,229 +1224,253 @@ struct ScanArgsG {
     int track;
 };
 
-constexpr int KG_CHUNK = 1024;          // tiles whose summaries k_scan_g stages in LDS at a time (48 KB)
-struct Top2 { int a, b; };              // latest and second-latest event tile, -1: none
-__device__ __forceinline__ Top2 top2_merge(Top2 l, Top2 r)      // r is later than l
+// my lane's tile of group g: summary, last detection, geometry
+__device__ __forceinline__ void load_lane_tile(const ScanArgsG& a, const int g, const int ch, TileSumG& gs, long& last_s, int& last_f, long& T0, int& tn)
 {
-    Top2 o;
-    if (r.a < 0) return l;
-    o.a = r.a;
-    o.b = r.b >= 0 ? r.b : l.a;
-    return o;
+    const int tl = g * GT + (int)threadIdx.x;
+    gs.pre_end1 = 0u; gs.first1 = 0u; gs.end0 = 0u; gs.last1 = 0u; gs.n_det_flags = 0u; gs.post_rest = 0u; gs.out_D = SPS; gs.out_N = 1;
+    last_s = 0; last_f = 0; tn = 0;
+    T0 = a.abs0 + (long)tl * TS;
+    if (tl < a.n_tiles) {
+        gs = a.gsum[(size_t)ch * a.n_tiles + tl];
+        const TileRec* rc = a.recs + (size_t)ch * a.n_tiles + tl;
+        last_s = rc->last_s; last_f = rc->last_f;
+        const long rem = a.n - (long)tl * TS;
+        tn = rem < TS ? (int)rem : TS;
+    }
 }
-__device__ __forceinline__ Top2 top2_shfl_up(Top2 v, int d)
+
+// pass A: group g with no carry-in -> its summary
+__device__ __forceinline__ void group_scan_g(const ScanArgsG& a, const int g, const int ch)
 {
-    Top2 o;
-    o.a = __shfl_up(v.a, d, 64); o.b = __shfl_up(v.b, d, 64);
-    return o;
+    const int lane = threadIdx.x, tile0 = g * GT;
+    TileSumG gs; long last_s, T0; int last_f, tn;
+    load_lane_tile(a, g, ch, gs, last_s, last_f, T0, tn);
+    CState C;
+    C.valid = 0; C.s = 0; C.D = SPS; C.N = 1; C.src = -2; C.f = 0;
+    const bool track = a.track != 0;
+    const GLanes L = scan_g_lanes(gs, last_s, last_f, C, track, T0, tn, tile0);
+    // the state the group ends in: after its latest event tile
+    const int ta = L.evm ? 63 - __builtin_clzll(L.evm) : -1, tb = ta >= 0 ? last_set_below(L.evm, ta) : -1;
+    const CState se = state_after_lane(ta, tb, C, track, gs, last_s, last_f, tile0);
+    const unsigned fl_a = (unsigned)__shfl((int)gs.n_det_flags, ta < 0 ? 0 : ta, 64) >> 16;
+    // the first detection
+    const unsigned long long dm = __ballot(gs.first1 != 0u);
+    const int fd = dm ? __builtin_ctzll(dm) : 0;
+    const unsigned long long after = L.evm & ~((2ull << fd) - 1ull);  // event tiles behind the first detection's
+    const int nx = after ? __builtin_ctzll(after) : 0;
+    const int e1 = L.evm ? __builtin_ctzll(L.evm) : 0;
+    // (uniform values, read from the lanes that hold them)
+    const unsigned first1 = (unsigned)__shfl((int)gs.first1, fd, 64), end0 = (unsigned)__shfl((int)gs.end0, fd, 64);
+    const unsigned flg_fd = (unsigned)__shfl((int)gs.n_det_flags, fd, 64) >> 16;
+    const long T0_fd = shfl_l(T0, fd);
+    const int tn_fd = __shfl(tn, fd, 64);
+    const unsigned long long base_first = __shfl(L.excl + (unsigned long long)L.pre, fd, 64) & ((1ull << 40) - 1);
+    const long nx_first = shfl_l(T0 + (long)gs.pre_end1 - 1, nx);
+    const long carry_end = shfl_l(T0 + (long)gs.pre_end1 - 1, e1);
+    if (lane == 0) {
+        GroupSumG S;
+        S.first_event = -1; S.carry_end = -1; S.first_seg_end = -1; S.after_first = 0ull; S.first_f = 0;
+        S.out_s = se.s; S.out_valid = se.valid; S.out_f = se.f; S.out_src = se.src; S.out_D = se.D; S.out_N = se.N;
+        S.n_sync = (unsigned)(L.total >> 40);
+        S.n_event_tiles = __popcll(L.evm);
+        S.pad_ = 0;
+        unsigned fl = 0u;
+        if (L.evm) { fl |= GS_HAS_EVENT; S.carry_end = carry_end; }
+        if (dm) {
+            S.first_event = T0_fd + (long)(first1 & 0xffffu) - 1;
+            S.first_f = frac3(first1 >> 16);
+            S.after_first = (L.total & ((1ull << 40) - 1)) - base_first;
+            if ((flg_fd & G_FIRST_TRACKS) && e1 == fd) fl |= GS_FIRST_TRACKS;      // (and no event tile in front of it)
+            long fse = T0_fd + (long)end0;
+            if (fse >= T0_fd + tn_fd) {                               // still open at its tile's end: runs on to the next event tile, or out of the group
+                if (after) fse = nx_first;
+                else { fse = a.abs0 + ((long)(tile0 + GT) * TS < a.n ? (long)(tile0 + GT) * TS : a.n); fl |= GS_SEG_OPEN; }
+            }
+            S.first_seg_end = fse;
+        }
+        // the clock the group ends on was taken from the carry-in: its only event tile holds one tracking detection
+        if (se.src >= 0 && tb < 0 && !(fl_a & G_OUT_PERIOD_KNOWN)) fl |= GS_OUT_FROM_CARRY;
+        S.flags = fl;
+        publish(&a.gsg[(size_t)ch * n_groups_of(a.n_tiles) + g], S);
+    }
 }
 
-struct CState { int valid; long s; int D, N; int src; int f; };
-
-#ifndef P25FE_JIT
-// NT threads, KC tiles staged per chunk.  <512, 1024> (48 KB of LDS) is the product's; <64, 256> (13 KB, ONE wave) is a measured
-// alternative for the place behind a pipelined call: there the 512-thread workgroup waits until the K1 beside it drains (170 us of
-// the receive stream's time per call), a one-wave workgroup gets the slot of the next K1 workgroup that retires -- and is then so
-// much slower at walking the tiles alone that the step loses 45 % (profiles/r05_tracking_pipeline.txt, P25FE_SCAN_G_WAVES).
-template <int NT, int KC> __global__ __launch_bounds__(NT) void k_scan_g_t(ScanArgsG a)
+// top: the groups of one channel under the range's carry-in (every lane runs the same walk; 64 summaries are fetched per step, one per
+// lane, and read lane by lane).  shard_resolve_impl's rule with the range's carry-in as the starting state.
+__device__ __forceinline__ void range_scan_g(const ScanArgsG& a, const int ch)
 {
-    // a chunk of summaries (and of the tiles' last detection positions) is staged in LDS: the per-tile work below is a chain
-    // of dependent reads (summary -> latest event tile's summary -> the one before) that cost a memory round trip each
-    // when they went to global memory (k_scan_g 45 us for config 2; 3 750 tiles)
-    __shared__ TileSumG GS[KC];
-    __shared__ long LS[KC];
-    __shared__ int LF[KC];
-    __shared__ unsigned CNT[KC], PRE[KC];
-    __shared__ Top2 sh2[NT / 64];
-    __shared__ unsigned long long shu[NT / 64];
-    __shared__ Top2 c_top;                                         // latest two event tiles before the chunk (global indices)
-    __shared__ unsigned long long c_cnt, c_ev, c_base_first;
-    __shared__ long c_first_event, c_carry_end, c_first_seg_end, c_first_seg_next;
-    __shared__ unsigned c_flags;
-    __shared__ int c_has_event, c_first_f;
-
-    const int tid = threadIdx.x, ch = blockIdx.x, lane = tid & 63, wv = tid >> 6;
-    const TileSumG* gsum = a.gsum + (size_t)ch * a.n_tiles;
-    const TileRec* recs = a.recs + (size_t)ch * a.n_tiles;
-    ScanOutG* outs = a.outs + (size_t)ch * a.n_tiles;
+    const int lane = threadIdx.x, n_groups = n_groups_of(a.n_tiles);
+    const bool track = a.track != 0;
     p25fe_anchor_t Ain;
     Ain.valid = 0; Ain.s = 0; Ain.hi = Ain.mid = Ain.lo = 0.f; Ain.period_d = SPS; Ain.period_n = 1;
     if (a.anchor_in) Ain = a.anchor_in[ch];
     if (!clock_plausible(Ain.period_d, Ain.period_n)) { Ain.period_d = SPS; Ain.period_n = 1; }
-    const bool track = a.track != 0;
-    if (tid == 0) {
-        c_top.a = c_top.b = -1;
-        c_cnt = 0; c_ev = 0; c_base_first = 0; c_first_event = -1; c_carry_end = -1; c_first_seg_end = -1; c_first_seg_next = -1; c_flags = 0u; c_has_event = 0; c_first_f = 0;
-    }
-    __syncthreads();
-
-    int cc0 = 0, ccn = 0;                                           // the chunk staged in LDS: tiles [cc0, cc0 + ccn)
-    auto sum_of = [&](int t) -> TileSumG { return (t >= cc0 && t < cc0 + ccn) ? GS[t - cc0] : gsum[t]; };
-    auto last_s_of = [&](int t) -> long { return (t >= cc0 && t < cc0 + ccn) ? LS[t - cc0] : recs[t].last_s; };
-    auto last_f_of = [&](int t) -> int { return (t >= cc0 && t < cc0 + ccn) ? LF[t - cc0] : recs[t].last_f; };
-    const int Ain_f = frac3((unsigned)Ain.valid >> 8);               // the carry-in's fraction rides in bits 8..10 of `valid`
-    // state after event tile t1 (t2: the event tile before it, -1: the range's carry-in)
-    auto state_after = [&](int t1, int t2) -> CState {
-        CState st;
-        if (t1 < 0) { st.valid = Ain.valid != 0; st.s = Ain.s; st.D = Ain.period_d; st.N = Ain.period_n; st.src = Ain.valid ? -1 : -2; st.f = Ain_f; return st; }
-        const TileSumG g = sum_of(t1);
-        const unsigned fl = g.n_det_flags >> 16;
-        if (!(fl & G_OUT_VALID)) { st.valid = 0; st.s = 0; st.D = SPS; st.N = 1; st.src = -2; st.f = 0; return st; }
-        st.valid = 1; st.src = t1; st.s = last_s_of(t1); st.f = last_f_of(t1);
-        if (fl & G_OUT_PERIOD_KNOWN) { st.D = g.out_D; st.N = g.out_N; return st; }
-        bool pv; long ps; int pf;
-        if (t2 >= 0) { pv = ((sum_of(t2).n_det_flags >> 16) & G_OUT_VALID) != 0; ps = pv ? last_s_of(t2) : 0; pf = pv ? last_f_of(t2) : 0; }
-        else { pv = Ain.valid != 0; ps = Ain.s; pf = Ain_f; }
-        clock_period(track, pv, ps, pf, st.s, st.f, st.D, st.N);
-        return st;
-    };
-    auto tile_len = [&](int k) -> int {
-        const long rem = a.n - (long)k * TS;
-        return rem < TS ? (int)rem : TS;
-    };
-
-    for (int c0 = 0; c0 < a.n_tiles; c0 += KC) {
-        const int cn = (a.n_tiles - c0 < KC) ? a.n_tiles - c0 : KC;
-        __syncthreads();                                            // the previous chunk's readers are done with GS / LS
-        for (int k = tid; k < cn; k += NT) { GS[k] = gsum[c0 + k]; LS[k] = recs[c0 + k].last_s; LF[k] = recs[c0 + k].last_f; }
-        cc0 = c0; ccn = cn;
-        __syncthreads();
-        const int per = (cn + NT - 1) / NT;
-        const int k0 = tid * per < cn ? tid * per : cn, k1 = (k0 + per < cn) ? k0 + per : cn;
-        // ---- latest two event tiles of my run -> exclusive scan
-        Top2 mine; mine.a = mine.b = -1;
-        for (int k = k0; k < k1; ++k)
-            if (GS[k].pre_end1) { mine.b = mine.a; mine.a = c0 + k; }
-        Top2 inc = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const Top2 o = top2_shfl_up(inc, d);
-            if (lane >= d) inc = top2_merge(o, inc);
-        }
-        if (lane == 63) sh2[wv] = inc;
-        __syncthreads();
-        Top2 carry = c_top;
-        for (int k = 0; k < wv; ++k) carry = top2_merge(carry, sh2[k]);
-        Top2 exc = top2_shfl_up(inc, 1);
-        if (lane == 0) { exc.a = exc.b = -1; }
-        exc = top2_merge(carry, exc);                              // latest two event tiles before my run
-        Top2 tot = c_top;
-        for (int k = 0; k < NT / 64; ++k) tot = top2_merge(tot, sh2[k]);
-        __syncthreads();
-
-        // ---- dibits / detections of every tile of my run
-        unsigned long long my_cnt = 0, my_ev = 0;
-        {
-            Top2 t2 = exc;
-            CState st = state_after(t2.a, t2.b);
-            for (int k = k0; k < k1; ++k) {
-                const TileSumG g = GS[k];
-                const long T0 = a.abs0 + (long)(c0 + k) * TS, TE = T0 + tile_len(c0 + k);
-                const long pre_hi = g.pre_end1 ? T0 + (long)g.pre_end1 - 1 : TE;
-                const unsigned pre = st.valid ? (unsigned)clock_count(st.s, st.D, st.N, T0, pre_hi) : 0u;
-                unsigned tot_k = pre;
-                if (g.first1) {
-                    const long s0 = T0 + (long)(g.first1 & 0xffffu) - 1 - W;
-                    int D0, N0;
-                    clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && st.valid, st.s, st.f, s0, frac3(g.first1 >> 16), D0, N0);
-                    tot_k += (unsigned)clock_count(s0, D0, N0, s0 + W + 1, T0 + g.end0) + g.post_rest;
+    CState cur;
+    cur.valid = Ain.valid != 0; cur.s = Ain.s; cur.D = Ain.period_d; cur.N = Ain.period_n; cur.src = Ain.valid ? -1 : -2;
+    cur.f = frac3((unsigned)Ain.valid >> 8);                         // the carry-in's fraction rides in bits 8..10 of `valid`
+    unsigned long long off = 0ull, ev = 0ull, base_first = 0ull;
+    long first_event = -1, carry_end = 0, fse = -1;
+    int first_f = 0, n_event_tiles = 0;
+    bool has_event = false, fse_open = false, last_from_carry = false;
+    unsigned fl_first = 0u;
+    const GroupSumG* gsg = a.gsg + (size_t)ch * n_groups;
+    GroupPreG* gpg = a.gpg + (size_t)ch * n_groups;
+    const long range_end = a.abs0 + a.n;
+    for (int c0 = 0; c0 < n_groups; c0 += WV) {
+        GroupSumG M;
+        M.first_event = -1; M.carry_end = -1; M.first_seg_end = -1; M.after_first = 0ull; M.out_s = 0; M.out_valid = 0; M.out_f = 0; M.out_src = -2;
+        M.out_D = SPS; M.out_N = 1; M.n_sync = 0u; M.flags = 0u; M.first_f = 0; M.n_event_tiles = 0; M.pad_ = 0;
+        if (c0 + lane < n_groups) M = gsg[c0 + lane];
+        const int cn = n_groups - c0 < WV ? n_groups - c0 : WV;
+        GroupPreG mine;                                             // the carry-in of group c0 + lane, kept by the lane that stores it
+        mine.s = 0; mine.dibit_off = 0ull; mine.valid = 0; mine.D = SPS; mine.N = 1; mine.src = -2; mine.f = 0; mine.event_off = 0u;
+        for (int j = 0; j < cn; ++j) {                               // uniform
+            GroupSumG R;
+            R.first_event = rdl_l(M.first_event, j); R.carry_end = rdl_l(M.carry_end, j); R.first_seg_end = rdl_l(M.first_seg_end, j);
+            R.after_first = (unsigned long long)rdl_l((long)M.after_first, j); R.out_s = rdl_l(M.out_s, j);
+            R.out_valid = rdl(M.out_valid, j); R.out_f = rdl(M.out_f, j); R.out_src = rdl(M.out_src, j);
+            R.out_D = rdl(M.out_D, j); R.out_N = rdl(M.out_N, j);
+            R.n_sync = (unsigned)rdl((int)M.n_sync, j); R.flags = (unsigned)rdl((int)M.flags, j);
+            R.first_f = rdl(M.first_f, j); R.n_event_tiles = rdl(M.n_event_tiles, j);
+            if (lane == j) {
+                mine.s = cur.s; mine.dibit_off = off; mine.valid = cur.valid; mine.D = cur.D; mine.N = cur.N; mine.src = cur.src; mine.f = cur.f;
+                mine.event_off = (unsigned)ev;
+            }
+            const long G0 = a.abs0 + (long)(c0 + j) * ((long)GT * TS);
+            const long G1 = G0 + (long)GT * TS < range_end ? G0 + (long)GT * TS : range_end;
+            const bool evt = (R.flags & GS_HAS_EVENT) != 0u;
+            const unsigned long long pre = cur.valid ? (unsigned long long)clock_count(cur.s, cur.D, cur.N, G0, evt ? R.carry_end : G1) : 0ull;
+            unsigned long long own = R.first_event >= 0 ? R.after_first : 0ull;
+            const bool tracks = track && (R.flags & GS_FIRST_TRACKS) && cur.valid;
+            if (R.first_event >= 0 && tracks) {
+                const long s0 = R.first_event - W;
+                int D0, N0;
+                clock_period(true, true, cur.s, cur.f, s0, R.first_f, D0, N0);
+                own = own - (unsigned long long)clock_count(s0, SPS, 1, s0 + W + 1, R.first_seg_end) +
+                      (unsigned long long)clock_count(s0, D0, N0, s0 + W + 1, R.first_seg_end);
+            }
+            if (evt && !has_event) { has_event = true; carry_end = R.carry_end; }
+            if (evt && first_event >= 0 && fse_open) { fse = R.carry_end; fse_open = false; }    // the event that ends the first detection's open interval
+            if (R.first_event >= 0 && first_event < 0) {
+                first_event = R.first_event; first_f = R.first_f;
+                base_first = off + pre;
+                fl_first = ((R.flags & GS_FIRST_TRACKS) && n_event_tiles == 0) ? 1u : 0u;
+                fse = R.first_seg_end; fse_open = (R.flags & GS_SEG_OPEN) != 0u;
+            }
+            off += pre + own;
+            ev += R.n_sync;
+            if (evt) {
+                n_event_tiles += R.n_event_tiles;
+                last_from_carry = (R.flags & GS_OUT_FROM_CARRY) != 0u;
+                if (R.out_valid) {
+                    CState nxt;
+                    nxt.valid = 1; nxt.s = R.out_s; nxt.D = R.out_D; nxt.N = R.out_N; nxt.src = R.out_src; nxt.f = R.out_f;
+                    if (R.flags & GS_OUT_FROM_CARRY) clock_period(track, cur.valid != 0, cur.s, cur.f, nxt.s, nxt.f, nxt.D, nxt.N);
+                    cur = nxt;
+                } else {
+                    cur.valid = 0; cur.s = 0; cur.D = SPS; cur.N = 1; cur.src = -2; cur.f = 0;
                 }
-                PRE[k] = pre; CNT[k] = tot_k;
-                my_cnt += tot_k; my_ev += g.n_det_flags & 0xffffu;
-                if (g.pre_end1) { t2.b = t2.a; t2.a = c0 + k; st = state_after(t2.a, t2.b); }
             }
         }
-        unsigned long long tot_pk;
-        const unsigned long long ipk = block_incl_sum<NT>(my_cnt | (my_ev << 40), shu, tid, tot_pk);
-        // ---- carry-ins
-        {
-            unsigned long long dc = c_cnt + (ipk & ((1ull << 40) - 1)) - my_cnt, ec = c_ev + (ipk >> 40) - my_ev;
-            Top2 t2 = exc;
-            CState st = state_after(t2.a, t2.b);
-            for (int k = k0; k < k1; ++k) {
-                const TileSumG g = GS[k];
-                ScanOutG o;
-                o.s = st.s; o.dibit_off = dc; o.src = st.src; o.event_off = (unsigned)ec; o.D = st.D; o.N = st.N; o.f = st.f; o.pad_ = 0;
-                outs[c0 + k] = o;
-                if (g.pre_end1 && t2.a < 0) {                      // the range's first event tile (one thread finds it)
-                    const long T0 = a.abs0 + (long)(c0 + k) * TS;
-                    c_carry_end = T0 + (long)g.pre_end1 - 1;
-                    c_has_event = 1;
-                }
-                if (g.first1 && c_first_event < 0) {
-                    // the range's first detection: the one tile with detections and none before it (every earlier event
-                    // tile holds lock drops only) -- exactly one thread gets here with ec == 0
-                    if (ec == 0) {
-                        const long T0 = a.abs0 + (long)(c0 + k) * TS;
-                        c_first_event = T0 + (long)(g.first1 & 0xffffu) - 1;
-                        c_first_f = frac3(g.first1 >> 16);
-                        c_first_seg_end = T0 + g.end0;              // inside its tile; an interval that is still open at the tile's end
-                        c_base_first = dc + PRE[k];                 // runs on to the next event tile (c_first_seg_next) or the range's end
-                        unsigned fl = 0u;
-                        if (((g.n_det_flags >> 16) & G_FIRST_TRACKS) && t2.a < 0) fl |= 1u;      // no lock drop between the range's start and it
-                        c_flags = fl;
-                    }
-                }
-                if (g.pre_end1 && t2.a >= 0) {
-                    // the event tile that follows the tile of the range's first detection (exactly one thread): the carry
-                    // into it -- that detection's clock, if it was its tile's last event -- ends here
-                    const TileSumG gp = sum_of(t2.a);
-                    if (gp.first1 && ec == (unsigned long long)(gp.n_det_flags & 0xffffu))
-                        c_first_seg_next = a.abs0 + (long)(c0 + k) * TS + (long)g.pre_end1 - 1;
-                }
-                dc += CNT[k]; ec += g.n_det_flags & 0xffffu;
-                if (g.pre_end1) { t2.b = t2.a; t2.a = c0 + k; st = state_after(t2.a, t2.b); }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            c_top = tot;
-            c_cnt += tot_pk & ((1ull << 40) - 1);
-            c_ev += tot_pk >> 40;
-        }
-        __syncthreads();
+        if (c0 + lane < n_groups) gpg[c0 + lane] = mine;
     }
-    ccn = 0;                                                        // (nothing staged any more: read the final tiles from global memory)
-    if (tid == 0) {
-        const CState st = state_after(c_top.a, c_top.b);
+    if (lane == 0) {
         p25fe_result_t r;
         r.n_baseband = a.n_baseband;
-        r.n_dibits = c_cnt;
-        r.n_sync = c_ev;
+        r.n_dibits = off;
+        r.n_sync = ev;
         p25fe_anchor_t A = Ain;
-        if (st.src >= 0) {
-            const TileRec t = recs[st.src];
+        if (cur.src >= 0) {
+            const TileRec t = a.recs[(size_t)ch * a.n_tiles + cur.src];
             // bit 0: locked; bits 8..10: the sync position's fraction (SPEC 3.8b) -- only when the clock tracks: with the fixed
             // stride the general receiver (a lock-drop list) hands on the same `valid = 1` as the one-tile fast path
-            A.valid = track ? (1 | ((st.f & 7) << 8)) : 1;
-            A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo; A.period_d = st.D; A.period_n = st.N;
-        } else if (st.src == -2) {
+            A.valid = track ? (1 | ((cur.f & 7) << 8)) : 1;
+            A.s = t.last_s; A.hi = t.hi; A.mid = t.mid; A.lo = t.lo; A.period_d = cur.D; A.period_n = cur.N;
+        } else if (cur.src == -2) {
             A.valid = 0;
         }
         r.anchor_out = A;
-        r.first_event = c_first_event;
-        r.n_dibits_after_first = c_first_event >= 0 ? c_cnt - c_base_first : 0;
+        r.first_event = first_event;
+        r.n_dibits_after_first = first_event >= 0 ? off - base_first : 0ull;
         // -1 means "no event": an event IN FRONT of index 0 (a lock drop at sample 0 or 1 of a fresh stream, which the tracking
         // clock's lookahead puts at -2 / -1; nothing can be locked there) is reported at 0
-        r.carry_end = c_has_event ? (c_carry_end > 0 ? c_carry_end : 0) : -1;
-        // where the first detection's governed interval ends IN THE RANGE: inside its tile, or -- still open at the tile's end
-        // -- at the next event tile's first event, or at the range's end (p25fe_shard_resolve recounts that interval
-        // under the detection's real clock)
-        long fse = c_first_seg_end;
-        if (c_first_event >= 0) {
-            const long ft = (c_first_event - a.abs0) / TS;           // its tile
-            const long te = a.abs0 + ((ft + 1) * TS < a.n ? (ft + 1) * TS : a.n);
-            if (fse >= te) fse = c_first_seg_next >= 0 ? c_first_seg_next : a.abs0 + a.n;
-        }
-        r.first_seg_end = fse;
-        unsigned fl = c_flags;
+        r.carry_end = has_event ? (carry_end > 0 ? carry_end : 0) : -1;
+        // where the first detection's governed interval ends IN THE RANGE: at the next event, or -- still open -- at the range's end
+        // (p25fe_shard_resolve recounts that interval under the detection's real clock)
+        r.first_seg_end = first_event >= 0 ? (fse_open ? range_end : fse) : -1;
+        unsigned fl = fl_first;
         // the clock the range ends on was taken from the carry-in: its only event is one tracking detection
-        if (st.src >= 0 && c_top.b < 0 && !((gsum[c_top.a].n_det_flags >> 16) & G_OUT_PERIOD_KNOWN)) fl |= 2u;
-        r.flags = fl; r.reserved = c_first_event >= 0 ? (unsigned)(c_first_f & 7) : 0u;     // the first own detection's fraction
+        if (cur.src >= 0 && n_event_tiles == 1 && last_from_carry) fl |= 2u;
+        r.flags = fl; r.reserved = first_event >= 0 ? (unsigned)(first_f & 7) : 0u;     // the first own detection's fraction
         a.result[ch] = r;
     }
 }
+
+#ifndef P25FE_JIT
+// pass B: one wave per group, the lane scan under the group's carry-in -> the tiles' carry-ins
+__global__ __launch_bounds__(WV, 4) void k_scan_g_groups(ScanArgsG a)
+{
+    const int g = blockIdx.x, ch = blockIdx.y, tile0 = g * GT;
+    TileSumG gs; long last_s, T0; int last_f, tn;
+    load_lane_tile(a, g, ch, gs, last_s, last_f, T0, tn);
+    const GroupPreG P = a.gpg[(size_t)ch * n_groups_of(a.n_tiles) + g];
+    CState C;
+    C.valid = P.valid; C.s = P.s; C.D = P.D; C.N = P.N; C.src = P.src; C.f = P.f;
+    const GLanes L = scan_g_lanes(gs, last_s, last_f, C, a.track != 0, T0, tn, tile0);
+    const int tl = tile0 + (int)threadIdx.x;
+    if (tl < a.n_tiles) {
+        ScanOutG o;
+        o.s = L.st.s; o.dibit_off = P.dibit_off + (L.excl & ((1ull << 40) - 1)); o.src = L.st.src;
+        o.event_off = P.event_off + (unsigned)(L.excl >> 40); o.D = L.st.D; o.N = L.st.N; o.f = L.st.f; o.pad_ = 0;
+        a.outs[(size_t)ch * a.n_tiles + tl] = o;
+    }
+}
+// the top step alone: a re-scan of summaries that are already there under another carry-in (p25fe_shard_pass2 and its device form),
+// and the record of an EMPTY range (no tile, no K2: the carry-in is handed through)
+__global__ __launch_bounds__(WV, 4) void k_range_scan_g(ScanArgsG a) { range_scan_g(a, (int)blockIdx.x); }
 #endif
+
+// K2's kernel: detection, then -- when the call wants the receiver's state too (tail.on) -- K3 in the tail: the group's last workgroup
+// scans the group, the channel's last group scans the groups (ScanTail; the general receiver: GroupSumG).
+// (GEN: 16 KB of LDS per one-wave workgroup -- the per-offset fraction table)
+template <bool GEN> __device__ __forceinline__ void detect_item(const DetArgs& a, const int tile, const int ch)
+{
+    if (a.head_flag && tile <= a.head_tile_max) {                   // uniform
+        // every head workgroup released its stores (agent scope) before it took its ticket; the acquire after seeing the
+        // flag keeps this wave from reading lines its caches held before that
+        // The wait is BOUNDED: the head sits behind the halo's ncclRecv on another stream, and a peer that stalls or dies
+        // would otherwise leave these workgroups spinning for ever with no way to abort the queue.  After HEAD_WAIT_TICKS of the 100 MHz
+        // wall clock the workgroup gives up, says so in head_err and carries on with whatever the planes hold: the step's results are
+        // then garbage, and p25fe_shard_head_check / p25fe_shard_offsets report P25FE_ERR_TIMEOUT instead of handing them out.
+        const unsigned long long t0 = wall_clock64();
+        bool gave_up = false;
+        while ((int)(__hip_atomic_load(a.head_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.head_seq) < 0) {
+            if (wall_clock64() - t0 > HEAD_WAIT_TICKS) { gave_up = true; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (gave_up && threadIdx.x == 0) __hip_atomic_store(a.head_err, a.head_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    detect_tile<GEN>(a, tile, ch);
+    if (!a.tail.on) return;                                         // uniform
+    const int g = tile / GT, n_groups = n_groups_of(a.n_tiles);
+    const int gn = a.n_tiles - g * GT < GT ? a.n_tiles - g * GT : GT;
+    unsigned* tickets = a.tail.tickets + (size_t)ch * (n_groups + 1);
+    if constexpr (!GEN) {
+        (void)tickets; (void)gn;                                    // (the fixed-stride receiver's K3 is k_scan_tiles)
+    } else {
+        ScanArgsG c;
+        c.gsum = a.gsum; c.recs = a.recs; c.outs = nullptr; c.gsg = a.tail.gsg; c.gpg = a.tail.gpg; c.tickets = a.tail.tickets;
+        c.n_tiles = a.n_tiles; c.n = a.n; c.abs0 = a.abs0; c.anchor_in = a.tail.anchor_in; c.result = a.tail.result;
+        c.n_baseband = a.tail.n_baseband; c.track = a.opt.track;
+        if (!last_arrival(tickets + g, (unsigned)gn)) return;
+        group_scan_g(c, g, ch);
+        if (!last_arrival(tickets + n_groups, (unsigned)n_groups)) return;
+        range_scan_g(c, ch);
+    }
+}
+template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 2 : 4) void k_detect(DetArgs a) { detect_item<GEN>(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 struct SliceArgsG {
     Planar pl;
@@ -1368,13 +1494,13 @@ struct SliceArgsG {
 };
 
 #ifndef P25FE_JIT
-__global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
+__device__ __forceinline__ void slice_g_item(const SliceArgsG& a, const int tile, const int ch)
 {
     __shared__ uint16_t EV[EVCAP];
     __shared__ uint32_t EG[EVCAP];
     __shared__ float ETH[EVTHR_N * 3];
     __shared__ float CI[P25FE_CLK_PHASES * 4];
-    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
@@ -1478,6 +1604,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a)
         rank += emit(sk, D, N, ek + 1, T0 + (long)(eg & 0x7fffu), h, m, l, rank);
     }
 }
+__global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a) { slice_g_item(a, (int)blockIdx.x, (int)blockIdx.y); }
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -1539,11 +1666,11 @@ struct EvArgs {
 };
 
 #ifndef P25FE_JIT
-__global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a)
+__device__ __forceinline__ void ev_collect_item(const EvArgs& a, const int tile, const int ch)
 {
     __shared__ uint16_t EV[EVCAP];
     __shared__ uint32_t EG[EVCAP];
-    const int lane = threadIdx.x, tile = blockIdx.x, ch = blockIdx.y;
+    const int lane = threadIdx.x;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
     const ScanOutG so = a.outs[(size_t)ch * a.n_tiles + tile];
@@ -1610,6 +1737,7 @@ __global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a)
         if (lane == 0) { EvRec* r = rec + 1 + so.event_off + k; r->hi = h; r->mid = m; r->lo = l; }
     }
 }
+__global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a) { ev_collect_item(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // k_ev_count: one lane per detection (grid-stride), the divisions of clock_count in parallel; k_ev_scan: ONE wave (it runs beside the
 // next call's K1, whose one-wave workgroups leave room for exactly that -- a 512-thread workgroup waits for K1 to drain, as k_scan_g
@@ -1813,7 +1941,8 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     d.pl = c.pl; d.n = c.n; d.abs0 = c.abs0; d.n_tiles = 1;
     d.recs = c.recs; d.tsum = c.tsum; d.evl = c.evl; d.evthr = c.evthr;
     d.opt.track = 0; d.opt.n_resync = 0; d.opt.resync = nullptr; d.opt.resync_stride = 0; d.gsum = nullptr; d.evg = nullptr;
-    d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1;
+    d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1; d.head_err = nullptr;
+    d.tail.on = 0;
     detect_tile<false>(d, 0, ch);
     wave_global_sync();
     // the scan of a one-tile range
@@ -1842,7 +1971,7 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     l.outs = nullptr; l.recs = c.recs; l.tsum = c.tsum; l.evl = c.evl; l.evthr = c.evthr; l.anchor_in = c.anchor_in;
     l.dibits = c.dibits; l.dibit_stride = c.dibit_stride;
     l.sync_pos = (c.sync_pos && c.sync_dibit) ? c.sync_pos : nullptr; l.sync_dibit = c.sync_dibit; l.sync_stride = c.sync_stride;
-    l.dibits2 = nullptr; l.fix.summ = nullptr;
+    l.dibits2 = nullptr; l.fix.summ = nullptr; l.gpre = nullptr;
     ScanOut so;
     so.src = -1; so.event_off = 0u; so.dibit_off = 0ull;
     slice_tile(l, 0, ch, so, u, A.valid, A.s, A.hi, A.mid, A.lo);

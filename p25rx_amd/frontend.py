@@ -27,7 +27,7 @@ class FrontEnd:
         # symbol_clock 0: fixed stride (the reference's receiver), 1: SPEC 3.8b, 2: 3.8b + 3.8c in run_dev / run_dev_pipelined / slice_dev
         cfg = _lib.make_config(n_channels=n_channels, device=device, decim_taps=decim_taps, chan_taps=chan_taps,
                                symbol_clock=symbol_clock, **spec)
-        self.symbol_clock = symbol_clock
+        self.symbol_clock = symbol_clock & 0xff                  # (without P25FE_CLOCK_CAUSAL_OK)
         self.cfg = cfg
         self.C = n_channels
         self.device = device

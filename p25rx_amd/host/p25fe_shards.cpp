@@ -94,6 +94,8 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
         die("device buffers", P25FE_ERR_NOMEM);
     (void)hipMemset(d_buf, 0, halo * 8);
     (void)hipMemcpy(d_buf + 2 * halo, host.data(), n * 8, hipMemcpyHostToDevice);
+    // once per stream the steps are given: the side stream must not share a hardware queue with it (no step checks: a step never blocks)
+    if ((rc = p25fe_shard_prepare(s, st)) != 0) die("prepare", rc);
     // -p: p25fe_shard_step_pipelined -- only K1 on `st`, the rest of a step behind the next step's K1
     auto step = pipelined ? p25fe_shard_step_pipelined : p25fe_shard_step;
     for (int k = 0; k < 2; ++k) {                                     // warm-up (communicator set-up, scratch allocation)
@@ -119,6 +121,11 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
     rc = p25fe_shard_offsets(s, off.data());
     if (rc) die("offsets", rc);
     const int ran = p25fe_shard_gather_ran(s);
+    p25fe_shard_info_t inf;
+    if ((rc = p25fe_shard_info(s, &inf)) != 0) die("info", rc);
+    // every rank says where it sits (the library's own evidence, not the launcher's arguments)
+    std::fprintf(stderr, "{\"rank\":%d,\"rccl_ranks\":%d,\"rccl_rank\":%d,\"device\":%d,\"pci_bus_id\":\"%s\",\"comms\":%d,\"pipe_layout\":%d}\n",
+                 inf.rank, inf.rccl_ranks, inf.rccl_rank, inf.device, inf.pci_bus_id, inf.comms, inf.pipe_layout);
     if (rank == 0) {
         std::vector<uint8_t> stream((size_t)off[(size_t)world]);
         (void)hipMemcpy(stream.data(), p25fe_shard_stream_dev(s), stream.size(), hipMemcpyDeviceToHost);
@@ -127,9 +134,10 @@ static int child(int rank, int world, int steps, bool shm, int clock, int gather
         std::fclose(g);
         std::printf("{\"ranks\":%d,\"samples_per_rank\":%zu,\"dibits\":%" PRIu64 ",\"steps\":%d,\"ms_per_step\":%.4f,\"host_enqueue_ms_per_step\":%.4f,"
                     "\"comm_ms_per_step\":{\"halo\":%.4f,\"summaries\":%.4f,\"dibit_gather\":%.4f,\"steps_averaged\":%" PRIu64 "},"
-                    "\"exchange\":\"%s\",\"gather\":\"%s\",\"pipelined\":%s}\n",
+                    "\"exchange\":\"%s\",\"gather\":\"%s\",\"pipelined\":%s,\"rccl_ranks\":%d,\"comms\":%d,\"pipe_layout\":%d,\"pci_bus_id\":\"%s\"}\n",
                     world, n, off[(size_t)world], steps, ms, enq_ms, cms[0], cms[1], cms[2], cn, shm ? "TEST HOOK: shared memory, one GPU" : "RCCL",
-                    ran == P25FE_GATHER_ROOT_EXACT ? "exact" : (ran == P25FE_GATHER_ROOT ? "rows" : "other"), pipelined ? "true" : "false");
+                    ran == P25FE_GATHER_ROOT_EXACT ? "exact" : (ran == P25FE_GATHER_ROOT ? "rows" : "other"), pipelined ? "true" : "false",
+                    inf.rccl_ranks, inf.comms, inf.pipe_layout, inf.pci_bus_id);
         std::remove(idfile.c_str());
         std::fflush(stdout);                                          // the child leaves through _Exit
     }

@@ -17,7 +17,14 @@ GATHER = {"none": 0, "root": 1, "all": 2, "root_exact": 3}
 
 SYMBOLS = ["p25fe_rccl_unique_id", "p25fe_shard_create", "p25fe_shard_destroy", "p25fe_shard_dibit_cap", "p25fe_shard_step",
            "p25fe_shard_offsets", "p25fe_shard_stream_dev", "p25fe_shard_comm_ms", "p25fe_shard_comm_timing", "p25fe_shard_gather_ran",
-           "p25fe_shard_step_pipelined", "p25fe_shard_join"]
+           "p25fe_shard_step_pipelined", "p25fe_shard_join", "p25fe_shard_info", "p25fe_shard_prepare"]
+
+
+class ShardInfo(C.Structure):
+    """p25fe_shard_info_t (include/p25fe_rccl.h)"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("rccl_ranks", C.c_int32), ("rccl_rank", C.c_int32), ("device", C.c_int32),
+                ("comms", C.c_int32), ("pipe_layout", C.c_int32), ("gather_ran", C.c_int32), ("staged", C.c_int32), ("head_wait", C.c_int32),
+                ("broken", C.c_int32), ("reserved", C.c_int32), ("steps", C.c_uint64), ("pci_bus_id", C.c_char * 32)]
 
 _LIB = None
 
@@ -46,6 +53,8 @@ def load():
     L.p25fe_shard_comm_ms.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_uint64)]
     L.p25fe_shard_comm_timing.argtypes = [vp, C.c_int]
     L.p25fe_shard_gather_ran.argtypes = [vp]
+    L.p25fe_shard_info.argtypes = [vp, C.POINTER(ShardInfo)]
+    L.p25fe_shard_prepare.argtypes = [vp, vp]
     _LIB = L
     return L
 
@@ -117,6 +126,25 @@ class ShardStep:
         raw.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "|u1", "version": 2,
                                         "data": (int(self.L.p25fe_shard_stream_dev(self.h)), False)}
         return torch.as_tensor(raw, device=device).clone()
+
+    def info(self):
+        """what the library itself knows about the job (p25fe_shard_info): RCCL's rank count, this rank's GPU, the agreed layout"""
+        i = ShardInfo()
+        rc = self.L.p25fe_shard_info(self.h, C.byref(i))
+        if rc:
+            raise _lib.P25feError(rc, "p25fe_shard_info")
+        d = {k: getattr(i, k) for k, _ in ShardInfo._fields_ if k != "reserved"}
+        d["pci_bus_id"] = i.pci_bus_id.decode(errors="replace")
+        d["gather_ran"] = {b: a for a, b in GATHER.items()}.get(int(i.gather_ran), "?")
+        return d
+
+    def prepare(self, device=None):
+        """once per stream: the side stream must not share a hardware queue with torch's current stream or the receive stream"""
+        import torch
+        st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        rc = self.L.p25fe_shard_prepare(self.h, st)
+        if rc:
+            raise _lib.P25feError(rc, "p25fe_shard_prepare")
 
     def comm_timing(self, every):
         """HIP events around the exchanges on every `every`-th step (0: never; library default 16)"""

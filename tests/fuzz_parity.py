@@ -127,7 +127,8 @@ def run_scene(seed, O, FE, torch, verbose=False):
     fkw = dict(xkw)
     if s["kernels"] == 1:
         fkw["specialize"] = 2                                        # FORCE: the build's own numbers go through hipRTC too
-    mk = lambda C_=Cn: FE(n_channels=C_, decim_taps=dt, chan_taps=ct, symbol_clock=s["clock"], **fkw)
+    # (mode 2 with P25FE_CLOCK_CAUSAL_OK: the scene runs the streaming / window / shard forms too, which have the causal rule only)
+    mk = lambda C_=Cn: FE(n_channels=C_, decim_taps=dt, chan_taps=ct, symbol_clock=(0x102 if s["clock"] == 2 else s["clock"]), **fkw)
     what = []
 
     def check(name, ok):

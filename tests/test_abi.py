@@ -66,7 +66,7 @@ def test_rust_binding_file_declares_the_whole_abi(lib):
 
 def test_default_config_matches_spec(lib, spec):
     cfg = lib.default_config()
-    assert cfg.abi_version == lib.ABI_VERSION == 5 and cfg.n_channels == 1 and cfg.symbol_clock == 0
+    assert cfg.abi_version == lib.ABI_VERSION == 6 and cfg.n_channels == 1 and cfg.symbol_clock == 0
     # ABI 5: Decimator::new(5)'s phase and MovingAverage::new(10) as a table (src/demod.rs:50, 52) default to the build's numbers
     assert cfg.decim_phase == spec["decim_phase"] == 4 and cfg.n_avg_taps == spec["boxcar_len"] == 10
     assert np.array_equal(np.array(cfg.avg_taps[:10], dtype=np.float32), np.array(spec["avg_taps"], dtype=np.float32))

@@ -237,7 +237,7 @@ def test_bench_two_ranks_time_shards_host_staged(scaling):
     env = dict(os.environ, P25FE_BENCH_HOST_STAGED="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "60"]
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--seconds", "60", "--strong-seconds", "40"]
                          + (["--scaling", "strong", "--gather", "root_exact"] if scaling == "strong" else []),     # weak + rows are the defaults (the driver's command)
                          env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -250,6 +250,17 @@ def test_bench_two_ranks_time_shards_host_staged(scaling):
     assert ("exactly the valid bytes" if scaling == "strong" else "whole rows") in d["config"]["sharding"]
     # weak: 60 s per rank = one 120 s capture; strong: the 60 s are the whole capture
     assert ("ONE 120 s capture" if scaling == "weak" else "ONE 60 s capture") in d["config"]["workload"] and d["value"] > 0
+    # the library's own evidence of the job (p25fe_shard_info from every rank): here the shared-memory hook, i.e. no communicator
+    ev = d["config"]["rccl"]
+    assert ev["staged_test_hook"] and ev["rccl_ranks"] == [0, 0] and ev["communicators"] == [0] and len(ev["pci_bus_id_of_rank"]) == 2
+    assert ev["distinct_gpus"] == 1 and not ev["broken"]
+    if scaling == "weak":
+        # configs[4] as worded rides along as an extra row of the default weak line, with its own gates
+        (row,) = d["extra"]
+        assert row["scaling"] == "strong" and "ONE 40 s capture" in row["config"] and row["parity_gate"].endswith("True")
+        assert row["gather_gate"].endswith("True") and row["value"] > 0 and row["rccl"]["staged_test_hook"]
+    else:
+        assert "extra" not in d
 
 
 @pytest.mark.timeout(300)
@@ -448,9 +459,20 @@ def _rccl_cabi_pipelined_worker(q):
     oks = []
     caps = [c4fm.synth(2.0, seed=78, snr_db=22.0, frame_dibits=400)[0], c4fm.synth(2.0, seed=79, snr_db=22.0, frame_dibits=900)[0]]
     n = min(len(c) for c in caps) // 8 * 8
-    for comm_id, clock in ((rccl.unique_id(), 0), (None, 0), (rccl.unique_id(), 1)):   # a one-rank RCCL communicator; no communicator at all;
-        fe = FrontEnd(symbol_clock=clock)                           # ... and the tracking clock (pass 2 = resolve kernel + general scan + slicer)
+    # a one-rank RCCL communicator; no communicator at all; the tracking clock (pass 2 = resolve kernel + re-scan + slicer); and a rank whose
+    # ncclCommSplit "failed" (P25FE_SHARD_SPLIT_FAIL): the layout every rank falls back to when ANY rank lacks a split -- one communicator,
+    # the step's own order on the receive stream -- which is what a real N-GPU box runs the day a split fails
+    for comm_id, clock, split_fail in ((rccl.unique_id(), 0, False), (None, 0, False), (rccl.unique_id(), 1, False), (rccl.unique_id(), 0, True)):
+        fe = FrontEnd(symbol_clock=clock)
+        if split_fail:
+            os.environ["P25FE_SHARD_SPLIT_FAIL"] = "all"
         ss = rccl.ShardStep(fe, 0, 1, n, comm_id)
+        os.environ.pop("P25FE_SHARD_SPLIT_FAIL", None)
+        ss.prepare()
+        inf = ss.info()
+        want = (0, 0, 2) if comm_id is None else ((1, 1, 1) if split_fail else (1, 3, 2))
+        oks.append((inf["rccl_ranks"], inf["comms"], inf["pipe_layout"]) == want and inf["world"] == 1 and not inf["staged"]
+                   and not inf["broken"] and len(inf["pci_bus_id"]) >= 7 and inf["device"] == 0)
         halo = fe.shard_halo()
         bufs, refs = [], []
         for iq in caps:
@@ -490,8 +512,9 @@ def _rccl_cabi_pipelined_worker(q):
 @pytest.mark.timeout(300)
 def test_c_abi_shard_step_pipelined():
     """p25fe_shard_step_pipelined: nine steps over two alternating captures enqueued back to back (every gather mode; with a one-rank
-    RCCL communicator and without one) leave, per step, the single-pass dibits of THAT step's capture, and the ordered stream of
-    the last one; a plain step behind a pipelined one needs no join."""
+    RCCL communicator, without one, and on the one-communicator fallback layout of a failed ncclCommSplit) leave, per step, the
+    single-pass dibits of THAT step's capture, and the ordered stream of the last one; a plain step behind a pipelined one needs no
+    join; p25fe_shard_info says which layout ran."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -500,7 +523,7 @@ def test_c_abi_shard_step_pipelined():
     res = q.get(timeout=240)
     p.join(60)
     assert p.exitcode == 0
-    assert res == [True] * 15
+    assert res == [True] * 24
 
 
 @pytest.mark.timeout(300)

@@ -130,10 +130,44 @@ def test_reslice_device_matches_oracle(O, FE, ppm, frame):
     fe.join_dev()
     nd = int(parse_results(res)[0]["n_dibits"])
     assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
-    # the streaming calls in this mode: mode 1's answer
-    fe3 = FE(symbol_clock=2)
+    # the streaming calls cannot run 3.8c: with P25FE_CLOCK_CAUSAL_OK they give mode 1's answer ...
+    fe3 = FE(symbol_clock=2 | 0x100)
     got3 = np.concatenate([fe3.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)])
     assert np.array_equal(got3, one[0])
+    dib, res = fe3.run_dev(t)                                        # (the resident calls of such a handle still run 3.8c)
+    nd = int(parse_results(res)[0]["n_dibits"])
+    assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
+
+
+def test_mode2_is_refused_where_it_cannot_run(O, FE):
+    """ABI 6: a handle created with symbol_clock = 2 asked for SPEC 3.8c.  The calls that see the stream in pieces -- host
+    streaming chunks, host windows, the passes of a time shard (and so p25fe_shard_create's step) -- have 3.8b's causal rule only: they
+    return P25FE_ERR_ARG instead of another receiver's dibits, move no state, and the resident calls of the same handle keep working.
+    With P25FE_CLOCK_CAUSAL_OK or-ed in they run, as mode 1."""
+    import torch
+    from p25rx_amd import c4fm, _lib
+    from p25rx_amd.frontend import parse_results
+    iq = c4fm.synth(1.0, seed=5, snr_db=25.0, clock_ppm=100.0)[0]
+    iq = iq[:len(iq) // 8 * 8]
+    t = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    bb = O.Demod().feed_cf32(iq)
+    fe = FE(symbol_clock=2)
+    refused = 0
+    for call in (lambda: fe.run_cf32(iq[:16384]), lambda: fe.run_u8(c4fm.to_u8(iq[:16384])), lambda: fe.slice(bb[:3000]),
+                 lambda: fe.run_host_windows(iq, window=65536), lambda: fe.shard_pass1(t, 0, len(iq), 0)):
+        with pytest.raises(_lib.P25feError) as e:
+            call()
+        refused += e.value.status == _lib.ERR_ARG
+    assert refused == 5
+    dib, res = fe.run_dev(t)                                         # nothing moved: a fresh-stream resident call gives 3.8c's dibits
+    ref = O.recv_range(bb, O.make_config(symbol_clock=2))
+    nd = int(parse_results(res)[0]["n_dibits"])
+    assert nd == len(ref[0]) and np.array_equal(dib[0, :nd].cpu().numpy(), ref[0])
+    ok = FE(symbol_clock=2 | _lib.CLOCK_CAUSAL_OK)
+    one = oracle_recv(O, bb, 1)
+    assert np.array_equal(np.concatenate([ok.run_cf32(iq[o:o + 16384]) for o in range(0, len(iq), 16384)]), one[0])
+    got, _ = FE(symbol_clock=2 | _lib.CLOCK_CAUSAL_OK).run_host_windows(iq, window=65536)
+    assert np.array_equal(got, one[0])
 
 
 def test_reslice_dense_events_and_lock_drops(O, FE):

@@ -25,3 +25,21 @@ def test_k1_isa_lint_and_resource_budget():
         vgpr = int(re.search(r"VGPRs: (\d+)", blk).group(1))
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
         assert vgpr <= 168 and scratch == 0, (name, vgpr, scratch)
+
+
+def test_shipped_sources_hold_no_measurement_code():
+    """VERDICT r5 (weak 9): the sources the library is built from -- and the ones embedded for hipRTC -- hold no measurement branches;
+    the truncated / stamped / unsafe builds of tools/ get the bodies of the (empty) P25FE_M_* hooks from p25fe_measure.inc, which only
+    a -DP25FE_MEASURE build includes and the Makefile's embed list does not name."""
+    csrc = os.path.join(ROOT, "p25rx_amd", "csrc")
+    switches = re.compile(r"P25FE_ABLATE|P25FE_EXP\b|P25FE_K1_STAMP|P25FE_DRIFT|P25FE_MEASURE_UNSAFE|P25FE_ABLATE6|P25FE_ABLATE_DET")
+    for name in ("p25fe_kernels.hip", "p25fe_recv.hip", "p25fe_api.hip", "p25fe_rccl.cpp", "p25fe_jit.cpp"):
+        src = open(os.path.join(csrc, name)).read()
+        assert not switches.search(src), (name, switches.search(src).group(0))
+    k = open(os.path.join(csrc, "p25fe_kernels.hip")).read()
+    assert k.count('#include "p25fe_measure.inc"') == 1 and "#ifdef P25FE_MEASURE\n#include \"p25fe_measure.inc\"" in k
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    embed = mk[mk.index("$(EMBED):"):mk.index("$(JITO):")]
+    assert "p25fe_measure" not in embed
+    assert "-DP25FE_MEASURE" in mk[mk.index("variant:"):]           # `make variant` is the door to the hooks
+    assert switches.search(open(os.path.join(csrc, "p25fe_measure.inc")).read())

@@ -11,6 +11,7 @@
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -126,6 +127,9 @@ for k, tag in ((next((x for x in vals if x.startswith("k_frontend<0")), None), "
         wr = k1["WRITE_SIZE"] * 1024.0
         out = {"kernel": "k_frontend<%s>" % tag, "fetch_size_kib_raw": k1["FETCH_SIZE"], "write_size_kib_raw": k1["WRITE_SIZE"],
                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-               "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE as reported; both KiB"}
+               "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE as reported; both KiB",
+               # which K1 the counters were read from: bench.py compares it with the source it runs and says so when they differ
+               "k1_source_sha16": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p25rx_amd", "csrc",
+                                                                   "p25fe_kernels.hip"), "rb").read()).hexdigest()[:16]}
         print("== K1<%s> HBM traffic per launch:" % tag, json.dumps(out))
         json.dump(out, open(os.path.join(d, "k1_pmc%s.json" % ("" if tag == "cf32" else "_u8")), "w"), indent=1)

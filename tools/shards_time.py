@@ -12,6 +12,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = 600 * 240000
 fe = FrontEnd()
 ss = rccl.ShardStep(fe, 0, 1, n, rccl.unique_id())
+ss.prepare()
 halo = fe.shard_halo()
 buf = torch.zeros((halo + n, 2), dtype=torch.float32, device="cuda")
 c4fm.synth_torch(n, seed=3, device=torch.device("cuda", 0), out=buf[halo:])

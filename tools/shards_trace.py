@@ -32,6 +32,7 @@ gather = sys.argv[1] if len(sys.argv) > 1 else "root"
 n = 600 * 240000
 fe = FrontEnd()
 ss = rccl.ShardStep(fe, 0, 1, n, rccl.unique_id())
+ss.prepare()
 halo = fe.shard_halo()
 buf = torch.zeros((halo + n, 2), dtype=torch.float32, device="cuda")
 c4fm.synth_torch(n, seed=3, device=torch.device("cuda", 0), out=buf[halo:])
