@@ -141,6 +141,8 @@ def load():
     L.p25fe_shard_compact_dev.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp]
     L.p25fe_shard_pass1_head.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp]
     L.p25fe_shard_pipe_begin.argtypes = [vp, vp, C.POINTER(C.c_void_p)]
+    L.p25fe_shard_head_check.argtypes = [C.c_void_p]
+    L.p25fe_rx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.p25fe_shard_pipe_end.argtypes = [vp, vp]
     L.p25fe_shard_pass1_k1.argtypes = [vp, vp, C.c_int, sz, sz, sz, u64, vp]
     L.p25fe_streams_share_queue.argtypes = [vp, vp, vp, C.POINTER(C.c_int)]

@@ -891,24 +891,20 @@ static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, siz
     return P25FE_OK;
 }
 
-// K2 on the planar scratch (abs_bb0: absolute index of the first PROCESSED sample = owned sample 0 minus h->look), and K3 in its tail
-// (ScanTail / GroupSumG in p25fe_recv.hip): d_anchor_in (nullable) is the range's carry-in, d_result receives the range's record.
+// K3's arguments (the fixed-stride receiver's k_scan_tiles / k_range_scan take them inside a DetArgs)
 static void scan_tail_args(p25fe_t* h, size_t n_bb, const p25fe_anchor_t* d_anchor_in, p25fe_result_t* d_result, ScanTail* t)
 {
-    t->on = 1;
-    t->gsg = h->gsg.as<GroupSumG>(); t->gpg = h->gpg.as<GroupPreG>();
     t->outs = h->outs.as<ScanOut>(); t->gagg = h->gagg.as<GroupAgg>(); t->gpre = h->gpre.as<GroupPre>();
     t->tickets = h->gtick.as<unsigned>(); t->anchor_in = d_anchor_in; t->result = d_result;
     t->n_baseband = n_bb;
 }
-static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc, bool wait_head_flag,
-                         const p25fe_anchor_t* d_anchor_in, p25fe_result_t* d_result)
+// K2 on the planar scratch (abs_bb0: absolute index of the first PROCESSED sample = owned sample 0 minus h->look)
+static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, const RecvCall& rc, bool wait_head_flag = false)
 {
     const PlanarGeo g(n_bb);
     DetArgs d;
     d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1; d.head_err = nullptr;
-    scan_tail_args(h, n_bb, d_anchor_in, d_result, &d.tail);
-    d.tail.on = rc.gen ? 1 : 0;                                      // (the fixed-stride receiver's K3 is a launch of its own: k_scan_tiles)
+    memset(&d.tail, 0, sizeof d.tail);                               // (K3's arguments: K2 does not read them)
     if (wait_head_flag) {
         d.head_flag = h->sh_flag.as<unsigned>(); d.head_seq = h->sh_seq; d.head_tile_max = h->sh_head_tile_max;
         d.head_err = h->sh_flag.as<unsigned>() + SH_FLAG_ERR;
@@ -924,9 +920,9 @@ static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, 
 }
 
 // What follows K2: the slicer (do_slice), in front of it whatever completes the per-tile carry-ins.
-//   scanned   K2 has just run in this call, for THIS carry-in: the general receiver's K3 ran in its tail, the fixed-stride receiver's is
-//             launched here (k_scan_tiles).  Otherwise the summaries in the scratch are re-scanned under d_anchor_in by the top step
-//             alone (k_range_scan / k_range_scan_g: a time shard's pass 2 under resolved anchors; an empty range, whose record is the
+//   scanned   K2 has just run in this call, for THIS carry-in: K3 is launched whole (k_scan_tiles / k_scan_tiles_g: group scans, then the
+//             range's).  Otherwise the group summaries in the scratch are re-scanned under d_anchor_in by the top step alone
+//             (k_range_scan / k_range_scan_g: a time shard's pass 2 under resolved anchors; an empty range, whose record is the
 //             carry-in handed through).
 //   ev_done   (nullable) attached to the LAST kernel this function launches (its completion = the receive side is done)
 //   d_dibits2 (nullable) second destination of the dibits
@@ -950,6 +946,10 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         c.n_baseband = n_bb; c.track = h->track;
         if (!scanned) {
             launch_ev(k_range_scan_g, dim3((unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
+            HIPCHK(h, hipGetLastError());
+            if (!slice) ev_pending = false;
+        } else if (n_tiles) {
+            launch_ev(k_scan_tiles_g, dim3((unsigned)n_groups_of(n_tiles), (unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
             HIPCHK(h, hipGetLastError());
             if (!slice) ev_pending = false;
         }
@@ -1078,7 +1078,7 @@ static int dev_slice(p25fe_t* h, const float* d_bb, size_t bb_stride, size_t n_h
                                  false, st, rcall, false);
     rc = launch_planarize(h, d_bb, bb_stride, n_hist_bb, n_bb, st);
     if (rc) return rc;
-    rc = launch_detect(h, n_bb, view0, st, rcall, false, d_anchor_in, d_result);
+    rc = launch_detect(h, n_bb, view0, st, rcall, false);
     if (rc) return rc;
     prof_mark(h, 2, st);
     return launch_scan_slice(h, n_bb, view0, d_anchor_in, d_dibits, dibit_stride, d_sync_pos, d_sync_dibit,
@@ -1195,8 +1195,11 @@ static int ensure_rx_stream(p25fe_t* h)
         }
         if (!h->rx_stream) {
             int prio_lo = 0, prio_hi = 0;
+            // (measurement knob P25FE_RX_PRIO: "normal" / "low" instead of the highest priority)
+            const char* pe = getenv("P25FE_RX_PRIO");
+            const bool p_norm = pe && !strcmp(pe, "normal"), p_low = pe && !strcmp(pe, "low");
             if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
-                hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+                hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, p_low ? prio_lo : (p_norm ? 0 : prio_hi)) != hipSuccess) {
                 (void)hipGetLastError();
                 h->rx_stream = nullptr;
                 HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));     // any non-blocking stream will do
@@ -1272,7 +1275,7 @@ int p25fe_run_dev_pipelined(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     if (!k1_done_attached) HIPCHK(h, hipEventRecord(k1_done, st));
     HIPCHK(h, hipStreamWaitEvent(h->rx_stream, k1_done, 0));
     if (n_bb) {
-        rc = launch_detect(h, n_bb, -h->look, h->rx_stream, rcall, false, nullptr, d_result);
+        rc = launch_detect(h, n_bb, -h->look, h->rx_stream, rcall, false);
         if (rc) return rc;
         prof_mark(h, 2, h->rx_stream);
     }
@@ -1311,7 +1314,7 @@ int p25fe_run_dev(p25fe_t* h, const void* d_iq, int fmt, size_t ch_stride, size_
     rc = launch_frontend(h, d_iq, fmt, ch_stride, 0, n, 0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g, 0, e0, e1);
     if (rc) return rc;
     prof_mark(h, 1, st);
-    rc = launch_detect(h, n_bb, -h->look, st, rcall, false, nullptr, d_result);
+    rc = launch_detect(h, n_bb, -h->look, st, rcall, false);
     if (rc) return rc;
     prof_mark(h, 2, st);
     rc = launch_scan_slice(h, n_bb, -h->look, nullptr, d_dibits, dibit_stride, nullptr, nullptr, 0, d_result, true, st, rcall, true);
@@ -1405,7 +1408,7 @@ static int shard_pass1_part(p25fe_t* h, const void* d_iq, int fmt, size_t ch_str
     const RecvCall rcall = recv_call(h);
     h->rs_n = 0;
     if (n_bb) {
-        rc = launch_detect(h, n_bb, abs_bb0, st, rcall, h->sh_head_flagged, nullptr, d_result);
+        rc = launch_detect(h, n_bb, abs_bb0, st, rcall, h->sh_head_flagged);
         if (rc) return rc;
     }
     h->sh_head_flagged = false;
@@ -1839,7 +1842,7 @@ int p25fe_slice(p25fe_t* h, const float* bb, size_t n, uint8_t* dibits, size_t c
         const RecvCall rcall = recv_call(h);                        // (a pending p25fe_resync_at_dev list belongs to this call: cleared below, once it has succeeded)
         rc = launch_planarize(h, db + BBPAD, bb_stride, hist, n, h->stream);
         if (rc) return rc;
-        rc = launch_detect(h, n, view0, h->stream, rcall, false, o.d_anc, o.d_res);
+        rc = launch_detect(h, n, view0, h->stream, rcall, false);
         if (rc) return rc;
         rc = launch_scan_slice(h, n, view0, o.d_anc, o.d_dib, o.dstride, sync_cap ? o.d_spos : nullptr,
                                sync_cap ? o.d_sdib : nullptr, o.sstride, o.d_res, true, h->stream, rcall, true);
@@ -1903,7 +1906,7 @@ static int run_host(p25fe_t* h, const void* iq, int fmt, size_t n, uint8_t* dibi
         rc = launch_frontend(h, sg.dev + SHARD_HALO * eb, fmt, sg.stride, sg.n_hist, n, h->abs_iq, -(long)PLPAD - h->look, nullptr, 0,
                              nullptr, h->stream, &g);
         if (rc) return rc;
-        rc = launch_detect(h, nb, view0, h->stream, rcall, false, o.d_anc, o.d_res);
+        rc = launch_detect(h, nb, view0, h->stream, rcall, false);
         if (rc) return rc;
         rc = launch_scan_slice(h, nb, view0, o.d_anc, o.d_dib, o.dstride, nullptr, nullptr, 0, o.d_res, true, h->stream, rcall, true);
         if (rc) return rc;
@@ -2077,7 +2080,7 @@ int p25fe_run_host_windows(p25fe_t* h, const void* iq, int fmt, size_t n, size_t
         const PlanarGeo g(nb ? nb : 1);
         if (nb) {
             rc = launch_frontend(h, dev + SHARD_HALO * eb, fmt, stride, n_hist, wn, abs0, -(long)PLPAD - h->look, nullptr, 0, nullptr, st, &g);
-            if (!rc) rc = launch_detect(h, nb, view0, st, rcall, false, d_anc + (size_t)b * C, d_res);
+            if (!rc) rc = launch_detect(h, nb, view0, st, rcall, false);
         }
         if (!rc) rc = launch_scan_slice(h, nb, view0, d_anc + (size_t)b * C, d_dib, dstride, nullptr, nullptr, 0, d_res, nb != 0, st, rcall, nb != 0);
         if (rc) { status = rc; break; }

@@ -276,14 +276,13 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask)      // set bi
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-// A record another workgroup of the SAME launch reads (K3 in K2's tail): written through (sc1: 8-byte relaxed agent-scope stores), so that
-// no release fence is needed -- a fence is `buffer_wbl2`, a write-back of the XCD's whole L2, and 3 750 of them made K2 four times slower
-// and K1 beside it 30 % slower (measured, round 6).  The writer drains (`s_waitcnt vmcnt(0)`) before it takes its ticket (last_arrival);
+// A record another workgroup of the SAME launch reads (K3's group aggregates): written through (sc1: 8-byte relaxed agent-scope stores), so
+// that no release fence is needed -- a fence is `buffer_wbl2`, a write-back of the XCD's whole L2 (with one in front of every ticket of a
+// first version, 3 750 per launch, K2 was four times slower and K1 beside it 30 % slower: measured, round 6).  The writer drains (`s_waitcnt vmcnt(0)`) before it takes its ticket (last_arrival);
 // the reader's acquire drops its CU's stale L1 lines.  cdna_hip_programming.md guideline 16, recipe R1.
-template <class T> __device__ __forceinline__ void publish(T* dst, const T& v, const bool through = true)
+template <class T> __device__ __forceinline__ void publish(T* dst, const T& v)
 {
     static_assert(sizeof(T) % 8 == 0 && alignof(T) >= 8, "whole 8-byte words");
-    if (!through) { *dst = v; return; }                             // (the reader is a LATER launch: a plain store)
     unsigned long long w[sizeof(T) / 8];
     __builtin_memcpy(w, &v, sizeof(T));
     unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
@@ -306,12 +305,13 @@ template <class T> __device__ __forceinline__ void publish(T* dst, const T& v, c
 //     applies one level up): tiles in front of the group's first own detection are governed by the group's carry-in, every later
 //     tile's offset grows by the instants that carry-in governs inside the group.
 // "Latest anchor wins" and event-free stretches counted in closed form -- the same algebra as k_scan, k_scan's results bit for bit.
-// WHERE the group scans run: the fixed-stride receiver launches them as k_scan_tiles (one wave per group: 51 - 59 VGPRs, no LDS, p90
-// 17 us beside K1), the general receiver in K2's own tail (the last detection workgroup of a group scans it: GroupSumG below).  The tail
-// form was measured for the fixed stride too and lost -- every one of 3 750 detection workgroups then lives ~4 us longer (drain of its
-// write-through stores + the ticket's round trip) and K1 beside them paid 10 - 25 us (profiles/r06_rx_grid_ab.txt); the general
-// receiver's K2 is 5 - 10 x longer anyway and saves a launch by it.  k_range_scan / k_range_scan_g are the top step alone: the re-scan
-// of a time shard under a resolved carry-in (p25fe_shard_pass2), and the record of an empty range.
+// WHERE the group scans run: in launches of their own, one wave per group -- k_scan_tiles (fixed stride: 51 - 59 VGPRs, no LDS, 5.8 us
+// alone, p90 17 us beside K1), k_scan_tiles_g + k_scan_g_groups (general receiver: GroupSumG below).  Running them in K2's own TAIL
+// instead (the last detection workgroup of a group scans it) was built and measured for both receivers: the fixed stride lost by it --
+// every one of 3 750 detection workgroups then lives ~4 us longer (drain of its write-through stores + the ticket's round trip) and K1
+// beside them paid 10 - 25 us (profiles/r06_rx_grid_ab.txt) --, the general receiver neither won nor lost (profiles/r06_tree_ab.txt):
+// K2 stays pure detection.  k_range_scan / k_range_scan_g are the top step alone: the re-scan of a time shard under a resolved carry-in
+// (p25fe_shard_pass2), and the record of an empty range.
 // ------------------------------------------------------------------------------------------
 constexpr int GT = 64;                                           // tiles per group (one per lane)
 #ifndef P25FE_HEAD_WAIT_TICKS
@@ -334,12 +334,7 @@ struct GroupPre {               // per (channel, group), from the range's point 
     unsigned event_off;         // detections of the range in front of the group
     unsigned pad_;
 };
-struct GroupSumG;
-struct GroupPreG;
-struct ScanTail {
-    int on;
-    GroupSumG* gsg;             // the general receiver's group summaries / carry-ins (k_detect<true>): [ch][n_groups]
-    GroupPreG* gpg;
+struct ScanTail {               // K3's own arguments (k_scan_tiles / k_range_scan; they ride in DetArgs beside K2's)
     ScanOut* outs;              // [ch][n_tiles] group-local carry-ins
     GroupAgg* gagg;             // [ch][n_groups]
     GroupPre* gpre;             // [ch][n_groups]
@@ -375,7 +370,7 @@ struct DetArgs {
     unsigned head_seq;
     int head_tile_max;
     unsigned* head_err;         // with head_flag: receives head_seq if a wait gave up (p25fe_shard_head_check)
-    ScanTail tail;              // tail.on: K3 runs in this launch's tail (the last workgroup of every group of tiles, then of the channel)
+    ScanTail tail;              // K3's (k_scan_tiles, k_range_scan): unused by K2 itself
 };
 
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
@@ -539,13 +534,13 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         if (lane == 0) {
             TileRec rc;
             rc.first_event = -1; rc.last_s = -1; rc.hi = rc.mid = rc.lo = 0.f; rc.n_events = 0; rc.post_count = 0; rc.last_f = 0; rc.pad_ = 0;
-            publish(&a.recs[(size_t)ch * a.n_tiles + tile], rc, a.tail.on != 0);
-            publish(&a.tsum[(size_t)ch * a.n_tiles + tile], 0ull, a.tail.on != 0);
+            a.recs[(size_t)ch * a.n_tiles + tile] = rc;
+            a.tsum[(size_t)ch * a.n_tiles + tile] = 0ull;
             if constexpr (GEN) {
                 TileSumG g;
                 g.pre_end1 = kill0 < a.abs0 + t0 + tn ? (unsigned)(kill0 - (a.abs0 + t0)) + 1u : 0u;   // a lock drop alone ends the carry-in
                 g.first1 = 0u; g.end0 = 0u; g.last1 = 0u; g.n_det_flags = 0u; g.post_rest = 0u; g.out_D = SPS; g.out_N = 1;
-                publish(&a.gsum[(size_t)ch * a.n_tiles + tile], g, a.tail.on != 0);
+                a.gsum[(size_t)ch * a.n_tiles + tile] = g;
             }
         }
         return;
@@ -619,7 +614,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
             }
             g.n_det_flags = (unsigned)n_ev | (fl << 16);
             g.post_rest = (unsigned)rest;
-            publish(&a.gsum[(size_t)ch * a.n_tiles + tile], g, a.tail.on != 0);
+            a.gsum[(size_t)ch * a.n_tiles + tile] = g;
         }
     }
     // thresholds of the first EVTHR_N detections (for K4) and of the last one (the anchor the tile hands on): looked up in
@@ -653,8 +648,8 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
         rc.post_count = post;
         rc.last_f = 0; rc.pad_ = 0;
         if constexpr (GEN) rc.last_f = frac3(fro_get(last_off));
-        publish(&a.recs[(size_t)ch * a.n_tiles + tile], rc, a.tail.on != 0);
-        publish(&a.tsum[(size_t)ch * a.n_tiles + tile], pack_tsum(first_off, last_off, n_ev, post), a.tail.on != 0);
+        a.recs[(size_t)ch * a.n_tiles + tile] = rc;
+        a.tsum[(size_t)ch * a.n_tiles + tile] = pack_tsum(first_off, last_off, n_ev, post);
     }
 }
 
@@ -1121,11 +1116,11 @@ struct CState { int valid; long s; int D, N; int src; int f; };
 // ------------------------------------------------------------------------------------------
 // The general receiver's scan, hierarchical like the fixed-stride one (ScanTail above) -- the 512-thread k_scan_g of rounds 3 - 5
 // (48 - 53 KB of LDS) is gone: beside a running K1 it waited for the drain, and the tracking clock's pipelined step paid for it.
-//   pass A   K2's tail: the last detection workgroup of a group of GT tiles scans the group with NO carry-in (scan_g_lanes: lane =
+//   pass A   k_scan_tiles_g, one wave per group of GT tiles: the group is scanned with NO carry-in (scan_g_lanes: lane =
 //            tile, the "latest two event tiles" rule by two bit scans of a ballot, neighbours' fields by lane shuffles) and leaves
 //            a summary of what a carry-in would change -- the same fields a time shard's pass 1 leaves in p25fe_result_t, for the
 //            same reason (GroupSumG);
-//   top      the channel's last group walks the summaries under the range's carry-in (range_scan_g: shard_resolve_impl's rule, one
+//   top      the channel's last group to arrive walks the summaries under the range's carry-in (range_scan_g: shard_resolve_impl's rule, one
 //            level down): every group's carry-in state and offsets (GroupPreG), and the range's record;
 //   pass B   k_scan_g_groups, one wave per group: the same lane scan under the group's real carry-in -> the per-tile carry-ins
 //            (ScanOutG) that k_slice_g / k_ev_collect read, as k_scan_g wrote them.
@@ -1429,11 +1424,17 @@ __global__ __launch_bounds__(WV, 4) void k_scan_g_groups(ScanArgsG a)
 // the top step alone: a re-scan of summaries that are already there under another carry-in (p25fe_shard_pass2 and its device form),
 // and the record of an EMPTY range (no tile, no K2: the carry-in is handed through)
 __global__ __launch_bounds__(WV, 4) void k_range_scan_g(ScanArgsG a) { range_scan_g(a, (int)blockIdx.x); }
+// pass A + the top step as a launch of their own (one wave per group; the channel's last group to arrive walks the groups)
+__global__ __launch_bounds__(WV, 4) void k_scan_tiles_g(ScanArgsG a)
+{
+    const int g = blockIdx.x, ch = blockIdx.y, n_groups = n_groups_of(a.n_tiles);
+    group_scan_g(a, g, ch);
+    if (!last_arrival(a.tickets + (size_t)ch * (n_groups + 1) + n_groups, (unsigned)n_groups)) return;
+    range_scan_g(a, ch);
+}
 #endif
 
-// K2's kernel: detection, then -- when the call wants the receiver's state too (tail.on) -- K3 in the tail: the group's last workgroup
-// scans the group, the channel's last group scans the groups (ScanTail; the general receiver: GroupSumG).
-// (GEN: 16 KB of LDS per one-wave workgroup -- the per-offset fraction table)
+// K2's kernel (GEN: 16 KB of LDS per one-wave workgroup -- the per-offset fraction table)
 template <bool GEN> __device__ __forceinline__ void detect_item(const DetArgs& a, const int tile, const int ch)
 {
     if (a.head_flag && tile <= a.head_tile_max) {                   // uniform
@@ -1453,22 +1454,6 @@ template <bool GEN> __device__ __forceinline__ void detect_item(const DetArgs& a
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     detect_tile<GEN>(a, tile, ch);
-    if (!a.tail.on) return;                                         // uniform
-    const int g = tile / GT, n_groups = n_groups_of(a.n_tiles);
-    const int gn = a.n_tiles - g * GT < GT ? a.n_tiles - g * GT : GT;
-    unsigned* tickets = a.tail.tickets + (size_t)ch * (n_groups + 1);
-    if constexpr (!GEN) {
-        (void)tickets; (void)gn;                                    // (the fixed-stride receiver's K3 is k_scan_tiles)
-    } else {
-        ScanArgsG c;
-        c.gsum = a.gsum; c.recs = a.recs; c.outs = nullptr; c.gsg = a.tail.gsg; c.gpg = a.tail.gpg; c.tickets = a.tail.tickets;
-        c.n_tiles = a.n_tiles; c.n = a.n; c.abs0 = a.abs0; c.anchor_in = a.tail.anchor_in; c.result = a.tail.result;
-        c.n_baseband = a.tail.n_baseband; c.track = a.opt.track;
-        if (!last_arrival(tickets + g, (unsigned)gn)) return;
-        group_scan_g(c, g, ch);
-        if (!last_arrival(tickets + n_groups, (unsigned)n_groups)) return;
-        range_scan_g(c, ch);
-    }
 }
 template <bool GEN> __global__ __launch_bounds__(WV, GEN ? 2 : 4) void k_detect(DetArgs a) { detect_item<GEN>(a, (int)blockIdx.x, (int)blockIdx.y); }
 
@@ -1942,7 +1927,6 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     d.recs = c.recs; d.tsum = c.tsum; d.evl = c.evl; d.evthr = c.evthr;
     d.opt.track = 0; d.opt.n_resync = 0; d.opt.resync = nullptr; d.opt.resync_stride = 0; d.gsum = nullptr; d.evg = nullptr;
     d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1; d.head_err = nullptr;
-    d.tail.on = 0;
     detect_tile<false>(d, 0, ch);
     wave_global_sync();
     // the scan of a one-tile range

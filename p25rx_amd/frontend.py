@@ -386,6 +386,10 @@ class FrontEnd:
         self._chk(self.L.p25fe_shard_pass1_head(self.h, C.c_void_p(ptr), fmt, stride, n_hist, n_total - offset, abs0,
                                                 self._stream()))
 
+    def shard_head_check(self):
+        """after a synchronise: raises P25feError(ERR_TIMEOUT) if a detection gave up waiting for a head segment (p25fe_shard_head_check)"""
+        self._chk(self.L.p25fe_shard_head_check(self.h))
+
     def shard_pipe_begin(self):
         """p25fe_shard_pipe_begin on torch's current stream -> the handle's receive stream as a torch stream: shard_pass1_main stays
         on the current stream, every later pass of the step is enqueued under `with torch.cuda.stream(rx)`; then shard_pipe_end()."""

@@ -1246,3 +1246,54 @@ def test_profile_hook_levels(FE):
         assert ms[0] > 0.0
         assert (ms[1] > 0.0 and ms[3] > 0.0) if level == 1 else (ms[1] == 0.0 and ms[2] == 0.0 and ms[3] == 0.0)
     fe.profile_enable(False)
+
+
+def test_head_that_never_arrives_times_out_instead_of_hanging(O, FE):
+    """the detection's first tiles poll the flag the head launch's last workgroup writes (p25fe_shard_pass1_head on another
+    stream: in the N > 1 step that stream sits behind the halo's ncclRecv).  If the head does not come -- here: its stream is held up
+    by a 5 s spin kernel in front of it -- the poll gives up after 2 s of device wall clock instead of spinning for ever, the queue
+    drains, and p25fe_shard_head_check (p25fe_shard_offsets in the RCCL step) reports P25FE_ERR_TIMEOUT.  The same procedure with the
+    head delivered in time reports OK and the plain pass 1's record."""
+    import time
+    import torch
+    from p25rx_amd import c4fm, _lib
+    from p25rx_amd.frontend import parse_results
+    iq, _, _ = c4fm.synth(1.0, seed=43, snr_db=20.0, frame_dibits=700)
+    t_all = torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda()
+    cut = 120008
+    halo = FE().shard_halo()
+    t = t_all[cut - halo:]
+    side = torch.cuda.Stream()
+    # a kernel that keeps a stream busy for ~5 s: torch's spin kernel, calibrated here
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(100_000_000)
+    torch.cuda.synchronize()
+    per_cycle = (time.perf_counter() - t0) / 1e8
+    hold = int(5.0 / per_cycle)
+    # warm-up of everything that is not the wait (allocations, first launches), head delivered: OK
+    fe = FE()
+    fe.shard_pass1_main(t, offset=halo, n_hist=halo, abs0=cut)
+    with torch.cuda.stream(side):
+        fe.shard_pass1_head(t, offset=halo, n_hist=halo, abs0=cut)
+    res = fe.shard_pass1_finish(t, offset=halo, n_hist=halo, abs0=cut)
+    torch.cuda.synchronize()
+    fe.shard_head_check()
+    ref = FE().shard_pass1(t, offset=halo, n_hist=halo, abs0=cut)
+    torch.cuda.synchronize()
+    assert parse_results(res)[0].tobytes() == parse_results(ref)[0].tobytes()
+    # the head held up for 5 s: the detection gives up after 2
+    fe.shard_pass1_main(t, offset=halo, n_hist=halo, abs0=cut)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(hold)
+        fe.shard_pass1_head(t, offset=halo, n_hist=halo, abs0=cut)
+    t0 = time.perf_counter()
+    fe.shard_pass1_finish(t, offset=halo, n_hist=halo, abs0=cut)     # detection: its first tiles wait for the head's flag
+    torch.cuda.current_stream().synchronize()                        # returns: the wait is bounded
+    waited = time.perf_counter() - t0
+    assert 1.5 < waited < 4.5, waited
+    torch.cuda.synchronize()                                         # (the head arrives, too late)
+    with pytest.raises(_lib.P25feError) as e:
+        fe.shard_head_check()
+    assert e.value.status == _lib.ERR_TIMEOUT

@@ -2,6 +2,8 @@
 "symbol-clock interpolator") and lock drops INSIDE device-resident ranges (MessageReceiver::resync, src/recv.rs:136, 179,
 at given sample indices).  Everything is compared with the CPU oracle bit for bit: dibits, sync positions, sync dibit
 indices."""
+import os
+
 import numpy as np
 import pytest
 
@@ -374,3 +376,34 @@ def test_dibit_row_capacity_is_a_hard_bound(O, FE, c4fm_1s):
         k = min(cap, len(ref))
         assert np.array_equal(got[2048:2048 + k], ref[:k])
         assert np.all(got[:2048] == 0xEE) and np.all(got[2048 + k:] == 0xEE), "cap %d" % cap
+
+
+def test_mode2_pipelined_three_deep_while_the_detection_list_grows(O, FE):
+    """the slicer by detection keeps ONE list of detections per handle (evrec / evnext / evoff), shared by all pipelined lanes --
+    safe because the receive kernels of consecutive calls run in order on one stream, and a list that has to GROW is freed and
+    re-allocated (hipFree synchronises the device).  Calls of growing size, three scratch sets deep, enqueued back to back: every call's
+    dibits are the oracle's two-pass answer for ITS capture."""
+    import torch
+    from p25rx_amd import c4fm
+    from p25rx_amd.frontend import parse_results
+    os.environ["P25FE_PIPE_DEPTH"] = "3"
+    try:
+        fe = FE(symbol_clock=2)
+    finally:
+        os.environ.pop("P25FE_PIPE_DEPTH", None)
+    caps, refs = [], []
+    for k, (secs, fd, ppm) in enumerate(((0.4, 200, 120.0), (0.9, 150, -180.0), (1.7, 96, 200.0), (0.5, 864, 0.0), (2.6, 64, 150.0))):
+        iq = c4fm.synth(secs, seed=90 + k, snr_db=28.0, frame_dibits=fd, clock_ppm=ppm)[0]
+        iq = iq[:len(iq) // 8 * 8]
+        caps.append(torch.from_numpy(iq.view(np.float32).reshape(-1, 2)).cuda())
+        refs.append(O.recv_range(O.Demod().feed_cf32(iq), O.make_config(symbol_clock=2))[0])
+    outs = []
+    for rnd in range(2):                                             # second round: the list no longer grows, the lanes still rotate
+        for t in caps:
+            outs.append(fe.run_dev_pipelined(t))                     # (fresh outputs per call: nothing is read before the join)
+    fe.join_dev()
+    torch.cuda.synchronize()
+    for k, (dib, res) in enumerate(outs):
+        ref = refs[k % len(caps)]
+        nd = int(parse_results(res)[0]["n_dibits"])
+        assert nd == len(ref) and np.array_equal(dib[0, :nd].cpu().numpy(), ref), k

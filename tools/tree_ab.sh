@@ -4,7 +4,7 @@
 #   usage: bash tools/tree_ab.sh <rounds> [extras=0|1]     extras=1: the full default run (configs[3] / [4] on one GPU are extras)
 R=${1:-2}; EX=${2:-0}
 for r in $(seq 1 $R); do
-  for t in build/r5tree .; do
+  for t in build/r3tree build/r5tree .; do
     [ -f $t/bench.py ] || continue
     if [ "$EX" == "1" ]; then
       line=$(cd $t && python3 bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | tail -1)
