@@ -1195,11 +1195,10 @@ static int ensure_rx_stream(p25fe_t* h)
         }
         if (!h->rx_stream) {
             int prio_lo = 0, prio_hi = 0;
-            // (measurement knob P25FE_RX_PRIO: "normal" / "low" instead of the highest priority)
-            const char* pe = getenv("P25FE_RX_PRIO");
-            const bool p_norm = pe && !strcmp(pe, "normal"), p_low = pe && !strcmp(pe, "low");
+            // (highest priority; normal and lowest were measured in round 6 and change nothing: 0.2647 - 0.2656 / 0.2647 - 0.2650 / 0.2651 -
+            // 0.2709 ms per step, docs/MEASUREMENTS.md)
             if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
-                hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, p_low ? prio_lo : (p_norm ? 0 : prio_hi)) != hipSuccess) {
+                hipStreamCreateWithPriority(&h->rx_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
                 (void)hipGetLastError();
                 h->rx_stream = nullptr;
                 HIPCHK(h, hipStreamCreateWithFlags(&h->rx_stream, hipStreamNonBlocking));     // any non-blocking stream will do

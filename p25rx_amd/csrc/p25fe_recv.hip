@@ -376,7 +376,8 @@ struct DetArgs {
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
 constexpr int K2_DCAP = 64;                                      // detections per tile whose thresholds K2 remembers (more: it recomputes)
 constexpr int K2_LANES = 60;                                     // 10 planes x 6 blocks of 4 words
-constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test
+constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test (256 -- 6.1 KB of LDS instead of
+                                                                 // 9.7, two workgroups in the LDS K1 leaves free per CU -- measured: no difference)
 
 template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a, const int tile, const int ch)
 {
@@ -1320,6 +1321,74 @@ __device__ __forceinline__ void range_scan_g(const ScanArgsG& a, const int ch)
         const int cn = n_groups - c0 < WV ? n_groups - c0 : WV;
         GroupPreG mine;                                             // the carry-in of group c0 + lane, kept by the lane that stores it
         mine.s = 0; mine.dibit_off = 0ull; mine.valid = 0; mine.D = SPS; mine.N = 1; mine.src = -2; mine.f = 0; mine.event_off = 0u;
+        // The common case, in parallel (lane = group): when every group of the step but its last has an event and ends in a state that
+        // does not depend on its own carry-in, the state a group STARTS in is simply what its left neighbour's summary hands on, and
+        // the 64 groups' counts (two to eight 64-bit divisions each under a tracked clock) are independent.  Anything else -- an
+        // event-free group, a group whose only detection takes its period from the carry-in -- takes the walk below.  Same numbers.
+        {
+            const bool act = c0 + lane < n_groups;
+            const bool evt = (M.flags & GS_HAS_EVENT) != 0u;
+            const int hands_on = (evt && !(M.flags & GS_OUT_FROM_CARRY)) ? 1 : 0;
+            const int left_ok = __shfl_up(hands_on, 1, 64);
+            if (__all(!act || lane == 0 || left_ok != 0)) {              // uniform
+                CState S;                                               // the state my group starts in
+                S.valid = __shfl_up(M.out_valid, 1, 64); S.s = (long)__shfl_up((unsigned long long)M.out_s, 1, 64);
+                S.D = __shfl_up(M.out_D, 1, 64); S.N = __shfl_up(M.out_N, 1, 64); S.src = __shfl_up(M.out_src, 1, 64); S.f = __shfl_up(M.out_f, 1, 64);
+                if (!S.valid) { S.s = 0; S.D = SPS; S.N = 1; S.src = -2; S.f = 0; }
+                if (lane == 0) S = cur;
+                const long G0 = a.abs0 + (long)(c0 + lane) * ((long)GT * TS);
+                const long G1 = G0 + (long)GT * TS < range_end ? G0 + (long)GT * TS : range_end;
+                unsigned long long pre = 0ull, own = 0ull;
+                if (act) {
+                    pre = S.valid ? (unsigned long long)clock_count(S.s, S.D, S.N, G0, evt ? M.carry_end : G1) : 0ull;
+                    own = M.first_event >= 0 ? M.after_first : 0ull;
+                    if (M.first_event >= 0 && track && (M.flags & GS_FIRST_TRACKS) && S.valid) {
+                        const long s0 = M.first_event - W;
+                        int D0, N0;
+                        clock_period(true, true, S.s, S.f, s0, M.first_f, D0, N0);
+                        own = own - (unsigned long long)clock_count(s0, SPS, 1, s0 + W + 1, M.first_seg_end) +
+                              (unsigned long long)clock_count(s0, D0, N0, s0 + W + 1, M.first_seg_end);
+                    }
+                }
+                const unsigned long long tot = pre + own, ie = wave_incl_sum64(act ? (unsigned long long)M.n_sync : 0ull, lane);
+                const unsigned long long it = wave_incl_sum64(tot, lane);
+                if (act) {
+                    mine.s = S.s; mine.dibit_off = off + (it - tot); mine.valid = S.valid; mine.D = S.D; mine.N = S.N; mine.src = S.src; mine.f = S.f;
+                    mine.event_off = (unsigned)(ev + (ie - (unsigned long long)M.n_sync));
+                    gpg[c0 + lane] = mine;
+                }
+                // the range's bookkeeping, in the walk's order
+                const unsigned long long evm = __ballot(act && evt), fdm = __ballot(act && M.first_event >= 0);
+                if (evm && !has_event) { has_event = true; carry_end = rdl_l(M.carry_end, __builtin_ctzll(evm)); }
+                if (evm && first_event >= 0 && fse_open) { fse = rdl_l(M.carry_end, __builtin_ctzll(evm)); fse_open = false; }
+                if (fdm && first_event < 0) {
+                    const int lf = __builtin_ctzll(fdm);
+                    first_event = rdl_l(M.first_event, lf); first_f = rdl(M.first_f, lf);
+                    base_first = off + (unsigned long long)rdl_l((long)(it - tot + pre), lf);
+                    fl_first = ((rdl((int)M.flags, lf) & (int)GS_FIRST_TRACKS) && n_event_tiles == 0 && !(evm & ((1ull << lf) - 1ull))) ? 1u : 0u;
+                    fse = rdl_l(M.first_seg_end, lf); fse_open = (rdl((int)M.flags, lf) & (int)GS_SEG_OPEN) != 0;
+                    const unsigned long long later = evm & ~((2ull << lf) - 1ull);
+                    if (fse_open && later) { fse = rdl_l(M.carry_end, __builtin_ctzll(later)); fse_open = false; }
+                }
+                n_event_tiles += wave_sum_i(act ? M.n_event_tiles : 0);
+                if (evm) last_from_carry = (rdl((int)M.flags, 63 - __builtin_clzll(evm)) & (int)GS_OUT_FROM_CARRY) != 0;
+                // the state after the step's last group
+                CState A = S;
+                if (act && evt) {
+                    if (M.out_valid) {
+                        A.valid = 1; A.s = M.out_s; A.D = M.out_D; A.N = M.out_N; A.src = M.out_src; A.f = M.out_f;
+                        if (M.flags & GS_OUT_FROM_CARRY) clock_period(track, S.valid != 0, S.s, S.f, A.s, A.f, A.D, A.N);
+                    } else {
+                        A.valid = 0; A.s = 0; A.D = SPS; A.N = 1; A.src = -2; A.f = 0;
+                    }
+                }
+                cur.valid = rdl(A.valid, cn - 1); cur.s = rdl_l(A.s, cn - 1); cur.D = rdl(A.D, cn - 1); cur.N = rdl(A.N, cn - 1);
+                cur.src = rdl(A.src, cn - 1); cur.f = rdl(A.f, cn - 1);
+                off += (unsigned long long)rdl_l((long)it, WV - 1);
+                ev += (unsigned long long)rdl_l((long)ie, WV - 1);
+                continue;
+            }
+        }
         for (int j = 0; j < cn; ++j) {                               // uniform
             GroupSumG R;
             R.first_event = rdl_l(M.first_event, j); R.carry_end = rdl_l(M.carry_end, j); R.first_seg_end = rdl_l(M.first_seg_end, j);
