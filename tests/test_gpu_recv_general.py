@@ -407,3 +407,33 @@ def test_mode2_pipelined_three_deep_while_the_detection_list_grows(O, FE):
         ref = refs[k % len(caps)]
         nd = int(parse_results(res)[0]["n_dibits"])
         assert nd == len(ref) and np.array_equal(dib[0, :nd].cpu().numpy(), ref), k
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", [1, 0])
+def test_general_receiver_over_more_than_64_groups(O, FE, mode):
+    """The general receiver's hierarchical scan walks the groups of a channel 64 at a time (k_scan_tiles_g's last workgroup: one group
+    per lane, the carried state handed from step to step).  700 s of one channel are 4 375 tiles = 69 groups -- two steps --, with
+    lock drops in groups of both steps, at a step's first group, and stretches of event-free groups (whole groups of noise) that force
+    the sequential walk beside the parallel common case.  Tracking clock (mode 1) and the fixed stride with a lock-drop list (mode 0):
+    dibits, sync positions and sync dibit indices equal the oracle's; the frames between clean sync words are the modulator's."""
+    import torch
+    from p25rx_amd import c4fm
+    n = 700 * 240000
+    dev = torch.device("cuda", 0)
+    iq_t, truth = c4fm.synth_torch(n, seed=1234, device=dev, snr_db=30.0, clock_ppm=100.0 if mode else 0.0)
+    # two silent stretches (no sync words for > one group of 64 tiles = 491 520 baseband samples): noise only
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    for a0, a1 in ((40 * 240000, 54 * 240000), (655 * 240000, 669 * 240000)):
+        iq_t[a0:a1] = 0.02 * torch.randn((a1 - a0, 2), generator=g, device=dev)
+    iq = iq_t.cpu().numpy().view(np.complex64).reshape(-1)
+    bb = O.Demod().feed_cf32(iq)
+    tile, group = 7680, 64 * 7680
+    drops = [3 * group + 100, 3 * group + 101, 64 * group, 64 * group + 5 * tile + 17, 66 * group - 1, 20 * group + 3 * tile, len(bb) - 5]
+    ref = oracle_recv(O, bb, mode, drops)
+    assert len(ref[1]) > 3000
+    fe = FE(symbol_clock=mode)
+    got = dev_slice(fe, bb, resync=drops, sync_cap=8192)
+    same(got, ref, "700 s, %d lock drops" % len(drops))
+    r = got[3]
+    assert int(r["n_sync"]) == len(ref[1]) and int(r["n_dibits"]) == len(ref[0])
