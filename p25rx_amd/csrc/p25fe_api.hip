@@ -134,7 +134,7 @@ struct p25fe {
     size_t rs_n = 0, rs_stride = 0;
     // scratch
     DevBuf pl_f, pl_bits, evl, evthr, recs, tsum, outs, power_partial, chunk_cnt;
-    DevBuf gagg, gpre, gtick;              // K3 in K2's tail: group aggregates, group carry-ins, the arrival counters (zero between launches)
+    DevBuf gagg, gpre, gtick;              // K3 (k_scan_tiles): group aggregates, group carry-ins, the arrival counters (zero between launches)
     PinBuf hin, hbb, hout;                 // streaming entry points: staged input ([history | new] IQ, [tail | new] baseband), results
     DevBuf gsum, gouts, evg, gsg, gpg;     // general receiver only (tracking clock / lock drops): allocated on first use
     DevBuf evrec, evnext, evoff;           // SPEC 3.8c (symbol_clock = 2, resident ranges): the list of detections, allocated on first use
@@ -891,9 +891,10 @@ static int launch_planarize(p25fe_t* h, const float* d_bb, size_t bb_stride, siz
     return P25FE_OK;
 }
 
-// K3's arguments (the fixed-stride receiver's k_scan_tiles / k_range_scan take them inside a DetArgs)
-static void scan_tail_args(p25fe_t* h, size_t n_bb, const p25fe_anchor_t* d_anchor_in, p25fe_result_t* d_result, ScanTail* t)
+// K3's arguments, fixed-stride receiver (k_scan_tiles / k_range_scan)
+static void scan_args(p25fe_t* h, size_t n_bb, long abs_bb0, int n_tiles, const p25fe_anchor_t* d_anchor_in, p25fe_result_t* d_result, ScanArgs* t)
 {
+    t->tsum = h->tsum.as<unsigned long long>(); t->recs = h->recs.as<TileRec>(); t->n_tiles = n_tiles; t->n = (long)n_bb; t->abs0 = abs_bb0;
     t->outs = h->outs.as<ScanOut>(); t->gagg = h->gagg.as<GroupAgg>(); t->gpre = h->gpre.as<GroupPre>();
     t->tickets = h->gtick.as<unsigned>(); t->anchor_in = d_anchor_in; t->result = d_result;
     t->n_baseband = n_bb;
@@ -904,7 +905,6 @@ static int launch_detect(p25fe_t* h, size_t n_bb, long abs_bb0, hipStream_t st, 
     const PlanarGeo g(n_bb);
     DetArgs d;
     d.head_flag = nullptr; d.head_seq = 0u; d.head_tile_max = -1; d.head_err = nullptr;
-    memset(&d.tail, 0, sizeof d.tail);                               // (K3's arguments: K2 does not read them)
     if (wait_head_flag) {
         d.head_flag = h->sh_flag.as<unsigned>(); d.head_seq = h->sh_seq; d.head_tile_max = h->sh_head_tile_max;
         d.head_err = h->sh_flag.as<unsigned>() + SH_FLAG_ERR;
@@ -1011,10 +1011,8 @@ static int launch_scan_slice(p25fe_t* h, size_t n_bb, long abs_bb0, const p25fe_
         return P25FE_OK;
     }
     if (!fix) {
-        DetArgs c;
-        memset(&c, 0, sizeof c);
-        c.n = (long)n_bb; c.abs0 = abs_bb0; c.n_tiles = n_tiles; c.recs = h->recs.as<TileRec>(); c.tsum = h->tsum.as<unsigned long long>();
-        scan_tail_args(h, n_bb, d_anchor_in, d_result, &c.tail);
+        ScanArgs c;
+        scan_args(h, n_bb, abs_bb0, n_tiles, d_anchor_in, d_result, &c);
         // K2 has just run: the whole scan (groups, then the range); otherwise only the range's, on the group aggregates that are there
         if (scanned && n_tiles) launch_ev(k_scan_tiles, dim3((unsigned)n_groups_of(n_tiles), (unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);
         else launch_ev(k_range_scan, dim3((unsigned)h->C), dim3(WV), 0, st, nullptr, slice ? nullptr : ev_done, c);

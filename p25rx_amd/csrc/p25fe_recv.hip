@@ -9,7 +9,7 @@
 //                 pass (0.08 % of random data) get the exact SPEC 3.7 arithmetic from the float planes, where a
 //                 24-symbol window is 96 contiguous bytes.  Same detections as evaluating c / e everywhere, bit for bit.
 //   K3          : the receiver's serial state (anchor in force, dibits / events so far) as a hierarchical scan over tile summaries by
-//                 one-wave workgroups (k_scan_tiles; the general receiver: in K2's tail + k_scan_g_groups) -- see ScanTail below.
+//                 one-wave workgroups (k_scan_tiles; the general receiver: k_scan_tiles_g + k_scan_g_groups) -- see ScanArgs below.
 //   K4 k_slice  : 4-level slicer (SPEC 3.8): a locked receiver reads ONE plane, contiguously.
 //   k_planarize : linear baseband -> planes + sign bits, for the entry points that are handed a 48 kHz float stream
 //                 (p25fe_slice / p25fe_slice_dev: the RecvEvent::Baseband hand-off of src/demod.rs:116).
@@ -334,7 +334,12 @@ struct GroupPre {               // per (channel, group), from the range's point 
     unsigned event_off;         // detections of the range in front of the group
     unsigned pad_;
 };
-struct ScanTail {               // K3's own arguments (k_scan_tiles / k_range_scan; they ride in DetArgs beside K2's)
+struct ScanArgs {               // K3, fixed-stride receiver (k_scan_tiles / k_range_scan)
+    const unsigned long long* tsum;     // [ch][n_tiles] K2's packed summaries
+    const TileRec* recs;        // [ch][n_tiles]
+    int n_tiles;
+    long n;                     // owned samples per channel
+    long abs0;
     ScanOut* outs;              // [ch][n_tiles] group-local carry-ins
     GroupAgg* gagg;             // [ch][n_groups]
     GroupPre* gpre;             // [ch][n_groups]
@@ -370,7 +375,6 @@ struct DetArgs {
     unsigned head_seq;
     int head_tile_max;
     unsigned* head_err;         // with head_flag: receives head_seq if a wait gave up (p25fe_shard_head_check)
-    ScanTail tail;              // K3's (k_scan_tiles, k_range_scan): unused by K2 itself
 };
 
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
@@ -683,9 +687,9 @@ __device__ __forceinline__ int last_set_below(unsigned long long mask, int lane)
 }
 
 // One group of tiles, no carry-in: lane = tile.
-__device__ __forceinline__ void group_scan(const DetArgs& a, const int g, const int ch)
+__device__ __forceinline__ void group_scan(const ScanArgs& a, const int g, const int ch)
 {
-    const ScanTail& t = a.tail;
+    const ScanArgs& t = a;
     const int lane = threadIdx.x, tl = g * GT + lane;
     const bool act = tl < a.n_tiles;
     const unsigned long long u = act ? a.tsum[(size_t)ch * a.n_tiles + tl] : 0ull;
@@ -731,9 +735,9 @@ __device__ __forceinline__ void group_scan(const DetArgs& a, const int g, const 
 }
 
 // The groups of one channel under the range's carry-in: lane = group, 64 groups per step, the carried state uniform.
-__device__ __forceinline__ void range_scan(const DetArgs& a, const int ch)
+__device__ __forceinline__ void range_scan(const ScanArgs& a, const int ch)
 {
-    const ScanTail& t = a.tail;
+    const ScanArgs& t = a;
     const int lane = threadIdx.x, n_groups = n_groups_of(a.n_tiles);
     p25fe_anchor_t Ain;
     Ain.valid = 0; Ain.s = 0; Ain.hi = Ain.mid = Ain.lo = 0.f; Ain.period_d = SPS; Ain.period_n = 1;
@@ -805,16 +809,16 @@ __device__ __forceinline__ void range_scan(const DetArgs& a, const int ch)
 #ifndef P25FE_JIT
 // The top step alone (fixed-stride receiver): a re-scan of group aggregates that are already there under another carry-in
 // (p25fe_shard_pass2 with host-resolved anchors), and the record of an EMPTY range (no tile, no K2: the carry-in is handed through).
-__global__ __launch_bounds__(WV, 4) void k_range_scan(DetArgs a) { range_scan(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(WV, 4) void k_range_scan(ScanArgs a) { range_scan(a, (int)blockIdx.x); }
 // K3 of the fixed-stride receiver as its own launch of ONE-WAVE workgroups, one per group of GT tiles (grid: groups x channels): the group
 // scan, then -- the channel's last group to arrive -- the scan of the groups.  It fits beside a running K1 (no LDS, 51 VGPRs), where the
 // 512-thread k_scan of rounds 2 - 5 waited for the drain.  (K2 keeps its tail-less form here: with the scan in K2's own tail, as the
 // general receiver has it, every one of 3 750 detection workgroups lives ~4 us longer -- drain + ticket -- and K1 beside them paid 20 us.)
-__global__ __launch_bounds__(WV, 4) void k_scan_tiles(DetArgs a)
+__global__ __launch_bounds__(WV, 4) void k_scan_tiles(ScanArgs a)
 {
     const int g = blockIdx.x, ch = blockIdx.y, n_groups = n_groups_of(a.n_tiles);
     group_scan(a, g, ch);
-    if (!last_arrival(a.tail.tickets + (size_t)ch * (n_groups + 1) + n_groups, (unsigned)n_groups)) return;
+    if (!last_arrival(a.tickets + (size_t)ch * (n_groups + 1) + n_groups, (unsigned)n_groups)) return;
     range_scan(a, ch);
 }
 #endif
@@ -909,7 +913,7 @@ struct SliceArgs {
     uint8_t* dibits2;           // nullable: a second destination of every dibit, same row layout (rank 0 of a time-sharded capture
                                 // slices straight into the ordered stream as well: its shard starts at offset 0)
     ShardFix fix;               // fix.summ != nullptr: pass 2 of a time shard, the combine done here (p25fe_shard_pass2_dev)
-    const GroupPre* gpre;       // non-null: `outs` are the group-local records of K2's tail, completed here (group_fix); null: k_scan's
+    const GroupPre* gpre;       // `outs` are k_scan_tiles' group-local records, completed here by the group's carry-in (group_fix)
 };
 
 // A tile's group-local carry-in record (group_scan) + its group's carry-in (range_scan) -> the record k_scan would have written.
@@ -1050,7 +1054,7 @@ __device__ __forceinline__ void slice_item(const SliceArgs& a, const int tile, c
     int valid = 0;
     long s_abs = 0;
     float hi = 0.f, mid = 0.f, lo = 0.f;
-    if (a.gpre) {                                                   // uniform: K3 ran in K2's tail
+    {
         const GroupPre P = a.gpre[(size_t)ch * n_groups_of(a.n_tiles) + tile / GT];
         so = group_fix(so, P, a.abs0, tile, valid, s_abs);
     }
@@ -1115,7 +1119,7 @@ struct ScanOutG {               // per (channel, tile) carry-in written by k_sca
 struct CState { int valid; long s; int D, N; int src; int f; };
 
 // ------------------------------------------------------------------------------------------
-// The general receiver's scan, hierarchical like the fixed-stride one (ScanTail above) -- the 512-thread k_scan_g of rounds 3 - 5
+// The general receiver's scan, hierarchical like the fixed-stride one (ScanArgs above) -- the 512-thread k_scan_g of rounds 3 - 5
 // (48 - 53 KB of LDS) is gone: beside a running K1 it waited for the drain, and the tracking clock's pipelined step paid for it.
 //   pass A   k_scan_tiles_g, one wave per group of GT tiles: the group is scanned with NO carry-in (scan_g_lanes: lane =
 //            tile, the "latest two event tiles" rule by two bit scans of a ballot, neighbours' fields by lane shuffles) and leaves
@@ -1210,7 +1214,7 @@ struct ScanArgsG {
     ScanOutG* outs;
     GroupSumG* gsg;                     // [ch][n_groups]
     GroupPreG* gpg;                     // [ch][n_groups]
-    unsigned* tickets;                  // [ch][n_groups + 1] (K2's tail)
+    unsigned* tickets;                  // [ch][n_groups + 1], zero between launches
     int n_tiles;
     long n;
     long abs0;                          // absolute index of the first PROCESSED sample (owned sample 0 minus the lookahead)
