@@ -380,30 +380,44 @@ struct DetArgs {
 constexpr int EVTHR_N = 4;                                       // detections per tile whose thresholds K2 hands to K4 (more: K4 recomputes)
 constexpr int K2_DCAP = 64;                                      // detections per tile whose thresholds K2 remembers (more: it recomputes)
 constexpr int K2_LANES = 60;                                     // 10 planes x 6 blocks of 4 words
-constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test (256 -- 6.1 KB of LDS instead of
-                                                                 // 9.7, two workgroups in the LDS K1 leaves free per CU -- measured: no difference)
+constexpr int K2_HCAP = 2048;                                    // screened positions awaiting the exact test (256 -- 3.6 KB of LDS less
+                                                                 // -- measured in round 6 on the fixed-stride kernel: no difference)
 
 template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a, const int tile, const int ch)
 {
-    __shared__ uint16_t HITS[K2_HCAP];
+    // LDS: what the exact test needs (screened positions, the current round's candidates) is dead when the sorted list is made, so the two
+    // phases share their bytes -- 7.1 KB per workgroup (general receiver: 8.4 KB) instead of 9.7 (16.1): beside a running front end a
+    // workgroup of the chain gets the LDS one retiring K1 workgroup frees plus the CU's spare, and a K1 workgroup wants the same bytes back.
+    // (The general detection with 21 KB waited for K1 to drain: 250 us instead of 20 alone; with 16 KB it still took 100 - 200, now 45.)
+    struct Phase1 {
+        uint16_t hits[K2_HCAP];
+        uint16_t cands[WV];
+        float cn[5][12];
+        // A candidate's thresholds (SPEC 3.8) come from the same 24 samples as its correlation: computed where those are in
+        // registers and remembered for the detections, instead of gathered again (a dependent round trip) for the summary.
+        float cthr[WV][3];                                       // per candidate of the current round
+    };
+    struct Phase2 {
+        uint16_t evs[EVCAP];                                     // the tile's detections, sorted list of decision offsets
+        uint16_t endo[GEN ? EVCAP : 1];                          // GEN: where each detection's governed interval ends
+    };
+    union Arena { Phase1 p1; Phase2 p2; };
+    __shared__ Arena AR;
+    auto& HITS = AR.p1.hits;
+    auto& CANDS = AR.p1.cands;
+    auto& CN = AR.p1.cn;
+    auto& CTHR = AR.p1.cthr;
+    auto& EVS = AR.p2.evs;
     __shared__ unsigned EVB[TS / 32];                            // detections of the tile, bit = decision offset
-    __shared__ uint16_t EVS[EVCAP];                              // the same, sorted list
-    __shared__ uint16_t CANDS[WV];
-    __shared__ float CN[5][12];
-    // A candidate's thresholds (SPEC 3.8) come from the same 24 samples as its correlation: computed where those are in
-    // registers and remembered for the detections, instead of gathered again (a dependent round trip) for the summary.
-    __shared__ float CTHR[WV][3];                                // per candidate of the current round
     __shared__ uint16_t DETE[K2_DCAP];                           // per detection: decision offset ...
     __shared__ float DETT[K2_DCAP][3];                           // ... and thresholds
     __shared__ unsigned DETN;
-    // GEN: per decision offset, the detection's position fraction (3 bits) -- one NIBBLE per offset: detections are more than W samples
-    // apart, so the two offsets of a byte never both hold one, and a byte is written whole (no clearing pass, no read-modify-write).
-    // (With the byte-per-offset table and a separate TRK array the workgroup needed 21 KB of LDS: more than ONE retiring K1 workgroup
-    // frees beside a running front end -- 6.9 KB spare + 13 KB -- so the general detection waited for K1 to drain: 250 us instead of 28.)
-    __shared__ uint8_t FRO[GEN ? TS / 2 : 4];
-    auto fro_set = [&](int off, int v) { FRO[off >> 1] = (uint8_t)((v & 7) << ((off & 1) * 4)); };
-    auto fro_get = [&](int off) -> unsigned { return ((unsigned)FRO[off >> 1] >> ((off & 1) * 4)) & 7u; };
-
+    // GEN: the detection's position fraction (3 bits), one byte per BLOCK of W + 1 decision offsets: detections are more than W samples
+    // apart, so a block never holds two, and a byte is written whole (no clearing pass, no read-modify-write); read only at detections.
+    static_assert(TS % (W + 1) == 0, "fraction table: whole blocks");
+    __shared__ uint8_t FRO[GEN ? TS / (W + 1) : 4];
+    auto fro_set = [&](int off, int v) { FRO[off / (W + 1)] = (uint8_t)(v & 7); };
+    auto fro_get = [&](int off) -> unsigned { return (unsigned)FRO[off / (W + 1)] & 7u; };
     const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
@@ -576,7 +590,7 @@ template <bool GEN> __device__ __forceinline__ void detect_tile(const DetArgs& a
     if constexpr (GEN) {
         // per detection k: where its governed interval ends (the next detection's decision index + 1, the next lock drop or
         // the tile's end) and whether detection k + 1 may take its period from the interval s_k -> s_{k+1} (no drop between)
-        __shared__ uint16_t ENDO[EVCAP];
+        auto& ENDO = AR.p2.endo;
         const long T0 = a.abs0 + t0, TE = T0 + tn;
         for (int k = lane; k < n_ev; k += WV) {
             const long ek = T0 + EVS[k];
@@ -680,6 +694,23 @@ __device__ __forceinline__ long rdl_l(long v, int j)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), j);
     return (long)(((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ float rdl_f(float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); }
+// The slicer's view of its tile's detections: one per lane, 64 at a time, read with v_readlane under a uniform index -- no LDS (K4 rides in
+// whatever a running front end leaves free), and the loads leave together with the tile's records instead of one round trip later.
+struct EvLanes {
+    unsigned ev;                // evl[lane]: decision offset of detection `lane`
+    unsigned eg;                // evg[lane] (general receiver)
+    float th;                   // evthr[lane], lane < 3 EVTHR_N: thresholds of the tile's first detections
+};
+__device__ __forceinline__ EvLanes ev_lanes_load(const uint16_t* evl, const uint32_t* evg, const float* evthr)
+{
+    EvLanes e;
+    e.ev = evl[threadIdx.x];                                         // (the lists are EVCAP >= 64 entries long whatever the tile holds)
+    e.eg = evg ? evg[threadIdx.x] : 0u;
+    e.th = threadIdx.x < EVTHR_N * 3 ? evthr[threadIdx.x] : 0.f;
+    return e;
+}
+static_assert(EVCAP >= WV && EVTHR_N * 3 <= WV, "EvLanes: one batch of the list, the thresholds in one register");
 __device__ __forceinline__ int last_set_below(unsigned long long mask, int lane)      // highest set bit of mask below `lane`, -1: none
 {
     const unsigned long long m = mask & ((1ull << lane) - 1ull);
@@ -935,22 +966,25 @@ __device__ __forceinline__ ScanOut group_fix(ScanOut so, const GroupPre& P, cons
 // so: the tile's carry-in record; u: its packed summary; (valid, s_abs, hi, mid, lo): the anchor in force at its first sample
 __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, const int ch, const ScanOut so,
                                            const unsigned long long u, const int valid, const long s_abs, const float hi,
-                                           const float mid, const float lo)
+                                           const float mid, const float lo, const EvLanes el)
 {
-    __shared__ uint16_t EV[EVCAP];
-    __shared__ float ETH[EVTHR_N * 3];
     const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
     const int n_ev = (int)((u >> (2 * TS_BITS)) & TS_MASK);
     if (!valid && n_ev == 0) return;                                // nothing decided yet: no instants
-    if (n_ev) {
-        const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
-        for (int k = lane; k < n_ev; k += WV) EV[k] = evl[k];
-        if (lane < EVTHR_N * 3) ETH[lane] = a.evthr[((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3) + lane];
-        phase_sync();
-    }
+    // detection k's decision offset: lane k % 64 of the batch in registers (a tile with more than 64 detections reloads, 64 at a time)
+    const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
+    unsigned evr = el.ev;
+    int batch = 0;
+    auto ev_at = [&](int k) -> int {
+        if ((k & ~(WV - 1)) != batch) {                             // uniform
+            batch = k & ~(WV - 1);
+            evr = batch + lane < EVCAP ? (unsigned)evl[batch + lane] : 0u;
+        }
+        return rdl((int)evr, k & (WV - 1));
+    };
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
     uint8_t* out2 = a.dibits2 ? a.dibits2 + (size_t)ch * a.dibit_stride + so.dibit_off : nullptr;
     // room left in this channel's row from the tile's first dibit on (<= 0: the row is full).  A receiver that re-anchors
@@ -998,12 +1032,14 @@ __device__ __forceinline__ void slice_tile(const SliceArgs& a, const int tile, c
             rank += emit((int)((SPS - ph) % (unsigned)SPS), 0, m_hi, hi, mid, lo, 0);
         }
     }
+    int e_nx = n_ev ? ev_at(0) : 0;
     for (int k = 0; k < n_ev; ++k) {
-        const int ek = EV[k];
-        const int m_hi = k + 1 < n_ev ? (int)EV[k + 1] + 1 : tn;
+        const int ek = e_nx;
+        if (k + 1 < n_ev) e_nx = ev_at(k + 1);
+        const int m_hi = k + 1 < n_ev ? e_nx + 1 : tn;
         float h, m, l;
         if (k < EVTHR_N) {                                          // K2 left the thresholds of the tile's first detections
-            h = ETH[3 * k]; m = ETH[3 * k + 1]; l = ETH[3 * k + 2];
+            h = rdl_f(el.th, 3 * k); m = rdl_f(el.th, 3 * k + 1); l = rdl_f(el.th, 3 * k + 2);
         } else {
             float v[NSYN];
             sync_gather(f, t0 + ek - W + PLPAD, v);                 // uniform window; same arithmetic as K2, same bits
@@ -1050,6 +1086,7 @@ __device__ __forceinline__ void slice_item(const SliceArgs& a, const int tile, c
     }
     ScanOut so = a.outs[(size_t)ch * a.n_tiles + tile];
     const unsigned long long u = a.tsum[(size_t)ch * a.n_tiles + tile];
+    const EvLanes el = ev_lanes_load(a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP, nullptr, a.evthr + ((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3));
     // carry-in anchor
     int valid = 0;
     long s_abs = 0;
@@ -1085,7 +1122,7 @@ __device__ __forceinline__ void slice_item(const SliceArgs& a, const int tile, c
             so.dibit_off += (unsigned long long)count_instants(cur.s, r_lo, sh_first_event >= 0 ? sh_first_event + 1 : r_hi);
         }
     }
-    slice_tile(a, tile, ch, so, u, valid, s_abs, hi, mid, lo);
+    slice_tile(a, tile, ch, so, u, valid, s_abs, hi, mid, lo, el);
 }
 #ifndef P25FE_JIT
 // (One workgroup per tile.  A BOUNDED grid of persistent workgroups walking the tiles -- 1 024, i.e. 4 per CU, which leave K1 beside
@@ -1507,7 +1544,7 @@ __global__ __launch_bounds__(WV, 4) void k_scan_tiles_g(ScanArgsG a)
 }
 #endif
 
-// K2's kernel (GEN: 16 KB of LDS per one-wave workgroup -- the per-offset fraction table)
+// K2's kernel (7.1 KB of LDS per one-wave workgroup; GEN: 8.4 KB with the fraction table)
 template <bool GEN> __device__ __forceinline__ void detect_item(const DetArgs& a, const int tile, const int ch)
 {
     if (a.head_flag && tile <= a.head_tile_max) {                   // uniform
@@ -1554,16 +1591,17 @@ struct SliceArgsG {
 #ifndef P25FE_JIT
 __device__ __forceinline__ void slice_g_item(const SliceArgsG& a, const int tile, const int ch)
 {
-    __shared__ uint16_t EV[EVCAP];
-    __shared__ uint32_t EG[EVCAP];
-    __shared__ float ETH[EVTHR_N * 3];
     __shared__ float CI[P25FE_CLK_PHASES * 4];
     const int lane = threadIdx.x;
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
-    const ScanOutG so = a.outs[(size_t)ch * a.n_tiles + tile];
-    const TileSumG g = a.gsum[(size_t)ch * a.n_tiles + tile];
+    const size_t ti = (size_t)ch * a.n_tiles + tile;
+    const ScanOutG so = a.outs[ti];
+    const TileSumG g = a.gsum[ti];
+    const uint16_t* evl = a.evl + ti * EVCAP;
+    const uint32_t* evg = a.evg + ti * EVCAP;
+    const EvLanes el = ev_lanes_load(evl, evg, a.evthr + ti * (EVTHR_N * 3));      // (with the tile's records: one round trip)
     const int n_ev = (int)(g.n_det_flags & 0xffffu);
     const bool track = a.track != 0;
 
@@ -1577,18 +1615,36 @@ __device__ __forceinline__ void slice_g_item(const SliceArgsG& a, const int tile
         valid = A.valid; hi = A.hi; mid = A.mid; lo = A.lo;
     }
     if (!valid && n_ev == 0) return;
-    if (track) for (int k = lane; k < P25FE_CLK_PHASES * 4; k += WV) CI[k] = P25FE_CLK_INTERP[k];
-    if (n_ev) {
-        const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
-        const uint32_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
-        for (int k = lane; k < n_ev; k += WV) { EV[k] = evl[k]; EG[k] = evg[k]; }
-        if (lane < EVTHR_N * 3) ETH[lane] = a.evthr[((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3) + lane];
+    if (track) {
+        for (int k = lane; k < P25FE_CLK_PHASES * 4; k += WV) CI[k] = P25FE_CLK_INTERP[k];
+        phase_sync();
     }
-    phase_sync();
+    // detection k: lane k % 64 of the batch in registers (a tile with more than 64 detections reloads, 64 at a time)
+    unsigned evr = el.ev, egr = el.eg;
+    int batch = 0;
+    auto ev_at = [&](int k, unsigned& eg) -> int {
+        if ((k & ~(WV - 1)) != batch) {                             // uniform
+            batch = k & ~(WV - 1);
+            const bool in = batch + lane < EVCAP;
+            evr = in ? (unsigned)evl[batch + lane] : 0u;
+            egr = in ? evg[batch + lane] : 0u;
+        }
+        eg = (unsigned)rdl((int)egr, k & (WV - 1));
+        return rdl((int)evr, k & (WV - 1));
+    };
     uint8_t* out = a.dibits + (size_t)ch * a.dibit_stride + so.dibit_off;
     uint8_t* out2 = a.dibits2 ? a.dibits2 + (size_t)ch * a.dibit_stride + so.dibit_off : nullptr;
     const long room = a.dibit_stride - (long)so.dibit_off;
     const long T0 = a.abs0 + t0, TE = T0 + tn;
+    // The tile's samples, by tile-local index d (>= -1 with the interpolator's first tap): planar position t0 + PLPAD + d, and t0 + PLPAD
+    // is a whole number of blocks -- counted from ONE BLOCK EARLIER every index below is a small non-negative int (planar_index's
+    // arithmetic, without its 64-bit divisions)
+    static_assert(TS % PL_BLK == 0 && PLPAD % PL_BLK == 0 && PLPAD >= PL_BLK, "a tile starts on a block of the planar layout");
+    const float* fb = f + ((t0 + PLPAD) / PL_BLK - 1) * (long)PL_BLK;
+    auto sample_at = [&](int e) -> float {                           // e = d + PL_BLK
+        const int sy = e / SPS, r = e - sy * SPS;
+        return fb[(sy >> 5) * PL_BLK + r * 32 + (sy & 31)];
+    };
 
     // instants of the clock (s, D, N) with index in [lo_, hi_) that it governs
     auto emit = [&](long s, int D, int N, long lo_, long hi_, float h, float m, float l, int rank) -> int {
@@ -1598,36 +1654,50 @@ __device__ __forceinline__ void slice_g_item(const SliceArgsG& a, const int tile
         long cnt_l = j_hi - j_lo + 1;                               // a tile holds at most TS / 6 instants under any clock the library makes;
         cnt_l = cnt_l < 0 ? 0 : (cnt_l > (long)TS ? (long)TS : cnt_l);   // clamp whatever a foreign anchor got past the plausibility test
         const int count = (int)cnt_l;
+        // instant j sits at s + (j D) div N, phase ((j D) mod N) 64 div N.  With j = j_lo + idx: (j_lo D) div / mod N once per call (uniform),
+        // then 32-bit arithmetic per instant whenever (j_lo D) mod N + (count - 1) D fits 32 bits -- it does for every interval between sync
+        // words shorter than ~1.4 M samples; longer ones (the spec allows 2^24) and foreign anchors keep the 64-bit form.  Same integers.
+        const long B = j_lo * (long)D;
+        long qb = B, rr = 0;                                        // N == 1: the nominal clock, no division
+        if (N != 1) { qb = B / (long)N; rr = B - qb * (long)N; }
+        const long ib = s + qb;                                     // position of instant j_lo
+        const unsigned rb = (unsigned)rr;
+        const bool narrow = B >= 0 && D > 0 && N < (1 << 26)
+                            && (unsigned long long)rr + (unsigned long long)(count > 0 ? count - 1 : 0) * (unsigned long long)D < (1ull << 32);
         uint8_t* dst = out + rank;
         for (int j0 = 0; j0 < count; j0 += WV) {
             const int idx = j0 + lane;
             if (idx < count) {
-                const long num = (j_lo + idx) * (long)D;
                 long i; int q = 0;
-                if (N == 1) { i = s + num; }
-                else { const long qu = num / N; i = s + qu; q = (int)(((num - qu * N) * P25FE_CLK_PHASES) / N); }
-                const long p = i - a.abs0 + PLPAD;                 // planar position of the instant's integer sample
+                if (narrow) {                                        // uniform
+                    const unsigned t = rb + (unsigned)idx * (unsigned)D;
+                    unsigned qu = t;
+                    if (N != 1) {
+                        qu = t / (unsigned)N;
+                        q = (int)(((t - qu * (unsigned)N) * (unsigned)P25FE_CLK_PHASES) / (unsigned)N);
+                    }
+                    i = ib + (long)qu;
+                } else {
+                    const long num = (j_lo + idx) * (long)D;
+                    const long qu = num / N;
+                    i = s + qu; q = (int)(((num - qu * N) * P25FE_CLK_PHASES) / N);
+                }
                 float v;
                 if (i < lo_ || i >= hi_) {
                     // cannot happen for a clock and a position the library produced; a foreign anchor whose position is so far away
                     // that j D wrapped 64 bits (p25fe_slice_dev's d_anchor_in) must not become a load outside the planes
                     v = 0.f;
-                } else if (track) {
-                    float b[4];
-#pragma unroll
-                    for (int tq = 0; tq < 4; ++tq) {
-                        const long pp = p - 1 + tq;
-                        const long sy = pp / SPS;
-                        b[tq] = f[planar_index(sy, (int)(pp - sy * SPS))];
-                    }
-                    const float* w = CI + 4 * q;
-                    v = w[0] * b[0];
-                    v = __builtin_fmaf(w[1], b[1], v);
-                    v = __builtin_fmaf(w[2], b[2], v);
-                    v = __builtin_fmaf(w[3], b[3], v);
                 } else {
-                    const long sy = p / SPS;
-                    v = f[planar_index(sy, (int)(p - sy * SPS))];
+                    const int e = (int)(i - T0) + PL_BLK;            // lo_ >= T0: in [PL_BLK, PL_BLK + TS)
+                    if (track) {
+                        const float* w = CI + 4 * (q & (P25FE_CLK_PHASES - 1));      // (the mask: a no-op for any clock the library makes)
+                        v = w[0] * sample_at(e - 1);
+                        v = __builtin_fmaf(w[1], sample_at(e), v);
+                        v = __builtin_fmaf(w[2], sample_at(e + 1), v);
+                        v = __builtin_fmaf(w[3], sample_at(e + 2), v);
+                    } else {
+                        v = sample_at(e);
+                    }
                 }
                 if (rank >= 0 && rank + idx < room) {
                     const unsigned char db = slice_dibit(v, h, m, l);
@@ -1641,18 +1711,20 @@ __device__ __forceinline__ void slice_g_item(const SliceArgsG& a, const int tile
 
     int rank = 0;
     if (valid) rank += emit(so.s, so.D, so.N, T0, g.pre_end1 ? T0 + (long)g.pre_end1 - 1 : TE, hi, mid, lo, 0);
+    unsigned eg = 0u, eg_prev = 0u;
+    int ev_prev = 0;
     for (int k = 0; k < n_ev; ++k) {
-        const long ek = T0 + EV[k], sk = ek - W;
-        const unsigned eg = EG[k];
+        const int evk = ev_at(k, eg);
+        const long ek = T0 + evk, sk = ek - W;
         int D, N;
         if (k == 0) clock_period(track, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && valid, so.s, so.f, sk, frac3(eg >> 16), D, N);
-        else clock_period(track, ((eg >> 15) & 1u) != 0, T0 + EV[k - 1] - W, frac3(EG[k - 1] >> 16), sk, frac3(eg >> 16), D, N);
+        else clock_period(track, ((eg >> 15) & 1u) != 0, T0 + ev_prev - W, frac3(eg_prev >> 16), sk, frac3(eg >> 16), D, N);
         float h, m, l;
         if (k < EVTHR_N) {
-            h = ETH[3 * k]; m = ETH[3 * k + 1]; l = ETH[3 * k + 2];
+            h = rdl_f(el.th, 3 * k); m = rdl_f(el.th, 3 * k + 1); l = rdl_f(el.th, 3 * k + 2);
         } else {
             float v[NSYN];
-            sync_gather(f, t0 + EV[k] - W + PLPAD, v);
+            sync_gather(f, t0 + evk - W + PLPAD, v);
             sync_thresholds(v, h, m, l);
         }
         if (lane == 0 && a.sync_pos && (long)(so.event_off + k) < a.sync_stride) {
@@ -1660,6 +1732,7 @@ __device__ __forceinline__ void slice_g_item(const SliceArgsG& a, const int tile
             a.sync_dibit[(size_t)ch * a.sync_stride + so.event_off + k] = so.dibit_off + (unsigned long long)rank;
         }
         rank += emit(sk, D, N, ek + 1, T0 + (long)(eg & 0x7fffu), h, m, l, rank);
+        ev_prev = evk; eg_prev = eg;
     }
 }
 __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a) { slice_g_item(a, (int)blockIdx.x, (int)blockIdx.y); }
@@ -2031,7 +2104,7 @@ __device__ __forceinline__ void recv_one_tile(const ChunkRecvArgs& c, const int 
     l.dibits2 = nullptr; l.fix.summ = nullptr; l.gpre = nullptr;
     ScanOut so;
     so.src = -1; so.event_off = 0u; so.dibit_off = 0ull;
-    slice_tile(l, 0, ch, so, u, A.valid, A.s, A.hi, A.mid, A.lo);
+    slice_tile(l, 0, ch, so, u, A.valid, A.s, A.hi, A.mid, A.lo, ev_lanes_load(c.evl + (size_t)ch * EVCAP, nullptr, c.evthr + (size_t)ch * (EVTHR_N * 3)));
     tail_extract(c, ch);
     if (c.done) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");              // system scope: the host sees dibits, result and tail before the flag

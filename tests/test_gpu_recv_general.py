@@ -424,7 +424,9 @@ def test_general_receiver_over_more_than_64_groups(O, FE, mode):
     iq_t, truth = c4fm.synth_torch(n, seed=1234, device=dev, snr_db=30.0, clock_ppm=100.0 if mode else 0.0)
     # two silent stretches (no sync words for > one group of 64 tiles = 491 520 baseband samples): noise only
     g = torch.Generator(device=dev); g.manual_seed(7)
-    for a0, a1 in ((40 * 240000, 54 * 240000), (655 * 240000, 669 * 240000)):
+    # (the first one 42 s long: the sync word behind it takes its period from an interval of 2 M samples, and the slicer's per-instant
+    # arithmetic for that clock no longer fits 32 bits -- the tiles of that frame take the 64-bit form beside everyone else's narrow one)
+    for a0, a1 in ((40 * 240000, 82 * 240000), (655 * 240000, 669 * 240000)):
         iq_t[a0:a1] = 0.02 * torch.randn((a1 - a0, 2), generator=g, device=dev)
     iq = iq_t.cpu().numpy().view(np.complex64).reshape(-1)
     bb = O.Demod().feed_cf32(iq)
@@ -437,3 +439,31 @@ def test_general_receiver_over_more_than_64_groups(O, FE, mode):
     same(got, ref, "700 s, %d lock drops" % len(drops))
     r = got[3]
     assert int(r["n_sync"]) == len(ref[1]) and int(r["n_dibits"]) == len(ref[0])
+
+
+def test_slicer_instant_arithmetic_narrow_and_wide_agree(FE):
+    """k_slice_g places instant j of a clock (s, D, N) at s + (j D) div N with phase ((j D) mod N) 64 div N: per call one 64-bit division
+    of j_lo D, then 32-bit arithmetic per instant whenever the numbers fit, the 64-bit form otherwise.  The clocks D / N and k D / k N
+    are the same clock; with k = 1 700 nothing fits 32 bits any more.  A range without a sync word, sliced under a carry-in anchor with
+    either clock: the same dibits, and as many as the integers say."""
+    import torch
+    from p25rx_amd.frontend import parse_results
+    n_bb = 3 * 7680 + 1234
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    t = 0.3 * torch.randn(n_bb + 64, generator=g, device="cuda")
+    fe = FE(symbol_clock=1)
+    outs = []
+    for k in (1, 1700):
+        D, N = (4 * 8641 + 1) * k, 4 * 864 * k
+        s0 = -40
+        dib, res, _, _ = fe.slice_dev(t, n_bb, anchor_in=[(s0, 0.2, 0.0, -0.2, 1, D, N)])
+        torch.cuda.synchronize()
+        r = parse_results(res)[0]
+        assert int(r["n_sync"]) == 0, "noise held a sync word: pick another seed"
+        # instants j >= 1 at s0 + (j D) div N inside the range (the tracking clock decides the last few samples one call later)
+        want = sum(1 for j in range(1, n_bb // 10 + 64) if max(0, s0 + 6) <= s0 + (j * D) // N < n_bb)
+        nd = int(r["n_dibits"])
+        assert want - 1 <= nd <= want, (k, nd, want)
+        outs.append(dib[0, :nd].cpu().numpy())
+    assert len(outs[0]) == len(outs[1]) and np.array_equal(outs[0], outs[1])
+    assert len(set(outs[0].tolist())) == 4                           # (a real slicer output, not a row of zeros)
