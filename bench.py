@@ -14,7 +14,9 @@ to rank 0, received at their offsets of ONE ordered stream.  torch.distributed (
 communicator id, the barriers around the timed region, the max over ranks, the gates.  Default `--scaling weak`: every GPU
 holds configs[1]'s 600 s (the N = 1 line and the N > 1 lines are one curve of fixed per-GPU work); `--scaling strong` is
 BASELINE.json configs[4] as worded, ONE 3 600 s capture cut N ways.  A plain `python bench.py --gpus N` (no WORLD_SIZE in
-the environment) starts the N ranks itself, as children, through torch.distributed.run.
+the environment) starts the N ranks itself, as children, through torch.distributed.run.  An N > 1 run that cannot produce its number
+(rendezvous, RCCL bootstrap, a rank that never arrives: a watchdog, P25FE_BENCH_WATCHDOG_S, default 900 s) still prints ONE line on rank 0:
+the contract's keys, value 0, `error` and the `stage` it happened in, and exits non-zero.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (K1) from HIP
 events recorded inside the library on the launch stream, and `cpu_baseline` from the CPU oracle timed on this box's
@@ -48,6 +50,39 @@ FLOPS_PER_SAMPLE = (2 * 2 * 31 + 2 * 2 * 41 + 30 + 10) / 5.0
 FLOPS_PER_SAMPLE_U8 = FLOPS_PER_SAMPLE + 4.0
 PMC_FILES = [os.path.join("profiles", "r06_k1_pmc.json"), os.path.join("profiles", "r05_k1_pmc.json"), os.path.join("profiles", "r04_k1_pmc.json")]
 PREWARM_MS = 150.0               # untimed steps before the W warm-up steps: the chip reaches its steady clock / power state
+
+
+STAGE = ["start"]                # where the run is (N > 1: what a failure line names)
+
+
+def stage(what):
+    STAGE[0] = what
+
+
+def failure_line(args, why):
+    """The one JSON line of a run that could not produce its number: the same keys, value 0, and what went wrong where -- a
+    rendezvous or an RCCL bootstrap that fails (or hangs: the watchdog) must leave a record, not silence."""
+    return json.dumps({"metric": "IQ Msamples/s through FM-demod+C4FM slice", "value": 0.0, "unit": "Msamples/s", "n_gpus": args.gpus,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                       "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                       "config": {"workload": "FAILED before a number existed"}, "error": why, "stage": STAGE[0]})
+
+
+def start_watchdog(args, rank):
+    """N > 1, rank 0: a run stuck in a collective prints a failure line and ends instead of hanging until somebody's timeout."""
+    import threading
+    limit = float(os.environ.get("P25FE_BENCH_WATCHDOG_S", "900"))
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(limit):
+            if rank == 0:
+                print(failure_line(args, "watchdog: no result after %.0f s" % limit), flush=True)
+            sys.stderr.write("bench.py rank %d: watchdog after %.0f s in stage '%s'\n" % (rank, limit, STAGE[0]))
+            sys.stderr.flush()
+            os._exit(5)
+    threading.Thread(target=watch, daemon=True).start()
+    return done
 GATHER_WORDS = {"root_exact": "point-to-point to rank 0, exactly the valid bytes, received at their offsets", "root": "point-to-point "
                 "gather of whole rows to rank 0 + compaction", "all": "all_gather of rows", "none": "nothing"}
 
@@ -733,7 +768,25 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)                                 # (before torch is imported: this process never touches the GPU)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return run(args)
+    rank = int(os.environ.get("RANK", "0"))
+    finished = start_watchdog(args, rank)
+    try:
+        run(args)
+    except SystemExit:
+        raise
+    except BaseException as e:                                     # N > 1: rank 0 leaves a line that says where
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            print(failure_line(args, "%s: %s" % (type(e).__name__, e)), flush=True)
+        os._exit(4)                                                # (not sys.exit: a rank stuck in a collective's teardown would hang the others)
+    finally:
+        finished.set()
 
+
+def run(args):
     import torch
     from p25rx_amd import c4fm
     from p25rx_amd.frontend import FrontEnd, parse_results
@@ -751,6 +804,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: gloo must not try to resolve the container's hostname
+        stage("process group (gloo / nccl rendezvous)")
         if staged or args.workload == "time":
             # time shards: the DATA path is libp25fe_rccl.so (RCCL inside the C ABI, p25rx_amd/rccl.py); torch.distributed is
             # the control plane only (communicator id, barrier, max over ranks, gates) and runs on gloo
@@ -801,9 +855,11 @@ def main():
         boot = [None]
         if rank == 0:
             boot[0] = ("/p25fe_bench_%d" % os.getpid()) if staged else rccl.unique_id()
+        stage("unique id broadcast")
         dist.broadcast_object_list(boot, src=0)
         if staged:
             os.environ["P25FE_SHARD_SHM"] = boot[0]
+        stage("p25fe_shard_create (ncclCommInitRank, ncclCommSplit x 2, agreement all-reduce)")
         ss = rccl.ShardStep(fe, rank, world, n, None if staged else boot[0])
         ss.prepare(dev)                                            # once per stream: the side stream off this stream's hardware queue
         dibits = torch.zeros((1, ss.dibit_cap), dtype=torch.uint8, device=dev)
@@ -818,6 +874,7 @@ def main():
 
     # untimed pre-warm (not part of W or K): the chip needs ~100 ms of this load to settle at its power-limited clock; the
     # driver's `--steps 20 --warmup 5` is a 6 ms timed region behind 1.5 ms of warm-up and otherwise times the clock ramp
+    stage("pre-warm steps")
     t_pw = time.perf_counter()
     n_prewarm = 0
     if world == 1:
@@ -839,7 +896,9 @@ def main():
     # K1's begin / end events ride on its own dispatch (hipExtLaunchKernelGGL: no extra packet between two kernels) --
     # on every step when there are at most 64 of them (the ring holds 64 slots), otherwise on every 8th, spread over the run
     fe.profile_enable(2 if (world > 1 or args.steps <= 64) else 3)
+    stage("timed steps")
     dt = timed(torch, step, args.steps, 0, dist, finish=fe.join_dev)
+    stage("after the timed steps (gates, extras)")
     kms, ncalls = fe.profile_read()
     comm_ms = None
     if world > 1 and not staged:
@@ -950,6 +1009,7 @@ def main():
     if world > 1 and not strong and not args.no_extra:
         # configs[4] AS WORDED rides along as an extra row of the default (weak) line: one 3 600 s capture cut N ways
         try:
+            stage("the strong row (configs[4] as worded): shard create + steps")
             strong_extra, strong_ok = strong_row(torch, dist, args, world, rank, local, dev, staged, max(3, min(args.steps, 100)),
                                                  args.strong_seconds)
         except Exception as e:

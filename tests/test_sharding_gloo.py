@@ -219,3 +219,31 @@ def test_bench_plain_invocation_reaches_the_launcher():
     assert out.returncode != 0                                           # no GPU: the ranks fail loudly ...
     assert out.stderr.count("No HIP GPUs are available") >= 2           # ... both of them, after the launcher started them
     assert "--gpus must equal WORLD_SIZE" not in out.stderr
+    # ... and rank 0 leaves ONE line that says what failed and where, with the contract's keys (a failed N > 1 run is a record, not silence)
+    import json
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 0.0 and d["n_gpus"] == 2 and "No HIP GPUs" in d["error"] and d["stage"] and d["metric"].startswith("IQ Msamples/s")
+
+
+def test_bench_watchdog_ends_a_rank_stuck_in_the_rendezvous():
+    """A rank whose peers never arrive (a dead GPU, a wedged RCCL bootstrap) must not hang until somebody else's timeout: after
+    P25FE_BENCH_WATCHDOG_S rank 0 prints the failure line -- with the stage it was stuck in -- and the process ends with code 5."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               P25FE_BENCH_WATCHDOG_S="20", P25FE_BENCH_HOST_STAGED="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--seconds", "1",
+                          "--no-extra", "--no-cpu"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 5, (out.returncode, out.stderr[-500:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["error"].startswith("watchdog") and "rendezvous" in d["stage"] and d["value"] == 0.0
