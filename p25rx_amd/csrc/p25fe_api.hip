@@ -529,9 +529,9 @@ int p25fe_create(const p25fe_config_t* cfg, p25fe_t** out)
         for (int k = 0; k < MAX_LANES - 1; ++k) h->spare[k].id = k + 1;
         const char* pd = getenv("P25FE_SHARD_PIPE_DEPTH");            // (measurement knob: 2 .. MAX_LANES)
         if (pd && atoi(pd) >= 2 && atoi(pd) <= MAX_LANES) h->sh_depth = atoi(pd);
-        // The general receiver's chain (tracking clock) holds k_scan_g, a 512-thread workgroup that finds room only when the K1 beside it
-        // drains: with two scratch sets the K1 after that waits for the slicer behind it (0.326 ms per pipelined step); with three it does
-        // not (0.286; profiles/r05_tracking_pipeline.txt).  The fixed-stride chain fits beside K1: two sets.
+        // The general receiver's chain (tracking clock) is the longer one: 150 - 230 us beside a K1 of 275.  Round 5's held a 512-thread
+        // k_scan_g that waited for K1's drain, and a third scratch set was worth 12 % (0.326 -> 0.286 ms per pipelined step); with the chain
+        // as one-wave work it still is worth 0.6 - 0.9 % (profiles/r06_run_depth.txt).  The fixed-stride chain: two sets.
         if (cfg->symbol_clock != P25FE_CLOCK_FIXED) h->run_depth = 3;
         const char* rd = getenv("P25FE_PIPE_DEPTH");
         if (rd && atoi(rd) >= 2 && atoi(rd) <= MAX_LANES) h->run_depth = atoi(rd);

@@ -6,7 +6,7 @@
 //                   (src/demod.rs:82-84, 87, 93, 109-111, 114) fused into one pass over HBM.  Writes the baseband
 //                   either linearly (the RecvEvent::Baseband hand-off) or in the blocked polyphase layout with one sign
 //                   bit per sample on the side (the fused path: PLPAD / planar_index below).
-//   K2 k_detect, K3 k_scan, K4 k_slice (p25fe_recv.hip, included below): frame-sync detection, the receiver's serial
+//   K2 k_detect, K3 k_scan_tiles, K4 k_slice (p25fe_recv.hip, included below): frame-sync detection, the receiver's serial
 //                   state as a scan, 4-level slicer -- the front half of MessageReceiver::feed (src/recv.rs:207).
 // Either side of the path (SURVEY.md section 8f / BASELINE.json config 3):
 //   K0 k_predecim   : 2.4 Msps -> 240 ksps, 80-tap 10:1 decimating FIR (config 3's extra stage).

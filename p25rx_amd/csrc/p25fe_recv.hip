@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(WV, 4) void k_slice(SliceArgs a) { slice_item(a, (i
 // follows independently in closed form (clock_count: two 64-bit divisions per anchor and interval), and a prefix sum
 // gives the offsets.
 // ------------------------------------------------------------------------------------------
-struct ScanOutG {               // per (channel, tile) carry-in written by k_scan_g
+struct ScanOutG {               // per (channel, tile) carry-in written by k_scan_g_groups
     long s;                     // position of the detection in force at the tile's first sample
     unsigned long long dibit_off;
     int src;                    // tile whose record holds that detection's thresholds; -1: the range's anchor_in; -2: not locked
@@ -1743,8 +1743,8 @@ __global__ __launch_bounds__(WV, 4) void k_slice_g(SliceArgsG a) { slice_g_item(
 //
 // A detection without a usable clock of its own (the first of a lock run) takes the clock of the interval that STARTS at it: the
 // backward clock of the next detection.  That look-ahead crosses tiles, and the clock changes how many instants the detection
-// governs, i.e. every later dibit's offset -- the tile-local bookkeeping of k_scan_g / k_slice_g has no place for it.  The list of
-// detections has: K2 and k_scan_g (unchanged) give every tile its carry-in and its first detection's index in the range;
+// governs, i.e. every later dibit's offset -- the tile-local bookkeeping of K3 / k_slice_g has no place for it.  The list of
+// detections has: K2 and the general receiver's K3 (unchanged) give every tile its carry-in and its first detection's index in the range;
 //   k_ev_collect  one wave per tile: its detections -> EvRec[1 + index] (position, backward clock + usable, where the governed
 //                 interval ends inside the tile, thresholds); the tile that ends an interval left OPEN by an earlier tile records
 //                 where (EvNext of that detection: position + the call's sequence number, so that nothing has to be cleared);
@@ -1788,7 +1788,7 @@ struct EvArgs {
     unsigned long long* off;             // [ch][ev_stride + 1]
     long ev_stride;
     unsigned long long seq;
-    p25fe_result_t* result;              // [ch] (k_scan_g's; n_sync is read, the counts are rewritten)
+    p25fe_result_t* result;              // [ch] (k_scan_tiles_g's; n_sync is read, the counts are rewritten)
     uint8_t* dibits;
     long dibit_stride;
     int64_t* sync_pos;                   // nullable
@@ -1871,8 +1871,8 @@ __device__ __forceinline__ void ev_collect_item(const EvArgs& a, const int tile,
 __global__ __launch_bounds__(WV, 4) void k_ev_collect(EvArgs a) { ev_collect_item(a, (int)blockIdx.x, (int)blockIdx.y); }
 
 // k_ev_count: one lane per detection (grid-stride), the divisions of clock_count in parallel; k_ev_scan: ONE wave (it runs beside the
-// next call's K1, whose one-wave workgroups leave room for exactly that -- a 512-thread workgroup waits for K1 to drain, as k_scan_g
-// in front of it already does), prefix sum of the counts, the range's record and the sync lists.
+// next call's K1, whose one-wave workgroups leave room for exactly that -- a 512-thread workgroup waits for K1 to drain, as rounds
+// 3 - 5's k_scan_g did), prefix sum of the counts, the range's record and the sync lists.
 __global__ __launch_bounds__(WV, 4) void k_ev_count(EvArgs a)
 {
     const int lane = threadIdx.x, ch = blockIdx.y;
