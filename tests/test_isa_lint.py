@@ -25,6 +25,17 @@ def test_k1_isa_lint_and_resource_budget():
         vgpr = int(re.search(r"VGPRs: (\d+)", blk).group(1))
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
         assert vgpr <= 168 and scratch == 0, (name, vgpr, scratch)
+    # the receive chain rides beside K1 in what its eleven one-wave workgroups per CU leave free (docs/ROUND6.md section 1):
+    # one wave per workgroup, no scratch, and LDS / VGPR footprints that a retiring K1 workgroup's share covers -- (name, LDS bytes, VGPRs)
+    for name, lds_max, vgpr_max in (("_ZN4p25k8k_detectILb0EEEvNS_7DetArgsE", 7168, 88), ("_ZN4p25k8k_detectILb1EEEvNS_7DetArgsE", 8448, 88),
+                                    ("_ZN4p25k12k_scan_tilesENS_8ScanArgsE", 0, 64), ("_ZN4p25k14k_scan_tiles_gENS_9ScanArgsGE", 0, 104),
+                                    ("_ZN4p25k15k_scan_g_groupsENS_9ScanArgsGE", 0, 48), ("_ZN4p25k7k_sliceENS_9SliceArgsE", 2560, 48),
+                                    ("_ZN4p25k9k_slice_gENS_10SliceArgsGE", 1024, 48)):
+        blk = res[res.index("Function Name: " + name):][:1500]
+        vgpr = int(re.search(r"VGPRs: (\d+)", blk).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", blk).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+        assert lds <= lds_max and vgpr <= vgpr_max and scratch == 0, (name, lds, vgpr, scratch)
 
 
 def test_shipped_sources_hold_no_measurement_code():
