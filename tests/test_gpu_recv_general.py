@@ -467,3 +467,36 @@ def test_slicer_instant_arithmetic_narrow_and_wide_agree(FE):
         outs.append(dib[0, :nd].cpu().numpy())
     assert len(outs[0]) == len(outs[1]) and np.array_equal(outs[0], outs[1])
     assert len(set(outs[0].tolist())) == 4                           # (a real slicer output, not a row of zeros)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_more_than_64_detections_in_one_tile(O, FE, mode):
+    """The slicers keep their tile's detections in registers, 64 at a time (one per lane, read by v_readlane), and reload for a tile
+    that holds more; K2 remembers the thresholds of 64.  Real traffic never gets there (a sync word is 240 samples long), but the
+    ten polyphase planes are independent sample sets: every plane carries its own back-to-back sync words, plane r's ending at
+    positions 240 m + 21 r -- ten detections per 240 samples, 21 or 51 samples apart, 320 per tile.  Dibits, sync positions and
+    sync dibit indices equal the oracle's under all three clocks."""
+    mask = 0x050cdf                                                  # P25FE_SYNC_SIGN_MASK: bit j = sync symbol j (oldest first) is +3
+    pat = np.array([1.0 if (mask >> j) & 1 else -1.0 for j in range(24)], dtype=np.float32)
+    n_bb = 3 * 7680 + 777
+    q = np.arange(n_bb, dtype=np.int64)
+    r = q % 10
+    bb = (0.24 * pat[((q - 21 * r + 230) // 10) % 24]).astype(np.float32)
+    bb += (0.004 * np.random.default_rng(11).standard_normal(n_bb)).astype(np.float32)
+    ref = oracle_recv(O, bb, mode)
+    per_tile = np.bincount((ref[1] + 5) // 7680, minlength=3)        # (decision index = sync position + W)
+    assert per_tile.max() > 256, per_tile
+    same(dev_slice(FE(symbol_clock=mode), bb, sync_cap=4096), ref, "320 detections per tile, mode %d" % mode)
+    # ... and with lock drops between them (fixed stride and causal clock: the lock-drop list makes both take the general kernels)
+    if mode < 2:
+        drops = [int(ref[1][70]) + 7, int(ref[1][200]) + 6, int(ref[1][201]) + 9, 2 * 7680 + 3]
+        same(dev_slice(FE(symbol_clock=mode), bb, resync=drops, sync_cap=4096), oracle_recv(O, bb, mode, drops), "with drops, mode %d" % mode)
+    # ... and through the streaming chunks of the reference's size (one wave runs detection, scan and slicer of a chunk: k_recv_chunk;
+    # 3 276 samples hold 136 of these detections)
+    if mode == 0:
+        fe2 = FE()
+        got_d, got_s = [], []
+        for o in range(0, n_bb, 3276):
+            dd, ss, _ = fe2.slice(bb[o:o + 3276])
+            got_d.append(dd); got_s.append(ss)
+        assert np.array_equal(np.concatenate(got_d), ref[0]) and np.array_equal(np.concatenate(got_s), ref[1])
