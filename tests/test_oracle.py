@@ -554,3 +554,36 @@ def test_tracking_clock_range_of_usefulness():
     t20, _ = errors(20.0, 1)
     assert k > 19000 and f150 > 50 and t150 < f150 // 8
     assert f20 == 0 and t20 == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_densest_detections_against_the_independent_batch_model(spec, mode):
+    """The ten polyphase planes of the baseband are independent sample sets: every plane carrying its own back-to-back sync words, plane
+    r's ending at positions 240 m + 21 r, makes ten detections per 240 samples -- 21 or 51 samples apart, 320 per 7 680 samples, denser
+    than any transmitter can be and close to SPEC 3.7's bound (detections are more than 5 samples apart).  The oracle's receivers (the
+    GPU tests' reference for this scene, tests/test_gpu_recv_general.py) against the batch model, all three clocks, with lock drops."""
+    import spec_model
+    mask = int(spec["sync_sign_mask"]) if "sync_sign_mask" in spec else 0x050cdf
+    pat = np.array([1.0 if (mask >> j) & 1 else -1.0 for j in range(24)], dtype=np.float32)
+    n_bb = 2 * 7680 + 333
+    q = np.arange(n_bb, dtype=np.int64)
+    bb = (0.24 * pat[((q - 21 * (q % 10) + 230) // 10) % 24]).astype(np.float32)
+    bb += (0.004 * np.random.default_rng(11).standard_normal(n_bb)).astype(np.float32)
+    for drops in ([], [1000, 1007, 5000, 7685, 12001]):
+        if mode == 2:
+            got = O.recv_range(bb, O.make_config(symbol_clock=2), drops)
+            ref = spec_model.Model(spec).receive_tracking(bb, spec, drops, reslice=True)
+        else:
+            r = O.Recv(O.make_config(symbol_clock=mode))
+            outs, o = [], 0
+            for c in sorted(set(drops + [n_bb])):
+                outs.append(r.feed(bb[o:c]))
+                if c in drops:
+                    r.resync()
+                o = c
+            got = [np.concatenate([x[k] for x in outs]) for k in range(3)]
+            m = spec_model.Model(spec)
+            ref = m.receive_tracking(bb, spec, drops) if mode == 1 else m.receive(bb, drops)
+        assert len(got[1]) > 600
+        for k in range(3):
+            assert len(got[k]) == len(ref[k]) and np.array_equal(got[k], np.asarray(ref[k]).astype(got[k].dtype)), (mode, drops, k)
