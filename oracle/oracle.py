@@ -267,7 +267,9 @@ class Recv:
 
     def feed(self, bb):
         bb = np.ascontiguousarray(bb, dtype=np.float32)
-        cap = bb.size // self.cfg.sps + 2
+        # (a receiver that re-anchors on every sync word can emit more than n / sps dibits: up to one per peak_w + 1 samples under the
+        # densest detections SPEC 3.7 allows, plus what an earlier feed left undecided)
+        cap = bb.size // (self.cfg.peak_w + 1) + 8
         dib = np.empty(cap, dtype=np.uint8)
         scap = bb.size // (self.cfg.peak_w + 1) + 2
         spos = np.empty(scap, dtype=np.int64)

@@ -329,6 +329,26 @@ def run_scene(seed, O, FE, torch, verbose=False):
     return len(what)
 
 
+def dense_scene(seed):
+    """A baseband no transmitter makes: the ten polyphase planes are independent sample sets, each active one carries its own
+    back-to-back sync words at its own alignment -- up to 320 detections per 7 680-sample tile (the slicers hold 64 in registers at a
+    time, K2 remembers the thresholds of 64), some of them closer than the peak test allows; any clock, lock drops.
+    -> (symbol_clock, baseband float32, lock-drop indices).  Its own generator: a scene is reproducible on the CPU from its seed."""
+    rng = np.random.default_rng(seed ^ 0xd15e)
+    mode = int(rng.choice([0, 0, 1, 2]))
+    pat = np.array([1.0 if (0x050cdf >> j) & 1 else -1.0 for j in range(24)], dtype=np.float32)
+    n_bb = int(rng.choice([3000, 7680, 7681, 2 * 7680 + 11, int(rng.integers(5000, 4 * 7680))]))
+    q = np.arange(n_bb, dtype=np.int64)
+    active = rng.random(10) < float(rng.choice([0.3, 0.7, 1.0]))
+    align = np.where(rng.random(10) < 0.5, 21 * np.arange(10), 10 * rng.integers(0, 24, size=10) + np.arange(10))
+    amp = float(rng.choice([0.1, 0.24, 0.5]))
+    bb = (amp * pat[((q - align[q % 10] + 230) // 10) % 24]).astype(np.float32)
+    bb = np.where(active[q % 10], bb, 0.0).astype(np.float32)
+    bb += (float(rng.choice([0.002, 0.02, 0.08])) * rng.standard_normal(n_bb)).astype(np.float32)
+    drops = sorted(set(int(x) for x in rng.integers(1, n_bb, size=int(rng.choice([0, 0, 2, 6])))))
+    return mode, bb, drops
+
+
 def run_aux_scene(seed, O, FE, torch, verbose=False):
     """The forms around the fresh-stream ones: an owned range INSIDE a longer device buffer (random start, random amount of
     history, absolute decimation grid), the wideband stages K0 (bit-exact) and K6 (fp64 oracle, 2e-6 tolerance) on random
@@ -412,6 +432,36 @@ def run_aux_scene(seed, O, FE, torch, verbose=False):
     fe._chk(fe.L.p25fe_nid(fe.h, d.ctypes.data_as(C_.c_void_p), len(d), sdib.ctypes.data_as(C_.c_void_p), spos.ctypes.data_as(C_.c_void_p),
                            nf, out.ctypes.data_as(C_.c_void_p)))
     check("nid", out.tobytes() == refn.tobytes(), nf=nf, flips=len(flips))
+    # ---- (d) the receiver on a baseband no transmitter makes (dense_scene below)
+    from p25rx_amd.frontend import parse_results
+    mode, bb, drops = dense_scene(seed)
+    n_bb = len(bb)
+    if mode == 2:
+        refd = O.recv_range(bb, O.make_config(symbol_clock=2), drops)
+    else:
+        rcv = O.Recv(O.make_config(symbol_clock=mode))
+        outs, o = [], 0
+        for c in drops + [n_bb]:
+            outs.append(rcv.feed(bb[o:c]))
+            if c < n_bb:
+                rcv.resync()
+            o = c
+        refd = [np.concatenate([x[k] for x in outs]) for k in range(3)]
+    fed = FE(symbol_clock=mode)
+    if drops:
+        fed.resync_at_dev(torch.tensor(drops, dtype=torch.int64, device="cuda"))
+    dib, res, sp, sd = fed.slice_dev(torch.from_numpy(bb).cuda(), n_bb, sync_cap=2048)
+    rr = parse_results(res)[0]
+    nd, ns = int(rr["n_dibits"]), int(rr["n_sync"])
+    check("dense planes: counts", nd == len(refd[0]) and ns == len(refd[1]), mode=mode, n_bb=n_bb, nd=nd, ns=ns, want=(len(refd[0]), len(refd[1])))
+    kd = min(nd, dib.shape[1])                                       # (the row's capacity bounds the stores, the count stays exact)
+    got_d = dib[0, :kd].cpu().numpy()
+    bad = np.nonzero(got_d != refd[0][:kd])[0]
+    check("dense planes: dibits", len(bad) == 0, mode=mode, n_bb=n_bb, nd=nd, cap=int(dib.shape[1]), drops=drops,
+          first_bad=[int(x) for x in bad[:8]], n_bad=len(bad))
+    check("dense planes: sync", np.array_equal(sp[0, :ns].cpu().numpy(), refd[1])
+          and np.array_equal(sd[0, :ns].cpu().numpy().astype(np.uint64), np.asarray(refd[2]).astype(np.uint64)), mode=mode, n_bb=n_bb, ns=ns)
+    fed.close()
     if verbose:
         print("aux seed %d ok: %d comparisons" % (seed, len(what)))
     return len(what)
