@@ -1799,8 +1799,6 @@ struct EvArgs {
 #ifndef P25FE_JIT
 __device__ __forceinline__ void ev_collect_item(const EvArgs& a, const int tile, const int ch)
 {
-    __shared__ uint16_t EV[EVCAP];
-    __shared__ uint32_t EG[EVCAP];
     const int lane = threadIdx.x;
     const long t0 = (long)tile * TS;
     const int tn = a.n - t0 < TS ? (int)(a.n - t0) : TS;
@@ -1832,19 +1830,20 @@ __device__ __forceinline__ void ev_collect_item(const EvArgs& a, const int tile,
     if (n_ev == 0) return;
     const uint16_t* evl = a.evl + ((size_t)ch * a.n_tiles + tile) * EVCAP;
     const uint32_t* evg = a.evg + ((size_t)ch * a.n_tiles + tile) * EVCAP;
-    for (int k = lane; k < n_ev; k += WV) { EV[k] = evl[k]; EG[k] = evg[k]; }
-    phase_sync();
+    // (one detection per lane: its own entry of K2's lists and its predecessor's, straight from memory -- no LDS)
     const float* f = a.pl.f + (size_t)ch * a.pl.f_ch;
     const float* eth = a.evthr + ((size_t)ch * a.n_tiles + tile) * (EVTHR_N * 3);
     for (int k0 = 0; k0 < n_ev; k0 += WV) {
         const int k = k0 + lane;
         if (k < n_ev) {
-            const unsigned eg = EG[k];
-            const long ek = T0 + EV[k], sk = ek - W;
+            const unsigned eg = evg[k];
+            const long ek = T0 + evl[k], sk = ek - W;
+            const unsigned eg_p = k ? evg[k - 1] : 0u;
+            const long s_p = k ? T0 + evl[k - 1] - W : 0;
             EvRec r;
             bool us;
             if (k == 0) clock_period(true, ((g.n_det_flags >> 16) & G_FIRST_TRACKS) && carry_valid, so.s, so.f, sk, frac3(eg >> 16), r.Db, r.Nb, &us);
-            else clock_period(true, ((eg >> 15) & 1u) != 0, T0 + EV[k - 1] - W, frac3(EG[k - 1] >> 16), sk, frac3(eg >> 16), r.Db, r.Nb, &us);
+            else clock_period(true, ((eg >> 15) & 1u) != 0, s_p, frac3(eg_p >> 16), sk, frac3(eg >> 16), r.Db, r.Nb, &us);
             r.s = sk; r.g_lo = ek + 1; r.g_hi = T0 + (long)(eg & 0x7fffu);
             r.D2 = r.Db; r.N2 = r.Nb;
             r.flags = EV_VALID | (us ? EV_USABLE : 0u) | ((k == n_ev - 1 && (int)(eg & 0x7fffu) == tn) ? EV_OPEN : 0u) | (((eg >> 16) & 7u) << 8);
@@ -1863,7 +1862,7 @@ __device__ __forceinline__ void ev_collect_item(const EvArgs& a, const int tile,
     // thresholds beyond the ones K2 handed over: recomputed from the sync word, one detection at a time (every lane, same window)
     for (int k = EVTHR_N; k < n_ev; ++k) {
         float v[NSYN], h, m, l;
-        sync_gather(f, t0 + EV[k] - W + PLPAD, v);
+        sync_gather(f, t0 + (int)evl[k] - W + PLPAD, v);
         sync_thresholds(v, h, m, l);
         if (lane == 0) { EvRec* r = rec + 1 + so.event_off + k; r->hi = h; r->mid = m; r->lo = l; }
     }

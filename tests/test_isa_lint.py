@@ -30,7 +30,8 @@ def test_k1_isa_lint_and_resource_budget():
     for name, lds_max, vgpr_max in (("_ZN4p25k8k_detectILb0EEEvNS_7DetArgsE", 7168, 88), ("_ZN4p25k8k_detectILb1EEEvNS_7DetArgsE", 8448, 88),
                                     ("_ZN4p25k12k_scan_tilesENS_8ScanArgsE", 0, 64), ("_ZN4p25k14k_scan_tiles_gENS_9ScanArgsGE", 0, 104),
                                     ("_ZN4p25k15k_scan_g_groupsENS_9ScanArgsGE", 0, 48), ("_ZN4p25k7k_sliceENS_9SliceArgsE", 2560, 48),
-                                    ("_ZN4p25k9k_slice_gENS_10SliceArgsGE", 1024, 48)):
+                                    ("_ZN4p25k9k_slice_gENS_10SliceArgsGE", 1024, 48), ("_ZN4p25k12k_ev_collectENS_6EvArgsE", 0, 40),
+                                    ("_ZN4p25k10k_ev_sliceENS_6EvArgsE", 1024, 40)):
         blk = res[res.index("Function Name: " + name):][:1500]
         vgpr = int(re.search(r"VGPRs: (\d+)", blk).group(1))
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", blk).group(1))
