@@ -16,7 +16,8 @@ holds configs[1]'s 600 s (the N = 1 line and the N > 1 lines are one curve of fi
 BASELINE.json configs[4] as worded, ONE 3 600 s capture cut N ways.  A plain `python bench.py --gpus N` (no WORLD_SIZE in
 the environment) starts the N ranks itself, as children, through torch.distributed.run.  An N > 1 run that cannot produce its number
 (rendezvous, RCCL bootstrap, a rank that never arrives: a watchdog, P25FE_BENCH_WATCHDOG_S, default 900 s) still prints ONE line on rank 0:
-the contract's keys, value 0, `error` and the `stage` it happened in, and exits non-zero.
+the contract's keys, value 0, `error` and the `stage` it happened in, and exits non-zero (also when the launcher ends rank 0 with SIGTERM
+because another rank failed first).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (K1) from HIP
 events recorded inside the library on the launch stream, and `cpu_baseline` from the CPU oracle timed on this box's
@@ -772,6 +773,23 @@ def main():
         return run(args)
     rank = int(os.environ.get("RANK", "0"))
     finished = start_watchdog(args, rank)
+    if rank == 0:
+        # torch.distributed.run ends the surviving ranks with SIGTERM when another rank fails first: rank 0 still leaves its line.  A
+        # Python-level handler alone would not run while the main thread sits inside a collective or a rendezvous: the C-level handler
+        # (whichever thread the signal lands on) writes to a wake-up pipe, and a thread blocked on that pipe prints the line and ends.
+        import signal
+        import threading
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.signal(signal.SIGTERM, lambda signum, frame: None)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+        def on_term():
+            os.read(rfd, 1)
+            if not finished.is_set():
+                print(failure_line(args, "terminated by the launcher (SIGTERM): another rank failed first -- see its traceback on stderr"), flush=True)
+            os._exit(6)
+        threading.Thread(target=on_term, daemon=True).start()
     try:
         run(args)
     except SystemExit:

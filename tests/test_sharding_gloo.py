@@ -247,3 +247,28 @@ def test_bench_watchdog_ends_a_rank_stuck_in_the_rendezvous():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["error"].startswith("watchdog") and "rendezvous" in d["stage"] and d["value"] == 0.0
+
+
+def test_bench_rank0_leaves_its_line_when_the_launcher_terminates_it():
+    """torch.distributed.run ends the surviving ranks with SIGTERM when another rank fails first; rank 0 -- the rank whose line the driver
+    reads -- still prints the failure line (exit code 6)."""
+    import json
+    import signal
+    import socket
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               P25FE_BENCH_WATCHDOG_S="200", P25FE_BENCH_HOST_STAGED="1")
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--seconds", "1",
+                          "--no-extra", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(8.0)                                                  # (the handler is installed before torch is imported)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 6, (p.returncode, err[-400:])
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert d["error"].startswith("terminated by the launcher") and d["value"] == 0.0 and d["n_gpus"] == 2
