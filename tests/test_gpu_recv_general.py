@@ -500,3 +500,15 @@ def test_more_than_64_detections_in_one_tile(O, FE, mode):
             dd, ss, _ = fe2.slice(bb[o:o + 3276])
             got_d.append(dd); got_s.append(ss)
         assert np.array_equal(np.concatenate(got_d), ref[0]) and np.array_equal(np.concatenate(got_s), ref[1])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_golden_dense_planes_fixture(FE, mode):
+    """The committed vector of the densest scene (tests/golden/dense_planes.npz, written by gen_golden_dense.py from the oracle and
+    checked against the independent model on the CPU side): the HIP receiver reproduces it from the file alone -- no generator, no
+    oracle in between -- for the three clocks, without and with lock drops."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dense_planes.npz"))
+    bb = g["bb_bits"].view(np.float32)
+    for tag, drops in (("", None), ("_drops", [int(x) for x in g["drops"]])):
+        want = (g["dibits_m%d%s" % (mode, tag)], g["sync_pos_m%d%s" % (mode, tag)], g["sync_dibit_m%d%s" % (mode, tag)].astype(np.uint64))
+        same(dev_slice(FE(symbol_clock=mode), bb, resync=drops, sync_cap=2048), want, "golden dense planes, mode %d%s" % (mode, tag))

@@ -187,6 +187,33 @@ def test_golden_fixture_matches():
         assert json.load(f)["t1"] == 31
 
 
+def test_golden_dense_planes_fixture_matches(spec):
+    """Self-generated golden of the receiver on the densest scene (tests/golden/gen_golden_dense.py: 320 detections per tile, three
+    clocks, with and without lock drops): the oracle, fed in ragged chunks where the clock streams, and the independent batch model
+    reproduce the committed vectors."""
+    import spec_model
+    g = np.load(os.path.join(GOLDEN, "dense_planes.npz"))
+    bb = g["bb_bits"].view(np.float32)
+    for mode in (0, 1, 2):
+        for tag, drops in (("", []), ("_drops", [int(x) for x in g["drops"]])):
+            want = [g["dibits_m%d%s" % (mode, tag)], g["sync_pos_m%d%s" % (mode, tag)], g["sync_dibit_m%d%s" % (mode, tag)]]
+            got = O.recv_range(bb, O.make_config(symbol_clock=mode), drops)
+            m = spec_model.Model(spec)
+            ref = m.receive(bb, drops) if mode == 0 else m.receive_tracking(bb, spec, drops, reslice=(mode == 2))
+            for k in range(3):
+                assert np.array_equal(got[k], want[k].astype(got[k].dtype)), (mode, tag, k)
+                assert np.array_equal(np.asarray(ref[k]).astype(want[k].dtype), want[k]), (mode, tag, k, "model")
+            if mode < 2:                                            # streaming: any chunking gives the same output
+                r = O.Recv(O.make_config(symbol_clock=mode))
+                outs, o = [], 0
+                for c in sorted(set(drops + [333, 3276, 3277, 9000, len(bb)])):
+                    outs.append(r.feed(bb[o:c]))
+                    if c in drops:
+                        r.resync()
+                    o = c
+                assert np.array_equal(np.concatenate([x[0] for x in outs]), want[0]) and np.array_equal(np.concatenate([x[1] for x in outs]), want[1])
+
+
 def test_predecim_fp64_and_chunking(spec):
     """Stage 0 (config 3, no reference counterpart): 10:1 decimating FIR vs scipy fp64; chunk invariance."""
     rng = np.random.default_rng(0)
